@@ -1,0 +1,188 @@
+/* msc.h -- C ABI of libmsc_hip.so: the MI355X (gfx950) kernels behind the U-Net segmentation hot
+ * path of neptune-ai/open-solution-mapping-challenge.
+ *
+ * The reference is pure Python and has no FFI of its own; every entry point below replaces a
+ * call the reference makes into a third-party native library (cuDNN/MKL-DNN through torch,
+ * scipy.ndimage, scikit-image, pydensecrf).  The reference call site each one stands in for is
+ * cited as file:line under /root/reference.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; msc_last_error() gives a thread-local text
+ *   - all tensors are raw DEVICE pointers owned by the caller (torch allocates them); no hidden
+ *     global state; `stream` is a hipStream_t passed as void* (0 = default stream)
+ *   - activations are NHWC: element (n,y,x,c) at ((n*H+y)*W+x)*ld + c, where `ld` (elements) >= C
+ *     lets a tensor be a channel slice of a wider buffer (skip-concats are never materialised)
+ *   - dtype: MSC_F32 (exact-fp32 parity mode, v_mfma_f32_16x16x4_f32) or MSC_BF16 (throughput mode,
+ *     v_mfma_f32_16x16x32_bf16, fp32 accumulate); bf16 values are raw uint16 bit patterns
+ *   - re-entrant per stream; one host thread per GPU/process, no internal threads
+ */
+#ifndef MSC_H
+#define MSC_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSC_DTYPE_F32 0
+#define MSC_DTYPE_BF16 1
+
+const char* msc_last_error(void);
+int msc_abi_version(void);
+
+/* ---------------------------------------------------------------- convolutions (network) ------
+ * nn.Conv2d / nn.ConvTranspose2d forward and data-gradient:
+ *   conv3x3+bias+ReLU  src/unet_models.py:21-34      ConvTranspose2d(k4,s2,p1)+ReLU  :138-140
+ *   final 1x1          src/unet_models.py:383,403    ResNet convs (torchvision)      :345-371
+ * mode 0 (gather):      out[q] = sum_t in[q*stride + off(t)] * W[.][t][.]   off = t-pad, or pad-t if flip
+ * mode 1 (transposed):  out[q] = sum_{t:(q+pad-t) even} in[(q+pad-t)/2] * W[.][t][.]   (stride must be 2)
+ * epilogue: v = acc*scale[c] + shift[c] (+ res) ; ReLU ; store.  scale/shift/res may be NULL.
+ * stats (mode 0 only, may be NULL): per-channel partial sum / sum of squares of the raw accumulators,
+ *   [msc_conv_stats_slices()][Cout][2] floats, reduced by msc_bn_finalize (BatchNorm2d training mode).
+ * weights: dtype [Cout][KH][KW][Cin].  Cin*sizeof(dtype) % 64 == 0, Cout % 32 == 0. */
+typedef struct msc_conv_desc {
+    const void* in;
+    const void* wt;
+    void* out;
+    const void* res;
+    const float* scale;
+    const float* shift;
+    float* stats;
+    int64_t in_ld, out_ld, res_ld;
+    int32_t dtype, mode;
+    int32_t N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, flip, relu;
+} msc_conv_desc;
+int msc_conv_igemm(const msc_conv_desc* d, void* stream);
+int msc_conv_stats_slices(const msc_conv_desc* d);
+
+/* weight gradient (autograd of the same modules; reference: loss.backward(), src/steps/pytorch/models.py:110)
+ *   dw[a][kh][kw][b] += sum_m p[m][a] * q[(y*stride-pad+kh, x*stride-pad+kw)][b]    (fp32 atomics, dw pre-zeroed)
+ *   conv: p = dY (a = Cout, Hp x Wp = output grid), q = X (b = Cin);  convT: p = X (a = Cin), q = dOut (b = Cout), stride 2 */
+typedef struct msc_wgrad_desc {
+    const void* p;
+    const void* q;
+    float* dw;
+    int64_t p_ld, q_ld;
+    int32_t dtype;
+    int32_t N, Hp, Wp, A, Hq, Wq, B, KH, KW, stride, pad;
+} msc_wgrad_desc;
+int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream);
+
+/* fp32 master weight -> compute copy.  msc_pack_cast: same layout.  msc_pack_transpose: [A][T][B] -> [B][T][A]
+ * (data-gradient / ConvTranspose2d operand).  msc_stem_pack: conv1 weight [64][3][7][7] (torch layout,
+ * src/unet_models.py:360) -> [64][7][8][4] (kh, kw padded to 8, ci padded to 4); msc_stem_unpack_grad is its adjoint. */
+int msc_pack_cast(const float* src, void* dst, int dtype, int64_t n, void* stream);
+int msc_pack_transpose(const float* src, void* dst, int dtype, int A, int T, int B, void* stream);
+int msc_stem_pack(const float* w, void* dst, int dtype, int cout, void* stream);
+int msc_stem_unpack_grad(const float* dpacked, float* dw, int cout, void* stream);
+
+/* network input: x f32 NCHW [N,3,H,W] (what the loaders hand to model(X), src/steps/pytorch/models.py:92)
+ * -> zero-padded NHWC4 image [N][H+6][W+8][4] (3 px top/left) so the 7x7/2 stem becomes an implicit GEMM. */
+int msc_stem_prepare(const float* x, void* xp, int dtype, int N, int H, int W, void* stream);
+
+/* MaxPool2d(2,2) (src/unet_models.py:356,363,392) forward / backward (first maximum wins, as torch) */
+int msc_maxpool2_fwd(const void* in, int64_t in_ld, void* out, int64_t out_ld, int dtype, int N, int Ho, int Wo, int C, void* stream);
+int msc_maxpool2_bwd(const void* dout, int64_t dout_ld, const void* in, int64_t in_ld, void* din, int64_t din_ld,
+                     int dtype, int N, int Ho, int Wo, int C, int accumulate, void* stream);
+
+/* BatchNorm2d, training mode (torchvision ResNet BNs; eps 1e-5, momentum 0.1).
+ * finalize: partial sums -> batch mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale;
+ *           running stats updated with the unbiased variance; mean / invstd saved for backward.
+ * apply:    out = act(y*scale + shift (+ res)). */
+int msc_bn_finalize(const float* partials, int slices, int C, int64_t count, const float* gamma, const float* beta,
+                    float eps, float momentum, float* running_mean, float* running_var,
+                    float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+/* eval mode (model.eval(), src/steps/pytorch/models.py:116): scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
+int msc_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                float eps, float* scale, float* shift, int C, void* stream);
+int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_t res_ld, void* out, int64_t out_ld,
+                 const float* scale, const float* shift, int relu, int dtype, int64_t pixels, int C, void* stream);
+/* backward of out = relu?(bn(y) (+res)):  dh = dout * [out>0] (if relu);
+ * reduce: partial[blk][C][2] = (sum dh, sum dh*y);  finalize: dgamma, dbeta (accumulated into fp32 grads) and
+ * per-channel coefficients coef[3][C];  apply: dy = coef0*dh + coef1*y + coef2 ; dres (optional) = dh (or += if dres_acc). */
+int msc_bn_bwd_blocks(int64_t pixels, int C);
+int msc_bn_bwd_reduce(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
+                      int relu, float* partials, int dtype, int64_t pixels, int C, void* stream);
+int msc_bn_bwd_finalize(const float* partials, int blocks, int C, int64_t count, const float* gamma,
+                        const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef, void* stream);
+int msc_bn_bwd_apply(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
+                     int relu, const float* coef, void* dy, int64_t dy_ld, void* dres, int64_t dres_ld, int dres_acc,
+                     int dtype, int64_t pixels, int C, void* stream);
+
+/* ReLU backward for the decoder (ConvRelu / deconv+ReLU): dx = dy*[y>0], optionally dx += */
+int msc_relu_bwd(const void* dy, int64_t dy_ld, const void* y, int64_t y_ld, void* dx, int64_t dx_ld,
+                 int accumulate, int dtype, int64_t pixels, int C, void* stream);
+/* per-channel bias gradient: db[c] += sum_pixels dy[p][c]  (conv bias of ConvRelu / ConvTranspose2d) */
+int msc_bias_grad(const void* dy, int64_t dy_ld, float* db, int dtype, int64_t pixels, int C, void* stream);
+
+/* final 1x1 conv 32 -> 2 with bias (src/unet_models.py:383,403; dropout p = 0) fused with the channel softmax
+ * the reference applies on the host afterwards (src/models.py:88-92, src/utils.py:231-273).
+ * in: NHWC dtype [pixels][C]; w f32 [2][C]; logits / probs: f32 NCHW [N,2,H,W] (either may be NULL). */
+int msc_final_fwd(const void* in, int64_t in_ld, const float* w, const float* b, float* logits, float* probs,
+                  int dtype, int N, int H, int W, int C, void* stream);
+/* backward: dlogits f32 NCHW -> din[p][c] = sum_k dlogits[k][p]*w[k][c] (masked by in>0: the ReLU of dec0),
+ * dw[k][c] += sum_p dlogits[k][p]*in[p][c], db[k] += sum_p dlogits[k][p] */
+int msc_final_bwd(const float* dlogits, const void* in, int64_t in_ld, const float* w, void* din, int64_t din_ld,
+                  float* dw, float* db, int dtype, int N, int H, int W, int C, void* stream);
+
+/* ---------------------------------------------------------------- losses / optimizer ----------
+ * mixed distance-weighted cross entropy + soft Dice (src/models.py:310-454, validation.py:8-16) or plain CE
+ * (validation.py:25-28).  logits f32 NCHW [N,2,H,W]; target f32 NCHW [N,tc,H,W] (tc = 1: class only, tc = 3:
+ * class, distance, sqrt(size)).  Two phases so the three Dice sums can be all-reduced across ranks between them:
+ *   msc_loss_sums:  sums[0..3] = (sum_p w*ce, sum p1*t, sum p1, sum t)   (double accumulation)
+ *   msc_loss_grad:  loss[0] = ce_weight*sums0/total_pixels + dice_weight*(1-(2*s1+smooth)/(s2+s3+smooth+eps));
+ *                   dlogits = d loss / d logits (NCHW f32), scaled by grad_scale */
+typedef struct msc_loss_cfg {
+    float w0, sigma, size_c;     /* get_weights(): 1 + w0*exp(-d^2/sigma^2), C = sqrt(h*w)/2 */
+    float dice_weight, ce_weight, smooth, eps;
+    int32_t weighted;            /* 0: plain CE (target channel 0 only), 1: distance/size weighted */
+} msc_loss_cfg;
+int msc_loss_sums(const float* logits, const float* target, int tc, const msc_loss_cfg* cfg, double* sums,
+                  int N, int H, int W, void* stream);
+int msc_loss_grad(const float* logits, const float* target, int tc, const msc_loss_cfg* cfg, const double* sums,
+                  double total_pixels, float grad_scale, float* loss, float* dlogits, int N, int H, int W, void* stream);
+
+/* Adam with L2 folded into the gradient (torch.optim.Adam(weight_decay), src/models.py:57,287-292) over one flat
+ * fp32 parameter buffer. */
+int msc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* ---------------------------------------------------------------- mask post-processing --------
+ * Batched over B images; each replaces a per-image Python/scipy/skimage loop of src/postprocessing.py. */
+/* resize_image (src/postprocessing.py:48-61): bilinear, scipy 'constant' edge rule; f32 [B,C,h,w] -> f32 [B,C,H,W] */
+int msc_resize_bilinear(const float* in, float* out, int B, int C, int h, int w, int H, int W, void* stream);
+/* crop_image_center_per_class (src/postprocessing.py:239-258) */
+int msc_crop_center(const float* in, float* out, int B, int C, int h, int w, int hc, int wc, void* stream);
+/* categorize_multilayer_image (src/postprocessing.py:77-84): layers[b][l] = probs[b][cls(l)] > thr(l); u8 */
+int msc_threshold_layers(const float* probs, uint8_t* layers, int B, int C, int H, int W,
+                         const int32_t* layer_class, const float* layer_thr, int L, void* stream);
+/* categorize_image (src/postprocessing.py:64-74): argmax over channels (first maximum), int32 [B,H,W] */
+int msc_argmax_channels(const float* probs, int32_t* out, int B, int C, int H, int W, void* stream);
+/* erosion / dilation with a k x k rectangle, skimage origin convention (src/postprocessing.py:148-154,172-179):
+ * window offsets -((k-1)/2) .. -((k-1)/2)+k-1 on both axes, clamped border; u8 or int32 images [B,H,W] */
+int msc_erode_u8(const uint8_t* in, uint8_t* out, int B, int H, int W, int k, void* stream);
+int msc_dilate_i32(const int32_t* in, int32_t* out, int B, int H, int W, int k, void* stream);
+/* label (src/utils.py:328-330 = scipy.ndimage.label, 4-connectivity, labels 1..n in raster order of each
+ * component's first pixel): mask u8 [B,H,W] (nonzero = foreground) -> int32 labels; counts[b] = n.
+ * workspace: msc_label_workspace_bytes(B,H,W) bytes. */
+int64_t msc_label_workspace_bytes(int B, int H, int W);
+int msc_label4(const uint8_t* mask, int32_t* labels, int32_t* counts, void* workspace, int B, int H, int W, void* stream);
+/* add_dropped_objects (src/utils.py:333-339): out = processed + [component of `original` with no surviving pixel];
+ * labels_orig = msc_label4(original); u8 result */
+int msc_add_dropped(const uint8_t* processed, const int32_t* labels_orig, uint8_t* out, void* workspace,
+                    int B, int H, int W, void* stream);
+/* build_score (src/postprocessing.py:228-236): per label, mean(prob over label) * sqrt(area).
+ * labels int32 [B,H,W], probs f32 [B,H,W] (the matching channel); sums f64 [B][max_labels], areas i32 [B][max_labels]
+ * are zeroed by the call; score[b][l-1] = sums/areas*sqrt(areas) (f64). */
+int msc_build_score(const int32_t* labels, const float* probs, double* sums, int32_t* areas, double* score,
+                    int B, int H, int W, int max_labels, void* stream);
+/* dense_crf (src/postprocessing.py:183-225), exact windowed mean field (see oracle/crf_ref.py: PARITY UNPINNED):
+ * probs f32 [B,2,H,W], rgb u8 [B,H,W,3] -> out f32 [B,2,H,W]; workspace msc_crf_workspace_bytes() */
+int64_t msc_crf_workspace_bytes(int B, int H, int W, int radius);
+int msc_dense_crf(const float* probs, const uint8_t* rgb, float* out, void* workspace, int B, int H, int W,
+                  float sxy_g, float compat_g, float sxy_b, float srgb, float compat_b, int iterations, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

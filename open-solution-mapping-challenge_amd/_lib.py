@@ -1,0 +1,116 @@
+"""ctypes binding of libmsc_hip.so (C ABI: include/msc.h).
+
+There is deliberately NO fallback: if the HIP library has not been built, importing any compute
+module of this package raises.  Build it with `python __graft_entry__.py build` (or
+`make -C open-solution-mapping-challenge_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get('MSC_HIP_LIB', os.path.join(_HERE, 'lib', 'libmsc_hip.so'))
+
+F32, BF16 = 0, 1
+
+
+class MscError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('in_', C.c_void_p), ('wt', C.c_void_p), ('out', C.c_void_p), ('res', C.c_void_p),
+                ('scale', C.c_void_p), ('shift', C.c_void_p), ('stats', C.c_void_p),
+                ('in_ld', C.c_int64), ('out_ld', C.c_int64), ('res_ld', C.c_int64),
+                ('dtype', C.c_int32), ('mode', C.c_int32),
+                ('N', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32), ('Cin', C.c_int32),
+                ('Ho', C.c_int32), ('Wo', C.c_int32), ('Cout', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32),
+                ('stride', C.c_int32), ('pad', C.c_int32), ('flip', C.c_int32), ('relu', C.c_int32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [('p', C.c_void_p), ('q', C.c_void_p), ('dw', C.c_void_p),
+                ('p_ld', C.c_int64), ('q_ld', C.c_int64), ('dtype', C.c_int32),
+                ('N', C.c_int32), ('Hp', C.c_int32), ('Wp', C.c_int32), ('A', C.c_int32),
+                ('Hq', C.c_int32), ('Wq', C.c_int32), ('B', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32),
+                ('stride', C.c_int32), ('pad', C.c_int32)]
+
+
+class LossCfg(C.Structure):
+    _fields_ = [('w0', C.c_float), ('sigma', C.c_float), ('size_c', C.c_float),
+                ('dice_weight', C.c_float), ('ce_weight', C.c_float), ('smooth', C.c_float), ('eps', C.c_float),
+                ('weighted', C.c_int32)]
+
+
+_vp, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+
+# name -> (restype, argtypes); every symbol declared in include/msc.h
+SIGNATURES = {
+    'msc_last_error': (C.c_char_p, []),
+    'msc_abi_version': (_i, []),
+    'msc_conv_igemm': (_i, [C.POINTER(ConvDesc), _vp]),
+    'msc_conv_stats_slices': (_i, [C.POINTER(ConvDesc)]),
+    'msc_conv_wgrad': (_i, [C.POINTER(WgradDesc), _vp]),
+    'msc_pack_cast': (_i, [_vp, _vp, _i, _i64, _vp]),
+    'msc_pack_transpose': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'msc_stem_pack': (_i, [_vp, _vp, _i, _i, _vp]),
+    'msc_stem_unpack_grad': (_i, [_vp, _vp, _i, _vp]),
+    'msc_stem_prepare': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'msc_maxpool2_fwd': (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
+    'msc_maxpool2_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
+    'msc_bn_finalize': (_i, [_vp, _i, _i, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'msc_bn_fold': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
+    'msc_bn_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i64, _i, _vp]),
+    'msc_bn_bwd_blocks': (_i, [_i64, _i]),
+    'msc_bn_bwd_reduce': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _i64, _i, _vp]),
+    'msc_bn_bwd_finalize': (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'msc_bn_bwd_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _i64, _vp, _i64, _i, _i, _i64, _i, _vp]),
+    'msc_relu_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i64, _i, _vp]),
+    'msc_bias_grad': (_i, [_vp, _i64, _vp, _i, _i64, _i, _vp]),
+    'msc_final_fwd': (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'msc_final_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'msc_loss_sums': (_i, [_vp, _vp, _i, C.POINTER(LossCfg), _vp, _i, _i, _i, _vp]),
+    'msc_loss_grad': (_i, [_vp, _vp, _i, C.POINTER(LossCfg), _vp, _d, _f, _vp, _vp, _i, _i, _i, _vp]),
+    'msc_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    'msc_resize_bilinear': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'msc_crop_center': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'msc_threshold_layers': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    'msc_argmax_channels': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'msc_erode_u8': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'msc_dilate_i32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'msc_label_workspace_bytes': (_i64, [_i, _i, _i]),
+    'msc_label4': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'msc_add_dropped': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'msc_build_score': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'msc_crf_workspace_bytes': (_i64, [_i, _i, _i, _i]),
+    'msc_dense_crf': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _f, _f, _i, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmsc_hip.so and bind every symbol of include/msc.h; raises MscError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise MscError('HIP library not built: %s is missing. Run `python __graft_entry__.py build`. '
+                       'There is no CPU fallback for the product path.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError -> missing export: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().msc_last_error()
+        raise MscError('%s failed (rc=%d): %s' % (what or 'msc call', rc, msg.decode() if msg else '?'))
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)

@@ -1,0 +1,93 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the U-Net hot path.
+// wave = 64 lanes; MFMA fragments as documented for gfx950:
+//   v_mfma_f32_16x16x32_bf16 : A lane l -> row l&15, k = 8*(l>>4)+j (j<8); B lane l -> col l&15, same k
+//   v_mfma_f32_16x16x4_f32   : A lane l -> row l&15, k = l>>4      ; B lane l -> col l&15, same k
+//   C/D (both)               : col = l&15, row = 4*(l>>4)+r (r<4)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define MSC_OK 0
+#define MSC_ERR_ARG (-1)
+#define MSC_ERR_HIP (-2)
+#define MSC_ERR_UNSUPPORTED (-3)
+
+// dtype enum of the C ABI (include/msc.h)
+#define MSC_F32 0
+#define MSC_BF16 1
+
+extern thread_local char msc_err_buf[512];
+int msc_fail(int code, const char* fmt, ...);
+int msc_check_launch(const char* what);
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                          // round to nearest even
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct ElemIO;
+template <> struct ElemIO<float> {
+    static __device__ __forceinline__ float load(const float* p) { return *p; }
+    static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct ElemIO<bf16_t> {
+    static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 16-byte vector of T as floats: 4 x f32 or 8 x bf16
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float* v) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float* v) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const bf16_t* p, float* v) {
+        uint4 t = *reinterpret_cast<const uint4*>(p);
+        uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float* v) {
+        uint4 t;
+        t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]);
+        t.z = pack_bf16x2(v[4], v[5]); t.w = pack_bf16x2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(p) = t;
+    }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

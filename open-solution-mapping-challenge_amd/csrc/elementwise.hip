@@ -1,0 +1,744 @@
+// HBM-bound kernels of the U-Net hot path on gfx950: weight packing, stem input preparation,
+// MaxPool2d(2,2), BatchNorm2d training statistics / apply / backward, decoder ReLU backward, bias
+// gradient, the final 1x1 conv fused with softmax, and Adam.  All activations NHWC with a channel
+// stride; every global access is a 16-byte vector per lane (4 f32 / 8 bf16), lanes run along the
+// channel (contiguous) dimension first.
+#include "common.h"
+#include "msc_internal.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+inline int ew_grid(long long work) {
+    long long b = (work + EW_THREADS - 1) / EW_THREADS;
+    if (b > 256 * 16) b = 256 * 16;  // grid-stride beyond ~16 blocks per CU
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------ packing
+template <typename T>
+__global__ void pack_cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        ElemIO<T>::store(dst + i, src[i]);
+}
+
+// [A][T][B] -> [B][T][A], tiled through LDS so both sides are coalesced
+template <typename T>
+__global__ void pack_transpose_kernel(const float* __restrict__ src, T* __restrict__ dst, int A, int Tn, int B) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int a = a0 + r, b = b0 + tx;
+        tile[r][tx] = (a < A && b < B) ? src[((long)a * Tn + t) * B + b] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int b = b0 + r, a = a0 + tx;
+        if (a < A && b < B) ElemIO<T>::store(dst + ((long)b * Tn + t) * A + a, tile[tx][r]);
+    }
+}
+
+// conv1 weight [co][3][7][7] -> [co][7][8][4]
+template <typename T>
+__global__ void stem_pack_kernel(const float* __restrict__ w, T* __restrict__ dst, int cout) {
+    const int n = cout * 7 * 32;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int ci = i & 3, kw = (i >> 2) & 7, kh = (i >> 5) % 7, co = i / (7 * 32);
+        float v = 0.f;
+        if (ci < 3 && kw < 7) v = w[((co * 3 + ci) * 7 + kh) * 7 + kw];
+        ElemIO<T>::store(dst + i, v);
+    }
+}
+__global__ void stem_unpack_grad_kernel(const float* __restrict__ dp, float* __restrict__ dw, int cout) {
+    const int n = cout * 3 * 49;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int kw = i % 7, kh = (i / 7) % 7, ci = (i / 49) % 3, co = i / 147;
+        dw[i] += dp[((co * 7 + kh) * 8 + kw) * 4 + ci];
+    }
+}
+
+// x f32 NCHW [N,3,H,W] -> xp [N][H+6][W+8][4], image at (3,3), zero elsewhere
+template <typename T>
+__global__ void stem_prepare_kernel(const float* __restrict__ x, T* __restrict__ xp, int N, int H, int W) {
+    const int Hp = H + 6, Wp = W + 8;
+    const long total = (long)N * Hp * Wp;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int px = (int)(i % Wp);
+        const int py = (int)((i / Wp) % Hp);
+        const int n = (int)(i / ((long)Wp * Hp));
+        const int y = py - 3, xx = px - 3;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) {
+            const long base = ((long)n * 3 * H + y) * W + xx;
+            v[0] = x[base]; v[1] = x[base + (long)H * W]; v[2] = x[base + 2L * H * W];
+        }
+        T* d = xp + i * 4;
+        if (sizeof(T) == 4) {
+            *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            *reinterpret_cast<uint2*>(d) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ maxpool 2x2 / 2
+template <typename T>
+__global__ void maxpool2_fwd_kernel(const T* __restrict__ in, long in_ld, T* __restrict__ out, long out_ld,
+                                    int N, int Ho, int Wo, int C) {
+    constexpr int CE = Vec16<T>::N;
+    const int cv = C / CE;
+    const long total = (long)N * Ho * Wo * cv;
+    const int Wi = Wo * 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * CE;
+        const long pix = i / cv;
+        const int ox = (int)(pix % Wo);
+        const long row = pix / Wo;  // n*Ho + oy
+        const long ibase = (row * 2 * Wi + 2 * ox);
+        float a[CE], b[CE], m[CE];
+        Vec16<T>::load(in + ibase * in_ld + c, m);
+        Vec16<T>::load(in + (ibase + 1) * in_ld + c, a);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) m[e] = a[e] > m[e] ? a[e] : m[e];
+        Vec16<T>::load(in + (ibase + Wi) * in_ld + c, a);
+        Vec16<T>::load(in + (ibase + Wi + 1) * in_ld + c, b);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { m[e] = a[e] > m[e] ? a[e] : m[e]; m[e] = b[e] > m[e] ? b[e] : m[e]; }
+        Vec16<T>::store(out + pix * out_ld + c, m);
+    }
+}
+
+template <typename T>
+__global__ void maxpool2_bwd_kernel(const T* __restrict__ dout, long dout_ld, const T* __restrict__ in, long in_ld,
+                                    T* __restrict__ din, long din_ld, int N, int Ho, int Wo, int C, int accumulate) {
+    constexpr int CE = Vec16<T>::N;
+    const int cv = C / CE;
+    const long total = (long)N * Ho * Wo * cv;
+    const int Wi = Wo * 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * CE;
+        const long pix = i / cv;
+        const int ox = (int)(pix % Wo);
+        const long row = pix / Wo;
+        const long ibase = (row * 2 * Wi + 2 * ox);
+        const long off[4] = {ibase, ibase + 1, ibase + Wi, ibase + Wi + 1};
+        float v[4][CE], g[CE];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Vec16<T>::load(in + off[k] * in_ld + c, v[k]);
+        Vec16<T>::load(dout + pix * dout_ld + c, g);
+        float o[4][CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+            int best = 0;
+            float bm = v[0][e];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (v[k][e] > bm) { bm = v[k][e]; best = k; }  // first maximum wins
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k][e] = (k == best) ? g[e] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (accumulate) {
+                float old[CE];
+                Vec16<T>::load(din + off[k] * din_ld + c, old);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) o[k][e] += old[e];
+            }
+            Vec16<T>::store(din + off[k] * din_ld + c, o[k]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ BatchNorm (training)
+// one block per 32 channels; 8 slice lanes; partials [slices][C][2]
+__global__ void bn_finalize_kernel(const float* __restrict__ partials, int slices, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                   float* running_mean, float* running_var, float* scale, float* shift,
+                                   float* save_mean, float* save_invstd) {
+    __shared__ double sh1[8][32], sh2[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        for (int s = sl; s < slices; s += 8) {
+            const float2 v = *reinterpret_cast<const float2*>(partials + ((long)s * C + c) * 2);
+            s1 += v.x; s2 += v.y;
+        }
+    }
+    sh1[sl][cl] = s1; sh2[sl][cl] = s2;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) { s1 += sh1[k][cl]; s2 += sh2[k][cl]; }
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        const float sc = g * invstd;
+        scale[c] = sc;
+        shift[c] = b - (float)mean * sc;
+        if (save_mean) save_mean[c] = (float)mean;
+        if (save_invstd) save_invstd[c] = invstd;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        if (running_var) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+// eval mode: fold running statistics into the conv epilogue, scale = gamma/sqrt(rv+eps), shift = beta - rm*scale
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+                               const float* __restrict__ rv, float eps, float* scale, float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float sc = (gamma ? gamma[c] : 1.f) / sqrtf(rv[c] + eps);
+        scale[c] = sc;
+        shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+    }
+}
+
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ y, long y_ld, const T* __restrict__ res, long res_ld,
+                                T* __restrict__ out, long out_ld, const float* __restrict__ scale,
+                                const float* __restrict__ shift, int relu, long pixels, int C) {
+    constexpr int CE = Vec16<T>::N;
+    const int cv = C / CE;
+    const long total = pixels * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * CE;
+        const long pix = i / cv;
+        float v[CE], r[CE];
+        Vec16<T>::load(y + pix * y_ld + c, v);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) v[e] = v[e] * scale[c + e] + shift[c + e];
+        if (res) {
+            Vec16<T>::load(res + pix * res_ld + c, r);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) v[e] += r[e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        Vec16<T>::store(out + pix * out_ld + c, v);
+    }
+}
+
+// backward reduce: block b handles pixel range; threads = (C/CE lanes along channels) x pixel lanes.
+// partial[b][C][2] = (sum dh, sum dh*y)
+constexpr int BNB_PIX = 2048;  // pixels per block
+template <typename T>
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dout, long dout_ld, const T* __restrict__ out, long out_ld,
+                                     const T* __restrict__ y, long y_ld, int relu, float* __restrict__ partials,
+                                     long pixels, int C) {
+    constexpr int CE = Vec16<T>::N;
+    extern __shared__ float red[];  // [rows][C][2] reduced over rows
+    const int cv = C / CE;                       // vectors per pixel
+    const int rows = EW_THREADS / min(cv, EW_THREADS) > 0 ? EW_THREADS / min(cv, EW_THREADS) : 1;
+    const long p0 = (long)blockIdx.x * BNB_PIX;
+    const long p1 = min(pixels, p0 + BNB_PIX);
+    // thread -> (vector column vc, row lane r); when cv > 256 each thread walks several columns
+    for (int vc0 = 0; vc0 < cv; vc0 += EW_THREADS) {
+        const int ncol = min(cv - vc0, EW_THREADS);
+        const int vc = vc0 + (threadIdx.x % ncol);
+        const int r = threadIdx.x / ncol;
+        const int nr = EW_THREADS / ncol;
+        float s1[CE], s2[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+        if (r < nr) {
+            for (long p = p0 + r; p < p1; p += nr) {
+                float d[CE], o[CE], yy[CE];
+                Vec16<T>::load(dout + p * dout_ld + vc * CE, d);
+                Vec16<T>::load(y + p * y_ld + vc * CE, yy);
+                if (relu) {
+                    Vec16<T>::load(out + p * out_ld + vc * CE, o);
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < CE; ++e) { s1[e] += d[e]; s2[e] += d[e] * yy[e]; }
+            }
+        }
+        // reduce over row lanes through LDS
+        float* mine = red + ((long)threadIdx.x) * 2 * CE;
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { mine[2 * e] = s1[e]; mine[2 * e + 1] = s2[e]; }
+        __syncthreads();
+        if (r == 0) {
+            for (int k = 1; k < nr; ++k) {
+                const float* o = red + ((long)(k * ncol + (threadIdx.x % ncol))) * 2 * CE;
+#pragma unroll
+                for (int e = 0; e < CE; ++e) { s1[e] += o[2 * e]; s2[e] += o[2 * e + 1]; }
+            }
+            float* dst = partials + ((long)blockIdx.x * C + vc * CE) * 2;
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { dst[2 * e] = s1[e]; dst[2 * e + 1] = s2[e]; }
+        }
+        __syncthreads();
+    }
+    (void)rows;
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int blocks, int C, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, float* dgamma, float* dbeta, float* coef) {
+    __shared__ double sh1[8][32], sh2[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        for (int s = sl; s < blocks; s += 8) {
+            const float2 v = *reinterpret_cast<const float2*>(partials + ((long)s * C + c) * 2);
+            s1 += v.x; s2 += v.y;
+        }
+    }
+    sh1[sl][cl] = s1; sh2[sl][cl] = s2;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) { s1 += sh1[k][cl]; s2 += sh2[k][cl]; }
+        const double mu = mean[c], is = invstd[c], g = gamma ? gamma[c] : 1.0;
+        const double dbe = s1;                        // sum dh
+        const double dga = is * (s2 - mu * s1);       // sum dh * xhat
+        if (dgamma) dgamma[c] += (float)dga;
+        if (dbeta) dbeta[c] += (float)dbe;
+        // dy = g*is*(dh - dbe/M - xhat*dga/M),  xhat = (y-mu)*is
+        const double a = g * is;
+        const double b = -g * is * is * dga / count;
+        const double k0 = -g * is * dbe / count - b * mu;
+        coef[c] = (float)a; coef[C + c] = (float)b; coef[2 * C + c] = (float)k0;
+    }
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, long dout_ld, const T* __restrict__ out, long out_ld,
+                                    const T* __restrict__ y, long y_ld, int relu, const float* __restrict__ coef,
+                                    T* __restrict__ dy, long dy_ld, T* __restrict__ dres, long dres_ld, int dres_acc,
+                                    long pixels, int C) {
+    constexpr int CE = Vec16<T>::N;
+    const int cv = C / CE;
+    const long total = pixels * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * CE;
+        const long pix = i / cv;
+        float d[CE], o[CE], yy[CE], r[CE];
+        Vec16<T>::load(dout + pix * dout_ld + c, d);
+        Vec16<T>::load(y + pix * y_ld + c, yy);
+        if (relu) {
+            Vec16<T>::load(out + pix * out_ld + c, o);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+        }
+        if (dres) {
+            if (dres_acc) {
+                Vec16<T>::load(dres + pix * dres_ld + c, r);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) r[e] += d[e];
+                Vec16<T>::store(dres + pix * dres_ld + c, r);
+            } else {
+                Vec16<T>::store(dres + pix * dres_ld + c, d);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < CE; ++e) yy[e] = coef[c + e] * d[e] + coef[C + c + e] * yy[e] + coef[2 * C + c + e];
+        Vec16<T>::store(dy + pix * dy_ld + c, yy);
+    }
+}
+
+template <typename T>
+__global__ void relu_bwd_kernel(const T* __restrict__ dy, long dy_ld, const T* __restrict__ y, long y_ld,
+                                T* __restrict__ dx, long dx_ld, int accumulate, long pixels, int C) {
+    constexpr int CE = Vec16<T>::N;
+    const int cv = C / CE;
+    const long total = pixels * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * CE;
+        const long pix = i / cv;
+        float d[CE], o[CE], r[CE];
+        Vec16<T>::load(dy + pix * dy_ld + c, d);
+        Vec16<T>::load(y + pix * y_ld + c, o);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+        if (accumulate) {
+            Vec16<T>::load(dx + pix * dx_ld + c, r);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) d[e] += r[e];
+        }
+        Vec16<T>::store(dx + pix * dx_ld + c, d);
+    }
+}
+
+// db[c] += sum_p dy[p][c]; same thread layout as bn_bwd_reduce, one atomic per channel per block
+template <typename T>
+__global__ void bias_grad_kernel(const T* __restrict__ dy, long dy_ld, float* __restrict__ db, long pixels, int C) {
+    constexpr int CE = Vec16<T>::N;
+    extern __shared__ float red[];
+    const int cv = C / CE;
+    const long p0 = (long)blockIdx.x * BNB_PIX;
+    const long p1 = min(pixels, p0 + BNB_PIX);
+    for (int vc0 = 0; vc0 < cv; vc0 += EW_THREADS) {
+        const int ncol = min(cv - vc0, EW_THREADS);
+        const int vc = vc0 + (threadIdx.x % ncol);
+        const int r = threadIdx.x / ncol;
+        const int nr = EW_THREADS / ncol;
+        float s1[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) s1[e] = 0.f;
+        if (r < nr) {
+            for (long p = p0 + r; p < p1; p += nr) {
+                float d[CE];
+                Vec16<T>::load(dy + p * dy_ld + vc * CE, d);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) s1[e] += d[e];
+            }
+        }
+        float* mine = red + ((long)threadIdx.x) * CE;
+#pragma unroll
+        for (int e = 0; e < CE; ++e) mine[e] = s1[e];
+        __syncthreads();
+        if (r == 0) {
+            for (int k = 1; k < nr; ++k) {
+                const float* o = red + ((long)(k * ncol + (threadIdx.x % ncol))) * CE;
+#pragma unroll
+                for (int e = 0; e < CE; ++e) s1[e] += o[e];
+            }
+#pragma unroll
+            for (int e = 0; e < CE; ++e) atomicAdd(db + vc * CE + e, s1[e]);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ final 1x1 conv (C -> 2) + softmax
+// one thread per pixel: reads C contiguous values (C*sizeof(T) bytes), writes 2 logits/probs into NCHW planes
+template <typename T>
+__global__ void final_fwd_kernel(const T* __restrict__ in, long in_ld, const float* __restrict__ w,
+                                 const float* __restrict__ b, float* __restrict__ logits, float* __restrict__ probs,
+                                 int N, long HW, int C) {
+    constexpr int CE = Vec16<T>::N;
+    extern __shared__ float sw[];  // [2][C]
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sw[i] = w[i];
+    __syncthreads();
+    const long total = (long)N * HW;
+    const float b0 = b ? b[0] : 0.f, b1 = b ? b[1] : 0.f;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int c = 0; c < C; c += CE) {
+            float v[CE];
+            Vec16<T>::load(in + p * in_ld + c, v);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { a0 = fmaf(v[e], sw[c + e], a0); a1 = fmaf(v[e], sw[C + c + e], a1); }
+        }
+        a0 += b0; a1 += b1;
+        const long n = p / HW, hw = p - n * HW;
+        const long o0 = (n * 2) * HW + hw;
+        if (logits) { logits[o0] = a0; logits[o0 + HW] = a1; }
+        if (probs) {
+            // numpy softmax of src/utils.py:231-273: subtract max, exp, divide by the sum
+            const float m = fmaxf(a0, a1);
+            const float e0 = expf(a0 - m), e1 = expf(a1 - m);
+            const float s = e0 + e1;
+            probs[o0] = e0 / s; probs[o0 + HW] = e1 / s;
+        }
+    }
+}
+
+template <typename T>
+__global__ void final_bwd_kernel(const float* __restrict__ dlogits, const T* __restrict__ in, long in_ld,
+                                 const float* __restrict__ w, T* __restrict__ din, long din_ld,
+                                 float* __restrict__ dw, float* __restrict__ db, int N, long HW, int C) {
+    constexpr int CE = Vec16<T>::N;
+    extern __shared__ float sm[];        // [2][C] weights, then [2][C]+2 accumulators
+    float* sw = sm;
+    float* acc = sm + 2 * C;             // dw[2][C], db[2]
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sw[i] = w[i];
+    for (int i = threadIdx.x; i < 2 * C + 2; i += blockDim.x) acc[i] = 0.f;
+    __syncthreads();
+    const long total = (long)N * HW;
+    const int lane = threadIdx.x & 63;
+    // every lane walks the same number of iterations so wave reductions stay full
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long iters = (total + stride - 1) / stride;
+    float g0s = 0.f, g1s = 0.f;
+    for (long it = 0; it < iters; ++it) {
+        const long p = it * stride + blockIdx.x * (long)blockDim.x + threadIdx.x;
+        const bool ok = p < total;
+        float g0 = 0.f, g1 = 0.f;
+        long pp = ok ? p : 0;
+        if (ok) {
+            const long n = p / HW, hw = p - n * HW;
+            g0 = dlogits[(n * 2) * HW + hw];
+            g1 = dlogits[(n * 2 + 1) * HW + hw];
+        }
+        g0s += g0; g1s += g1;
+        for (int c = 0; c < C; c += CE) {
+            float v[CE], d[CE];
+            if (ok) Vec16<T>::load(in + pp * in_ld + c, v);
+            else {
+#pragma unroll
+                for (int e = 0; e < CE; ++e) v[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                // dec0 ends in a ReLU (src/unet_models.py:401): gradient flows only where its output > 0
+                d[e] = v[e] > 0.f ? g0 * sw[c + e] + g1 * sw[C + c + e] : 0.f;
+            }
+            if (ok) Vec16<T>::store(din + pp * din_ld + c, d);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                const float t0 = wave_sum(g0 * v[e]);
+                const float t1 = wave_sum(g1 * v[e]);
+                if (lane == 0) { atomicAdd(&acc[c + e], t0); atomicAdd(&acc[C + c + e], t1); }
+            }
+        }
+    }
+    g0s = wave_sum(g0s); g1s = wave_sum(g1s);
+    if (lane == 0) { atomicAdd(&acc[2 * C], g0s); atomicAdd(&acc[2 * C + 1], g1s); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(dw + i, acc[i]);
+    if (threadIdx.x < 2 && db) atomicAdd(db + threadIdx.x, acc[2 * C + threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ Adam (+L2), torch.optim.Adam semantics
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
+                            float bc1, float bc2_sqrt, float gscale) {
+    const long n4 = n / 4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 P = reinterpret_cast<float4*>(p)[i];
+        const float4 G = reinterpret_cast<const float4*>(g)[i];
+        float4 M = reinterpret_cast<float4*>(m)[i];
+        float4 V = reinterpret_cast<float4*>(v)[i];
+        float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x, G.y, G.z, G.w};
+        float mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {V.x, V.y, V.z, V.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = gg[e] * gscale + wd * pp[e];
+            mm[e] = b1 * mm[e] + (1.f - b1) * gr;
+            vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+            const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+            pp[e] -= (lr / bc1) * (mm[e] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    }
+    // tail
+    for (long i = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gr = g[i] * gscale + wd * p[i];
+        const float mm = b1 * m[i] + (1.f - b1) * gr;
+        const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mm; v[i] = vv;
+        p[i] -= (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    }
+}
+
+}  // namespace
+
+#define DT_CHECK(name, dtype) \
+    if ((dtype) != MSC_BF16 && (dtype) != MSC_F32) return msc_fail(MSC_ERR_ARG, name ": dtype %d", (int)(dtype))
+#define VEC_CHECK(name, dtype, C) \
+    if ((C) % ((dtype) == MSC_BF16 ? 8 : 4)) return msc_fail(MSC_ERR_UNSUPPORTED, name ": C=%d must be a multiple of the 16-byte vector", (int)(C))
+
+extern "C" int msc_pack_cast(const float* src, void* dst, int dtype, int64_t n, void* stream) {
+    DT_CHECK("msc_pack_cast", dtype);
+    if (!src || !dst || n < 0) return msc_fail(MSC_ERR_ARG, "msc_pack_cast: bad argument");
+    if (n == 0) return MSC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MSC_BF16) hipLaunchKernelGGL(pack_cast_kernel<bf16_t>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, st, src, (bf16_t*)dst, (long)n);
+    else hipLaunchKernelGGL(pack_cast_kernel<float>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, st, src, (float*)dst, (long)n);
+    return msc_check_launch("msc_pack_cast");
+}
+
+extern "C" int msc_pack_transpose(const float* src, void* dst, int dtype, int A, int T, int B, void* stream) {
+    DT_CHECK("msc_pack_transpose", dtype);
+    if (!src || !dst || A <= 0 || T <= 0 || B <= 0 || T > 65535) return msc_fail(MSC_ERR_ARG, "msc_pack_transpose: bad argument");
+    dim3 grid(ceil_div(B, 32), ceil_div(A, 32), T);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MSC_BF16) hipLaunchKernelGGL(pack_transpose_kernel<bf16_t>, grid, dim3(256), 0, st, src, (bf16_t*)dst, A, T, B);
+    else hipLaunchKernelGGL(pack_transpose_kernel<float>, grid, dim3(256), 0, st, src, (float*)dst, A, T, B);
+    return msc_check_launch("msc_pack_transpose");
+}
+
+extern "C" int msc_stem_pack(const float* w, void* dst, int dtype, int cout, void* stream) {
+    DT_CHECK("msc_stem_pack", dtype);
+    if (!w || !dst || cout <= 0) return msc_fail(MSC_ERR_ARG, "msc_stem_pack: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int n = cout * 7 * 32;
+    if (dtype == MSC_BF16) hipLaunchKernelGGL(stem_pack_kernel<bf16_t>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, st, w, (bf16_t*)dst, cout);
+    else hipLaunchKernelGGL(stem_pack_kernel<float>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, st, w, (float*)dst, cout);
+    return msc_check_launch("msc_stem_pack");
+}
+
+extern "C" int msc_stem_unpack_grad(const float* dpacked, float* dw, int cout, void* stream) {
+    if (!dpacked || !dw || cout <= 0) return msc_fail(MSC_ERR_ARG, "msc_stem_unpack_grad: bad argument");
+    hipLaunchKernelGGL(stem_unpack_grad_kernel, dim3(ew_grid(cout * 147)), dim3(EW_THREADS), 0, (hipStream_t)stream, dpacked, dw, cout);
+    return msc_check_launch("msc_stem_unpack_grad");
+}
+
+extern "C" int msc_stem_prepare(const float* x, void* xp, int dtype, int N, int H, int W, void* stream) {
+    DT_CHECK("msc_stem_prepare", dtype);
+    if (!x || !xp || N <= 0 || H <= 0 || W <= 0) return msc_fail(MSC_ERR_ARG, "msc_stem_prepare: bad argument");
+    const long total = (long)N * (H + 6) * (W + 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MSC_BF16) hipLaunchKernelGGL(stem_prepare_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, x, (bf16_t*)xp, N, H, W);
+    else hipLaunchKernelGGL(stem_prepare_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, x, (float*)xp, N, H, W);
+    return msc_check_launch("msc_stem_prepare");
+}
+
+extern "C" int msc_maxpool2_fwd(const void* in, int64_t in_ld, void* out, int64_t out_ld, int dtype, int N, int Ho, int Wo, int C, void* stream) {
+    DT_CHECK("msc_maxpool2_fwd", dtype);
+    VEC_CHECK("msc_maxpool2_fwd", dtype, C);
+    if (!in || !out) return msc_fail(MSC_ERR_ARG, "msc_maxpool2_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)N * Ho * Wo * (C / (dtype == MSC_BF16 ? 8 : 4));
+    if (dtype == MSC_BF16) hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)in, (long)in_ld, (bf16_t*)out, (long)out_ld, N, Ho, Wo, C);
+    else hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const float*)in, (long)in_ld, (float*)out, (long)out_ld, N, Ho, Wo, C);
+    return msc_check_launch("msc_maxpool2_fwd");
+}
+
+extern "C" int msc_maxpool2_bwd(const void* dout, int64_t dout_ld, const void* in, int64_t in_ld, void* din, int64_t din_ld,
+                                int dtype, int N, int Ho, int Wo, int C, int accumulate, void* stream) {
+    DT_CHECK("msc_maxpool2_bwd", dtype);
+    VEC_CHECK("msc_maxpool2_bwd", dtype, C);
+    if (!dout || !in || !din) return msc_fail(MSC_ERR_ARG, "msc_maxpool2_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)N * Ho * Wo * (C / (dtype == MSC_BF16 ? 8 : 4));
+    if (dtype == MSC_BF16) hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)dout, (long)dout_ld, (const bf16_t*)in, (long)in_ld, (bf16_t*)din, (long)din_ld, N, Ho, Wo, C, accumulate);
+    else hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const float*)dout, (long)dout_ld, (const float*)in, (long)in_ld, (float*)din, (long)din_ld, N, Ho, Wo, C, accumulate);
+    return msc_check_launch("msc_maxpool2_bwd");
+}
+
+extern "C" int msc_bn_finalize(const float* partials, int slices, int C, int64_t count, const float* gamma, const float* beta,
+                               float eps, float momentum, float* running_mean, float* running_var,
+                               float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
+    if (!partials || !scale || !shift || slices <= 0 || C <= 0 || count <= 0) return msc_fail(MSC_ERR_ARG, "msc_bn_finalize: bad argument");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, partials, slices, C, (double)count,
+                       gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
+    return msc_check_launch("msc_bn_finalize");
+}
+
+extern "C" int msc_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                            float eps, float* scale, float* shift, int C, void* stream) {
+    if (!running_mean || !running_var || !scale || !shift || C <= 0) return msc_fail(MSC_ERR_ARG, "msc_bn_fold: bad argument");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps, scale, shift, C);
+    return msc_check_launch("msc_bn_fold");
+}
+
+extern "C" int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_t res_ld, void* out, int64_t out_ld,
+                            const float* scale, const float* shift, int relu, int dtype, int64_t pixels, int C, void* stream) {
+    DT_CHECK("msc_bn_apply", dtype);
+    VEC_CHECK("msc_bn_apply", dtype, C);
+    if (!y || !out || !scale || !shift) return msc_fail(MSC_ERR_ARG, "msc_bn_apply: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const long total = pixels * (C / (dtype == MSC_BF16 ? 8 : 4));
+    if (dtype == MSC_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)y, (long)y_ld, (const bf16_t*)res, (long)res_ld, (bf16_t*)out, (long)out_ld, scale, shift, relu, (long)pixels, C);
+    else hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const float*)y, (long)y_ld, (const float*)res, (long)res_ld, (float*)out, (long)out_ld, scale, shift, relu, (long)pixels, C);
+    return msc_check_launch("msc_bn_apply");
+}
+
+extern "C" int msc_bn_bwd_blocks(int64_t pixels, int C) { (void)C; return ceil_div(pixels, BNB_PIX); }
+
+extern "C" int msc_bn_bwd_reduce(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
+                                 int relu, float* partials, int dtype, int64_t pixels, int C, void* stream) {
+    DT_CHECK("msc_bn_bwd_reduce", dtype);
+    VEC_CHECK("msc_bn_bwd_reduce", dtype, C);
+    if (!dout || !y || !partials || (relu && !out)) return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_reduce: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int ce = dtype == MSC_BF16 ? 8 : 4;
+    const size_t shm = (size_t)EW_THREADS * 2 * ce * sizeof(float);
+    const int blocks = ceil_div(pixels, BNB_PIX);
+    if (dtype == MSC_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(EW_THREADS), shm, st, (const bf16_t*)dout, (long)dout_ld, (const bf16_t*)out, (long)out_ld, (const bf16_t*)y, (long)y_ld, relu, partials, (long)pixels, C);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(EW_THREADS), shm, st, (const float*)dout, (long)dout_ld, (const float*)out, (long)out_ld, (const float*)y, (long)y_ld, relu, partials, (long)pixels, C);
+    return msc_check_launch("msc_bn_bwd_reduce");
+}
+
+extern "C" int msc_bn_bwd_finalize(const float* partials, int blocks, int C, int64_t count, const float* gamma,
+                                   const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef, void* stream) {
+    if (!partials || !save_mean || !save_invstd || !coef || blocks <= 0 || C <= 0) return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_finalize: bad argument");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, partials, blocks, C, (double)count,
+                       gamma, save_mean, save_invstd, dgamma, dbeta, coef);
+    return msc_check_launch("msc_bn_bwd_finalize");
+}
+
+extern "C" int msc_bn_bwd_apply(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
+                                int relu, const float* coef, void* dy, int64_t dy_ld, void* dres, int64_t dres_ld, int dres_acc,
+                                int dtype, int64_t pixels, int C, void* stream) {
+    DT_CHECK("msc_bn_bwd_apply", dtype);
+    VEC_CHECK("msc_bn_bwd_apply", dtype, C);
+    if (!dout || !y || !coef || !dy || (relu && !out)) return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_apply: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const long total = pixels * (C / (dtype == MSC_BF16 ? 8 : 4));
+    if (dtype == MSC_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)dout, (long)dout_ld, (const bf16_t*)out, (long)out_ld, (const bf16_t*)y, (long)y_ld, relu, coef, (bf16_t*)dy, (long)dy_ld, (bf16_t*)dres, (long)dres_ld, dres_acc, (long)pixels, C);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const float*)dout, (long)dout_ld, (const float*)out, (long)out_ld, (const float*)y, (long)y_ld, relu, coef, (float*)dy, (long)dy_ld, (float*)dres, (long)dres_ld, dres_acc, (long)pixels, C);
+    return msc_check_launch("msc_bn_bwd_apply");
+}
+
+extern "C" int msc_relu_bwd(const void* dy, int64_t dy_ld, const void* y, int64_t y_ld, void* dx, int64_t dx_ld,
+                            int accumulate, int dtype, int64_t pixels, int C, void* stream) {
+    DT_CHECK("msc_relu_bwd", dtype);
+    VEC_CHECK("msc_relu_bwd", dtype, C);
+    if (!dy || !y || !dx) return msc_fail(MSC_ERR_ARG, "msc_relu_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const long total = pixels * (C / (dtype == MSC_BF16 ? 8 : 4));
+    if (dtype == MSC_BF16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)dy, (long)dy_ld, (const bf16_t*)y, (long)y_ld, (bf16_t*)dx, (long)dx_ld, accumulate, (long)pixels, C);
+    else hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const float*)dy, (long)dy_ld, (const float*)y, (long)y_ld, (float*)dx, (long)dx_ld, accumulate, (long)pixels, C);
+    return msc_check_launch("msc_relu_bwd");
+}
+
+extern "C" int msc_bias_grad(const void* dy, int64_t dy_ld, float* db, int dtype, int64_t pixels, int C, void* stream) {
+    DT_CHECK("msc_bias_grad", dtype);
+    VEC_CHECK("msc_bias_grad", dtype, C);
+    if (!dy || !db) return msc_fail(MSC_ERR_ARG, "msc_bias_grad: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int ce = dtype == MSC_BF16 ? 8 : 4;
+    const size_t shm = (size_t)EW_THREADS * ce * sizeof(float);
+    const int blocks = ceil_div(pixels, BNB_PIX);
+    if (dtype == MSC_BF16) hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(blocks), dim3(EW_THREADS), shm, st, (const bf16_t*)dy, (long)dy_ld, db, (long)pixels, C);
+    else hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(blocks), dim3(EW_THREADS), shm, st, (const float*)dy, (long)dy_ld, db, (long)pixels, C);
+    return msc_check_launch("msc_bias_grad");
+}
+
+extern "C" int msc_final_fwd(const void* in, int64_t in_ld, const float* w, const float* b, float* logits, float* probs,
+                             int dtype, int N, int H, int W, int C, void* stream) {
+    DT_CHECK("msc_final_fwd", dtype);
+    VEC_CHECK("msc_final_fwd", dtype, C);
+    if (!in || !w || (!logits && !probs)) return msc_fail(MSC_ERR_ARG, "msc_final_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const long hw = (long)H * W;
+    const size_t shm = 2 * C * sizeof(float);
+    if (dtype == MSC_BF16) hipLaunchKernelGGL(final_fwd_kernel<bf16_t>, dim3(ew_grid((long)N * hw)), dim3(EW_THREADS), shm, st, (const bf16_t*)in, (long)in_ld, w, b, logits, probs, N, hw, C);
+    else hipLaunchKernelGGL(final_fwd_kernel<float>, dim3(ew_grid((long)N * hw)), dim3(EW_THREADS), shm, st, (const float*)in, (long)in_ld, w, b, logits, probs, N, hw, C);
+    return msc_check_launch("msc_final_fwd");
+}
+
+extern "C" int msc_final_bwd(const float* dlogits, const void* in, int64_t in_ld, const float* w, void* din, int64_t din_ld,
+                             float* dw, float* db, int dtype, int N, int H, int W, int C, void* stream) {
+    DT_CHECK("msc_final_bwd", dtype);
+    VEC_CHECK("msc_final_bwd", dtype, C);
+    if (!dlogits || !in || !w || !din || !dw) return msc_fail(MSC_ERR_ARG, "msc_final_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const long hw = (long)H * W;
+    const size_t shm = (4 * C + 2) * sizeof(float);
+    long blocks = ((long)N * hw + EW_THREADS - 1) / EW_THREADS;
+    if (blocks > 1024) blocks = 1024;
+    if (dtype == MSC_BF16) hipLaunchKernelGGL(final_bwd_kernel<bf16_t>, dim3((int)blocks), dim3(EW_THREADS), shm, st, dlogits, (const bf16_t*)in, (long)in_ld, w, (bf16_t*)din, (long)din_ld, dw, db, N, hw, C);
+    else hipLaunchKernelGGL(final_bwd_kernel<float>, dim3((int)blocks), dim3(EW_THREADS), shm, st, dlogits, (const float*)in, (long)in_ld, w, (float*)din, (long)din_ld, dw, db, N, hw, C);
+    return msc_check_launch("msc_final_bwd");
+}
+
+extern "C" int msc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || n < 0 || step < 1) return msc_fail(MSC_ERR_ARG, "msc_adam_step: bad argument");
+    if (n == 0) return MSC_OK;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return msc_fail(MSC_ERR_ARG, "msc_adam_step: buffers must be 16-byte aligned");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2, eps,
+                       weight_decay, bc1, sqrtf(bc2), grad_scale);
+    return msc_check_launch("msc_adam_step");
+}

@@ -1,0 +1,486 @@
+// Mask post-processing on gfx950: the per-image Python / scipy / scikit-image / pydensecrf loops of
+// src/postprocessing.py:48-258 and src/utils.py:328-339 as batched HIP kernels.  All of it is
+// HBM/latency-bound integer & byte work over [B,H,W] planes: one launch covers the whole batch
+// (grid.y = image), lanes run along x so every access is coalesced.
+//
+// Integer results (threshold layers, labels, erosion/dilation, dropped objects) are bit-exact
+// against oracle/post_ref.py; float results (resize, score, CRF) within the tolerances in tests/.
+#include "common.h"
+#include "msc_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {  // scipy.ndimage 'reflect' (d c b a | a b c d | d c b a)
+    if (i < 0) i = -i - 1;
+    if (i >= n) i = 2 * n - i - 1;
+    return min(max(i, 0), n - 1);
+}
+
+// ------------------------------------------------------------------ resize / crop / threshold / argmax
+__global__ void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int H, int W) {
+    const long total = (long)planes * H * W;
+    const double fy = (double)h / H, fx = (double)w / W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % W), oy = (int)((i / W) % H);
+        const long pl = i / ((long)W * H);
+        const double ys = (oy + 0.5) * fy - 0.5, xs = (ox + 0.5) * fx - 0.5;
+        float r = 0.f;
+        // scipy 'constant' mode: no interpolation beyond the edges -> cval
+        if (ys >= 0.0 && ys <= (double)(h - 1) && xs >= 0.0 && xs <= (double)(w - 1)) {
+            int y0 = (int)floor(ys), x0 = (int)floor(xs);
+            y0 = min(max(y0, 0), h - 1); x0 = min(max(x0, 0), w - 1);
+            const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+            const double ay = ys - y0, ax = xs - x0;
+            const float* p = in + pl * (long)h * w;
+            const double v = (1 - ay) * (1 - ax) * p[(long)y0 * w + x0] + (1 - ay) * ax * p[(long)y0 * w + x1] +
+                             ay * (1 - ax) * p[(long)y1 * w + x0] + ay * ax * p[(long)y1 * w + x1];
+            r = (float)v;
+        }
+        out[i] = r;
+    }
+}
+
+__global__ void crop_center_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int hc, int wc, int hs, int ws) {
+    const long total = (long)planes * hc * wc;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % wc), y = (int)((i / wc) % hc);
+        const long pl = i / ((long)wc * hc);
+        out[i] = in[(pl * h + y + hs) * w + x + ws];
+    }
+}
+
+__global__ void threshold_layers_kernel(const float* __restrict__ probs, uint8_t* __restrict__ layers, int B, int C, long HW,
+                                        const int32_t* __restrict__ layer_class, const float* __restrict__ layer_thr, int L) {
+    const long total = (long)B * L * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long hw = i % HW;
+        const int l = (int)((i / HW) % L);
+        const long b = i / (HW * L);
+        layers[i] = probs[(b * C + layer_class[l]) * HW + hw] > layer_thr[l] ? 1 : 0;
+    }
+}
+
+__global__ void argmax_channels_kernel(const float* __restrict__ probs, int32_t* __restrict__ out, int B, int C, long HW) {
+    const long total = (long)B * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long hw = i % HW, b = i / HW;
+        int best = 0;
+        float bv = probs[(b * C) * HW + hw];
+        for (int c = 1; c < C; ++c) {
+            const float v = probs[(b * C + c) * HW + hw];
+            if (v > bv) { bv = v; best = c; }
+        }
+        out[i] = best;
+    }
+}
+
+// ------------------------------------------------------------------ k x k rectangle min / max filters
+template <typename T, bool IS_MAX>
+__global__ void rect_filter_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int lo, int hi) {
+    const long total = (long)B * H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const long b = i / ((long)W * H);
+        const T* p = in + b * (long)H * W;
+        T acc = p[(long)reflect_idx(y + lo, H) * W + reflect_idx(x + lo, W)];
+        for (int dy = lo; dy <= hi; ++dy) {
+            const int yy = reflect_idx(y + dy, H);
+            for (int dx = lo; dx <= hi; ++dx) {
+                const T v = p[(long)yy * W + reflect_idx(x + dx, W)];
+                acc = IS_MAX ? (v > acc ? v : acc) : (v < acc ? v : acc);
+            }
+        }
+        out[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------ connected components, 4-connectivity
+// Union-find over pixel indices with atomicMin links: the root of a component is its smallest pixel
+// index = its first pixel in raster order, so numbering roots by an exclusive prefix count in raster
+// order reproduces scipy.ndimage.label's numbering exactly.
+__device__ __forceinline__ int uf_load(const int* L, int a) {
+    return __hip_atomic_load(L + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int uf_find(const int* L, int a) {
+    int p = uf_load(L, a);
+    while (p != a) { a = p; p = uf_load(L, a); }
+    return a;
+}
+__device__ __forceinline__ void uf_union(int* L, int a, int b) {
+    bool done = false;
+    while (!done) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a < b) {
+            const int old = atomicMin(L + b, a);
+            done = (old == b);
+            b = old;
+        } else if (b < a) {
+            const int old = atomicMin(L + a, b);
+            done = (old == a);
+            a = old;
+        } else {
+            done = true;
+        }
+    }
+}
+
+__global__ void ccl_init_kernel(const uint8_t* __restrict__ mask, int32_t* __restrict__ L, long HW) {
+    const long b = blockIdx.y;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x)
+        L[b * HW + p] = mask[b * HW + p] ? (int)p : -1;
+}
+__global__ void ccl_merge_kernel(const uint8_t* __restrict__ mask, int32_t* __restrict__ L, int H, int W) {
+    const long HW = (long)H * W;
+    const long b = blockIdx.y;
+    const uint8_t* m = mask + b * HW;
+    int* l = L + b * HW;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+        if (!m[p]) continue;
+        const int x = (int)(p % W);
+        if (x > 0 && m[p - 1]) uf_union(l, (int)p, (int)p - 1);
+        if (p >= W && m[p - W]) uf_union(l, (int)p, (int)(p - W));
+    }
+}
+__global__ void ccl_compress_kernel(int32_t* __restrict__ L, long HW) {
+    const long b = blockIdx.y;
+    int* l = L + b * HW;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+        const int v = uf_load(l, (int)p);
+        if (v >= 0 && v != (int)p) {
+            const int r = uf_find(l, v);
+            __hip_atomic_store(l + p, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// one block per image: rank[p] = number of roots before p (raster order), for roots only
+__global__ __launch_bounds__(1024) void ccl_rank_kernel(const int32_t* __restrict__ L, int32_t* __restrict__ rank,
+                                                        int32_t* __restrict__ counts, long HW) {
+    __shared__ int part[1024];
+    const long b = blockIdx.x;
+    const int* l = L + b * HW;
+    int* r = rank + b * HW;
+    const long seg = (HW + 1023) / 1024;
+    const long beg = threadIdx.x * seg, end = min(HW, beg + seg);
+    int c = 0;
+    for (long p = beg; p < end; ++p) c += (l[p] == (int)p);
+    part[threadIdx.x] = c;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 1024 per-thread counts
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int base = part[threadIdx.x] - c;
+    for (long p = beg; p < end; ++p)
+        if (l[p] == (int)p) r[p] = base++;
+    if (threadIdx.x == 1023 && counts) counts[b] = part[1023];
+}
+__global__ void ccl_relabel_kernel(int32_t* __restrict__ L, const int32_t* __restrict__ rank, long HW) {
+    const long b = blockIdx.y;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+        const int root = L[b * HW + p];
+        L[b * HW + p] = root >= 0 ? rank[b * HW + root] + 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------ add_dropped_objects
+__global__ void dropped_mark_kernel(const uint8_t* __restrict__ processed, const int32_t* __restrict__ lab, int32_t* __restrict__ alive, long HW) {
+    const long b = blockIdx.y;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+        const int l = lab[b * HW + p];
+        if (l > 0 && processed[b * HW + p]) alive[b * HW + l - 1] = 1;
+    }
+}
+__global__ void dropped_apply_kernel(const uint8_t* __restrict__ processed, const int32_t* __restrict__ lab,
+                                     const int32_t* __restrict__ alive, uint8_t* __restrict__ out, long HW) {
+    const long b = blockIdx.y;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+        const int l = lab[b * HW + p];
+        const int add = (l > 0 && !alive[b * HW + l - 1]) ? 1 : 0;
+        out[b * HW + p] = (uint8_t)(processed[b * HW + p] + add);
+    }
+}
+
+// ------------------------------------------------------------------ build_score
+__global__ void score_accum_kernel(const int32_t* __restrict__ labels, const float* __restrict__ probs, double* __restrict__ sums,
+                                   int32_t* __restrict__ areas, long HW, int max_labels) {
+    const long b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long iters = (HW + stride - 1) / stride;
+    for (long it = 0; it < iters; ++it) {
+        const long p = it * stride + blockIdx.x * (long)blockDim.x + threadIdx.x;
+        int lab = 0;
+        float pr = 0.f;
+        if (p < HW) { lab = labels[b * HW + p]; pr = probs[b * HW + p]; }
+        bool active = lab > 0 && lab <= max_labels;
+        // wave-level aggregation: one atomic per distinct label per wave (a row segment has 1-3)
+        unsigned long long todo = __ballot(active);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int l0 = __shfl(lab, leader, 64);
+            const bool mine = active && lab == l0;
+            const double s = wave_sum_d(mine ? (double)pr : 0.0);
+            const unsigned long long mm = __ballot(mine);
+            if (lane == leader) {
+                atomicAdd(sums + b * max_labels + l0 - 1, s);
+                atomicAdd(areas + b * max_labels + l0 - 1, (int)__popcll(mm));
+            }
+            active = active && !mine;
+            todo &= ~mm;
+        }
+    }
+}
+__global__ void score_final_kernel(const double* __restrict__ sums, const int32_t* __restrict__ areas, double* __restrict__ score, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int a = areas[i];
+        score[i] = a > 0 ? sums[i] / (double)a * sqrt((double)a) : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------ dense CRF, exact windowed mean field
+struct CrfP { int H, W, rg, rb; float inv2g, inv2b, inv2rgb, compat_g, compat_b; };
+
+__device__ __forceinline__ float rgb_d2(const uint8_t* a, const uint8_t* b) {
+    const float d0 = (float)a[0] - (float)b[0], d1 = (float)a[1] - (float)b[1], d2 = (float)a[2] - (float)b[2];
+    return d0 * d0 + d1 * d1 + d2 * d2;
+}
+
+__global__ void crf_norm_kernel(const uint8_t* __restrict__ rgb, float* __restrict__ ng, float* __restrict__ nb, CrfP c) {
+    const long HW = (long)c.H * c.W, b = blockIdx.y;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(p % c.W), y = (int)(p / c.W);
+        const uint8_t* me = rgb + (b * HW + p) * 3;
+        float sg = 0.f, sb = 0.f;
+        for (int dy = -c.rg; dy <= c.rg; ++dy) {
+            const int yy = y + dy;
+            if ((unsigned)yy >= (unsigned)c.H) continue;
+            for (int dx = -c.rg; dx <= c.rg; ++dx)
+                if ((unsigned)(x + dx) < (unsigned)c.W) sg += expf(-(float)(dy * dy + dx * dx) * c.inv2g);
+        }
+        for (int dy = -c.rb; dy <= c.rb; ++dy) {
+            const int yy = y + dy;
+            if ((unsigned)yy >= (unsigned)c.H) continue;
+            for (int dx = -c.rb; dx <= c.rb; ++dx) {
+                const int xx = x + dx;
+                if ((unsigned)xx >= (unsigned)c.W) continue;
+                sb += expf(-(float)(dy * dy + dx * dx) * c.inv2b - rgb_d2(me, rgb + (b * HW + (long)yy * c.W + xx) * 3) * c.inv2rgb);
+            }
+        }
+        ng[b * HW + p] = 1.f / sqrtf(sg + 1e-20f);
+        nb[b * HW + p] = 1.f / sqrtf(sb + 1e-20f);
+    }
+}
+
+__device__ __forceinline__ void softmax2(float a0, float a1, float* q0, float* q1) {
+    const float m = fmaxf(a0, a1);
+    const float e0 = expf(a0 - m), e1 = expf(a1 - m);
+    const float s = e0 + e1;
+    *q0 = e0 / s; *q1 = e1 / s;
+}
+
+__global__ void crf_init_kernel(const float* __restrict__ probs, float* __restrict__ q, long HW) {
+    const long b = blockIdx.y;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+        const float u0 = -logf(fminf(fmaxf(probs[(b * 2) * HW + p], 1e-5f), 1.f));
+        const float u1 = -logf(fminf(fmaxf(probs[(b * 2 + 1) * HW + p], 1e-5f), 1.f));
+        softmax2(-u0, -u1, &q[(b * 2) * HW + p], &q[(b * 2 + 1) * HW + p]);
+    }
+}
+
+__global__ void crf_iter_kernel(const float* __restrict__ probs, const uint8_t* __restrict__ rgb, const float* __restrict__ ng,
+                                const float* __restrict__ nb, const float* __restrict__ qin, float* __restrict__ qout, CrfP c) {
+    const long HW = (long)c.H * c.W, b = blockIdx.y;
+    const float* q0 = qin + (b * 2) * HW;
+    const float* q1 = q0 + HW;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(p % c.W), y = (int)(p / c.W);
+        const uint8_t* me = rgb + (b * HW + p) * 3;
+        float g0 = 0.f, g1 = 0.f, b0 = 0.f, b1 = 0.f;
+        for (int dy = -c.rg; dy <= c.rg; ++dy) {
+            const int yy = y + dy;
+            if ((unsigned)yy >= (unsigned)c.H) continue;
+            for (int dx = -c.rg; dx <= c.rg; ++dx) {
+                const int xx = x + dx;
+                if ((unsigned)xx >= (unsigned)c.W) continue;
+                const long j = (long)yy * c.W + xx;
+                const float k = expf(-(float)(dy * dy + dx * dx) * c.inv2g) * ng[b * HW + j];
+                g0 += k * q0[j]; g1 += k * q1[j];
+            }
+        }
+        for (int dy = -c.rb; dy <= c.rb; ++dy) {
+            const int yy = y + dy;
+            if ((unsigned)yy >= (unsigned)c.H) continue;
+            for (int dx = -c.rb; dx <= c.rb; ++dx) {
+                const int xx = x + dx;
+                if ((unsigned)xx >= (unsigned)c.W) continue;
+                const long j = (long)yy * c.W + xx;
+                const float k = expf(-(float)(dy * dy + dx * dx) * c.inv2b - rgb_d2(me, rgb + (b * HW + j) * 3) * c.inv2rgb) * nb[b * HW + j];
+                b0 += k * q0[j]; b1 += k * q1[j];
+            }
+        }
+        const float u0 = -logf(fminf(fmaxf(probs[(b * 2) * HW + p], 1e-5f), 1.f));
+        const float u1 = -logf(fminf(fmaxf(probs[(b * 2 + 1) * HW + p], 1e-5f), 1.f));
+        const float n_g = ng[b * HW + p], n_b = nb[b * HW + p];
+        const float t0 = -u0 + c.compat_g * g0 * n_g + c.compat_b * b0 * n_b;
+        const float t1 = -u1 + c.compat_g * g1 * n_g + c.compat_b * b1 * n_b;
+        softmax2(t0, t1, &qout[(b * 2) * HW + p], &qout[(b * 2 + 1) * HW + p]);
+    }
+}
+
+inline dim3 plane_grid(long HW, int B) {
+    long bx = (HW + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    return dim3((int)bx, B);
+}
+inline int flat_grid(long n) {
+    long b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+#define POST_DIMS(name) \
+    if (B <= 0 || H <= 0 || W <= 0 || (long)H * W > 0x3fffffffL) return msc_fail(MSC_ERR_ARG, name ": bad dims B=%d H=%d W=%d", B, H, W)
+
+extern "C" int msc_resize_bilinear(const float* in, float* out, int B, int C, int h, int w, int H, int W, void* stream) {
+    if (!in || !out || B <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return msc_fail(MSC_ERR_ARG, "msc_resize_bilinear: bad argument");
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(flat_grid((long)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, in, out, B * C, h, w, H, W);
+    return msc_check_launch("msc_resize_bilinear");
+}
+
+extern "C" int msc_crop_center(const float* in, float* out, int B, int C, int h, int w, int hc, int wc, void* stream) {
+    if (!in || !out || B <= 0 || C <= 0 || hc <= 0 || wc <= 0 || hc > h || wc > w) return msc_fail(MSC_ERR_ARG, "msc_crop_center: bad argument");
+    const int hs = (int)((h - hc) / 2.), ws = (int)((w - wc) / 2.);
+    // the reference slices [hs:-hs]: it is only well defined when the margins are symmetric and > 0
+    if (hs <= 0 || ws <= 0 || h - 2 * hs != hc || w - 2 * ws != wc)
+        return msc_fail(MSC_ERR_UNSUPPORTED, "msc_crop_center: reference slicing [s:-s] needs symmetric non-zero margins (h=%d hc=%d w=%d wc=%d)", h, hc, w, wc);
+    hipLaunchKernelGGL(crop_center_kernel, dim3(flat_grid((long)B * C * hc * wc)), dim3(256), 0, (hipStream_t)stream, in, out, B * C, h, w, hc, wc, hs, ws);
+    return msc_check_launch("msc_crop_center");
+}
+
+extern "C" int msc_threshold_layers(const float* probs, uint8_t* layers, int B, int C, int H, int W,
+                                    const int32_t* layer_class, const float* layer_thr, int L, void* stream) {
+    POST_DIMS("msc_threshold_layers");
+    if (!probs || !layers || !layer_class || !layer_thr || L <= 0 || C <= 0) return msc_fail(MSC_ERR_ARG, "msc_threshold_layers: bad argument");
+    hipLaunchKernelGGL(threshold_layers_kernel, dim3(flat_grid((long)B * L * H * W)), dim3(256), 0, (hipStream_t)stream, probs, layers, B, C, (long)H * W, layer_class, layer_thr, L);
+    return msc_check_launch("msc_threshold_layers");
+}
+
+extern "C" int msc_argmax_channels(const float* probs, int32_t* out, int B, int C, int H, int W, void* stream) {
+    POST_DIMS("msc_argmax_channels");
+    if (!probs || !out || C <= 0) return msc_fail(MSC_ERR_ARG, "msc_argmax_channels: bad argument");
+    hipLaunchKernelGGL(argmax_channels_kernel, dim3(flat_grid((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, probs, out, B, C, (long)H * W);
+    return msc_check_launch("msc_argmax_channels");
+}
+
+static int window(int k, int H, int W, const char* name, int* lo, int* hi) {
+    if (k <= 0) return msc_fail(MSC_ERR_ARG, "%s: selem size must be > 0 (the reference returns the input unchanged otherwise)", name);
+    *lo = -((k - 1) / 2);
+    *hi = *lo + k - 1;
+    if (*hi >= H || *hi >= W) return msc_fail(MSC_ERR_UNSUPPORTED, "%s: selem %d larger than the image", name, k);
+    return MSC_OK;
+}
+
+extern "C" int msc_erode_u8(const uint8_t* in, uint8_t* out, int B, int H, int W, int k, void* stream) {
+    POST_DIMS("msc_erode_u8");
+    if (!in || !out || in == out) return msc_fail(MSC_ERR_ARG, "msc_erode_u8: bad pointers");
+    int lo, hi, rc = window(k, H, W, "msc_erode_u8", &lo, &hi);
+    if (rc) return rc;
+    hipLaunchKernelGGL((rect_filter_kernel<uint8_t, false>), dim3(flat_grid((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, lo, hi);
+    return msc_check_launch("msc_erode_u8");
+}
+
+extern "C" int msc_dilate_i32(const int32_t* in, int32_t* out, int B, int H, int W, int k, void* stream) {
+    POST_DIMS("msc_dilate_i32");
+    if (!in || !out || in == out) return msc_fail(MSC_ERR_ARG, "msc_dilate_i32: bad pointers");
+    int lo, hi, rc = window(k, H, W, "msc_dilate_i32", &lo, &hi);
+    if (rc) return rc;
+    hipLaunchKernelGGL((rect_filter_kernel<int32_t, true>), dim3(flat_grid((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, lo, hi);
+    return msc_check_launch("msc_dilate_i32");
+}
+
+extern "C" int64_t msc_label_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (int64_t)B * H * W * 4;
+}
+
+extern "C" int msc_label4(const uint8_t* mask, int32_t* labels, int32_t* counts, void* workspace, int B, int H, int W, void* stream) {
+    POST_DIMS("msc_label4");
+    if (!mask || !labels || !workspace) return msc_fail(MSC_ERR_ARG, "msc_label4: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const long HW = (long)H * W;
+    const dim3 g = plane_grid(HW, B);
+    int32_t* rank = (int32_t*)workspace;
+    hipLaunchKernelGGL(ccl_init_kernel, g, dim3(256), 0, st, mask, labels, HW);
+    hipLaunchKernelGGL(ccl_merge_kernel, g, dim3(256), 0, st, mask, labels, H, W);
+    hipLaunchKernelGGL(ccl_compress_kernel, g, dim3(256), 0, st, labels, HW);
+    hipLaunchKernelGGL(ccl_rank_kernel, dim3(B), dim3(1024), 0, st, labels, rank, counts, HW);
+    hipLaunchKernelGGL(ccl_relabel_kernel, g, dim3(256), 0, st, labels, rank, HW);
+    return msc_check_launch("msc_label4");
+}
+
+extern "C" int msc_add_dropped(const uint8_t* processed, const int32_t* labels_orig, uint8_t* out, void* workspace,
+                               int B, int H, int W, void* stream) {
+    POST_DIMS("msc_add_dropped");
+    if (!processed || !labels_orig || !out || !workspace) return msc_fail(MSC_ERR_ARG, "msc_add_dropped: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const long HW = (long)H * W;
+    if (hipMemsetAsync(workspace, 0, (size_t)B * HW * 4, st) != hipSuccess) return msc_fail(MSC_ERR_HIP, "msc_add_dropped: memset failed");
+    const dim3 g = plane_grid(HW, B);
+    hipLaunchKernelGGL(dropped_mark_kernel, g, dim3(256), 0, st, processed, labels_orig, (int32_t*)workspace, HW);
+    hipLaunchKernelGGL(dropped_apply_kernel, g, dim3(256), 0, st, processed, labels_orig, (const int32_t*)workspace, out, HW);
+    return msc_check_launch("msc_add_dropped");
+}
+
+extern "C" int msc_build_score(const int32_t* labels, const float* probs, double* sums, int32_t* areas, double* score,
+                               int B, int H, int W, int max_labels, void* stream) {
+    POST_DIMS("msc_build_score");
+    if (!labels || !probs || !sums || !areas || !score || max_labels <= 0) return msc_fail(MSC_ERR_ARG, "msc_build_score: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const long HW = (long)H * W;
+    const long n = (long)B * max_labels;
+    if (hipMemsetAsync(sums, 0, n * sizeof(double), st) != hipSuccess || hipMemsetAsync(areas, 0, n * sizeof(int32_t), st) != hipSuccess)
+        return msc_fail(MSC_ERR_HIP, "msc_build_score: memset failed");
+    hipLaunchKernelGGL(score_accum_kernel, plane_grid(HW, B), dim3(256), 0, st, labels, probs, sums, areas, HW, max_labels);
+    hipLaunchKernelGGL(score_final_kernel, dim3(flat_grid(n)), dim3(256), 0, st, sums, areas, score, n);
+    return msc_check_launch("msc_build_score");
+}
+
+extern "C" int64_t msc_crf_workspace_bytes(int B, int H, int W, int radius) {
+    (void)radius;
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (int64_t)B * H * W * 4 * (2 + 2 + 2);  // two norms + two ping-pong Q buffers of 2 channels
+}
+
+extern "C" int msc_dense_crf(const float* probs, const uint8_t* rgb, float* out, void* workspace, int B, int H, int W,
+                             float sxy_g, float compat_g, float sxy_b, float srgb, float compat_b, int iterations, void* stream) {
+    POST_DIMS("msc_dense_crf");
+    if (!probs || !rgb || !out || !workspace || sxy_g <= 0 || sxy_b <= 0 || srgb <= 0 || iterations < 0)
+        return msc_fail(MSC_ERR_ARG, "msc_dense_crf: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const long HW = (long)H * W;
+    CrfP c;
+    c.H = H; c.W = W;
+    c.rg = (int)ceilf(5.f * sxy_g); c.rb = (int)ceilf(5.f * sxy_b);
+    c.inv2g = 0.5f / (sxy_g * sxy_g); c.inv2b = 0.5f / (sxy_b * sxy_b); c.inv2rgb = 0.5f / (srgb * srgb);
+    c.compat_g = compat_g; c.compat_b = compat_b;
+    float* ng = (float*)workspace;
+    float* nb = ng + (long)B * HW;
+    float* qa = nb + (long)B * HW;
+    float* qb = qa + 2L * B * HW;
+    const dim3 g = plane_grid(HW, B);
+    hipLaunchKernelGGL(crf_norm_kernel, g, dim3(256), 0, st, rgb, ng, nb, c);
+    hipLaunchKernelGGL(crf_init_kernel, g, dim3(256), 0, st, probs, iterations == 0 ? out : qa, HW);
+    float* cur = qa;
+    for (int it = 0; it < iterations; ++it) {
+        float* dst = (it == iterations - 1) ? out : (cur == qa ? qb : qa);
+        hipLaunchKernelGGL(crf_iter_kernel, g, dim3(256), 0, st, probs, rgb, ng, nb, cur, dst, c);
+        cur = dst;
+    }
+    return msc_check_launch("msc_dense_crf");
+}

@@ -1,0 +1,763 @@
+"""UNetResNet on MI355X: drop-in for the reference's `src/unet_models.py:315-403`.
+
+Same constructor, same parameter / buffer names (so reference checkpoints load, including the
+`module.` prefix DataParallel adds, src/steps/pytorch/models.py:148-160), same
+`forward(x: f32[N,3,H,W]) -> logits f32[N,2,H,W]` -- but every FLOP runs in the hand-written
+gfx950 kernels behind include/msc.h.  torch is used for device memory, the module / parameter
+containers and (optionally) to hang the whole network into autograd as ONE node.
+
+Execution model: for a given (N, H, W, dtype, train/eval) the network is compiled once into a
+static launch list over pre-allocated NHWC buffers (288 GB of HBM: nothing is recomputed or
+re-allocated, the skip-concats of :395-399 are channel slices of one buffer), which is also what
+makes the whole train step capturable into one hipGraph.
+
+  eval : conv -> (BN folded into the conv epilogue) -> ReLU, 1 launch per conv
+  train: conv (raw output + per-tile BN partial sums in the epilogue) -> bn_finalize -> bn_apply
+         backward: bn_bwd_reduce -> bn_bwd_finalize -> bn_bwd_apply -> wgrad -> dgrad
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import ConvDesc, WgradDesc, F32, BF16
+
+_ENC = {34: ('basic', [3, 4, 6, 3], 512), 101: ('bottle', [3, 4, 23, 3], 2048), 152: ('bottle', [3, 8, 36, 3], 2048)}
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+# ----------------------------------------------------------------------------- parameter containers
+# Plain torch.nn modules used ONLY as named parameter/buffer holders (never called): the names are the
+# torchvision ResNet ones the reference's state_dict carries (src/unet_models.py:345-371).
+class _BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, cin, planes, stride, down):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = down
+        self.stride = stride
+
+
+class _Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cin, planes, stride, down):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = down
+        self.stride = stride
+
+
+class _ResNetParams(nn.Module):
+    def __init__(self, kind, layers):
+        super().__init__()
+        block = _BasicBlock if kind == 'basic' else _Bottleneck
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)      # present in the reference's module tree, unused (:356)
+        cin = 64
+        for li, (planes, n, stride) in enumerate(zip((64, 128, 256, 512), layers, (1, 2, 2, 2)), start=1):
+            blocks = []
+            for b in range(n):
+                s = stride if b == 0 else 1
+                down = None
+                if b == 0 and (s != 1 or cin != planes * block.expansion):
+                    down = nn.Sequential(nn.Conv2d(cin, planes * block.expansion, 1, s, bias=False),
+                                         nn.BatchNorm2d(planes * block.expansion))
+                blocks.append(block(cin, planes, s, down))
+                cin = planes * block.expansion
+            setattr(self, 'layer%d' % li, nn.Sequential(*blocks))
+        self.avgpool = nn.AvgPool2d(7, stride=1)
+        self.fc = nn.Linear(cin, 1000)            # dead weights kept so reference checkpoints load strictly
+
+
+class _ConvReluParams(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, 3, padding=1)
+        self.activation = nn.ReLU(inplace=True)
+
+
+class _DecoderParams(nn.Module):
+    def __init__(self, cin, cmid, cout):
+        super().__init__()
+        self.in_channels = cin
+        self.block = nn.Sequential(_ConvReluParams(cin, cmid),
+                                   nn.ConvTranspose2d(cmid, cout, kernel_size=4, stride=2, padding=1),
+                                   nn.ReLU(inplace=True))
+
+
+# ----------------------------------------------------------------------------- NHWC activation views
+class Act:
+    """Channel slice [c0, c0+C) of an NHWC buffer [N,H,W,Ct]."""
+    __slots__ = ('buf', 'c0', 'C')
+
+    def __init__(self, buf, c0=0, C=None):
+        self.buf, self.c0 = buf, c0
+        self.C = buf.shape[3] - c0 if C is None else C
+
+    @property
+    def N(self): return self.buf.shape[0]
+
+    @property
+    def H(self): return self.buf.shape[1]
+
+    @property
+    def W(self): return self.buf.shape[2]
+
+    @property
+    def ld(self): return self.buf.shape[3]
+
+    @property
+    def ptr(self): return self.buf.data_ptr() + self.c0 * self.buf.element_size()
+
+    @property
+    def pixels(self): return self.buf.shape[0] * self.buf.shape[1] * self.buf.shape[2]
+
+    def view(self):
+        return self.buf[..., self.c0:self.c0 + self.C]
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream_of(device):
+    return torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0
+
+
+class _Program:
+    """Static launch list for one (N,H,W,dtype,training) configuration."""
+
+    def __init__(self):
+        self.fwd, self.bwd, self.keep = [], [], []
+        self.x_in = None        # f32 NCHW input staging buffer
+        self.logits = None      # f32 NCHW
+        self.probs = None       # f32 NCHW (eval)
+        self.dlogits = None     # f32 NCHW (train)
+        self.bytes = 0
+
+    @staticmethod
+    def run(launches, stream):
+        for fn, args in launches:
+            rc = fn(*args, stream)
+            if rc != 0:
+                _lib.check(rc, fn.__name__)
+
+
+# ----------------------------------------------------------------------------- the network
+class UNetResNet(nn.Module):
+    """PyTorch-API U-Net with ResNet(34, 101 or 152) encoder executing on hand-written HIP kernels.
+
+    Args mirror src/unet_models.py:338-339.  `pretrained` cannot download ImageNet weights offline
+    and is ignored (weights come from load_state_dict); `is_deconv` must be True and `dropout_2d`
+    0.0, the only values any shipped configuration uses (src/models.py:32-46).
+    Extra keyword: compute_dtype 'bf16' (throughput mode, default) or 'fp32' (exact-f32 parity mode).
+    """
+
+    def __init__(self, encoder_depth, num_classes, num_filters=32, dropout_2d=0.2, pretrained=False,
+                 is_deconv=False, compute_dtype='bf16'):
+        super().__init__()
+        if encoder_depth not in _ENC:
+            raise NotImplementedError('only 34, 101, 152 version of Resnet are implemented')
+        if num_classes != 2:
+            raise NotImplementedError('HIP path implements the 2-class head of the mapping challenge (num_classes=2)')
+        if not is_deconv:
+            raise NotImplementedError('HIP path implements the is_deconv=True decoder (every shipped config, src/models.py:32-46)')
+        if dropout_2d != 0.0:
+            raise NotImplementedError('HIP path implements dropout_2d=0.0 (every shipped config, src/models.py:34,39,44)')
+        if num_filters % 32:
+            raise NotImplementedError('num_filters must be a multiple of 32')
+        self.num_classes, self.dropout_2d, self.encoder_depth = num_classes, dropout_2d, encoder_depth
+        kind, layers, bottom = _ENC[encoder_depth]
+        self._kind, self._bottom, self._nf = kind, bottom, num_filters
+        nf = num_filters
+        self.encoder = _ResNetParams(kind, layers)
+        self.pool = nn.MaxPool2d(2, 2)
+        self.relu = nn.ReLU(inplace=True)
+        # same aliasing as the reference (:360-371): state_dict carries both key sets
+        self.conv1 = nn.Sequential(self.encoder.conv1, self.encoder.bn1, self.encoder.relu, self.pool)
+        self.conv2, self.conv3 = self.encoder.layer1, self.encoder.layer2
+        self.conv4, self.conv5 = self.encoder.layer3, self.encoder.layer4
+        self.center = _DecoderParams(bottom, nf * 16, nf * 8)
+        self.dec5 = _DecoderParams(bottom + nf * 8, nf * 16, nf * 8)
+        self.dec4 = _DecoderParams(bottom // 2 + nf * 8, nf * 16, nf * 8)
+        self.dec3 = _DecoderParams(bottom // 4 + nf * 8, nf * 8, nf * 2)
+        self.dec2 = _DecoderParams(bottom // 8 + nf * 2, nf * 4, nf * 4)
+        self.dec1 = _DecoderParams(nf * 4, nf * 4, nf)
+        self.dec0 = _ConvReluParams(nf, nf)
+        self.final = nn.Conv2d(nf, num_classes, kernel_size=1)
+        self.set_compute_dtype(compute_dtype)
+        self._programs = {}
+        self._flat = None
+        self._version = 0          # bumped whenever master weights change -> packed copies are stale
+        self._packed_version = -1
+        self._folded_version = -1
+
+    # ------------------------------------------------------------------ configuration
+    def set_compute_dtype(self, compute_dtype):
+        if compute_dtype not in ('bf16', 'fp32'):
+            raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
+        self.compute_dtype = compute_dtype
+        self._tdtype = torch.bfloat16 if compute_dtype == 'bf16' else torch.float32
+        self._dt = BF16 if compute_dtype == 'bf16' else F32
+        self._programs = {}
+        self._pack = None
+        return self
+
+    def weights_changed(self):
+        """Call after modifying parameters outside HipAdam / load_state_dict."""
+        self._version += 1
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        # accept DataParallel-prefixed checkpoints (reference Model.load wraps first, models.py:151-156)
+        if state_dict and all(k.startswith('module.') for k in state_dict):
+            state_dict = {k[len('module.'):]: v for k, v in state_dict.items()}
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._version += 1
+        return out
+
+    # ------------------------------------------------------------------ flat parameter storage
+    def _trainable(self):
+        return [(n, p) for n, p in self.named_parameters() if not n.startswith('encoder.fc.')]
+
+    def flatten_parameters(self, device=None):
+        """Move all trainable parameters into ONE flat fp32 buffer (and gradients into another);
+        conv / deconv weights are stored channels-last, i.e. physically [Cout][KH][KW][Cin]
+        ([Cin][KH][KW][Cout] for ConvTranspose2d) -- the k-contiguous layout the kernels read --
+        while keeping their torch-logical shapes, so state_dicts stay interchangeable."""
+        device = torch.device(device if device is not None else 'cuda')
+        params = self._trainable()
+        offs, total = [], 0
+        for _, p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(total, dtype=torch.float32, device=device)
+        grad = torch.zeros(total, dtype=torch.float32, device=device)
+        gptr = {}
+        for (name, p), off in zip(params, offs):
+            n = p.numel()
+            if p.dim() == 4 and not name.endswith('encoder.conv1.weight') and p.shape[2] * p.shape[3] * p.shape[1] > 1:
+                a, b, kh, kw = p.shape
+                view = flat[off:off + n].view(a, kh, kw, b).permute(0, 3, 1, 2)
+                gview = grad[off:off + n].view(a, kh, kw, b).permute(0, 3, 1, 2)
+            else:
+                view = flat[off:off + n].view(p.shape)
+                gview = grad[off:off + n].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = gview
+            gptr[id(p)] = gview.data_ptr()
+        for b in self.buffers():
+            b.data = b.data.to(device)
+        self.encoder.fc.to(device)
+        self._flat = (flat, grad, params[0][1].data_ptr())
+        self._gptr = gptr
+        self._programs = {}
+        self._pack = None
+        self._version += 1
+        return flat, grad
+
+    def _ensure_flat(self, device):
+        first = self._trainable()[0][1]
+        if self._flat is None or self._flat[0].device != device or first.data_ptr() != self._flat[2]:
+            self.flatten_parameters(device)
+        return self._flat[0], self._flat[1]
+
+    def _g(self, param):
+        """device address of `param`'s gradient inside the flat gradient buffer"""
+        return self._gptr[id(param)]
+
+    @property
+    def flat_params(self):
+        return None if self._flat is None else self._flat[0]
+
+    @property
+    def flat_grads(self):
+        return None if self._flat is None else self._flat[1]
+
+    # ------------------------------------------------------------------ weight packing
+    def _conv_list(self):
+        """[(name, module, kind)] for every conv on the path, in forward order."""
+        out = [('encoder.conv1', self.encoder.conv1, 'stem')]
+        for li in range(1, 5):
+            for bi, blk in enumerate(getattr(self.encoder, 'layer%d' % li)):
+                base = 'encoder.layer%d.%d' % (li, bi)
+                names = ['conv1', 'conv2'] + (['conv3'] if self._kind == 'bottle' else [])
+                for cn in names:
+                    out.append(('%s.%s' % (base, cn), getattr(blk, cn), 'conv'))
+                if blk.downsample is not None:
+                    out.append((base + '.downsample.0', blk.downsample[0], 'conv'))
+        for dn in ('center', 'dec5', 'dec4', 'dec3', 'dec2', 'dec1'):
+            d = getattr(self, dn)
+            out.append((dn + '.block.0.conv', d.block[0].conv, 'conv'))
+            out.append((dn + '.block.1', d.block[1], 'deconv'))
+        out.append(('dec0.conv', self.dec0.conv, 'conv'))
+        return out
+
+    def _build_pack(self):
+        """Allocate compute copies of the weights and the launch list that refreshes them."""
+        lib = _lib.load()
+        dev = self._flat[0].device
+        pk = {'ops': [], 'w': {}, 'wt': {}}
+        for name, m, kind in self._conv_list():
+            w = m.weight
+            if kind == 'stem':
+                buf = torch.empty(64 * 7 * 32, dtype=self._tdtype, device=dev)
+                pk['w'][name] = buf
+                pk['ops'].append((lib.msc_stem_pack, (w.data_ptr(), buf.data_ptr(), self._dt, 64)))
+                continue
+            a, b, kh, kw = w.shape            # physical [a][kh][kw][b]
+            n = w.numel()
+            direct = w if self._dt == F32 else None
+            if direct is None:
+                direct = torch.empty(n, dtype=self._tdtype, device=dev)
+                pk['ops'].append((lib.msc_pack_cast, (w.data_ptr(), direct.data_ptr(), self._dt, n)))
+            trans = None
+            if True:
+                trans = torch.empty(n, dtype=self._tdtype, device=dev)
+                pk['ops'].append((lib.msc_pack_transpose, (w.data_ptr(), trans.data_ptr(), self._dt, a, kh * kw, b)))
+            if kind == 'conv':       # master [Cout][..][Cin]: forward uses direct, dgrad the transpose
+                pk['w'][name], pk['wt'][name] = direct, trans
+            else:                    # master [Cin][..][Cout]: forward uses the transpose, dgrad direct
+                pk['w'][name], pk['wt'][name] = trans, direct
+        return pk
+
+    def _refresh_weights(self, stream):
+        if self._pack is None:
+            self._pack = self._build_pack()
+            self._programs = {}
+            self._packed_version = -1
+        if self._packed_version != self._version:
+            _Program.run(self._pack['ops'], stream)
+            self._packed_version = self._version
+
+    # ------------------------------------------------------------------ program construction
+    def _program(self, N, H, W, training, device):
+        key = (N, H, W, training, self.compute_dtype)
+        prog = self._programs.get(key)
+        if prog is None:
+            if H % 64 or W % 64:
+                raise ValueError('UNetResNet needs H and W divisible by 64 (got %dx%d): the reference fails at the '
+                                 'first skip-concat otherwise (src/unet_models.py:360-363,392-397)' % (H, W))
+            prog = _Builder(self, N, H, W, training, device).build()
+            self._programs[key] = prog
+        return prog
+
+    # ------------------------------------------------------------------ execution
+    def _run_forward(self, x, training):
+        if not x.is_cuda and not getattr(self, '_host_interpreter', False):
+            # tests/emu.py sets _host_interpreter and swaps _Program.run to check the HOST logic without a GPU
+            raise _lib.MscError('UNetResNet (HIP) needs a CUDA/ROCm tensor; there is no CPU path in the product')
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError('expected input of shape [N,3,H,W], got %s' % (tuple(x.shape),))
+        _lib.load()
+        dev = x.device
+        self._ensure_flat(dev)
+        stream = _stream_of(dev)
+        self._refresh_weights(stream)
+        N, _, H, W = x.shape
+        prog = self._program(N, H, W, training, dev)
+        prog.x_in.copy_(x.detach().to(torch.float32))
+        if not training and prog.fold_version != self._version:
+            _Program.run(prog.fold, stream)
+            prog.fold_version = self._version
+        _Program.run(prog.fwd, stream)
+        return prog
+
+    def _run_backward(self, prog, dlogits, zero_grads=True):
+        stream = _stream_of(dlogits.device)
+        if zero_grads:
+            self._flat[1].zero_()
+        if dlogits.data_ptr() != prog.dlogits.data_ptr():
+            prog.dlogits.copy_(dlogits)
+        prog.stem_dw.zero_()
+        _Program.run(prog.bwd, stream)
+
+    def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            return _UNetFunction.apply(x, self, *[p for _, p in self._trainable()])
+        prog = self._run_forward(x, training=self.training)
+        return prog.logits.clone()
+
+    def predict_proba(self, x):
+        """eval forward fused with the channel softmax the reference runs on the host afterwards
+        (src/models.py:88-92): returns f32[N,2,H,W] probabilities (a view of the program's buffer)."""
+        was = self.training
+        self.eval()
+        try:
+            prog = self._run_forward(x, training=False)
+        finally:
+            self.train(was)
+        return prog.probs
+
+    # training fast path used by models.py / bench.py (no autograd graph)
+    def train_forward(self, x):
+        return self._run_forward(x, training=True)
+
+    def train_backward(self, prog, dlogits=None):
+        self._run_backward(prog, prog.dlogits if dlogits is None else dlogits)
+
+
+class _UNetFunction(torch.autograd.Function):
+    """The whole network as one autograd node: lets the reference's own training loop
+    (`loss.backward(); optimizer.step()`, src/steps/pytorch/models.py:110-111) drive the HIP engine."""
+
+    @staticmethod
+    def forward(ctx, x, net, *params):
+        prog = net._run_forward(x, training=True)
+        ctx.net, ctx.prog = net, prog
+        return prog.logits.clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        net, prog = ctx.net, ctx.prog
+        flat_g = net._flat[1]
+        saved = flat_g.clone()           # .grad accumulated so far lives in the same flat buffer
+        net._run_backward(prog, dlogits.contiguous().to(torch.float32), zero_grads=True)
+        grads = [g.clone() for g in net._grad_views()]
+        flat_g.copy_(saved)              # autograd adds `grads` onto it (or assigns if .grad is None)
+        return (None, None) + tuple(grads)
+
+
+def _grad_views(self):
+    flat_g = self._flat[1]
+    out, total = [], 0
+    for name, p in self._trainable():
+        n = p.numel()
+        if p.dim() == 4 and not name.endswith('encoder.conv1.weight') and p.shape[2] * p.shape[3] * p.shape[1] > 1:
+            a, b, kh, kw = p.shape
+            out.append(flat_g[total:total + n].view(a, kh, kw, b).permute(0, 3, 1, 2))
+        else:
+            out.append(flat_g[total:total + n].view(p.shape))
+        total += (n + 3) // 4 * 4
+    return out
+
+
+UNetResNet._grad_views = _grad_views
+
+
+# ----------------------------------------------------------------------------- program builder
+class _Builder:
+    def __init__(self, net, N, H, W, training, device):
+        self.net, self.N, self.H, self.W, self.training, self.dev = net, N, H, W, training, device
+        self.lib = _lib.load()
+        self.dt, self.tdtype = net._dt, net._tdtype
+        self.es = 2 if self.dt == BF16 else 4
+        self.prog = _Program()
+        self.prog.training = training
+        self.prog.fold, self.prog.fold_version = [], -1
+        self.ops = []                 # backward emitters, forward order
+        self.gbuf = {}                # id(buffer) -> grad buffer
+        self.gwritten = set()         # (id(gbuf), c0, C) already written in this backward
+        self.slices = {}              # id(buffer) -> set of (c0, C)
+
+    # ---- memory
+    def buf(self, H, W, C, dtype=None):
+        t = torch.empty((self.N, H, W, C), dtype=dtype or self.tdtype, device=self.dev)
+        self.prog.bytes += t.numel() * t.element_size()
+        self.prog.keep.append(t)
+        return t
+
+    def vec(self, n, dtype=torch.float32, zero=False):
+        t = (torch.zeros if zero else torch.empty)(n, dtype=dtype, device=self.dev)
+        self.prog.bytes += t.numel() * t.element_size()
+        self.prog.keep.append(t)
+        return t
+
+    def act(self, H, W, C):
+        return Act(self.buf(H, W, C))
+
+    def slice(self, buf, c0, C):
+        self.slices.setdefault(id(buf), set()).add((c0, C))
+        return Act(buf, c0, C)
+
+    def grad_of(self, a):
+        g = self.gbuf.get(id(a.buf))
+        if g is None:
+            g = torch.empty_like(a.buf)
+            self.prog.bytes += g.numel() * g.element_size()
+            self.gbuf[id(a.buf)] = g
+            self.slices[id(g)] = self.slices.get(id(a.buf), set())
+            self.prog.keep.append(g)
+        return Act(g, a.c0, a.C)
+
+    def grad_acc(self, a):
+        """1 if the gradient slice was already written during this backward (-> accumulate), else
+        marks it (and every registered sub-slice it covers) written and returns 0."""
+        key = (id(a.buf), a.c0, a.C)
+        if key in self.gwritten:
+            return 1
+        self.gwritten.add(key)
+        for (c0, C) in self.slices.get(id(a.buf), ()):
+            if c0 >= a.c0 and c0 + C <= a.c0 + a.C:
+                self.gwritten.add((id(a.buf), c0, C))
+        return 0
+
+    # ---- launch helpers
+    def emit(self, lst, fn, *args):
+        lst.append((fn, args))
+
+    def conv_desc(self, x, wt, out, KH, KW, stride, pad, mode=0, flip=0, relu=0, scale=None, shift=None, res=None,
+                  stats=None, in_hw=None, in_ld=None, cin=None, out_hw=None):
+        d = ConvDesc()
+        d.in_, d.wt, d.out = x.ptr, wt.data_ptr(), out.ptr
+        d.res = res.ptr if res is not None else None
+        d.scale, d.shift, d.stats = _p(scale), _p(shift), _p(stats)
+        d.in_ld = in_ld if in_ld is not None else x.ld
+        d.out_ld = out.ld
+        d.res_ld = res.ld if res is not None else 0
+        d.dtype, d.mode = self.dt, mode
+        d.N = self.N
+        d.Hi, d.Wi = in_hw if in_hw is not None else (x.H, x.W)
+        d.Cin = cin if cin is not None else x.C
+        d.Ho, d.Wo = out_hw if out_hw is not None else (out.H, out.W)
+        d.Cout = out.C
+        d.KH, d.KW, d.stride, d.pad, d.flip, d.relu = KH, KW, stride, pad, flip, relu
+        self.prog.keep.append(d)
+        return d
+
+    def conv(self, lst, *a, **k):
+        d = self.conv_desc(*a, **k)
+        self.emit(lst, self.lib.msc_conv_igemm, C.byref(d))
+        return d
+
+    def wgrad(self, lst, p, q, dw, KH, KW, stride, pad, q_hw=None, q_ld=None, B=None):
+        d = WgradDesc()
+        d.p, d.q, d.dw = p.ptr, q.ptr, dw if isinstance(dw, int) else dw.data_ptr()
+        d.p_ld = p.ld
+        d.q_ld = q_ld if q_ld is not None else q.ld
+        d.dtype = self.dt
+        d.N, d.Hp, d.Wp, d.A = self.N, p.H, p.W, p.C
+        d.Hq, d.Wq = q_hw if q_hw is not None else (q.H, q.W)
+        d.B = B if B is not None else q.C
+        d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+        self.prog.keep.append(d)
+        self.emit(lst, self.lib.msc_conv_wgrad, C.byref(d))
+
+    # ---- layers -------------------------------------------------------------------------------
+    def conv_bn(self, name, x, conv, bn, stride, relu, out, res=None, stem=None):
+        """conv (no bias) + BatchNorm2d (+ residual) (+ ReLU) -> out.  `stem`: (Hp, Wp) of the prepared
+        NHWC4 image when this is encoder.conv1 expressed as a 7-tap x 32-wide implicit GEMM."""
+        net, lib, P, fwd = self.net, self.lib, self.prog, self.prog.fwd
+        w = net._pack['w'][name]
+        cout = conv.out_channels
+        if stem is not None:
+            geo = dict(KH=7, KW=1, stride=2, pad=0, in_hw=stem, in_ld=4, cin=32)
+        else:
+            k = conv.kernel_size[0]
+            geo = dict(KH=k, KW=k, stride=stride, pad=conv.padding[0])
+        scale, shift = self.vec(cout), self.vec(cout)
+        if not self.training:
+            # eval: BN folds into the conv epilogue (scale = gamma/sqrt(rv+eps), shift = beta - rm*scale)
+            self.emit(P.fold, lib.msc_bn_fold, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                      bn.running_var.data_ptr(), BN_EPS, scale.data_ptr(), shift.data_ptr(), cout)
+            self.conv(fwd, x, w, out, relu=int(relu), scale=scale, shift=shift, res=res, **geo)
+            return
+        y = self.act(out.H, out.W, cout)
+        d = self.conv_desc(x, w, y, **geo)
+        slices = lib.msc_conv_stats_slices(C.byref(d))
+        if slices <= 0:
+            _lib.check(-1, 'msc_conv_stats_slices')
+        part = self.vec(slices * cout * 2)
+        d.stats = part.data_ptr()
+        self.emit(fwd, lib.msc_conv_igemm, C.byref(d))
+        mean, invstd = self.vec(cout), self.vec(cout)
+        count = self.N * out.H * out.W
+        self.emit(fwd, lib.msc_bn_finalize, part.data_ptr(), slices, cout, count, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                  BN_EPS, BN_MOMENTUM, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                  scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr())
+        self.emit(fwd, lib.msc_bn_apply, y.ptr, y.ld, res.ptr if res is not None else None, res.ld if res is not None else 0,
+                  out.ptr, out.ld, scale.data_ptr(), shift.data_ptr(), int(relu), self.dt, count, cout)
+        self.ops.append(lambda: self._conv_bn_bwd(name, x, conv, bn, geo, relu, out, res, y, mean, invstd, count, stem))
+
+    def _conv_bn_bwd(self, name, x, conv, bn, geo, relu, out, res, y, mean, invstd, count, stem):
+        net, lib, P, bwd = self.net, self.lib, self.prog, self.prog.bwd
+        cout = conv.out_channels
+        dout = self.grad_of(out)
+        blocks = lib.msc_bn_bwd_blocks(count, cout)
+        part = self.vec(blocks * cout * 2)
+        coef = self.vec(3 * cout)
+        self.emit(bwd, lib.msc_bn_bwd_reduce, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, int(relu), part.data_ptr(),
+                  self.dt, count, cout)
+        self.emit(bwd, lib.msc_bn_bwd_finalize, part.data_ptr(), blocks, cout, count, bn.weight.data_ptr(),
+                  mean.data_ptr(), invstd.data_ptr(), net._g(bn.weight), net._g(bn.bias), coef.data_ptr())
+        dres_ptr, dres_ld, dres_acc = None, 0, 0
+        if res is not None:
+            gres = self.grad_of(res)
+            dres_acc = self.grad_acc(res)
+            dres_ptr, dres_ld = gres.ptr, gres.ld
+        # dy overwrites y in place (each element is read, then written, by the same lane)
+        self.emit(bwd, lib.msc_bn_bwd_apply, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, int(relu), coef.data_ptr(),
+                  y.ptr, y.ld, dres_ptr, dres_ld, dres_acc, self.dt, count, cout)
+        dy = y
+        if stem is not None:
+            self.wgrad(bwd, dy, x, P.stem_dw.data_ptr(), 7, 1, 2, 0, q_hw=stem, q_ld=4, B=32)
+            self.emit(bwd, lib.msc_stem_unpack_grad, P.stem_dw.data_ptr(), net._g(conv.weight), 64)
+            return                                    # the network input needs no gradient
+        self.wgrad(bwd, dy, x, net._g(conv.weight), geo['KH'], geo['KW'], geo['stride'], geo['pad'])
+        gx = self.grad_of(x)
+        acc = self.grad_acc(x)
+        wt = net._pack['wt'][name]
+        k = geo['KH']
+        if geo['stride'] == 1:
+            self.conv(bwd, dy, wt, gx, KH=k, KW=k, stride=1, pad=geo['pad'], flip=1, res=gx if acc else None)
+        else:
+            self.conv(bwd, dy, wt, gx, KH=k, KW=k, stride=2, pad=geo['pad'], mode=1, res=gx if acc else None)
+
+    def conv_relu(self, name, x, conv, out):
+        """ConvRelu (src/unet_models.py:25-34): 3x3, pad 1, bias, ReLU."""
+        net, lib, P = self.net, self.lib, self.prog
+        self.conv(P.fwd, x, net._pack['w'][name], out, KH=3, KW=3, stride=1, pad=1, relu=1, shift=conv.bias)
+        if self.training:
+            self.ops.append(lambda: self._conv_relu_bwd(name, x, conv, out))
+
+    def _conv_relu_bwd(self, name, x, conv, out, masked=False):
+        net, lib, P, bwd = self.net, self.lib, self.prog, self.prog.bwd
+        dout = self.grad_of(out)
+        count = out.pixels
+        if not masked:   # dmask = dout * [out > 0], in place: `out` has exactly one consumer
+            self.emit(bwd, lib.msc_relu_bwd, dout.ptr, dout.ld, out.ptr, out.ld, dout.ptr, dout.ld, 0, self.dt, count, out.C)
+        self.emit(bwd, lib.msc_bias_grad, dout.ptr, dout.ld, net._g(conv.bias), self.dt, count, out.C)
+        self.wgrad(bwd, dout, x, net._g(conv.weight), 3, 3, 1, 1)
+        gx = self.grad_of(x)
+        acc = self.grad_acc(x)
+        self.conv(bwd, dout, net._pack['wt'][name], gx, KH=3, KW=3, stride=1, pad=1, flip=1, res=gx if acc else None)
+
+    def deconv_relu(self, name, x, deconv, out):
+        """ConvTranspose2d(k4,s2,p1)+bias+ReLU (src/unet_models.py:138-140) as 4 output-parity phases of 2x2 taps."""
+        net, P = self.net, self.prog
+        self.conv(P.fwd, x, net._pack['w'][name], out, KH=4, KW=4, stride=2, pad=1, mode=1, relu=1, shift=deconv.bias)
+        if self.training:
+            self.ops.append(lambda: self._deconv_relu_bwd(name, x, deconv, out))
+
+    def _deconv_relu_bwd(self, name, x, deconv, out):
+        net, lib, P, bwd = self.net, self.lib, self.prog, self.prog.bwd
+        dout = self.grad_of(out)
+        count = out.pixels
+        dm = self.act(out.H, out.W, out.C)           # compact masked gradient (dout may be a slice of a concat)
+        self.emit(bwd, lib.msc_relu_bwd, dout.ptr, dout.ld, out.ptr, out.ld, dm.ptr, dm.ld, 0, self.dt, count, out.C)
+        self.emit(bwd, lib.msc_bias_grad, dm.ptr, dm.ld, net._g(deconv.bias), self.dt, count, out.C)
+        # dW[ci][kh][kw][co] = sum_coarse x[c][ci] * dm[2c-1+k][co]
+        self.wgrad(bwd, x, dm, net._g(deconv.weight), 4, 4, 2, 1)
+        gx = self.grad_of(x)
+        acc = self.grad_acc(x)
+        self.conv(bwd, dm, net._pack['wt'][name], gx, KH=4, KW=4, stride=2, pad=1, res=gx if acc else None)
+
+    def maxpool(self, x, out):
+        lib, P = self.lib, self.prog
+        self.emit(P.fwd, lib.msc_maxpool2_fwd, x.ptr, x.ld, out.ptr, out.ld, self.dt, self.N, out.H, out.W, out.C)
+        if self.training:
+            def bwd():
+                dout, gx = self.grad_of(out), self.grad_of(x)
+                acc = self.grad_acc(x)
+                self.emit(P.bwd, lib.msc_maxpool2_bwd, dout.ptr, dout.ld, x.ptr, x.ld, gx.ptr, gx.ld, self.dt, self.N,
+                          out.H, out.W, out.C, acc)
+            self.ops.append(bwd)
+
+    # ---- the network (src/unet_models.py:385-403) -----------------------------------------------
+    def build(self):
+        net, lib, P = self.net, self.lib, self.prog
+        N, H, W = self.N, self.H, self.W
+        nf, bottom = net._nf, net._bottom
+        enc = net.encoder
+        exp = 1 if net._kind == 'basic' else 4
+        P.x_in = torch.empty((N, 3, H, W), dtype=torch.float32, device=self.dev)
+        P.logits = torch.empty((N, 2, H, W), dtype=torch.float32, device=self.dev)
+        P.probs = torch.empty((N, 2, H, W), dtype=torch.float32, device=self.dev)
+        P.dlogits = torch.empty((N, 2, H, W), dtype=torch.float32, device=self.dev) if self.training else None
+        P.stem_dw = torch.zeros(64 * 7 * 32, dtype=torch.float32, device=self.dev)
+
+        # concat buffers: [decoder part | encoder skip]; encoder stages write straight into their slice
+        cat2 = self.buf(H // 4, W // 4, nf * 2 + 64 * exp)
+        cat3 = self.buf(H // 8, W // 8, nf * 8 + 128 * exp)
+        cat4 = self.buf(H // 16, W // 16, nf * 8 + 256 * exp)
+        cat5 = self.buf(H // 32, W // 32, nf * 8 + 512 * exp)
+        skips = {1: self.slice(cat2, nf * 2, 64 * exp), 2: self.slice(cat3, nf * 8, 128 * exp),
+                 3: self.slice(cat4, nf * 8, 256 * exp), 4: self.slice(cat5, nf * 8, 512 * exp)}
+
+        # stem: conv7x7/2 + BN + ReLU + MaxPool2d(2,2)   (:360-363)
+        xp = torch.zeros((N, H + 6, W + 8, 4), dtype=self.tdtype, device=self.dev)
+        P.bytes += xp.numel() * xp.element_size()
+        self.emit(P.fwd, lib.msc_stem_prepare, P.x_in.data_ptr(), xp.data_ptr(), self.dt, N, H, W)
+        s1 = self.act(H // 2, W // 2, 64)
+        self.conv_bn('encoder.conv1', Act(xp), enc.conv1, enc.bn1, 2, True, s1, stem=(H + 6, W + 8))
+        cur = self.act(H // 4, W // 4, 64)
+        self.maxpool(s1, cur)
+
+        # encoder.layer1-4 (torchvision BasicBlock / Bottleneck)
+        for li in range(1, 5):
+            blocks = getattr(enc, 'layer%d' % li)
+            for bi, blk in enumerate(blocks):
+                base = 'encoder.layer%d.%d' % (li, bi)
+                s = blk.stride
+                hh, ww = cur.H, cur.W
+                ho, wo = hh // s, ww // s
+                planes = blk.conv1.out_channels
+                last = bi == len(blocks) - 1
+                out = skips[li] if last else self.act(ho, wo, planes * exp)
+                idt = cur
+                if blk.downsample is not None:
+                    idt = self.act(ho, wo, planes * exp)
+                    self.conv_bn(base + '.downsample.0', cur, blk.downsample[0], blk.downsample[1], s, False, idt)
+                if net._kind == 'basic':
+                    a = self.act(ho, wo, planes)
+                    self.conv_bn(base + '.conv1', cur, blk.conv1, blk.bn1, s, True, a)
+                    self.conv_bn(base + '.conv2', a, blk.conv2, blk.bn2, 1, True, out, res=idt)
+                else:
+                    a = self.act(hh, ww, planes)
+                    self.conv_bn(base + '.conv1', cur, blk.conv1, blk.bn1, 1, True, a)
+                    b = self.act(ho, wo, planes)
+                    self.conv_bn(base + '.conv2', a, blk.conv2, blk.bn2, s, True, b)
+                    self.conv_bn(base + '.conv3', b, blk.conv3, blk.bn3, 1, True, out, res=idt)
+                cur = out
+        c5 = cur
+
+        # decoder (:392-401)
+        pooled = self.act(H // 64, W // 64, c5.C)
+        self.maxpool(c5, pooled)
+        specs = [('center', pooled, self.slice(cat5, 0, nf * 8)), ('dec5', Act(cat5), self.slice(cat4, 0, nf * 8)),
+                 ('dec4', Act(cat4), self.slice(cat3, 0, nf * 8)), ('dec3', Act(cat3), self.slice(cat2, 0, nf * 2))]
+        for dn, xin, dst in specs:
+            d = getattr(net, dn)
+            mid = self.act(xin.H, xin.W, d.block[0].conv.out_channels)
+            self.conv_relu(dn + '.block.0.conv', xin, d.block[0].conv, mid)
+            self.deconv_relu(dn + '.block.1', mid, d.block[1], dst)
+        x = Act(cat2)
+        for dn in ('dec2', 'dec1'):
+            d = getattr(net, dn)
+            mid = self.act(x.H, x.W, d.block[0].conv.out_channels)
+            self.conv_relu(dn + '.block.0.conv', x, d.block[0].conv, mid)
+            up = self.act(x.H * 2, x.W * 2, d.block[1].out_channels)
+            self.deconv_relu(dn + '.block.1', mid, d.block[1], up)
+            x = up
+        d0 = self.act(H, W, nf)
+        self.conv(P.fwd, x, net._pack['w']['dec0.conv'], d0, KH=3, KW=3, stride=1, pad=1, relu=1, shift=net.dec0.conv.bias)
+        fin = net.final
+        self.emit(P.fwd, lib.msc_final_fwd, d0.ptr, d0.ld, fin.weight.data_ptr(), fin.bias.data_ptr(), P.logits.data_ptr(),
+                  None if self.training else P.probs.data_ptr(), self.dt, N, H, W, nf)
+        if self.training:
+            gd0 = self.grad_of(d0)
+            self.grad_acc(d0)
+            # final 1x1 backward also applies dec0's ReLU mask, so dec0's backward skips it
+            self.emit(P.bwd, lib.msc_final_bwd, P.dlogits.data_ptr(), d0.ptr, d0.ld, fin.weight.data_ptr(), gd0.ptr, gd0.ld,
+                      net._g(fin.weight), net._g(fin.bias), self.dt, N, H, W, nf)
+            self._conv_relu_bwd('dec0.conv', x, net.dec0.conv, d0, masked=True)
+            for op in reversed(self.ops):
+                op()
+        P.keep += [xp]
+        P.acts = {'c1': s1, 'd0': d0, 'cat2': cat2, 'cat3': cat3, 'cat4': cat4, 'cat5': cat5}
+        return P
