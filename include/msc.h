@@ -145,7 +145,10 @@ int msc_loss_grad(const float* logits, const float* target, int tc, const msc_lo
 /* Adam with L2 folded into the gradient (torch.optim.Adam(weight_decay), src/models.py:57,287-292) over one flat
  * fp32 parameter buffer. */
 int msc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int step, float grad_scale, void* stream);
+                  float eps, float weight_decay, int step, float grad_scale, const float* state, void* stream);
+/* `state` (device f32[2] = {step count, learning rate}, may be NULL): when given it overrides `step` and `lr`, so a
+ * captured hipGraph replays with the bias corrections of the current iteration; msc_adam_tick does state[0] += 1. */
+int msc_adam_tick(float* state, void* stream);
 
 /* ---------------------------------------------------------------- mask post-processing --------
  * Batched over B images; each replaces a per-image Python/scipy/skimage loop of src/postprocessing.py. */

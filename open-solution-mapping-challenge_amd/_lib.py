@@ -70,7 +70,8 @@ SIGNATURES = {
     'msc_final_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'msc_loss_sums': (_i, [_vp, _vp, _i, C.POINTER(LossCfg), _vp, _i, _i, _i, _vp]),
     'msc_loss_grad': (_i, [_vp, _vp, _i, C.POINTER(LossCfg), _vp, _d, _f, _vp, _vp, _i, _i, _i, _vp]),
-    'msc_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    'msc_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
+    'msc_adam_tick': (_i, [_vp, _vp]),
     'msc_resize_bilinear': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'msc_crop_center': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'msc_threshold_layers': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),

@@ -504,9 +504,19 @@ __global__ void final_bwd_kernel(const float* __restrict__ dlogits, const T* __r
 }
 
 // ------------------------------------------------------------------ Adam (+L2), torch.optim.Adam semantics
+// `state` (device, optional) = [step count, learning rate]: lets a captured hipGraph replay the step with the
+// bias corrections / lr of the CURRENT iteration (msc_adam_tick advances it inside the graph).
+__global__ void adam_tick_kernel(float* state) { state[0] += 1.f; }
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
-                            float bc1, float bc2_sqrt, float gscale) {
+                            float bc1, float bc2_sqrt, float gscale, const float* __restrict__ state) {
+    if (state) {
+        const float step = state[0];
+        lr = state[1];
+        bc1 = 1.f - powf(b1, step);
+        bc2_sqrt = sqrtf(1.f - powf(b2, step));
+    }
     const long n4 = n / 4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 P = reinterpret_cast<float4*>(p)[i];
@@ -731,14 +741,20 @@ extern "C" int msc_final_bwd(const float* dlogits, const void* in, int64_t in_ld
     return msc_check_launch("msc_final_bwd");
 }
 
+extern "C" int msc_adam_tick(float* state, void* stream) {
+    if (!state) return msc_fail(MSC_ERR_ARG, "msc_adam_tick: null state");
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+    return msc_check_launch("msc_adam_tick");
+}
+
 extern "C" int msc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                             float eps, float weight_decay, int step, float grad_scale, void* stream) {
-    if (!p || !g || !m || !v || n < 0 || step < 1) return msc_fail(MSC_ERR_ARG, "msc_adam_step: bad argument");
+                             float eps, float weight_decay, int step, float grad_scale, const float* state, void* stream) {
+    if (!p || !g || !m || !v || n < 0 || (!state && step < 1)) return msc_fail(MSC_ERR_ARG, "msc_adam_step: bad argument");
     if (n == 0) return MSC_OK;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return msc_fail(MSC_ERR_ARG, "msc_adam_step: buffers must be 16-byte aligned");
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2 = 1.f - powf(beta2, (float)step);
+    const float bc1 = 1.f - powf(beta1, (float)(step < 1 ? 1 : step));
+    const float bc2 = 1.f - powf(beta2, (float)(step < 1 ? 1 : step));
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2, eps,
-                       weight_decay, bc1, sqrtf(bc2), grad_scale);
+                       weight_decay, bc1, sqrtf(bc2), grad_scale, state);
     return msc_check_launch("msc_adam_step");
 }

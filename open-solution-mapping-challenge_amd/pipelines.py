@@ -1,0 +1,154 @@
+"""Pipeline graphs for the hot path: `unet`, `unet_weighted` and `mask_postprocessing`
+(reference: src/pipelines.py:12-52, 248-304), built from the HIP transformers.
+
+`config` has the shape of the reference's SOLUTION_CONFIG (src/pipeline_config.py:33-166): attribute or
+key access to `env.cache_dirpath`, `execution.stream_mode`, `unet`, `postprocessor.mask_erosion /
+mask_dilation`.  The loader Step is whatever the caller supplies (the reference's loaders are CPU image
+decoding and out of scope); `synthetic_loader` feeds pre-built tensors for tests and benchmarks.
+
+Two post-processing graphs are offered:
+  mask_postprocessing        the reference's six Steps, each a per-image apply-transformer over a
+                             reference-signature HIP function (exact API compatibility)
+  mask_postprocessing_fused  ONE Step that keeps the batch on the device through all six stages
+                             (postprocessing.postprocess_batch) and emits the same `images_with_scores`
+"""
+from functools import partial
+
+import torch
+
+from . import postprocessing as post
+from .models import PyTorchUNet, PyTorchUNetStream, PyTorchUNetWeighted, PyTorchUNetWeightedStream
+from .steps import BaseTransformer, Dummy, Step, make_apply_transformer
+
+
+def _get(cfg, key):
+    return cfg[key] if isinstance(cfg, dict) else getattr(cfg, key)
+
+
+class SyntheticLoader(BaseTransformer):
+    """Stand-in for the reference's Metadata*Loader.transform (src/loaders.py:192-204): hands back
+    `{'datagen': (batches, steps), 'validation_datagen': ...}` built from in-memory tensors."""
+
+    def __init__(self, batch_size):
+        self.batch_size = batch_size
+
+    def _gen(self, X, y):
+        if X is None:
+            return None
+        n = X.shape[0]
+        batches = []
+        for i in range(0, n, self.batch_size):
+            batches.append([X[i:i + self.batch_size]] if y is None else [X[i:i + self.batch_size], y[i:i + self.batch_size]])
+        return batches, len(batches)
+
+    def transform(self, X, y=None, X_valid=None, y_valid=None, train_mode=True, **kwargs):
+        return {'datagen': self._gen(X, y if train_mode else None), 'validation_datagen': self._gen(X_valid, y_valid)}
+
+
+def synthetic_loader(config, batch_size):
+    return Step(name='loader', transformer=SyntheticLoader(batch_size), input_data=['input'],
+                adapter={'X': ([('input', 'X')]), 'y': ([('input', 'y')]), 'train_mode': ([('input', 'train_mode')])},
+                cache_dirpath=_get(_get(config, 'env'), 'cache_dirpath'))
+
+
+class MaskPostprocessingHIP(BaseTransformer):
+    """All of mask_postprocessing as one transformer; `images` may be a numpy array [N,2,h,w], a list of
+    per-image arrays, or an iterable of cuda batches (PyTorchUNet.transform_device)."""
+
+    def __init__(self, erode_selem_size=0, dilate_selem_size=0, batch_size=64):
+        self.erode, self.dilate, self.batch_size = erode_selem_size, dilate_selem_size, batch_size
+
+    def transform(self, images, target_sizes):
+        out = []
+        sizes = list(target_sizes)
+        if isinstance(images, torch.Tensor) or hasattr(images, 'shape'):
+            images = [images[i:i + self.batch_size] for i in range(0, len(images), self.batch_size)]
+        pos = 0
+        for batch in images:
+            t = batch if isinstance(batch, torch.Tensor) else torch.as_tensor(batch)
+            if t.dim() == 3:
+                t = t[None]
+            size = tuple(sizes[pos]) if sizes else None
+            pos += t.shape[0]
+            out += post.postprocess_batch(t, size, self.erode, self.dilate)
+        return {'images_with_scores': out}
+
+
+def mask_postprocessing(model, config, make_transformer=make_apply_transformer, **kwargs):
+    """src/pipelines.py:248-304 with the HIP functions of postprocessing.py."""
+    cache = _get(_get(config, 'env'), 'cache_dirpath')
+    pp = _get(config, 'postprocessor')
+    mask_resize = Step(name='mask_resize',
+                       transformer=make_transformer(post.resize_image, output_name='resized_images',
+                                                    apply_on=['images', 'target_sizes']),
+                       input_data=['input'], input_steps=[model],
+                       adapter={'images': ([(model.name, 'multichannel_map_prediction')]),
+                                'target_sizes': ([('input', 'target_sizes')])},
+                       cache_dirpath=cache, cache_output=True, **kwargs)
+    category_mapper = Step(name='category_mapper',
+                           transformer=make_transformer(post.categorize_multilayer_image, output_name='categorized_images'),
+                           input_steps=[mask_resize], adapter={'images': ([('mask_resize', 'resized_images')])},
+                           cache_dirpath=cache, **kwargs)
+    mask_erosion = Step(name='mask_erosion',
+                        transformer=make_transformer(partial(_erode_layers, **dict(_get(pp, 'mask_erosion'))),
+                                                     output_name='eroded_images'),
+                        input_steps=[category_mapper], adapter={'images': ([(category_mapper.name, 'categorized_images')])},
+                        cache_dirpath=cache, **kwargs)
+    labeler = Step(name='labeler',
+                   transformer=make_transformer(post.label_multilayer_image, output_name='labeled_images'),
+                   input_steps=[mask_erosion], adapter={'images': ([(mask_erosion.name, 'eroded_images')])},
+                   cache_dirpath=cache, **kwargs)
+    mask_dilation = Step(name='mask_dilation',
+                         transformer=make_transformer(partial(post.dilate_image, **dict(_get(pp, 'mask_dilation'))),
+                                                      output_name='dilated_images'),
+                         input_steps=[labeler], adapter={'images': ([(labeler.name, 'labeled_images')])},
+                         cache_dirpath=cache, **kwargs)
+    score_builder = Step(name='score_builder',
+                         transformer=make_transformer(post.build_score, output_name='images_with_scores',
+                                                      apply_on=['images', 'probabilities']),
+                         input_steps=[mask_dilation, mask_resize],
+                         adapter={'images': ([(mask_dilation.name, 'dilated_images')]),
+                                  'probabilities': ([(mask_resize.name, 'resized_images')])},
+                         cache_dirpath=cache, **kwargs)
+    return score_builder
+
+
+def _erode_layers(mask, erode_selem_size):
+    # the shipped configuration has erode_selem_size 0 (neptune.yaml:69): passthrough, like the reference
+    return post.erode_image(mask, erode_selem_size)
+
+
+def mask_postprocessing_fused(model, config, **kwargs):
+    cache = _get(_get(config, 'env'), 'cache_dirpath')
+    pp = _get(config, 'postprocessor')
+    tr = MaskPostprocessingHIP(erode_selem_size=dict(_get(pp, 'mask_erosion')).get('erode_selem_size', 0),
+                               dilate_selem_size=dict(_get(pp, 'mask_dilation')).get('dilate_selem_size', 0))
+    return Step(name='score_builder', transformer=tr, input_data=['input'], input_steps=[model],
+                adapter={'images': ([(model.name, 'multichannel_map_prediction')]),
+                         'target_sizes': ([('input', 'target_sizes')])},
+                cache_dirpath=cache, **kwargs)
+
+
+def unet(config, train_mode, loader=None, fused_postprocessing=False, weighted=False):
+    """src/pipelines.py:12-38 (and :41-52 with weighted=True)."""
+    cache = _get(_get(config, 'env'), 'cache_dirpath')
+    stream = bool(_get(_get(config, 'execution'), 'stream_mode'))
+    unet_cfg = dict(_get(config, 'unet'))
+    if loader is None:
+        loader = synthetic_loader(config, _get(_get(config, 'execution'), 'batch_size_train'))
+    cls = {(False, False): PyTorchUNet, (False, True): PyTorchUNetStream,
+           (True, False): PyTorchUNetWeighted, (True, True): PyTorchUNetWeightedStream}[(weighted, stream)]
+    unet_step = Step(name='unet', transformer=cls(**unet_cfg), input_data=['callback_input'], input_steps=[loader],
+                     cache_dirpath=cache, is_trainable=True)
+    post_step = (mask_postprocessing_fused if fused_postprocessing else mask_postprocessing)(unet_step, config)
+    return Step(name='output', transformer=Dummy(), input_steps=[post_step],
+                adapter={'y_pred': ([(post_step.name, 'images_with_scores')])}, cache_dirpath=cache)
+
+
+def unet_weighted(config, train_mode, loader=None, fused_postprocessing=False):
+    return unet(config, train_mode, loader=loader, fused_postprocessing=fused_postprocessing, weighted=True)
+
+
+PIPELINES = {'unet': {'train': partial(unet, train_mode=True), 'inference': partial(unet, train_mode=False)},
+             'unet_weighted': {'train': partial(unet_weighted, train_mode=True),
+                               'inference': partial(unet_weighted, train_mode=False)}}

@@ -364,6 +364,9 @@ class UNetResNet(nn.Module):
             raise _lib.MscError('UNetResNet (HIP) needs a CUDA/ROCm tensor; there is no CPU path in the product')
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError('expected input of shape [N,3,H,W], got %s' % (tuple(x.shape),))
+        if x.shape[2] % 64 or x.shape[3] % 64:
+            raise ValueError('UNetResNet needs H and W divisible by 64 (got %dx%d): the reference fails at the '
+                             'first skip-concat otherwise (src/unet_models.py:360-363,392-397)' % (x.shape[2], x.shape[3]))
         _lib.load()
         dev = x.device
         self._ensure_flat(dev)

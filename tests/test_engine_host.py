@@ -1,0 +1,76 @@
+"""CPU: host logic of the HIP engine (program construction, buffer wiring, concat slices, gradient
+accumulation flags, weight layouts) checked by executing its launch lists with tests/emu.py -- a numpy
+interpreter of the documented C-ABI semantics -- against the torch-CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import emu
+from mapping_challenge_amd import unet_models as um
+from oracle import unet_ref, losses_ref
+
+
+@pytest.fixture()
+def interpreted(monkeypatch):
+    monkeypatch.setattr(um._Program, 'run', staticmethod(emu.run))
+
+
+def build(depth):
+    ref = unet_ref.UNetResNetRef(depth)
+    sd = unet_ref.seeded_state_dict(ref)
+    ref.load_state_dict(sd)
+    net = um.UNetResNet(depth, 2, num_filters=32, dropout_2d=0.0, is_deconv=True, compute_dtype='fp32')
+    net.load_state_dict({'module.' + k: v for k, v in sd.items()})      # DataParallel-prefixed, like reference checkpoints
+    net._host_interpreter = True
+    net.flatten_parameters('cpu')
+    return ref, net
+
+
+@pytest.mark.parametrize('depth', [34, 101])
+def test_eval_and_train_match_oracle(interpreted, depth):
+    ref, net = build(depth)
+    x = unet_ref.synthetic_batch(2, 64, 64)
+    ref.eval(); net.eval()
+    with torch.no_grad():
+        assert (ref(x) - net(x)).abs().max() < 1e-4
+    ref.train(); net.train()
+    tgt = losses_ref.synthetic_target(2, 64, 64)
+    loss = losses_ref.mixed_dice_ce(ref(x), tgt)
+    loss.backward()
+    loss2 = losses_ref.mixed_dice_ce(net(x), tgt)
+    loss2.backward()
+    assert abs(loss.item() - loss2.item()) < 1e-5
+    pr = dict(ref.named_parameters())
+    for n, p in net._trainable():
+        scale = pr[n].grad.abs().max().item() + 1e-12
+        assert (p.grad - pr[n].grad).abs().max().item() / scale < 2e-3, n   # tiny BN populations at 64x64
+    for (n, b), (_, b2) in zip(sorted(ref.named_buffers()), sorted(net.named_buffers())):
+        if 'running' in n:
+            assert (b - b2).abs().max() < 1e-5, n
+
+
+def test_state_dict_roundtrip_and_flat_views(interpreted):
+    ref, net = build(34)
+    sd = net.state_dict()
+    assert set(sd) == set(ref.state_dict())
+    for k, v in ref.state_dict().items():
+        assert v.shape == sd[k].shape and torch.equal(v, sd[k].cpu()), k
+    # parameters are views of ONE flat buffer; conv weights are physically [Cout][KH][KW][Cin]
+    w = net.encoder.layer1[0].conv1.weight
+    assert w.shape == (64, 64, 3, 3) and w.stride() == (576, 1, 192, 64)
+    flat = net.flat_params
+    assert flat.data_ptr() <= w.data_ptr() < flat.data_ptr() + flat.numel() * 4
+    assert not any(n.startswith('encoder.fc') for n, _ in net._trainable())
+
+
+def test_rejects_unsupported_configurations():
+    with pytest.raises(NotImplementedError):
+        um.UNetResNet(50, 2, is_deconv=True, dropout_2d=0.0)
+    with pytest.raises(NotImplementedError):
+        um.UNetResNet(34, 2, is_deconv=False, dropout_2d=0.0)
+    net = um.UNetResNet(34, 2, is_deconv=True, dropout_2d=0.0)
+    with pytest.raises(Exception, match='no CPU path'):
+        net(torch.zeros(1, 3, 64, 64))
+    net._host_interpreter = True
+    with pytest.raises(ValueError, match='divisible by 64'):
+        net.eval()(torch.zeros(1, 3, 300, 300))       # 300x300 is not a legal network input

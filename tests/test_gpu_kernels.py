@@ -1,0 +1,208 @@
+"""GPU: single-kernel parity through the C ABI against torch-CPU fp32 references of the same op.
+fp32 mode (v_mfma_f32_16x16x4_f32) is held to 1e-4-class tolerances; bf16 mode to bf16 rounding."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).float()      # values representable in dtype
+
+
+def nhwc(t, dtype):
+    return t.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+
+
+def to_nchw(t):
+    return t.float().cpu().permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('cin,cout,k,stride,hw,n', [(64, 64, 3, 1, 12, 2), (64, 128, 1, 1, 9, 3), (128, 64, 3, 2, 16, 2),
+                                                    (64, 256, 1, 2, 14, 2), (32, 32, 3, 1, 20, 1), (320, 128, 3, 1, 8, 2),
+                                                    (64, 64, 3, 1, 40, 4), (256, 512, 3, 1, 33, 2)])
+def test_conv_forward_epilogues(dtype, cin, cout, k, stride, hw, n):
+    from mapping_challenge_amd import ops
+    pad = k // 2
+    x = rnd((n, cin, hw, hw), dtype, 1)
+    w = rnd((cout, cin, k, k), dtype, 2, (2.0 / (cin * k * k)) ** 0.5)
+    ho = (hw + 2 * pad - k) // stride + 1
+    res = rnd((n, cout, ho, ho), dtype, 3)
+    scale, shift = torch.rand(cout) + 0.5, torch.randn(cout) * 0.1
+    ref = F.conv2d(x, w, stride=stride, padding=pad)
+    wk = w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    out = torch.empty((n, ho, ho, cout), dtype=dtype, device='cuda')
+    ops.conv_igemm(nhwc(x, dtype), wk, out, stride=stride, pad=pad)
+    assert torch.allclose(to_nchw(out), ref, **tol(dtype))
+    ops.conv_igemm(nhwc(x, dtype), wk, out, stride=stride, pad=pad, relu=True, scale=scale.cuda(), shift=shift.cuda(),
+                   res=nhwc(res, dtype))
+    ref2 = torch.relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    assert torch.allclose(to_nchw(out), ref2, **tol(dtype))
+
+
+@pytest.mark.parametrize('dtype', DT)
+def test_conv_channel_slices_and_stats(dtype):
+    """input / output / residual as channel slices of wider buffers; BN partial statistics"""
+    from mapping_challenge_amd import ops
+    n, hw, cin, cout = 2, 10, 64, 64
+    x = rnd((n, cin, hw, hw), dtype, 1)
+    w = rnd((cout, cin, 3, 3), dtype, 2, 0.06)
+    xbuf = torch.zeros((n, hw, hw, 192), dtype=dtype, device='cuda')
+    xbuf[..., 64:128] = nhwc(x, dtype)
+    obuf = torch.full((n, hw, hw, 160), 7.0, dtype=dtype, device='cuda')
+    xin, out = xbuf[..., 64:128], obuf[..., 32:96]
+    slices = ops.conv_stats_slices(xin, w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda(), out, 1, 1)
+    stats = torch.zeros((slices, cout, 2), dtype=torch.float32, device='cuda')
+    ops.conv_igemm(xin, w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda(), out, stride=1, pad=1, stats=stats)
+    ref = F.conv2d(x, w, padding=1)
+    assert torch.allclose(to_nchw(out), ref, **tol(dtype))
+    assert (obuf[..., :32] == 7).all() and (obuf[..., 96:] == 7).all()          # neighbours untouched
+    s = stats.sum(0).cpu()
+    assert torch.allclose(s[:, 0], ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+    assert torch.allclose(s[:, 1], (ref * ref).sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('cin,cout,hw', [(64, 64, 6), (512, 256, 4), (128, 32, 16)])
+def test_conv_transpose_forward(dtype, cin, cout, hw):
+    from mapping_challenge_amd import ops
+    n = 2
+    x = rnd((n, cin, hw, hw), dtype, 1)
+    wt = rnd((cin, cout, 4, 4), dtype, 2, (2.0 / (cin * 4)) ** 0.5)
+    bias = torch.randn(cout) * 0.1
+    ref = torch.relu(F.conv_transpose2d(x, wt, bias, stride=2, padding=1))
+    master = wt.permute(0, 2, 3, 1).contiguous()                          # [Cin][kh][kw][Cout]
+    wk = ops.pack_transpose(master.view(cin, 16, cout).cuda(), dtype).view(cout, 4, 4, cin)
+    out = torch.empty((n, 2 * hw, 2 * hw, cout), dtype=dtype, device='cuda')
+    ops.conv_igemm(nhwc(x, dtype), wk, out, stride=2, pad=1, mode=1, relu=True, shift=bias.cuda())
+    assert torch.allclose(to_nchw(out), ref, **tol(dtype))
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('cin,cout,k,stride,hw', [(64, 64, 3, 1, 10), (64, 128, 1, 1, 7), (64, 128, 3, 2, 12),
+                                                  (64, 256, 1, 2, 12), (128, 64, 4, 2, 16)])
+def test_data_gradient(dtype, cin, cout, k, stride, hw):
+    """dgrad of conv (stride 1: flipped gather; stride 2: transposed mode) and of ConvTranspose2d (k4: gather s2)"""
+    from mapping_challenge_amd import ops
+    n = 2
+    deconv = k == 4
+    if deconv:           # forward: x[cin, hw] -> out[cout, 2hw]; dgrad wrt x
+        x = rnd((n, cin, hw, hw), dtype, 1).requires_grad_(True)
+        wt = rnd((cin, cout, 4, 4), dtype, 2, 0.05)
+        y = F.conv_transpose2d(x, wt, stride=2, padding=1)
+        dy = rnd(tuple(y.shape), dtype, 3)
+        y.backward(dy)
+        wk = wt.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()          # [Cin][kh][kw][Cout]: used directly
+        gx = torch.empty((n, hw, hw, cin), dtype=dtype, device='cuda')
+        ops.conv_igemm(nhwc(dy, dtype), wk, gx, stride=2, pad=1)
+    else:
+        pad = k // 2
+        x = rnd((n, cin, hw, hw), dtype, 1).requires_grad_(True)
+        w = rnd((cout, cin, k, k), dtype, 2, 0.05)
+        y = F.conv2d(x, w, stride=stride, padding=pad)
+        dy = rnd(tuple(y.shape), dtype, 3)
+        y.backward(dy)
+        master = w.permute(0, 2, 3, 1).contiguous()                         # [Cout][kh][kw][Cin]
+        wk = ops.pack_transpose(master.view(cout, k * k, cin).cuda(), dtype).view(cin, k, k, cout)
+        gx = torch.empty((n, hw, hw, cin), dtype=dtype, device='cuda')
+        if stride == 1:
+            ops.conv_igemm(nhwc(dy, dtype), wk, gx, stride=1, pad=pad, flip=1)
+        else:
+            ops.conv_igemm(nhwc(dy, dtype), wk, gx, stride=2, pad=pad, mode=1)
+    assert torch.allclose(to_nchw(gx), x.grad, **tol(dtype))
+    # accumulate form: res aliases out
+    if deconv:
+        ops.conv_igemm(nhwc(dy, dtype), wk, gx, stride=2, pad=1, res=gx)
+    elif stride == 1:
+        ops.conv_igemm(nhwc(dy, dtype), wk, gx, stride=1, pad=pad, flip=1, res=gx)
+    else:
+        ops.conv_igemm(nhwc(dy, dtype), wk, gx, stride=2, pad=pad, mode=1, res=gx)
+    t = tol(dtype)
+    assert torch.allclose(to_nchw(gx), 2 * x.grad, rtol=2 * t['rtol'], atol=2 * t['atol'])
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('cin,cout,k,stride,hw,n', [(64, 64, 3, 1, 12, 2), (64, 128, 1, 1, 9, 3), (128, 64, 3, 2, 16, 2),
+                                                    (32, 32, 3, 1, 24, 2), (256, 128, 3, 1, 8, 4), (64, 32, 4, 2, 10, 2)])
+def test_weight_gradient(dtype, cin, cout, k, stride, hw, n):
+    from mapping_challenge_amd import ops
+    if k == 4:           # ConvTranspose2d: dW[cin][kh][kw][cout]
+        x = rnd((n, cin, hw, hw), dtype, 1)
+        wt = rnd((cin, cout, 4, 4), dtype, 2, 0.05).requires_grad_(True)
+        y = F.conv_transpose2d(x, wt, stride=2, padding=1)
+        dy = rnd(tuple(y.shape), dtype, 3)
+        y.backward(dy)
+        dw = torch.zeros((cin, 4, 4, cout), dtype=torch.float32, device='cuda')
+        ops.conv_wgrad(nhwc(x, dtype), nhwc(dy, dtype), dw, 4, 4, stride=2, pad=1)
+        ref = wt.grad.permute(0, 2, 3, 1)
+    else:
+        pad = k // 2
+        x = rnd((n, cin, hw, hw), dtype, 1)
+        w = rnd((cout, cin, k, k), dtype, 2, 0.05).requires_grad_(True)
+        y = F.conv2d(x, w, stride=stride, padding=pad)
+        dy = rnd(tuple(y.shape), dtype, 3)
+        y.backward(dy)
+        dw = torch.zeros((cout, k, k, cin), dtype=torch.float32, device='cuda')
+        ops.conv_wgrad(nhwc(dy, dtype), nhwc(x, dtype), dw, k, k, stride=stride, pad=pad)
+        ref = w.grad.permute(0, 2, 3, 1)
+    scale = ref.abs().max().item()
+    assert (dw.cpu() - ref).abs().max().item() / scale < (2e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize('dtype', DT)
+def test_maxpool_forward_backward(dtype):
+    from mapping_challenge_amd import ops
+    x = rnd((2, 64, 12, 16), dtype, 1).requires_grad_(True)
+    y = F.max_pool2d(x, 2, 2)
+    dy = rnd(tuple(y.shape), dtype, 2)
+    y.backward(dy)
+    xd = nhwc(x.detach(), dtype)
+    assert torch.equal(to_nchw(ops.maxpool2_fwd(xd)), y.detach())
+    assert torch.equal(to_nchw(ops.maxpool2_bwd(nhwc(dy, dtype), xd)), x.grad)
+
+
+def test_adam_matches_torch_optim():
+    from mapping_challenge_amd import ops
+    torch.manual_seed(0)
+    p0 = torch.randn(10007)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pr], lr=5e-4, weight_decay=1e-4)
+    n = (10007 + 3) // 4 * 4
+    p = torch.zeros(n, device='cuda'); p[:10007] = p0.cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 6):
+        g = torch.randn(10007)
+        pr.grad = g.clone()
+        opt.step()
+        gd = torch.zeros(n, device='cuda'); gd[:10007] = g.cuda()
+        ops.adam_step(p, gd, m, v, 5e-4, 0.9, 0.999, 1e-8, 1e-4, step)
+        assert torch.allclose(p[:10007].cpu(), pr.data, atol=1e-6)
+
+
+def test_loss_kernels_match_oracle_and_golden(golden_dir):
+    import os
+    from mapping_challenge_amd.trainer import LossSpec, loss_forward_backward
+    from oracle import losses_ref
+    g = np.load(os.path.join(golden_dir, 'loss.npz'))
+    rng = np.random.default_rng(1234)
+    logits = torch.from_numpy(rng.standard_normal((2, 2, 64, 64)).astype(np.float32) * 3)
+    tgt = losses_ref.synthetic_target(2, 64, 64, seed=7)
+    arch = {'weighted_cross_entropy': {'w0': 50, 'sigma': 10, 'imsize': (256, 256)},
+            'loss_weights': {'dice_mask': 0.2, 'bce_mask': 1.0}, 'dice': {'smooth': 1, 'dice_activation': 'softmax'}}
+    for name, spec, t in (('ce', LossSpec.plain_ce(), tgt[:, :1].contiguous()), ('mixed', LossSpec.mixed(arch), tgt)):
+        d = torch.empty((2, 2, 64, 64), device='cuda')
+        loss = torch.zeros(1, device='cuda')
+        sums = torch.zeros(4, dtype=torch.float64, device='cuda')
+        loss_forward_backward(logits.cuda(), t.cuda(), spec, d, loss, sums)
+        assert abs(loss.item() - float(g['loss_' + name])) < 2e-5
+        assert np.allclose(d.cpu().numpy(), g['dlogits_' + name], atol=2e-8, rtol=1e-4)

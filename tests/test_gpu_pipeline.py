@@ -1,0 +1,68 @@
+"""GPU: the drop-in boundary -- PIPELINES['unet'] / ['unet_weighted'] built from HIP transformers run
+fit_transform / transform through the Step API on synthetic tiles (config 1 of BASELINE.json, on the GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_ref, losses_ref, post_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def make_config(tmp_path, dtype='fp32', stream=False, dilate=2):
+    unet_cfg = {
+        'architecture_config': {'model_params': {'encoder': 'ResNet34', 'compute_dtype': dtype},
+                                'optimizer_params': {'lr': 5e-4},
+                                'regularizer_params': {'regularize': True, 'weight_decay_conv2d': 1e-4},
+                                'weights_init': {'function': 'he'},
+                                'loss_weights': {'bce_mask': 1.0, 'dice_mask': 0.2},
+                                'weighted_cross_entropy': {'w0': 50, 'sigma': 10, 'imsize': (256, 256)},
+                                'dice': {'smooth': 1, 'dice_activation': 'softmax'}},
+        'training_config': {'epochs': 1},
+        'callbacks_config': {'model_checkpoint': {'filepath': str(tmp_path / 'checkpoints' / 'unet' / 'best.torch')},
+                             'exp_lr_scheduler': {'gamma': 1.0}}}
+    return {'env': {'cache_dirpath': str(tmp_path)}, 'execution': {'stream_mode': stream, 'batch_size_train': 2},
+            'unet': unet_cfg,
+            'postprocessor': {'mask_erosion': {'erode_selem_size': 0}, 'mask_dilation': {'dilate_selem_size': dilate}}}
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_unet_weighted_pipeline_fit_transform(tmp_path, fused):
+    from mapping_challenge_amd.pipelines import PIPELINES
+    cfg = make_config(tmp_path)
+    pipe = PIPELINES['unet_weighted']['train'](cfg, fused_postprocessing=fused)
+    X = unet_ref.synthetic_batch(4, 64, 64)
+    y = losses_ref.synthetic_target(4, 64, 64)
+    data = {'input': {'X': X, 'y': y, 'train_mode': True, 'target_sizes': [(75, 75)] * 4}, 'callback_input': {'meta_valid': None}}
+    # seeded weights instead of ImageNet weights (no network): load before fitting
+    tr = pipe.get_step('unet').transformer
+    tr.model.load_state_dict(unet_ref.seeded_state_dict(tr.model))
+    out = pipe.fit_transform(data)
+    assert len(out['y_pred']) == 4
+    labels, scores = out['y_pred'][0]
+    assert labels.shape == (2, 75, 75) and labels.dtype == np.int32 and len(scores) == 2
+    assert all(len(s) == int(l.max()) for s, l in zip(scores, labels))
+    assert pipe.get_step('unet').transformer_is_cached
+    # inference pipeline loads the transformer the training pipeline saved (module.-prefixed state_dict)
+    sd = torch.load(str(tmp_path / 'transformers' / 'unet'), map_location='cpu')
+    assert all(k.startswith('module.') for k in sd)
+    inf = PIPELINES['unet_weighted']['inference'](cfg, fused_postprocessing=fused)
+    data['input']['train_mode'] = False
+    out2 = inf.transform(data)
+    # post-processing parity: recompute the chain with the oracle from the model's own probabilities
+    probs = inf.get_step('unet').transformer.transform(([[X]], 1))['multichannel_map_prediction']
+    for p, (lab, sc) in zip(probs, out2['y_pred']):
+        r = post_ref.resize_image(p, (75, 75)).astype(np.float32)
+        exp = post_ref.dilate_image(post_ref.label_multilayer_image(post_ref.categorize_multilayer_image(r)), 2)
+        assert (lab == exp).all()
+
+
+def test_stream_mode_yields_per_image_maps(tmp_path):
+    from mapping_challenge_amd.models import PyTorchUNetStream
+    cfg = make_config(tmp_path)['unet']
+    tr = PyTorchUNetStream(**cfg)
+    tr.model.load_state_dict(unet_ref.seeded_state_dict(tr.model))
+    X = unet_ref.synthetic_batch(3, 64, 64)
+    gen = tr.transform(([[X[:2]], [X[2:]]], 2))['multichannel_map_prediction']
+    maps = list(gen)
+    assert len(maps) == 3 and maps[0].shape == (2, 64, 64) and np.allclose(maps[0].sum(0), 1, atol=1e-5)

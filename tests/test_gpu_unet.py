@@ -1,0 +1,164 @@
+"""GPU: the whole network through the HIP engine against the torch-CPU oracle and the golden vectors
+produced by the reference's own UNetResNet.  fp32 mode: logits within 1e-4 (the north star's bound);
+bf16 mode: documented looser bound + mask agreement."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_ref, losses_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def build(depth, dtype, sd=None):
+    from mapping_challenge_amd.unet_models import UNetResNet
+    ref = unet_ref.UNetResNetRef(depth)
+    sd = sd or unet_ref.seeded_state_dict(ref)
+    ref.load_state_dict(sd)
+    net = UNetResNet(depth, 2, num_filters=32, dropout_2d=0.0, pretrained=True, is_deconv=True, compute_dtype=dtype)
+    net.load_state_dict(sd)
+    net.flatten_parameters('cuda')
+    return ref, net
+
+
+@pytest.mark.parametrize('depth', [34, 101])
+def test_eval_logits_fp32_within_1e4_of_reference_golden(golden_dir, depth):
+    g = np.load(os.path.join(golden_dir, 'unet_r%d_64.npz' % depth))
+    ref, net = build(depth, 'fp32')
+    n = g['logits_eval'].shape[0]
+    x = unet_ref.synthetic_batch(n, 64, 64)
+    net.eval()
+    with torch.no_grad():
+        y = net(x.cuda()).cpu().numpy()
+    assert y.shape == g['logits_eval'].shape
+    assert np.abs(y - g['logits_eval']).max() < 1e-4
+
+
+@pytest.mark.parametrize('depth,hw,n', [(34, 128, 3), (101, 128, 2), (152, 64, 2), (34, 256, 2)])
+def test_eval_logits_fp32_vs_oracle(depth, hw, n):
+    ref, net = build(depth, 'fp32')
+    x = unet_ref.synthetic_batch(n, hw, hw, seed=5)
+    ref.eval(); net.eval()
+    with torch.no_grad():
+        yr = ref(x)
+        yh = net(x.cuda()).cpu()
+        ph = net.predict_proba(x.cuda()).cpu()
+    assert (yr - yh).abs().max().item() < 1e-4
+    assert (torch.softmax(yr, 1) - ph).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize('depth', [34, 101])
+def test_eval_bf16_close_and_masks_agree(depth):
+    ref, net = build(depth, 'bf16')
+    x = unet_ref.synthetic_batch(2, 128, 128, seed=6)
+    ref.eval()
+    with torch.no_grad():
+        yr = ref(x)
+    ph = net.predict_proba(x.cuda()).cpu()
+    pr = torch.softmax(yr, 1)
+    # bf16 storage of every activation (8 mantissa bits) through 35-100+ layers: tolerance on probabilities 0.1
+    # absolute, and >= 97% of thresholded mask pixels identical
+    assert (pr - ph).abs().max().item() < 0.15
+    assert ((pr[:, 1] > 0.5) == (ph[:, 1] > 0.5)).float().mean().item() > 0.97
+
+
+@pytest.mark.parametrize('depth', [34, 101])
+def test_train_step_fp32_matches_reference_golden(golden_dir, depth):
+    """forward (batch-stat BN) + mixed loss + backward: loss, selected gradients and BN running stats against
+    the reference's own modules (golden), all gradients against the oracle"""
+    from mapping_challenge_amd.trainer import LossSpec, loss_forward_backward
+    g = np.load(os.path.join(golden_dir, 'unet_r%d_64.npz' % depth))
+    ref, net = build(depth, 'fp32')
+    n = g['logits_train'].shape[0]
+    x = unet_ref.synthetic_batch(n, 64, 64)
+    tgt = losses_ref.synthetic_target(n, 64, 64)
+    net.train()
+    prog = net.train_forward(x.cuda())
+    assert np.abs(prog.logits.cpu().numpy() - g['logits_train']).max() < 2e-4
+    arch = {'weighted_cross_entropy': {'w0': 50, 'sigma': 10, 'imsize': (256, 256)},
+            'loss_weights': {'dice_mask': 0.2, 'bce_mask': 1.0}, 'dice': {'smooth': 1, 'dice_activation': 'softmax'}}
+    loss = torch.zeros(1, device='cuda')
+    sums = torch.zeros(4, dtype=torch.float64, device='cuda')
+    loss_forward_backward(prog.logits, tgt.cuda(), LossSpec.mixed(arch), prog.dlogits, loss, sums)
+    net.train_backward(prog)
+    assert abs(loss.item() - float(g['loss'])) < 1e-4
+    grads = {n_: gv.cpu() for (n_, _), gv in zip(net._trainable(), net._grad_views())}
+
+    def close(a, b, rel=2e-3):
+        return (a - torch.from_numpy(b)).abs().max().item() <= rel * (np.abs(b).max() + 1e-12)
+    assert close(grads['final.weight'], g['g_final_w']) and close(grads['final.bias'], g['g_final_b'])
+    assert close(grads['encoder.conv1.weight'][:8], g['g_conv1'])
+    assert close(grads['encoder.bn1.weight'], g['g_bn1_w'])
+    assert close(grads['dec1.block.1.weight'][:4, :4], g['g_dec1_deconv'])
+    assert close(grads['center.block.0.conv.bias'], g['g_center_conv_b'])
+    assert close(grads['encoder.layer2.0.conv1.weight'][:4, :8], g['g_l2_conv1'])
+    assert np.allclose(net.encoder.bn1.running_mean.cpu().numpy(), g['rm_bn1'], atol=1e-5)
+    assert np.allclose(net.encoder.bn1.running_var.cpu().numpy(), g['rv_bn1'], atol=1e-5)
+    # every gradient against the oracle
+    ref.train()
+    lr = losses_ref.mixed_dice_ce(ref(x), tgt)
+    lr.backward()
+    for n_, p in ref.named_parameters():
+        if n_ in grads and p.grad is not None:
+            assert close(grads[n_], p.grad.numpy(), rel=5e-3), n_
+
+
+def test_autograd_node_drives_reference_style_loop():
+    """loss.backward(); optimizer.step() exactly as src/steps/pytorch/models.py:104-111 does, with torch's Adam"""
+    ref, net = build(34, 'fp32')
+    x = unet_ref.synthetic_batch(2, 64, 64)
+    tgt = losses_ref.synthetic_target(2, 64, 64)
+    net.train(); ref.train()
+    opt_h = torch.optim.Adam([p for _, p in net._trainable()], lr=5e-4, weight_decay=1e-4)
+    opt_r = torch.optim.Adam([p for n_, p in ref.named_parameters() if not n_.startswith('encoder.fc')], lr=5e-4, weight_decay=1e-4)
+    for _ in range(2):
+        opt_h.zero_grad(); opt_r.zero_grad()
+        lh = losses_ref.mixed_dice_ce(net(x.cuda()), tgt.cuda())
+        lh.backward(); opt_h.step(); net.weights_changed()
+        lr = losses_ref.mixed_dice_ce(ref(x), tgt)
+        lr.backward(); opt_r.step()
+        assert abs(lh.item() - lr.item()) < 1e-3
+    a = dict(ref.named_parameters())['dec0.conv.weight']
+    b = dict(net.named_parameters())['dec0.conv.weight'].detach().cpu()
+    assert (a - b).abs().max().item() < 5e-4
+
+
+def test_hip_train_loop_graph_equals_eager_and_tracks_oracle():
+    from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
+    arch = {'weighted_cross_entropy': {'w0': 50, 'sigma': 10, 'imsize': (256, 256)},
+            'loss_weights': {'dice_mask': 0.2, 'bce_mask': 1.0}, 'dice': {'smooth': 1, 'dice_activation': 'softmax'}}
+    x = unet_ref.synthetic_batch(2, 64, 64).cuda()
+    tgt = losses_ref.synthetic_target(2, 64, 64).cuda()
+    out = {}
+    for mode in ('eager', 'graph'):
+        ref, net = build(34, 'fp32')
+        net.train()
+        step = TrainStep(net, LossSpec.mixed(arch), HipAdam(net, lr=5e-4, weight_decay=1e-4), use_graph=(mode == 'graph'))
+        losses = [step(x, tgt).item() for _ in range(4)]
+        out[mode] = (losses, net.flat_params.clone())
+    assert np.allclose(out['eager'][0], out['graph'][0], rtol=1e-4)
+    assert (out['eager'][1] - out['graph'][1]).abs().max().item() < 1e-4
+    # oracle: same 4 steps with torch Adam
+    ref.train()
+    opt = torch.optim.Adam([p for n_, p in ref.named_parameters() if not n_.startswith('encoder.fc')], lr=5e-4, weight_decay=1e-4)
+    ref_losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        l = losses_ref.mixed_dice_ce(ref(x.cpu()), tgt.cpu())
+        l.backward(); opt.step()
+        ref_losses.append(l.item())
+    assert np.allclose(out['eager'][0], ref_losses, rtol=5e-3)
+    assert out['eager'][0][-1] < out['eager'][0][0]
+
+
+def test_bf16_train_step_runs_and_reduces_loss():
+    from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
+    ref, net = build(34, 'bf16')
+    net.train()
+    step = TrainStep(net, LossSpec.plain_ce(), HipAdam(net, lr=1e-3))
+    x = unet_ref.synthetic_batch(4, 64, 64).cuda()
+    tgt = losses_ref.synthetic_target(4, 64, 64)[:, :1].contiguous().cuda()
+    losses = [step(x, tgt).item() for _ in range(8)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]

@@ -1,0 +1,183 @@
+"""CPU: the oracle against (a) the reference's own code run through shims (only where /root/reference
+exists), (b) the committed golden vectors (everywhere), (c) the one known-answer test the reference
+holds (label_multiclass_image docstring, src/postprocessing.py:96-111)."""
+import os
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_import, unet_ref, post_ref, losses_ref, crf_ref
+
+needs_ref = pytest.mark.skipif(not ref_import.available(), reason='/root/reference not present')
+
+KAT_IN = np.array([[0, 0, 1, 1], [1, 0, 0, 0], [1, 1, 1, 0], [0, 0, 1, 0]])
+KAT_OUT = np.array([[[1, 1, 0, 0], [0, 1, 1, 1], [0, 0, 0, 1], [2, 2, 0, 1]],
+                    [[0, 0, 1, 1], [2, 0, 0, 0], [2, 2, 2, 0], [0, 0, 2, 0]]])
+
+
+def test_label_docstring_known_answer():
+    assert (post_ref.label_multiclass_image(KAT_IN) == KAT_OUT).all()
+    for c in range(2):
+        assert (post_ref.label_unionfind(KAT_IN == c) == KAT_OUT[c]).all()
+
+
+def test_unionfind_matches_scipy_on_adversarial_masks():
+    rng = np.random.default_rng(0)
+    masks = [rng.random((23, 31)) > t for t in (0.3, 0.5, 0.7)]
+    masks += [np.indices((16, 16)).sum(0) % 2 == 0, np.ones((9, 9), bool), np.zeros((9, 9), bool)]
+    for m in masks:
+        assert (post_ref.label_unionfind(m) == post_ref.label(m)).all()
+
+
+def test_post_chain_matches_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'post.npz'))
+    assert (post_ref.label_multiclass_image(KAT_IN) == g['kat_multiclass']).all()
+    probs = post_ref.synthetic_probs(3, 64, 64, seed=1234, smooth=2.0)
+    for i, p in enumerate(probs):
+        r = post_ref.resize_image(p, (75, 75))
+        assert np.allclose(r, g['resized_%d' % i], atol=1e-6)
+        lay = post_ref.categorize_multilayer_image(r)
+        assert (lay == g['layers_%d' % i]).all()
+        lab = post_ref.label_multilayer_image(lay)
+        assert (lab == g['labels_%d' % i]).all() and lab.dtype == np.int32
+        assert (post_ref.dilate_image(lab, 2) == g['dilated2_%d' % i]).all()
+        assert (post_ref.dilate_image(lab, 3) == g['dilated3_%d' % i]).all()
+        assert (post_ref.erode_image(lay[1], 3) == g['eroded3_%d' % i]).all()
+        _, sc = post_ref.build_score(post_ref.dilate_image(lab, 2), r)
+        assert np.allclose(sc[0], g['scores0_%d' % i], rtol=1e-12) and np.allclose(sc[1], g['scores1_%d' % i], rtol=1e-12)
+
+
+def test_unet_oracle_matches_golden(golden_dir):
+    for depth, n in ((34, 2), (101, 1)):
+        g = np.load(os.path.join(golden_dir, 'unet_r%d_64.npz' % depth))
+        net = unet_ref.UNetResNetRef(depth)
+        net.load_state_dict(unet_ref.seeded_state_dict(net))
+        x = unet_ref.synthetic_batch(n, 64, 64)
+        net.eval()
+        with torch.no_grad():
+            assert np.allclose(net(x).numpy(), g['logits_eval'], atol=2e-5)
+        net.train()
+        out = net(x)
+        loss = losses_ref.mixed_dice_ce(out, losses_ref.synthetic_target(n, 64, 64))
+        loss.backward()
+        assert abs(loss.item() - float(g['loss'])) < 1e-5
+        assert np.allclose(net.final.weight.grad.numpy(), g['g_final_w'], rtol=1e-4, atol=1e-6)
+        assert np.allclose(net.encoder.conv1.weight.grad.numpy()[:8], g['g_conv1'], rtol=1e-3, atol=1e-6)
+
+
+def test_loss_oracle_matches_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'loss.npz'))
+    rng = np.random.default_rng(1234)
+    logits = torch.from_numpy(rng.standard_normal((2, 2, 64, 64)).astype(np.float32) * 3).requires_grad_(True)
+    tgt = losses_ref.synthetic_target(2, 64, 64, seed=7)
+    loss = losses_ref.segmentation_ce(logits, tgt[:, :1])
+    loss.backward()
+    assert abs(loss.item() - float(g['loss_ce'])) < 1e-6 and np.allclose(logits.grad.numpy(), g['dlogits_ce'], atol=1e-8)
+    logits.grad = None
+    loss = losses_ref.mixed_dice_ce(logits, tgt)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss_mixed'])) < 1e-5 and np.allclose(logits.grad.numpy(), g['dlogits_mixed'], atol=1e-7)
+
+
+def test_adam_oracle_matches_torch_optim():
+    torch.manual_seed(0)
+    p0 = torch.randn(1000)
+    p_ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([p_ref], lr=5e-4, weight_decay=1e-4)
+    p, m, v = p0.clone(), torch.zeros(1000), torch.zeros(1000)
+    for step in range(1, 4):
+        g = torch.randn(1000)
+        p_ref.grad = g.clone()
+        opt.step()
+        losses_ref.adam_l2_step(p, g, m, v, step)
+        assert torch.allclose(p, p_ref.data, atol=1e-7)
+
+
+def test_crf_oracle_properties():
+    rng = np.random.default_rng(0)
+    probs = post_ref.synthetic_probs(1, 24, 24, seed=3, smooth=2.0)[0]
+    img = rng.standard_normal((3, 24, 24)).astype(np.float32)
+    q = crf_ref.dense_crf(img, probs, post_ref_mean(), post_ref_std(), iterations=2)
+    assert q.shape == probs.shape and np.allclose(q.sum(0), 1, atol=1e-5) and (q >= 0).all()
+    q0 = crf_ref.dense_crf(img, probs, post_ref_mean(), post_ref_std(), iterations=0)
+    assert np.allclose(q0, np.clip(probs, 1e-5, 1) / np.clip(probs, 1e-5, 1).sum(0), atol=1e-5)
+
+
+def post_ref_mean():
+    return [0.485, 0.456, 0.406]
+
+
+def post_ref_std():
+    return [0.229, 0.224, 0.225]
+
+
+# ---------------------------------------------------------------- against the literal reference code
+@needs_ref
+def test_oracle_unet_equals_reference_class():
+    um = ref_import.ref('unet_models')
+    for depth in (34, 101):
+        a = um.UNetResNet(depth, 2, num_filters=32, dropout_2d=0.0, pretrained=True, is_deconv=True)
+        b = unet_ref.UNetResNetRef(depth)
+        assert set(a.state_dict()) == set(b.state_dict())
+        sd = unet_ref.seeded_state_dict(a)
+        a.load_state_dict(sd)
+        b.load_state_dict(sd)
+        x = unet_ref.synthetic_batch(1, 64, 64)
+        for mode in ('eval', 'train'):
+            getattr(a, mode)()
+            getattr(b, mode)()
+            with torch.no_grad():
+                assert torch.equal(a(x), b(x))
+
+
+@needs_ref
+def test_oracle_post_equals_reference_functions():
+    pp = ref_import.ref('postprocessing')
+    ru = ref_import.ref('utils')
+    probs = post_ref.synthetic_probs(2, 96, 96, seed=5, smooth=3.0)
+    for p in probs:
+        a, b = pp.resize_image(p, (112, 112)), post_ref.resize_image(p, (112, 112))
+        assert np.allclose(a, b, atol=1e-12)
+        la, lb = pp.categorize_multilayer_image(a), post_ref.categorize_multilayer_image(b)
+        assert (la == lb).all()
+        lab = pp.label_multilayer_image(la)
+        assert (lab == post_ref.label_multilayer_image(lb)).all()
+        for k in (1, 2, 3, 4, 5):
+            assert (pp.dilate_image(lab, k) == post_ref.dilate_image(lab, k)).all()
+            assert (pp.erode_image(la[1], k) == post_ref.erode_image(lb[1], k)).all()
+        sa, sb = pp.build_score(lab, a), post_ref.build_score(lab, b)
+        assert all(np.allclose(x, y, rtol=1e-12) for x, y in zip(sa[1], sb[1]))
+        assert (pp.crop_image_center_per_class(a, 100, 100) == post_ref.crop_image_center_per_class(a, 100, 100)).all()
+        assert np.allclose(ru.softmax(p, axis=0), post_ref.softmax(p, axis=0))
+        assert (pp.categorize_image(p) == post_ref.categorize_image(p)).all()
+
+
+@needs_ref
+def test_oracle_losses_equal_reference_functions():
+    rm = ref_import.ref('models')
+    val = ref_import.ref('steps.pytorch.validation')
+    torch.manual_seed(0)
+    out = torch.randn(2, 2, 48, 48) * 2
+    t = losses_ref.synthetic_target(2, 48, 48, seed=3)
+    wf = partial(rm.get_weights, w0=50, sigma=10, imsize=(256, 256))
+    assert torch.allclose(rm.multiclass_weighted_cross_entropy(out, t, weights_function=wf),
+                          losses_ref.weighted_ce(out, t, 50, 10, (256, 256)), rtol=1e-6)
+    mix = rm.mixed_dice_cross_entropy_loss(out, t, dice_weight=0.2, cross_entropy_weight=1.0,
+                                           dice_loss=partial(rm.multiclass_dice_loss, excluded_classes=[0]),
+                                           cross_entropy_loss=partial(rm.multiclass_weighted_cross_entropy, weights_function=wf),
+                                           smooth=1, dice_activation='softmax')
+    assert torch.allclose(mix, losses_ref.mixed_dice_ce(out, t), rtol=1e-6)
+    assert torch.allclose(val.multiclass_segmentation_loss(out, t[:, :1]), losses_ref.segmentation_ce(out, t[:, :1]))
+
+
+@needs_ref
+def test_reference_dense_crf_runs_on_oracle_shim():
+    pp = ref_import.ref('postprocessing')
+    rng = np.random.default_rng(1)
+    probs = post_ref.synthetic_probs(1, 20, 20, seed=2, smooth=2.0)[0]
+    img = rng.standard_normal((3, 20, 20)).astype(np.float32)
+    a = pp.dense_crf(img, probs, iterations=3)
+    b = crf_ref.dense_crf(img, probs, post_ref_mean(), post_ref_std(), iterations=3)
+    assert np.allclose(a, b, atol=1e-6)
