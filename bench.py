@@ -1,0 +1,253 @@
+"""Benchmark of the U-Net hot path on MI355X (contract: see the task statement / DESIGN.md section 5).
+
+    python bench.py --gpus N --steps K --warmup W [--workload train|infer|post] [--encoder 101] [--dtype bf16]
+
+One "step" = one pass of the hot path over one synthetic batch resident in HBM:
+  train (default, BASELINE.json metric / configs[2]): ResNet101-U-Net forward + mixed weighted-CE/Dice loss + backward +
+        Adam(+L2), batch 32 per GPU, 300x300 tiles resized to the 256x256 network input (the reference's default
+        loader_mode, neptune.yaml:23,27-28), bf16 compute / fp32 accumulate & master weights
+  infer (configs[1]): ResNet34-U-Net eval forward + fused softmax, batch 32
+  post  (configs[3]): resize 256->300, threshold, 4-connected labelling, 2x2 label dilation, scoring, batch 64 masks
+N > 1: launched by torch.distributed.run, one rank per GPU, batch sharded (weak scaling), loss sums and gradients
+all-reduced over RCCL.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# forward GFLOP/img (2 x MACs of Conv2d + ConvTranspose2d), train = 3x
+PEAK_BF16, PEAK_F32, PEAK_HBM = 2.5e15, 157.3e12, 8.0e12
+ARCH = {'weighted_cross_entropy': {'w0': 50, 'sigma': 10, 'imsize': (256, 256)},
+        'loss_weights': {'dice_mask': 0.2, 'bce_mask': 1.0}, 'dice': {'smooth': 1, 'dice_activation': 'softmax'}}
+
+
+def conv_flops(d):
+    """algorithmic FLOPs (2 x MACs) of one msc_conv_igemm launch"""
+    macs = d.N * d.Ho * d.Wo * d.Cout * d.Cin * d.KH * d.KW
+    if d.mode == 1:
+        macs /= 4.0          # each output parity phase uses a quarter of the taps
+    return 2.0 * macs
+
+
+def wgrad_flops(d):
+    return 2.0 * d.N * d.Hp * d.Wp * d.A * d.B * d.KH * d.KW
+
+
+def family_times(launches, stream, repeats=2):
+    """HIP-event time per kernel family over a launch list, on the stream the kernels run on."""
+    fam = {}
+    for _ in range(repeats):
+        evs = []
+        for fn, args in launches:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = fn(*args, stream)
+            assert rc == 0, fn.__name__
+            b.record()
+            evs.append((fn.__name__, args, a, b))
+        torch.cuda.synchronize()
+        for name, args, a, b in evs:
+            f = fam.setdefault(name, {'ms': 0.0, 'launches': 0, 'flops': 0.0})
+            f['ms'] += a.elapsed_time(b) / repeats
+            f['launches'] += 1.0 / repeats
+            if name == 'msc_conv_igemm':
+                f['flops'] += conv_flops(args[0]._obj) / repeats
+            elif name == 'msc_conv_wgrad':
+                f['flops'] += wgrad_flops(args[0]._obj) / repeats
+    return fam
+
+
+def cpu_baseline_train(encoder, hw, budget_s=25.0):
+    """The oracle (torch-CPU fp32 restatement of the reference modules + losses + torch Adam) timed on the host
+    cores on a bounded sample of the same workload: batch 2, as many steps as fit the budget (>= 1)."""
+    from oracle import losses_ref, unet_ref
+    torch.set_num_threads(os.cpu_count())
+    net = unet_ref.UNetResNetRef(encoder)
+    net.load_state_dict(unet_ref.seeded_state_dict(net))
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4, weight_decay=1e-4)
+    n = 2
+    x, t = unet_ref.synthetic_batch(n, hw, hw), losses_ref.synthetic_target(n, hw, hw)
+
+    def step():
+        opt.zero_grad()
+        losses_ref.mixed_dice_ce(net(x), t).backward()
+        opt.step()
+    step()
+    t0, k = time.time(), 0
+    while k < 1 or (time.time() - t0) < budget_s and k < 8:
+        step()
+        k += 1
+    dt = time.time() - t0
+    return {'value': n * k / dt, 'unit': 'img/s', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': 'oracle UNetResNetRef(%d) fp32 torch-CPU train step (fwd+mixed loss+bwd+Adam), batch %d at %dx%d, %d steps'
+                      % (encoder, n, hw, hw, k)}
+
+
+def cpu_baseline_infer(encoder, hw, budget_s=20.0):
+    from oracle import unet_ref
+    torch.set_num_threads(os.cpu_count())
+    net = unet_ref.UNetResNetRef(encoder)
+    net.load_state_dict(unet_ref.seeded_state_dict(net))
+    net.eval()
+    n = 4
+    x = unet_ref.synthetic_batch(n, hw, hw)
+    with torch.no_grad():
+        net(x)
+        t0, k = time.time(), 0
+        while k < 1 or (time.time() - t0) < budget_s and k < 10:
+            torch.softmax(net(x), 1)
+            k += 1
+    dt = time.time() - t0
+    return {'value': n * k / dt, 'unit': 'img/s', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': 'oracle UNetResNetRef(%d) fp32 torch-CPU eval forward + softmax, batch %d at %dx%d, %d passes' % (encoder, n, hw, hw, k)}
+
+
+def cpu_baseline_post(probs, target, dilate, budget_s=15.0):
+    from oracle import post_ref
+    t0, k = time.time(), 0
+    for p in probs:
+        post_ref.postprocess(p, target, 0, dilate)
+        k += 1
+        if time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    return {'value': k / dt, 'unit': 'img/s', 'cores': 1, 'kind': 'port',
+            'sample': 'oracle post_ref.postprocess (numpy/scipy, single thread as the reference runs it) on %d masks' % k}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='train', choices=['train', 'infer', 'post'])
+    ap.add_argument('--encoder', type=int, default=None)
+    ap.add_argument('--batch', type=int, default=None)
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-breakdown', action='store_true')
+    args = ap.parse_args()
+
+    from mapping_challenge_amd.distributed import World
+    world = World.from_env()
+    if args.gpus != world.size:
+        raise SystemExit('--gpus %d but WORLD_SIZE is %d (launch N>1 with torch.distributed.run)' % (args.gpus, world.size))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    hw = args.size
+    result = {'n_gpus': world.size, 'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True, 'scaling': 'weak',
+              'vs_baseline': None, 'data': 'synthetic', 'dtype': args.dtype}
+
+    def timed(step_fn):
+        for _ in range(args.warmup):
+            step_fn()
+        world.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn()
+        torch.cuda.synchronize()
+        world.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world.size > 1:
+            import torch.distributed as dist
+            world.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return float(dt.item())
+
+    if args.workload in ('train', 'infer'):
+        from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
+        from mapping_challenge_amd.unet_models import UNetResNet
+        from oracle import losses_ref, unet_ref     # synthetic data / seeded weights only (inputs, not the product path)
+        enc = args.encoder or (101 if args.workload == 'train' else 34)
+        batch = args.batch or 32
+        net = UNetResNet(enc, 2, num_filters=32, dropout_2d=0.0, is_deconv=True, compute_dtype=args.dtype)
+        net.load_state_dict(unet_ref.seeded_state_dict(net))
+        net.flatten_parameters(dev)
+        world.sync_model(net)
+        x = unet_ref.synthetic_batch(batch, hw, hw, seed=1234 + world.rank).to(dev)
+        fwd_gf = None
+        if args.workload == 'train':
+            tgt = losses_ref.synthetic_target(min(batch, 4), hw, hw, seed=world.rank)
+            tgt = tgt.repeat((batch + tgt.shape[0] - 1) // tgt.shape[0], 1, 1, 1)[:batch].contiguous().to(dev)
+            net.train()
+            step = TrainStep(net, LossSpec.mixed(ARCH), HipAdam(net, lr=5e-4, weight_decay=1e-4), world=world,
+                             use_graph=not args.no_graph)
+            dt = timed(lambda: step(x, tgt))
+            prog = step.prog
+            loss = float(step.loss.item())
+            result.update(metric='images/sec (train fwd+bwd) ResNet%d-U-Net' % enc, unit='img/s',
+                          config={'workload': 'ResNet%d-U-Net train step (fwd + weighted-CE/Dice loss + bwd + Adam+L2), batch %d/GPU, '
+                                              '300x300 tiles as %dx%d network input (reference loader_mode resize), bf16 compute, '
+                                              'fp32 master weights; random-init seeded weights' % (enc, batch, hw, hw),
+                                  'global_batch': batch * world.size, 'parallelism': 'dp%d' % world.size, 'hipgraph': step.graph is not None,
+                                  'final_loss': loss})
+        else:
+            net.eval()
+            dt = timed(lambda: net.predict_proba(x))
+            prog = net._program(batch, hw, hw, False, dev)
+            result.update(metric='images/sec (inference forward) ResNet%d-U-Net' % enc, unit='img/s',
+                          config={'workload': 'ResNet%d-U-Net eval forward + fused softmax, batch %d, %dx%d network input' % (enc, batch, hw, hw),
+                                  'global_batch': batch * world.size, 'parallelism': 'dp%d' % world.size})
+        value = batch * world.size * args.steps / dt
+        result.update(value=value, ms_per_step=1e3 * dt / args.steps)
+        if world.rank == 0 and not args.no_breakdown:
+            launches = list(prog.fwd) + (list(prog.bwd) if args.workload == 'train' else [])
+            if args.workload == 'train':
+                net._flat[1].zero_()
+            fam = family_times(launches, stream)
+            conv = fam.get('msc_conv_igemm', {'ms': 0, 'launches': 0, 'flops': 0})
+            wg = fam.get('msc_conv_wgrad', {'ms': 0, 'launches': 0, 'flops': 0})
+            total_ms = sum(f['ms'] for f in fam.values())
+            dom = max(fam.items(), key=lambda kv: kv[1]['ms'])
+            peak = PEAK_BF16 if args.dtype == 'bf16' else PEAK_F32
+            ach = conv['flops'] / (conv['ms'] * 1e-3) if conv['ms'] else 0.0
+            result['roofline'] = {
+                'kernel': 'conv_igemm_kernel (implicit-GEMM conv / dgrad / deconv, %d launches per step)' % round(conv['launches']),
+                'bound': 'mfma', 'achieved': ach / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+                'avg_launch_us': 1e3 * conv['ms'] / max(conv['launches'], 1),
+                'algorithmic_gflop_per_step': conv['flops'] / 1e9,
+                'wgrad': {'achieved': (wg['flops'] / (wg['ms'] * 1e-3) / 1e12) if wg['ms'] else None, 'ms_per_step': wg['ms'],
+                          'launches': round(wg['launches'])},
+                'dominant_family': dom[0], 'family_ms_per_step': {k: round(v['ms'], 3) for k, v in sorted(fam.items())},
+                'sum_kernel_ms_per_step': total_ms,
+                'whole_step_frac_of_mfma_peak': (conv['flops'] + wg['flops']) * (args.steps / dt) / peak}
+        if world.rank == 0 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline_train(enc, hw) if args.workload == 'train' else cpu_baseline_infer(enc, hw)
+    else:
+        from mapping_challenge_amd import postprocessing as post
+        from oracle import post_ref
+        batch = args.batch or 64
+        probs_h = post_ref.synthetic_probs(batch, 256, 256, seed=1234 + world.rank)
+        probs = torch.from_numpy(probs_h).to(dev)
+        dt = timed(lambda: post.postprocess_batch(probs, (300, 300), 0, 2))
+        value = batch * world.size * args.steps / dt
+        bytes_per_img = 3.4e6
+        result.update(metric='post-processing images/sec (resize 256->300, threshold, label, dilate k=2, score)', unit='img/s',
+                      value=value, ms_per_step=1e3 * dt / args.steps, dtype='u8/i32/f32',
+                      config={'workload': 'mask post-processing of %d 256x256 2-class probability maps per step' % batch,
+                              'ms_per_img': 1e3 / value * world.size},
+                      roofline={'bound': 'hbm', 'achieved': value * bytes_per_img / 1e9 / world.size, 'peak': PEAK_HBM / 1e9, 'unit': 'GB/s',
+                                'frac': value * bytes_per_img / world.size / PEAK_HBM, 'traffic': None,
+                                'note': 'whole chain incl. the final D2H of labels; latency/launch bound'})
+        if world.rank == 0 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline_post(probs_h, (300, 300), 2)
+    if world.rank == 0:
+        print(json.dumps(result))
+    world.barrier()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,19 @@
+#!/bin/bash
+# One GPU-box session: probes, parity tests, smoke, bench.  Logs go to gpurun_out/.
+cd "${GRAFT_REPO_ROOT:-.}"
+mkdir -p gpurun_out
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+STAGES="${1:-probe tests smoke bench}"
+for s in $STAGES; do
+case $s in
+probe) timeout 60 ./probes/tr_probe > gpurun_out/tr_probe.txt 2>&1; echo "probe rc=$?";;
+tests) timeout 1500 python -m pytest tests -m gpu -q -rf --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -40 gpurun_out/pytest_gpu.log;;
+smoke) timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -5 gpurun_out/smoke.log;;
+bench) timeout 900 python bench.py --workload infer --steps 10 --warmup 3 > gpurun_out/bench_infer.log 2>&1; echo "bench infer rc=$?"; tail -3 gpurun_out/bench_infer.log
+       timeout 900 python bench.py --workload post --steps 10 --warmup 3 > gpurun_out/bench_post.log 2>&1; echo "bench post rc=$?"; tail -3 gpurun_out/bench_post.log
+       timeout 1200 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_train.log 2>&1; echo "bench train rc=$?"; tail -3 gpurun_out/bench_train.log;;
+prof)  cd /tmp; export TMPDIR=/tmp
+       timeout 1200 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_train" -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_train.log" 2>&1; echo "prof rc=$?"
+       cd "$GRAFT_REPO_ROOT";;
+esac
+done
