@@ -38,7 +38,7 @@ int msc_abi_version(void);
  * mode 1 (transposed):  out[q] = sum_{t:(q+pad-t) even} in[(q+pad-t)/2] * W[.][t][.]   (stride must be 2)
  * epilogue: v = acc*scale[c] + shift[c] (+ res) ; ReLU ; store.  scale/shift/res may be NULL.
  * stats (mode 0 only, may be NULL): per-channel partial sum / sum of squares of the raw accumulators,
- *   [msc_conv_stats_slices()][Cout][2] floats, reduced by msc_bn_finalize (BatchNorm2d training mode).
+ *   [Cout][msc_conv_stats_slices()][2] floats, reduced by msc_bn_finalize (BatchNorm2d training mode).
  * weights: dtype [Cout][KH][KW][Cin].  Cin*sizeof(dtype) % 64 == 0, Cout % 32 == 0. */
 typedef struct msc_conv_desc {
     const void* in;
@@ -98,7 +98,7 @@ int msc_bn_fold(const float* gamma, const float* beta, const float* running_mean
 int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_t res_ld, void* out, int64_t out_ld,
                  const float* scale, const float* shift, int relu, int dtype, int64_t pixels, int C, void* stream);
 /* backward of out = relu?(bn(y) (+res)):  dh = dout * [out>0] (if relu);
- * reduce: partial[blk][C][2] = (sum dh, sum dh*y);  finalize: dgamma, dbeta (accumulated into fp32 grads) and
+ * reduce: partial[C][msc_bn_bwd_blocks()][2] = (sum dh, sum dh*y) (deterministic, no atomics);  finalize: dgamma, dbeta (accumulated into fp32 grads) and
  * per-channel coefficients coef[3][C];  apply: dy = coef0*dh + coef1*y + coef2 ; dres (optional) = dh (or += if dres_acc). */
 int msc_bn_bwd_blocks(int64_t pixels, int C);
 int msc_bn_bwd_reduce(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
@@ -112,8 +112,10 @@ int msc_bn_bwd_apply(const void* dout, int64_t dout_ld, const void* out, int64_t
 /* ReLU backward for the decoder (ConvRelu / deconv+ReLU): dx = dy*[y>0], optionally dx += */
 int msc_relu_bwd(const void* dy, int64_t dy_ld, const void* y, int64_t y_ld, void* dx, int64_t dx_ld,
                  int accumulate, int dtype, int64_t pixels, int C, void* stream);
-/* per-channel bias gradient: db[c] += sum_pixels dy[p][c]  (conv bias of ConvRelu / ConvTranspose2d) */
-int msc_bias_grad(const void* dy, int64_t dy_ld, float* db, int dtype, int64_t pixels, int C, void* stream);
+/* per-channel bias gradient: db[c] += sum_pixels dy[p][c]  (conv bias of ConvRelu / ConvTranspose2d);
+ * workspace: msc_bias_grad_workspace_bytes() bytes */
+int64_t msc_bias_grad_workspace_bytes(int64_t pixels, int C);
+int msc_bias_grad(const void* dy, int64_t dy_ld, float* db, void* workspace, int dtype, int64_t pixels, int C, void* stream);
 
 /* final 1x1 conv 32 -> 2 with bias (src/unet_models.py:383,403; dropout p = 0) fused with the channel softmax
  * the reference applies on the host afterwards (src/models.py:88-92, src/utils.py:231-273).

@@ -152,44 +152,7 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ dout, long dout_ld, co
     }
 }
 
-// ------------------------------------------------------------------ BatchNorm (training)
-// one block per 32 channels; 8 slice lanes; partials [slices][C][2]
-__global__ void bn_finalize_kernel(const float* __restrict__ partials, int slices, int C, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
-                                   float* running_mean, float* running_var, float* scale, float* shift,
-                                   float* save_mean, float* save_invstd) {
-    __shared__ double sh1[8][32], sh2[8][32];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C) {
-        for (int s = sl; s < slices; s += 8) {
-            const float2 v = *reinterpret_cast<const float2*>(partials + ((long)s * C + c) * 2);
-            s1 += v.x; s2 += v.y;
-        }
-    }
-    sh1[sl][cl] = s1; sh2[sl][cl] = s2;
-    __syncthreads();
-    if (sl == 0 && c < C) {
-        for (int k = 1; k < 8; ++k) { s1 += sh1[k][cl]; s2 += sh2[k][cl]; }
-        const double mean = s1 / count;
-        double var = s2 / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-        const float sc = g * invstd;
-        scale[c] = sc;
-        shift[c] = b - (float)mean * sc;
-        if (save_mean) save_mean[c] = (float)mean;
-        if (save_invstd) save_invstd[c] = invstd;
-        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-        if (running_var) {
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-        }
-    }
-}
-
+// ------------------------------------------------------------------ BatchNorm (statistics kernels: reduce.hip)
 // eval mode: fold running statistics into the conv epilogue, scale = gamma/sqrt(rv+eps), shift = beta - rm*scale
 __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
                                const float* __restrict__ rv, float eps, float* scale, float* shift, int C) {
@@ -225,92 +188,6 @@ __global__ void bn_apply_kernel(const T* __restrict__ y, long y_ld, const T* __r
             for (int e = 0; e < CE; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         Vec16<T>::store(out + pix * out_ld + c, v);
-    }
-}
-
-// backward reduce: block b handles pixel range; threads = (C/CE lanes along channels) x pixel lanes.
-// partial[b][C][2] = (sum dh, sum dh*y)
-constexpr int BNB_PIX = 2048;  // pixels per block
-template <typename T>
-__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dout, long dout_ld, const T* __restrict__ out, long out_ld,
-                                     const T* __restrict__ y, long y_ld, int relu, float* __restrict__ partials,
-                                     long pixels, int C) {
-    constexpr int CE = Vec16<T>::N;
-    extern __shared__ float red[];  // [rows][C][2] reduced over rows
-    const int cv = C / CE;                       // vectors per pixel
-    const int rows = EW_THREADS / min(cv, EW_THREADS) > 0 ? EW_THREADS / min(cv, EW_THREADS) : 1;
-    const long p0 = (long)blockIdx.x * BNB_PIX;
-    const long p1 = min(pixels, p0 + BNB_PIX);
-    // thread -> (vector column vc, row lane r); when cv > 256 each thread walks several columns
-    for (int vc0 = 0; vc0 < cv; vc0 += EW_THREADS) {
-        const int ncol = min(cv - vc0, EW_THREADS);
-        const int vc = vc0 + (threadIdx.x % ncol);
-        const int r = threadIdx.x / ncol;
-        const int nr = EW_THREADS / ncol;
-        float s1[CE], s2[CE];
-#pragma unroll
-        for (int e = 0; e < CE; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-        if (r < nr) {
-            for (long p = p0 + r; p < p1; p += nr) {
-                float d[CE], o[CE], yy[CE];
-                Vec16<T>::load(dout + p * dout_ld + vc * CE, d);
-                Vec16<T>::load(y + p * y_ld + vc * CE, yy);
-                if (relu) {
-                    Vec16<T>::load(out + p * out_ld + vc * CE, o);
-#pragma unroll
-                    for (int e = 0; e < CE; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
-                }
-#pragma unroll
-                for (int e = 0; e < CE; ++e) { s1[e] += d[e]; s2[e] += d[e] * yy[e]; }
-            }
-        }
-        // reduce over row lanes through LDS
-        float* mine = red + ((long)threadIdx.x) * 2 * CE;
-#pragma unroll
-        for (int e = 0; e < CE; ++e) { mine[2 * e] = s1[e]; mine[2 * e + 1] = s2[e]; }
-        __syncthreads();
-        if (r == 0) {
-            for (int k = 1; k < nr; ++k) {
-                const float* o = red + ((long)(k * ncol + (threadIdx.x % ncol))) * 2 * CE;
-#pragma unroll
-                for (int e = 0; e < CE; ++e) { s1[e] += o[2 * e]; s2[e] += o[2 * e + 1]; }
-            }
-            float* dst = partials + ((long)blockIdx.x * C + vc * CE) * 2;
-#pragma unroll
-            for (int e = 0; e < CE; ++e) { dst[2 * e] = s1[e]; dst[2 * e + 1] = s2[e]; }
-        }
-        __syncthreads();
-    }
-    (void)rows;
-}
-
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int blocks, int C, double count,
-                                       const float* __restrict__ gamma, const float* __restrict__ mean,
-                                       const float* __restrict__ invstd, float* dgamma, float* dbeta, float* coef) {
-    __shared__ double sh1[8][32], sh2[8][32];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C) {
-        for (int s = sl; s < blocks; s += 8) {
-            const float2 v = *reinterpret_cast<const float2*>(partials + ((long)s * C + c) * 2);
-            s1 += v.x; s2 += v.y;
-        }
-    }
-    sh1[sl][cl] = s1; sh2[sl][cl] = s2;
-    __syncthreads();
-    if (sl == 0 && c < C) {
-        for (int k = 1; k < 8; ++k) { s1 += sh1[k][cl]; s2 += sh2[k][cl]; }
-        const double mu = mean[c], is = invstd[c], g = gamma ? gamma[c] : 1.0;
-        const double dbe = s1;                        // sum dh
-        const double dga = is * (s2 - mu * s1);       // sum dh * xhat
-        if (dgamma) dgamma[c] += (float)dga;
-        if (dbeta) dbeta[c] += (float)dbe;
-        // dy = g*is*(dh - dbe/M - xhat*dga/M),  xhat = (y-mu)*is
-        const double a = g * is;
-        const double b = -g * is * is * dga / count;
-        const double k0 = -g * is * dbe / count - b * mu;
-        coef[c] = (float)a; coef[C + c] = (float)b; coef[2 * C + c] = (float)k0;
     }
 }
 
@@ -369,47 +246,6 @@ __global__ void relu_bwd_kernel(const T* __restrict__ dy, long dy_ld, const T* _
             for (int e = 0; e < CE; ++e) d[e] += r[e];
         }
         Vec16<T>::store(dx + pix * dx_ld + c, d);
-    }
-}
-
-// db[c] += sum_p dy[p][c]; same thread layout as bn_bwd_reduce, one atomic per channel per block
-template <typename T>
-__global__ void bias_grad_kernel(const T* __restrict__ dy, long dy_ld, float* __restrict__ db, long pixels, int C) {
-    constexpr int CE = Vec16<T>::N;
-    extern __shared__ float red[];
-    const int cv = C / CE;
-    const long p0 = (long)blockIdx.x * BNB_PIX;
-    const long p1 = min(pixels, p0 + BNB_PIX);
-    for (int vc0 = 0; vc0 < cv; vc0 += EW_THREADS) {
-        const int ncol = min(cv - vc0, EW_THREADS);
-        const int vc = vc0 + (threadIdx.x % ncol);
-        const int r = threadIdx.x / ncol;
-        const int nr = EW_THREADS / ncol;
-        float s1[CE];
-#pragma unroll
-        for (int e = 0; e < CE; ++e) s1[e] = 0.f;
-        if (r < nr) {
-            for (long p = p0 + r; p < p1; p += nr) {
-                float d[CE];
-                Vec16<T>::load(dy + p * dy_ld + vc * CE, d);
-#pragma unroll
-                for (int e = 0; e < CE; ++e) s1[e] += d[e];
-            }
-        }
-        float* mine = red + ((long)threadIdx.x) * CE;
-#pragma unroll
-        for (int e = 0; e < CE; ++e) mine[e] = s1[e];
-        __syncthreads();
-        if (r == 0) {
-            for (int k = 1; k < nr; ++k) {
-                const float* o = red + ((long)(k * ncol + (threadIdx.x % ncol))) * CE;
-#pragma unroll
-                for (int e = 0; e < CE; ++e) s1[e] += o[e];
-            }
-#pragma unroll
-            for (int e = 0; e < CE; ++e) atomicAdd(db + vc * CE + e, s1[e]);
-        }
-        __syncthreads();
     }
 }
 
@@ -623,15 +459,6 @@ extern "C" int msc_maxpool2_bwd(const void* dout, int64_t dout_ld, const void* i
     return msc_check_launch("msc_maxpool2_bwd");
 }
 
-extern "C" int msc_bn_finalize(const float* partials, int slices, int C, int64_t count, const float* gamma, const float* beta,
-                               float eps, float momentum, float* running_mean, float* running_var,
-                               float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
-    if (!partials || !scale || !shift || slices <= 0 || C <= 0 || count <= 0) return msc_fail(MSC_ERR_ARG, "msc_bn_finalize: bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, partials, slices, C, (double)count,
-                       gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
-    return msc_check_launch("msc_bn_finalize");
-}
-
 extern "C" int msc_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                             float eps, float* scale, float* shift, int C, void* stream) {
     if (!running_mean || !running_var || !scale || !shift || C <= 0) return msc_fail(MSC_ERR_ARG, "msc_bn_fold: bad argument");
@@ -649,30 +476,6 @@ extern "C" int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_
     if (dtype == MSC_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)y, (long)y_ld, (const bf16_t*)res, (long)res_ld, (bf16_t*)out, (long)out_ld, scale, shift, relu, (long)pixels, C);
     else hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const float*)y, (long)y_ld, (const float*)res, (long)res_ld, (float*)out, (long)out_ld, scale, shift, relu, (long)pixels, C);
     return msc_check_launch("msc_bn_apply");
-}
-
-extern "C" int msc_bn_bwd_blocks(int64_t pixels, int C) { (void)C; return ceil_div(pixels, BNB_PIX); }
-
-extern "C" int msc_bn_bwd_reduce(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
-                                 int relu, float* partials, int dtype, int64_t pixels, int C, void* stream) {
-    DT_CHECK("msc_bn_bwd_reduce", dtype);
-    VEC_CHECK("msc_bn_bwd_reduce", dtype, C);
-    if (!dout || !y || !partials || (relu && !out)) return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_reduce: null pointer");
-    hipStream_t st = (hipStream_t)stream;
-    const int ce = dtype == MSC_BF16 ? 8 : 4;
-    const size_t shm = (size_t)EW_THREADS * 2 * ce * sizeof(float);
-    const int blocks = ceil_div(pixels, BNB_PIX);
-    if (dtype == MSC_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(EW_THREADS), shm, st, (const bf16_t*)dout, (long)dout_ld, (const bf16_t*)out, (long)out_ld, (const bf16_t*)y, (long)y_ld, relu, partials, (long)pixels, C);
-    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(EW_THREADS), shm, st, (const float*)dout, (long)dout_ld, (const float*)out, (long)out_ld, (const float*)y, (long)y_ld, relu, partials, (long)pixels, C);
-    return msc_check_launch("msc_bn_bwd_reduce");
-}
-
-extern "C" int msc_bn_bwd_finalize(const float* partials, int blocks, int C, int64_t count, const float* gamma,
-                                   const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef, void* stream) {
-    if (!partials || !save_mean || !save_invstd || !coef || blocks <= 0 || C <= 0) return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_finalize: bad argument");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, partials, blocks, C, (double)count,
-                       gamma, save_mean, save_invstd, dgamma, dbeta, coef);
-    return msc_check_launch("msc_bn_bwd_finalize");
 }
 
 extern "C" int msc_bn_bwd_apply(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
@@ -698,19 +501,6 @@ extern "C" int msc_relu_bwd(const void* dy, int64_t dy_ld, const void* y, int64_
     if (dtype == MSC_BF16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)dy, (long)dy_ld, (const bf16_t*)y, (long)y_ld, (bf16_t*)dx, (long)dx_ld, accumulate, (long)pixels, C);
     else hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const float*)dy, (long)dy_ld, (const float*)y, (long)y_ld, (float*)dx, (long)dx_ld, accumulate, (long)pixels, C);
     return msc_check_launch("msc_relu_bwd");
-}
-
-extern "C" int msc_bias_grad(const void* dy, int64_t dy_ld, float* db, int dtype, int64_t pixels, int C, void* stream) {
-    DT_CHECK("msc_bias_grad", dtype);
-    VEC_CHECK("msc_bias_grad", dtype, C);
-    if (!dy || !db) return msc_fail(MSC_ERR_ARG, "msc_bias_grad: null pointer");
-    hipStream_t st = (hipStream_t)stream;
-    const int ce = dtype == MSC_BF16 ? 8 : 4;
-    const size_t shm = (size_t)EW_THREADS * ce * sizeof(float);
-    const int blocks = ceil_div(pixels, BNB_PIX);
-    if (dtype == MSC_BF16) hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(blocks), dim3(EW_THREADS), shm, st, (const bf16_t*)dy, (long)dy_ld, db, (long)pixels, C);
-    else hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(blocks), dim3(EW_THREADS), shm, st, (const float*)dy, (long)dy_ld, db, (long)pixels, C);
-    return msc_check_launch("msc_bias_grad");
 }
 
 extern "C" int msc_final_fwd(const void* in, int64_t in_ld, const float* w, const float* b, float* logits, float* probs,

@@ -236,9 +236,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
             }
         }
         if (pl == 0) {
-            float* dst = p.stats + ((long)(blockIdx.x * WP + wp) * p.Cout + cb) * 2;
+            // layout [Cout][slices][2]: msc_bn_finalize gives each channel one wavefront over its slices
+            const long nsl = (long)gridDim.x * WP, sl = (long)blockIdx.x * WP + wp;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) { dst[2 * j] = s1[j]; dst[2 * j + 1] = s2[j]; }
+            for (int j = 0; j < NV; ++j) *reinterpret_cast<float2*>(p.stats + ((cb + j) * nsl + sl) * 2) = make_float2(s1[j], s2[j]);
         }
     }
 }

@@ -1,0 +1,217 @@
+// Per-channel reductions over the pixel dimension of NHWC tensors on gfx950 (HBM-bound):
+// BatchNorm2d training statistics finalisation, BatchNorm2d backward sums, conv-bias gradients.
+//
+// Pattern: column reduce.  A block owns 128 pixels x up to 64 16-byte channel vectors; lanes run along
+// the channel dimension (coalesced 16-B loads), row lanes stride over pixels, LDS folds the row lanes,
+// one partial per (channel, pixel-chunk) is written to a [C][S][K] workspace.  A second kernel gives
+// every channel one wavefront that sums its S partials with coalesced loads (64-lane shuffle reduce)
+// and applies the per-channel formula.  No atomics: results are deterministic run to run.
+#include "common.h"
+#include "msc_internal.h"
+
+namespace {
+
+constexpr int RED_PIX = 128;   // pixels per block
+
+// K = 2: (sum dh, sum dh*y) with dh = dout*[out>0] (BatchNorm backward);  K = 1: sum d (bias gradient)
+template <typename T, int K>
+__global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ dout, long dout_ld, const T* __restrict__ out, long out_ld,
+                                                        const T* __restrict__ y, long y_ld, int relu, float* __restrict__ partials,
+                                                        long pixels, int C, int cols, int S) {
+    constexpr int CE = Vec16<T>::N;
+    __shared__ float red[256 * K * CE];
+    const int tid = threadIdx.x;
+    const int col = tid % cols, r = tid / cols, R = 256 / cols;
+    const int vc = blockIdx.y * cols + col;
+    const long p0 = (long)blockIdx.x * RED_PIX;
+    const long p1 = min(pixels, p0 + RED_PIX);
+    float s1[CE], s2[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    const bool live = vc * CE < C;
+    if (live) {
+        for (long p = p0 + r; p < p1; p += R) {
+            float d[CE];
+            Vec16<T>::load(dout + p * dout_ld + vc * CE, d);
+            if (relu) {
+                float o[CE];
+                Vec16<T>::load(out + p * out_ld + vc * CE, o);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+            }
+            if (K == 2) {
+                float yy[CE];
+                Vec16<T>::load(y + p * y_ld + vc * CE, yy);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) s2[e] += d[e] * yy[e];
+            }
+#pragma unroll
+            for (int e = 0; e < CE; ++e) s1[e] += d[e];
+        }
+    }
+    float* mine = red + tid * K * CE;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+        mine[e] = s1[e];
+        if (K == 2) mine[CE + e] = s2[e];
+    }
+    __syncthreads();
+    if (r == 0 && live) {
+        for (int k = 1; k < R; ++k) {
+            const float* o = red + (k * cols + col) * K * CE;
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                s1[e] += o[e];
+                if (K == 2) s2[e] += o[CE + e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+            float* dst = partials + ((long)(vc * CE + e) * S + blockIdx.x) * K;
+            dst[0] = s1[e];
+            if (K == 2) dst[1] = s2[e];
+        }
+    }
+}
+
+// one wavefront per channel over partials [C][S][K]
+template <int K>
+__device__ __forceinline__ void channel_sums(const float* __restrict__ partials, int S, int c, int lane, double* a, double* b) {
+    double s1 = 0.0, s2 = 0.0;
+    const float* p = partials + (long)c * S * K;
+    for (int s = lane; s < S; s += 64) {
+        if (K == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(p + 2 * s);
+            s1 += v.x; s2 += v.y;
+        } else {
+            s1 += p[s];
+        }
+    }
+    *a = wave_sum_d(s1);
+    *b = K == 2 ? wave_sum_d(s2) : 0.0;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int S, int C, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                          float momentum, float* running_mean, float* running_var, float* scale,
+                                                          float* shift, float* save_mean, float* save_invstd) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    double s1, s2;
+    channel_sums<2>(partials, S, c, lane, &s1, &s2);
+    if (lane == 0) {
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        const float sc = g * invstd;
+        scale[c] = sc;
+        shift[c] = b - (float)mean * sc;
+        if (save_mean) save_mean[c] = (float)mean;
+        if (save_invstd) save_invstd[c] = invstd;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        if (running_var) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int S, int C, double count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, float* dgamma, float* dbeta, float* coef) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    double s1, s2;
+    channel_sums<2>(partials, S, c, lane, &s1, &s2);
+    if (lane == 0) {
+        const double mu = mean[c], is = invstd[c], g = gamma ? gamma[c] : 1.0;
+        const double dbe = s1;                        // sum dh
+        const double dga = is * (s2 - mu * s1);       // sum dh * xhat
+        if (dgamma) dgamma[c] += (float)dga;
+        if (dbeta) dbeta[c] += (float)dbe;
+        // dy = g*is*(dh - dbe/M - xhat*dga/M),  xhat = (y-mu)*is   ->   dy = a*dh + b*y + k0
+        const double a = g * is;
+        const double b = -g * is * is * dga / count;
+        const double k0 = -g * is * dbe / count - b * mu;
+        coef[c] = (float)a; coef[C + c] = (float)b; coef[2 * C + c] = (float)k0;
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_finalize_kernel(const float* __restrict__ partials, int S, int C, float* db) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    double s1, s2;
+    channel_sums<1>(partials, S, c, lane, &s1, &s2);
+    if (lane == 0) db[c] += (float)s1;
+}
+
+template <typename T, int K>
+int launch_colreduce(const void* dout, long dout_ld, const void* out, long out_ld, const void* y, long y_ld, int relu,
+                     float* partials, long pixels, int C, hipStream_t st) {
+    constexpr int CE = Vec16<T>::N;
+    const int cv = C / CE;
+    int cols = 64;
+    while (cols > cv) cols >>= 1;                 // 4..64, power of two
+    if (cols < 1 || cv % cols) return msc_fail(MSC_ERR_UNSUPPORTED, "column reduce: C=%d not supported", C);
+    const int S = ceil_div(pixels, RED_PIX);
+    dim3 grid(S, cv / cols);
+    hipLaunchKernelGGL((colreduce_kernel<T, K>), grid, dim3(256), 0, st, (const T*)dout, dout_ld, (const T*)out, out_ld, (const T*)y, y_ld,
+                       relu, partials, pixels, C, cols, S);
+    return msc_check_launch("colreduce");
+}
+
+}  // namespace
+
+#define DT_CHECK(name, dtype) \
+    if ((dtype) != MSC_BF16 && (dtype) != MSC_F32) return msc_fail(MSC_ERR_ARG, name ": dtype %d", (int)(dtype))
+
+extern "C" int msc_bn_finalize(const float* partials, int slices, int C, int64_t count, const float* gamma, const float* beta,
+                               float eps, float momentum, float* running_mean, float* running_var,
+                               float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
+    if (!partials || !scale || !shift || slices <= 0 || C <= 0 || count <= 0) return msc_fail(MSC_ERR_ARG, "msc_bn_finalize: bad argument");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, slices, C, (double)count,
+                       gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
+    return msc_check_launch("msc_bn_finalize");
+}
+
+extern "C" int msc_bn_bwd_blocks(int64_t pixels, int C) { (void)C; return ceil_div(pixels, RED_PIX); }
+
+extern "C" int msc_bn_bwd_reduce(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
+                                 int relu, float* partials, int dtype, int64_t pixels, int C, void* stream) {
+    DT_CHECK("msc_bn_bwd_reduce", dtype);
+    if (!dout || !y || !partials || (relu && !out) || pixels <= 0) return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_reduce: bad argument");
+    if (C % (dtype == MSC_BF16 ? 32 : 16)) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bn_bwd_reduce: C=%d must be a multiple of %d", C, dtype == MSC_BF16 ? 32 : 16);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MSC_BF16) return launch_colreduce<bf16_t, 2>(dout, dout_ld, out, out_ld, y, y_ld, relu, partials, pixels, C, st);
+    return launch_colreduce<float, 2>(dout, dout_ld, out, out_ld, y, y_ld, relu, partials, pixels, C, st);
+}
+
+extern "C" int msc_bn_bwd_finalize(const float* partials, int blocks, int C, int64_t count, const float* gamma,
+                                   const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef, void* stream) {
+    if (!partials || !save_mean || !save_invstd || !coef || blocks <= 0 || C <= 0) return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_finalize: bad argument");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, blocks, C, (double)count,
+                       gamma, save_mean, save_invstd, dgamma, dbeta, coef);
+    return msc_check_launch("msc_bn_bwd_finalize");
+}
+
+extern "C" int64_t msc_bias_grad_workspace_bytes(int64_t pixels, int C) {
+    if (pixels <= 0 || C <= 0) return 0;
+    return (int64_t)ceil_div(pixels, RED_PIX) * C * (int64_t)sizeof(float);
+}
+
+extern "C" int msc_bias_grad(const void* dy, int64_t dy_ld, float* db, void* workspace, int dtype, int64_t pixels, int C, void* stream) {
+    DT_CHECK("msc_bias_grad", dtype);
+    if (!dy || !db || !workspace || pixels <= 0) return msc_fail(MSC_ERR_ARG, "msc_bias_grad: bad argument");
+    if (C % (dtype == MSC_BF16 ? 32 : 16)) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bias_grad: C=%d must be a multiple of %d", C, dtype == MSC_BF16 ? 32 : 16);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = dtype == MSC_BF16 ? launch_colreduce<bf16_t, 1>(dy, dy_ld, nullptr, 0, nullptr, 0, 0, (float*)workspace, pixels, C, st)
+                               : launch_colreduce<float, 1>(dy, dy_ld, nullptr, 0, nullptr, 0, 0, (float*)workspace, pixels, C, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bias_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, ceil_div(pixels, RED_PIX), C, db);
+    return msc_check_launch("msc_bias_grad");
+}

@@ -151,14 +151,17 @@ class TrainStep:
             self._body()
             return self.loss
         if self.graph is None:
-            # warm up once eagerly (builds the program, packs, allocates), then capture
+            # the first step runs eagerly (builds the program, allocates, packs) and IS this call's step;
+            # capturing afterwards does not execute anything, replays start with the next call
             self._body()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._body_captured()
             self.graph = g
+            return self.loss
         self.graph.replay()
+        self.opt.steps += 1
         return self.loss
 
     def _body_captured(self):

@@ -484,6 +484,13 @@ class _Builder:
     def act(self, H, W, C):
         return Act(self.buf(H, W, C))
 
+    def bias_ws(self, pixels, C):
+        """shared scratch for msc_bias_grad (launches are stream-ordered, so one buffer serves all)"""
+        need = self.lib.msc_bias_grad_workspace_bytes(pixels, C) // 4
+        if getattr(self, '_bias_ws', None) is None or self._bias_ws.numel() < need:
+            self._bias_ws = self.vec(max(need, 1 << 20))
+        return self._bias_ws.data_ptr()
+
     def slice(self, buf, c0, C):
         self.slices.setdefault(id(buf), set()).add((c0, C))
         return Act(buf, c0, C)
@@ -634,7 +641,7 @@ class _Builder:
         count = out.pixels
         if not masked:   # dmask = dout * [out > 0], in place: `out` has exactly one consumer
             self.emit(bwd, lib.msc_relu_bwd, dout.ptr, dout.ld, out.ptr, out.ld, dout.ptr, dout.ld, 0, self.dt, count, out.C)
-        self.emit(bwd, lib.msc_bias_grad, dout.ptr, dout.ld, net._g(conv.bias), self.dt, count, out.C)
+        self.emit(bwd, lib.msc_bias_grad, dout.ptr, dout.ld, net._g(conv.bias), self.bias_ws(count, out.C), self.dt, count, out.C)
         self.wgrad(bwd, dout, x, net._g(conv.weight), 3, 3, 1, 1)
         gx = self.grad_of(x)
         acc = self.grad_acc(x)
@@ -653,7 +660,7 @@ class _Builder:
         count = out.pixels
         dm = self.act(out.H, out.W, out.C)           # compact masked gradient (dout may be a slice of a concat)
         self.emit(bwd, lib.msc_relu_bwd, dout.ptr, dout.ld, out.ptr, out.ld, dm.ptr, dm.ld, 0, self.dt, count, out.C)
-        self.emit(bwd, lib.msc_bias_grad, dm.ptr, dm.ld, net._g(deconv.bias), self.dt, count, out.C)
+        self.emit(bwd, lib.msc_bias_grad, dm.ptr, dm.ld, net._g(deconv.bias), self.bias_ws(count, out.C), self.dt, count, out.C)
         # dW[ci][kh][kw][co] = sum_coarse x[c][ci] * dm[2c-1+k][co]
         self.wgrad(bwd, x, dm, net._g(deconv.weight), 4, 4, 2, 1)
         gx = self.grad_of(x)

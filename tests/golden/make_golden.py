@@ -30,7 +30,7 @@ def main():
     um, pp, rm = ref_import.ref('unet_models'), ref_import.ref('postprocessing'), ref_import.ref('models')
     torch.manual_seed(1234)
     # ---- network: reference UNetResNet, eval logits + one training backward (mixed loss)
-    for depth, hw, n in ((34, 64, 2), (101, 64, 1)):
+    for depth, hw, n in ((34, 64, 2), (101, 64, 2)):
         net = um.UNetResNet(depth, 2, num_filters=32, dropout_2d=0.0, pretrained=True, is_deconv=True)
         net.load_state_dict(unet_ref.seeded_state_dict(net))
         x = unet_ref.synthetic_batch(n, hw, hw)

@@ -46,7 +46,7 @@ def test_eval_logits_fp32_vs_oracle(depth, hw, n):
         yh = net(x.cuda()).cpu()
         ph = net.predict_proba(x.cuda()).cpu()
     assert (yr - yh).abs().max().item() < 1e-4
-    assert (torch.softmax(yr, 1) - ph).abs().max().item() < 1e-5
+    assert (torch.softmax(yr, 1) - ph).abs().max().item() < 3e-5     # softmax of logits that agree to 1e-4
 
 
 @pytest.mark.parametrize('depth', [34, 101])

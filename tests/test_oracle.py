@@ -50,8 +50,9 @@ def test_post_chain_matches_golden(golden_dir):
 
 
 def test_unet_oracle_matches_golden(golden_dir):
-    for depth, n in ((34, 2), (101, 1)):
+    for depth in (34, 101):
         g = np.load(os.path.join(golden_dir, 'unet_r%d_64.npz' % depth))
+        n = g['logits_eval'].shape[0]
         net = unet_ref.UNetResNetRef(depth)
         net.load_state_dict(unet_ref.seeded_state_dict(net))
         x = unet_ref.synthetic_batch(n, 64, 64)
