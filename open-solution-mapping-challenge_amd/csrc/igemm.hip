@@ -392,12 +392,238 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgK p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v2 of the same kernel: operands go HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per
+// wave-instruction) instead of through VGPRs + ds_write_b128, which removes the LDS-write pass that
+// bounded v1 (ds_write_b128 sustains ~79 B/clk/CU: 16 KiB per k-step = ~200 cycles against ~257
+// cycles of MFMA).  An LDS-DMA destination is wave-uniform base + lane*16, so the tile image is
+// linear [row][64 B]; bank conflicts of the ds_read_b128 fragment reads are removed by permuting
+// the 16-byte k-chunks of every row on the SOURCE side (lane loads chunk slot^S[q]) and applying
+// the same involution on the read: q = (row>>2)&3 for pixel rows, (row/NV)&3 for weight rows,
+// S = {0,2,3,1}, which makes the four lane groups of ds_read_b128 hit 16 distinct 16-byte slots.
+// Out-of-image taps load from a 64-byte zero page instead of being zero-filled in registers.
+template <typename T, int TP, int TC, int WP, int WC, int MODE>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p, const char* __restrict__ zero_page) {
+    constexpr int ES = sizeof(T);
+    constexpr int KE = 64 / ES;
+    constexpr int CE = 16 / ES;
+    constexpr int WTP = TP / WP, WTC = TC / WC;
+    constexpr int FM = WTC / 16, FN = WTP / 16;
+    constexpr int NV = FM * 4;
+    constexpr int XI = TP / 64, WI = (TC + 63) / 64;
+    constexpr int BUF = (TP + TC) * 64;
+    static_assert(WP * WC == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wid / WC, wc = wid % WC;
+    const int g = lane >> 4, pl = lane & 15;
+    const int m0 = blockIdx.x * TP;
+    const int c0 = blockIdx.y * TC;
+    const int ph = MODE ? (int)blockIdx.z : 0;
+    const int py = ph >> 1, px = ph & 1;
+    auto swz = [](int q) { return (0x1320 >> (4 * (q & 3))) & 3; };   // S = {0,2,3,1}
+
+    int kh0 = 0, kw0 = 0, nkh = p.KH, nkw = p.KW;
+    if (MODE) {
+        kh0 = (py + p.pad) & 1; kw0 = (px + p.pad) & 1;
+        nkh = p.KH > kh0 ? (p.KH - kh0 + 1) / 2 : 0;
+        nkw = p.KW > kw0 ? (p.KW - kw0 + 1) / 2 : 0;
+    }
+    const int cps = p.Cin / KE;
+    const int nsteps = nkh * nkw * cps;
+
+    const int lrow = tid >> 2, slot = tid & 3;
+    const int kcx = slot ^ swz(lrow >> 2);           // source k-chunk this lane fetches for pixel rows
+    const int kcw = slot ^ swz(lrow / NV);           // ... and for weight rows
+    int xn[XI], xby[XI], xbx[XI];
+    bool xv[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int m = m0 + lrow + i * 64;
+        xv[i] = m < p.M;
+        const int mm = xv[i] ? m : 0;
+        const int n = mm / (p.Hq * p.Wq);
+        const int rem = mm - n * (p.Hq * p.Wq);
+        const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+        xn[i] = n * p.Hi;
+        xby[i] = MODE ? qy : qy * p.stride;
+        xbx[i] = MODE ? qx : qx * p.stride;
+    }
+    const T* in = reinterpret_cast<const T*>(p.in);
+    const T* wt = reinterpret_cast<const T*>(p.wt);
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    auto issue = [&](int s, int buf) {
+        const int tap = s / cps;
+        const int cch = s - tap * cps;
+        const int khi = tap / nkw, kwi = tap - khi * nkw;
+        const int kh = MODE ? kh0 + 2 * khi : khi;
+        const int kw = MODE ? kw0 + 2 * kwi : kwi;
+        int dy, dx;
+        if (MODE) { dy = (py + p.pad - kh) / 2; dx = (px + p.pad - kw) / 2; }
+        else if (p.flip) { dy = p.pad - kh; dx = p.pad - kw; }
+        else { dy = kh - p.pad; dx = kw - p.pad; }
+        char* sx = smem + buf * BUF;
+        char* sw = sx + TP * 64;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int iy = xby[i] + dy, ix = xbx[i] + dx;
+            const bool ok = xv[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const char* src = ok ? reinterpret_cast<const char*>(in + ((long)(xn[i] + iy) * p.Wi + ix) * p.in_ld + cch * KE + kcx * CE)
+                                 : zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sx + (i * 4 + wid) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            if (TC >= 64 || wid < TC / 16) {       // wave-uniform: a 32-row weight tile is filled by waves 0 and 1
+                const int row = lrow + i * 64;
+                const bool ok = c0 + row < p.Cout;
+                const char* src = ok ? reinterpret_cast<const char*>(wt + ((long)((c0 + row) * p.KH + kh) * p.KW + kw) * p.Cin + cch * KE + kcw * CE)
+                                     : zero_page;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sw + (i * 4 + wid) * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int rslot = (g ^ swz(pl >> 2)) * 16;       // both fragment kinds: (row>>2)&3 resp. (row/NV)&3 equals pl>>2
+    if (nsteps > 0) {
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            if (s + 1 < nsteps) issue(s + 1, (s + 1) & 1);
+            const char* sx = smem + (s & 1) * BUF;
+            const char* sw = sx + TP * 64;
+            uint4 af[FM], bf[FN];
+#pragma unroll
+            for (int a = 0; a < FM; ++a) {
+                const int row = wc * WTC + (pl >> 2) * NV + a * 4 + (pl & 3);
+                af[a] = *reinterpret_cast<const uint4*>(sw + row * 64 + rslot);
+            }
+#pragma unroll
+            for (int b = 0; b < FN; ++b)
+                bf[b] = *reinterpret_cast<const uint4*>(sx + (wp * WTP + b * 16 + pl) * 64 + rslot);
+#pragma unroll
+            for (int a = 0; a < FM; ++a)
+#pragma unroll
+                for (int b = 0; b < FN; ++b) Mma<T>::run(af[a], bf[b], acc[a][b]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed in the other buffer
+            __syncthreads();
+        }
+    }
+
+    const int cb = c0 + wc * WTC + g * NV;
+    float sc[NV], sh[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        sc[j] = p.scale ? p.scale[cb + j] : 1.f;
+        sh[j] = p.shift ? p.shift[cb + j] : 0.f;
+    }
+    float s1[NV], s2[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    T* out = reinterpret_cast<T*>(p.out);
+    const T* res = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+    for (int b = 0; b < FN; ++b) {
+        const int m = m0 + wp * WTP + b * 16 + pl;
+        float v[NV];
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][b][r];
+        if (p.stats) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+        }
+        if (m < p.M) {
+            long opix = m;
+            if (MODE) {
+                const int n = m / (p.Hq * p.Wq);
+                const int rem = m - n * (p.Hq * p.Wq);
+                const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+                opix = ((long)n * p.Ho + 2 * qy + py) * p.Wo + 2 * qx + px;
+            }
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j] = v[j] * sc[j] + sh[j];
+            if (res) {
+#pragma unroll
+                for (int j = 0; j < NV; j += CE) {
+                    float rv[CE];
+                    Vec16<T>::load(res + opix * p.res_ld + cb + j, rv);
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) v[j + e] += rv[e];
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < NV; j += CE) Vec16<T>::store(out + opix * p.out_ld + cb + j, v + j);
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                s1[j] += __shfl_xor(s1[j], o, 64);
+                s2[j] += __shfl_xor(s2[j], o, 64);
+            }
+        }
+        if (pl == 0) {
+            const long nsl = (long)gridDim.x * WP, sl = (long)blockIdx.x * WP + wp;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) *reinterpret_cast<float2*>(p.stats + ((cb + j) * nsl + sl) * 2) = make_float2(s1[j], s2[j]);
+        }
+    }
+}
+
+// 64-byte zero page per device for the out-of-image taps of the DMA kernels (allocated on first use,
+// never freed: the only piece of library-owned device memory)
+const char* zero_page_for_current_device() {
+    static const char* pages[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!pages[dev]) {
+        void* ptr = nullptr;
+        if (hipMalloc(&ptr, 256) != hipSuccess) return nullptr;
+        if (hipMemset(ptr, 0, 256) != hipSuccess) return nullptr;
+        pages[dev] = (const char*)ptr;
+    }
+    return pages[dev];
+}
+
+bool use_v1_conv() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MSC_CONV_V1"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 template <typename T, int TP, int TC, int WP, int WC>
 int launch_conv(const ConvK& k, int mode, hipStream_t st) {
     dim3 grid(ceil_div(k.M, TP), ceil_div(k.Cout, TC), mode ? 4 : 1);
-    if (mode) hipLaunchKernelGGL((conv_igemm_kernel<T, TP, TC, WP, WC, 1>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((conv_igemm_kernel<T, TP, TC, WP, WC, 0>), grid, dim3(256), 0, st, k);
-    return msc_check_launch("conv_igemm");
+    if (use_v1_conv()) {
+        if (mode) hipLaunchKernelGGL((conv_igemm_kernel<T, TP, TC, WP, WC, 1>), grid, dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((conv_igemm_kernel<T, TP, TC, WP, WC, 0>), grid, dim3(256), 0, st, k);
+        return msc_check_launch("conv_igemm");
+    }
+    const char* zp = zero_page_for_current_device();
+    if (!zp) return msc_fail(MSC_ERR_HIP, "conv_igemm: cannot allocate the zero page");
+    if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1>), grid, dim3(256), 0, st, k, zp);
+    else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0>), grid, dim3(256), 0, st, k, zp);
+    return msc_check_launch("conv_igemm_dma");
 }
 
 // tile choice: TC follows Cout (128 / 64 / 32); the pixel tile shrinks when the launch would not

@@ -62,12 +62,12 @@ def test_conv_channel_slices_and_stats(dtype):
     obuf = torch.full((n, hw, hw, 160), 7.0, dtype=dtype, device='cuda')
     xin, out = xbuf[..., 64:128], obuf[..., 32:96]
     slices = ops.conv_stats_slices(xin, w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda(), out, 1, 1)
-    stats = torch.zeros((slices, cout, 2), dtype=torch.float32, device='cuda')
+    stats = torch.zeros((cout, slices, 2), dtype=torch.float32, device='cuda')      # layout [Cout][slices][2]
     ops.conv_igemm(xin, w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda(), out, stride=1, pad=1, stats=stats)
     ref = F.conv2d(x, w, padding=1)
     assert torch.allclose(to_nchw(out), ref, **tol(dtype))
     assert (obuf[..., :32] == 7).all() and (obuf[..., 96:] == 7).all()          # neighbours untouched
-    s = stats.sum(0).cpu()
+    s = stats.sum(1).cpu()
     assert torch.allclose(s[:, 0], ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
     assert torch.allclose(s[:, 1], (ref * ref).sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
 
