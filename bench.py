@@ -41,6 +41,33 @@ def wgrad_flops(d):
     return 2.0 * d.N * d.Hp * d.Wp * d.A * d.B * d.KH * d.KW
 
 
+def dump_launches(launches, stream, path, repeats=3):
+    """per-launch HIP-event timing of the conv / wgrad launches (shape, us, TFLOP/s) -> JSON, for tuning"""
+    rows = []
+    for fn, args in launches:
+        name = fn.__name__
+        if name not in ('msc_conv_igemm', 'msc_conv_wgrad'):
+            continue
+        best = 1e30
+        for _ in range(repeats):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            assert fn(*args, stream) == 0
+            b.record()
+            torch.cuda.synchronize()
+            best = min(best, a.elapsed_time(b))
+        d = args[0]._obj
+        if name == 'msc_conv_igemm':
+            rows.append({'k': 'conv', 'mode': d.mode, 'flip': d.flip, 'N': d.N, 'Hi': d.Hi, 'Wi': d.Wi, 'Cin': d.Cin, 'Ho': d.Ho, 'Wo': d.Wo,
+                         'Cout': d.Cout, 'KH': d.KH, 'KW': d.KW, 'stride': d.stride, 'stats': bool(d.stats), 'res': bool(d.res),
+                         'us': 1e3 * best, 'tflops': conv_flops(d) / (best * 1e-3) / 1e12})
+        else:
+            rows.append({'k': 'wgrad', 'N': d.N, 'Hp': d.Hp, 'Wp': d.Wp, 'A': d.A, 'Hq': d.Hq, 'Wq': d.Wq, 'B': d.B, 'KH': d.KH, 'KW': d.KW,
+                         'stride': d.stride, 'us': 1e3 * best, 'tflops': wgrad_flops(d) / (best * 1e-3) / 1e12})
+    with open(path, 'w') as f:
+        json.dump(rows, f)
+
+
 def family_times(launches, stream, repeats=2):
     """HIP-event time per kernel family over a launch list, on the stream the kernels run on."""
     fam = {}
@@ -147,6 +174,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true')
+    ap.add_argument('--dump-launches', default=None, help='write per-launch conv/wgrad timings to this JSON file')
     args = ap.parse_args()
 
     from mapping_challenge_amd.distributed import World
@@ -218,6 +246,8 @@ def main():
             if args.workload == 'train':
                 net._flat[1].zero_()
             fam = family_times(launches, stream)
+            if args.dump_launches:
+                dump_launches(launches, stream, args.dump_launches)
             conv = fam.get('msc_conv_igemm', {'ms': 0, 'launches': 0, 'flops': 0})
             wg = fam.get('msc_conv_wgrad', {'ms': 0, 'launches': 0, 'flops': 0})
             total_ms = sum(f['ms'] for f in fam.values())

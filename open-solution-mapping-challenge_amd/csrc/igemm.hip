@@ -21,6 +21,21 @@
 //         1 = transposed, stride 2, by output parity phase (blockIdx.z):
 //                      fine[q] = sum_{t: (q+pad-t) even} coarse[(q+pad-t)/2] W[t]
 //                                                                     (convT fwd, stride-2 dgrad)
+//
+// Two generations of each kernel are kept:
+//   *_kernel      v1: operands staged HBM -> VGPR -> ds_write_b128 -> LDS, 2 LDS buffers, all addressing
+//                 recomputed every k-step.  Measured 0.23-0.25 PFLOP/s (9-10 % of the bf16 MFMA peak): the
+//                 64-bit address arithmetic of every k-step sits in front of the MFMAs of an in-order wave.
+//   *_dma_kernel  v2: operands go HBM -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per
+//                 wave-instruction) through a 4-stage LDS ring with counted s_waitcnt vmcnt(N) and one raw
+//                 s_barrier per k-step; per-lane byte offsets are 32-bit, computed once per filter tap, the
+//                 k-chunk advance is the instruction's scalar offset; out-of-image taps are out-of-range
+//                 buffer offsets, which the hardware returns as zeros (no zero-fill code, no branches).
+//                 The LDS image is linear (DMA destination = wave base + lane*16), so bank conflicts are
+//                 removed by permuting 16-byte k-chunks on the SOURCE side and applying the same involution
+//                 on the fragment reads.
+#include <stdlib.h>
+
 #include "common.h"
 #include "msc_internal.h"
 
@@ -32,6 +47,7 @@ struct ConvK {
     long in_ld, out_ld, res_ld;
     int N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, flip, relu;
     int M, Hq, Wq;
+    unsigned in_bytes, wt_bytes;     // extents for the buffer descriptors of the DMA kernel
 };
 
 template <typename T> struct Mma;
@@ -49,7 +65,110 @@ template <> struct Mma<float> {
     }
 };
 
-constexpr int ROWB = 80;  // LDS row pitch: 64 B of K + 16 B pad (16-B slots 5r+g mod 16 spread rows)
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned OOB_OFF = 0x80000000u;   // >= any buffer extent we accept: the load returns zeros
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void raw_barrier() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// One LDS-DMA wave-instruction: 64 lanes x 16 bytes from buffer offsets `voff` (+ scalar `soff`) to LDS bytes
+// [lds_wave_base, +1024).  Issued through inline asm on purpose: a compiler-visible LDS-DMA makes hipcc put
+// s_waitcnt vmcnt(0) in front of every ds_read of the loop (it cannot disambiguate the ring slots), which
+// serialises the pipeline; hidden from it, the ring is ordered by our own counted vmcnt + s_barrier.
+// M0 (the DMA's LDS base) is compiler-reserved: saved, set and restored inside the one statement.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t make_srd(const void* base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    u32x4_t r;
+    r.x = (unsigned)b; r.y = (unsigned)(b >> 32) & 0xffffu; r.z = bytes; r.w = 0x00020000u;   // raw buffer, stride 0
+    return r;
+}
+__device__ __forceinline__ void dma16(u32x4_t srd, char* lds_wave_base, unsigned voff, int soff) {
+    const unsigned lds_addr = (unsigned)(size_t)(lds_ptr_t)lds_wave_base;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
+                 : "memory");
+}
+
+// shared epilogue: lane holds NV consecutive channels cb.. of pixel rows (b*16+pl), b < FN
+template <typename T, int FM, int FN, int WTP, int WP, int MODE>
+__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][FN], int m0, int wp, int cb, int pl, int py, int px) {
+    constexpr int NV = FM * 4;
+    constexpr int CE = 16 / (int)sizeof(T);
+    float sc[NV], sh[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        sc[j] = p.scale ? p.scale[cb + j] : 1.f;
+        sh[j] = p.shift ? p.shift[cb + j] : 0.f;
+    }
+    float s1[NV], s2[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    T* out = reinterpret_cast<T*>(p.out);
+    const T* res = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+    for (int b = 0; b < FN; ++b) {
+        const int m = m0 + wp * WTP + b * 16 + pl;
+        float v[NV];
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][b][r];
+        if (p.stats) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+        }
+        if (m < p.M) {
+            long opix = m;
+            if (MODE) {
+                const int n = m / (p.Hq * p.Wq);
+                const int rem = m - n * (p.Hq * p.Wq);
+                const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+                opix = ((long)n * p.Ho + 2 * qy + py) * p.Wo + 2 * qx + px;
+            }
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j] = v[j] * sc[j] + sh[j];
+            if (res) {
+#pragma unroll
+                for (int j = 0; j < NV; j += CE) {
+                    float rv[CE];
+                    Vec16<T>::load(res + opix * p.res_ld + cb + j, rv);
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) v[j + e] += rv[e];
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < NV; j += CE) Vec16<T>::store(out + opix * p.out_ld + cb + j, v + j);
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                s1[j] += __shfl_xor(s1[j], o, 64);
+                s2[j] += __shfl_xor(s2[j], o, 64);
+            }
+        }
+        if (pl == 0) {
+            // layout [Cout][slices][2]: msc_bn_finalize gives each channel one wavefront over its slices
+            const long nsl = (long)gridDim.x * WP, sl = (long)blockIdx.x * WP + wp;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) *reinterpret_cast<float2*>(p.stats + ((cb + j) * nsl + sl) * 2) = make_float2(s1[j], s2[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ v1
+constexpr int ROWB = 80;  // v1 LDS row pitch: 64 B of K + 16 B pad
 
 template <typename T, int TP, int TC, int WP, int WC, int MODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
@@ -81,7 +200,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
     const int cps = p.Cin / KE;            // k-steps per tap
     const int nsteps = nkh * nkw * cps;
 
-    // ---- per-thread load coordinates
     const int lrow = tid >> 2, kc = tid & 3;
     int xn[XI], xby[XI], xbx[XI];
     bool xv[XI];
@@ -173,90 +291,165 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
             __syncthreads();
         }
     }
+    conv_epilogue<T, FM, FN, WTP, WP, MODE>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px);
+}
 
-    // ---- epilogue: lane holds channels cb .. cb+NV-1 of pixel rows (b*16+pl), b < FN
-    const int cb = c0 + wc * WTC + g * NV;
-    float sc[NV], sh[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        sc[j] = p.scale ? p.scale[cb + j] : 1.f;
-        sh[j] = p.shift ? p.shift[cb + j] : 0.f;
+// ------------------------------------------------------------------------------------------------ v2 (DMA)
+// LDS image per stage: [TP pixel rows][64 B] then [TC weight rows][64 B], linear.  Row r keeps its four
+// 16-byte k-chunks permuted: slot = chunk ^ S[q], q = (r>>2)&3 for pixel rows and (r/NV)&3 for weight rows,
+// S = {0,2,3,1}: the four lane groups of ds_read_b128 ({0-3,12-15,20-27}, ...) then hit 16 distinct slots.
+template <typename T, int TP, int TC, int WP, int WC, int MODE, int NST>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
+    constexpr int ES = sizeof(T);
+    constexpr int KE = 64 / ES;
+    constexpr int WTP = TP / WP, WTC = TC / WC;
+    constexpr int FM = WTC / 16, FN = WTP / 16;
+    constexpr int NV = FM * 4;
+    constexpr int XI = TP / 64, WI = (TC + 63) / 64;
+    constexpr int STAGE = (TP + TC) * 64;
+    constexpr int LPW = XI + WI;                 // DMA instructions per wave per stage (uniform over waves)
+    static_assert(WP * WC == 4, "4 waves");
+    static_assert(NST >= 3 && (NST & (NST - 1)) == 0, "power-of-two ring");
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wid / WC, wc = wid % WC;
+    const int g = lane >> 4, pl = lane & 15;
+    const int m0 = blockIdx.x * TP;
+    const int c0 = blockIdx.y * TC;
+    const int ph = MODE ? (int)blockIdx.z : 0;
+    const int py = ph >> 1, px = ph & 1;
+    auto swz = [](int q) { return (0x1320 >> (4 * (q & 3))) & 3; };   // S = {0,2,3,1}
+
+    int kh0 = 0, kw0 = 0, nkh = p.KH, nkw = p.KW;
+    if (MODE) {
+        kh0 = (py + p.pad) & 1; kw0 = (px + p.pad) & 1;
+        nkh = p.KH > kh0 ? (p.KH - kh0 + 1) / 2 : 0;
+        nkw = p.KW > kw0 ? (p.KW - kw0 + 1) / 2 : 0;
     }
-    float s1[NV], s2[NV];
+    const int cps = p.Cin / KE;
+    const int nsteps = nkh * nkw * cps;
+
+    const u32x4_t rx = make_srd(p.in, p.in_bytes);
+    const u32x4_t rw = make_srd(p.wt, p.wt_bytes);
+
+    const int lrow = tid >> 2, slot = tid & 3;
+    const unsigned kcx = (unsigned)(slot ^ swz(lrow >> 2)) * 16u;     // source k-chunk (bytes) fetched for pixel rows
+    const unsigned kcw = (unsigned)(slot ^ swz(lrow / NV)) * 16u;     // ... and for weight rows
+    int xn[XI], xby[XI], xbx[XI];
+    bool xv[XI];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    T* out = reinterpret_cast<T*>(p.out);
-    const T* res = reinterpret_cast<const T*>(p.res);
+    for (int i = 0; i < XI; ++i) {
+        const int m = m0 + lrow + i * 64;
+        xv[i] = m < p.M;
+        const int mm = xv[i] ? m : 0;
+        const int n = mm / (p.Hq * p.Wq);
+        const int rem = mm - n * (p.Hq * p.Wq);
+        const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+        xn[i] = n * p.Hi;
+        xby[i] = MODE ? qy : qy * p.stride;
+        xbx[i] = MODE ? qx : qx * p.stride;
+    }
+    const unsigned pix_bytes = (unsigned)p.in_ld * ES;
+    const unsigned tap_bytes = (unsigned)p.Cin * ES;
+    unsigned wrow[WI];
 #pragma unroll
-    for (int b = 0; b < FN; ++b) {
-        const int m = m0 + wp * WTP + b * 16 + pl;
-        float v[NV];
+    for (int i = 0; i < WI; ++i) {
+        const int row = (lrow + i * 64) & (TC - 1);        // a 32-row weight tile is fetched twice (waves 2,3 repeat 0,1)
+        const int co = c0 + row;
+        wrow[i] = co < p.Cout ? (unsigned)co * (unsigned)(p.KH * p.KW) * tap_bytes + kcw : OOB_OFF;
+    }
+
+    // ---- issue iterator: (tap, k-chunk) of the next stage to fetch; per-lane offsets refreshed once per tap
+    int itap = 0, icch = 0;
+    unsigned xoff[XI], woff[WI];
+    auto set_tap = [&](int tap) {
+        const int khi = tap / nkw, kwi = tap - khi * nkw;
+        const int kh = MODE ? kh0 + 2 * khi : khi;
+        const int kw = MODE ? kw0 + 2 * kwi : kwi;
+        int dy, dx;
+        if (MODE) { dy = (py + p.pad - kh) / 2; dx = (px + p.pad - kw) / 2; }
+        else if (p.flip) { dy = p.pad - kh; dx = p.pad - kw; }
+        else { dy = kh - p.pad; dx = kw - p.pad; }
 #pragma unroll
-        for (int a = 0; a < FM; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][b][r];
-        if (p.stats) {
-#pragma unroll
-            for (int j = 0; j < NV; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+        for (int i = 0; i < XI; ++i) {
+            const int iy = xby[i] + dy, ix = xbx[i] + dx;
+            const bool ok = xv[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            xoff[i] = ok ? (unsigned)((xn[i] + iy) * p.Wi + ix) * pix_bytes + kcx : OOB_OFF;
         }
-        if (m < p.M) {
-            long opix = m;
-            if (MODE) {
-                const int n = m / (p.Hq * p.Wq);
-                const int rem = m - n * (p.Hq * p.Wq);
-                const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
-                opix = ((long)n * p.Ho + 2 * qy + py) * p.Wo + 2 * qx + px;
-            }
+        const unsigned toff = (unsigned)(kh * p.KW + kw) * tap_bytes;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) v[j] = v[j] * sc[j] + sh[j];
-            if (res) {
+        for (int i = 0; i < WI; ++i) woff[i] = wrow[i] == OOB_OFF ? OOB_OFF : wrow[i] + toff;
+    };
+    auto issue = [&](int stage) {
+        if (icch == 0) set_tap(itap);
+        const int soff = icch * 64;
+        char* sx = smem + stage * STAGE;
+        char* sw = sx + TP * 64;
 #pragma unroll
-                for (int j = 0; j < NV; j += CE) {
-                    float rv[CE];
-                    Vec16<T>::load(res + opix * p.res_ld + cb + j, rv);
+        for (int i = 0; i < XI; ++i) dma16(rx, sx + (i * 4 + wid) * 1024, xoff[i], soff);
 #pragma unroll
-                    for (int e = 0; e < CE; ++e) v[j + e] += rv[e];
-                }
-            }
-            if (p.relu) {
+        for (int i = 0; i < WI; ++i) dma16(rw, sw + (i * 4 + (TC >= 64 ? wid : (wid & (TC / 16 - 1)))) * 1024, woff[i], soff);
+        if (++icch == cps) { icch = 0; ++itap; }
+    };
+
+    f32x4 acc[FM][FN];
 #pragma unroll
-                for (int j = 0; j < NV; ++j) v[j] = fmaxf(v[j], 0.f);
-            }
+    for (int a = 0; a < FM; ++a)
 #pragma unroll
-            for (int j = 0; j < NV; j += CE) Vec16<T>::store(out + opix * p.out_ld + cb + j, v + j);
+        for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets within a stage (both kinds: the swizzle key equals pl>>2)
+    const int rslot = (g ^ swz(pl >> 2)) * 16;
+    int aoff[FM], boff[FN];
+#pragma unroll
+    for (int a = 0; a < FM; ++a) aoff[a] = TP * 64 + (wc * WTC + (pl >> 2) * NV + a * 4 + (pl & 3)) * 64 + rslot;
+#pragma unroll
+    for (int b = 0; b < FN; ++b) boff[b] = (wp * WTP + b * 16 + pl) * 64 + rslot;
+
+    if (nsteps > 0) {
+#pragma unroll
+        for (int st = 0; st < NST - 1; ++st)
+            if (st < nsteps) issue(st);
+        for (int s = 0; s < nsteps; ++s) {
+            // stage s must have landed; stages s+1 .. s+NST-2 may stay in flight
+            if (s + NST - 2 <= nsteps - 1) wait_vmcnt<(NST - 2) * LPW>();
+            else wait_vmcnt<0>();
+            raw_barrier();                       // everyone's DMA of stage s is in LDS, everyone is done with stage s-1
+            if (s + NST - 1 < nsteps) issue((s + NST - 1) & (NST - 1));
+            const char* sb = smem + (s & (NST - 1)) * STAGE;
+            uint4 af[FM], bf[FN];
+#pragma unroll
+            for (int a = 0; a < FM; ++a) af[a] = *reinterpret_cast<const uint4*>(sb + aoff[a]);
+#pragma unroll
+            for (int b = 0; b < FN; ++b) bf[b] = *reinterpret_cast<const uint4*>(sb + boff[b]);
+#pragma unroll
+            for (int a = 0; a < FM; ++a)
+#pragma unroll
+                for (int b = 0; b < FN; ++b) Mma<T>::run(af[a], bf[b], acc[a][b]);
         }
     }
-    if (p.stats) {
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                s1[j] += __shfl_xor(s1[j], o, 64);
-                s2[j] += __shfl_xor(s2[j], o, 64);
-            }
-        }
-        if (pl == 0) {
-            // layout [Cout][slices][2]: msc_bn_finalize gives each channel one wavefront over its slices
-            const long nsl = (long)gridDim.x * WP, sl = (long)blockIdx.x * WP + wp;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) *reinterpret_cast<float2*>(p.stats + ((cb + j) * nsl + sl) * 2) = make_float2(s1[j], s2[j]);
-        }
-    }
+    conv_epilogue<T, FM, FN, WTP, WP, MODE>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px);
 }
 
 // ------------------------------------------------------------------------------------------------
 // weight gradient:  dW[a][kh][kw][b] += sum_m P[m][a] * Q[pix(m)*stride - pad + (kh,kw)][b]
 //   conv  wgrad: P = dY (a = cout), Q = X  (b = cin)
 //   convT wgrad: P = X  (a = cin, coarse grid), Q = dOut (b = cout, fine grid), stride 2
-// GEMM K = pixels, which is the strided dimension of NHWC: both operands are staged
-// pixel-major in LDS and the k-contiguous fragments are gathered element-wise from LDS.
+// GEMM K = pixels, the strided dimension of NHWC: both operands are staged pixel-major in LDS and the
+// k-contiguous MFMA fragments are produced by a transposing LDS read.
 struct WgK {
     const char* p; const char* q; float* dw;
     long p_ld, q_ld;
     int N, Hp, Wp, A, Hq, Wq, B, KH, KW, stride, pad;
     int M, mchunk, tiles_b;
+    unsigned p_bytes, q_bytes;
+    float rcp_hw, rcp_w;
 };
 
+// v1: register staging, element-wise (ds_read_u16) gather of the fragments
 template <typename T, int TA, int TB>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgK p) {
     constexpr int ES = sizeof(T);
@@ -329,7 +522,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgK p) {
             if (row < KP) *reinterpret_cast<uint4*>(sq + row * LDB + cc * 16) = qr[i];
         }
     };
-    // k-contiguous fragment of channel `ch` (local) for lane group g, gathered from a pixel-major tile
     auto frag = [&](const char* base, int ld, int ch) -> uint4 {
         uint4 r;
         if (ES == 2) {
@@ -392,101 +584,158 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgK p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// v2 of the same kernel: operands go HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per
-// wave-instruction) instead of through VGPRs + ds_write_b128, which removes the LDS-write pass that
-// bounded v1 (ds_write_b128 sustains ~79 B/clk/CU: 16 KiB per k-step = ~200 cycles against ~257
-// cycles of MFMA).  An LDS-DMA destination is wave-uniform base + lane*16, so the tile image is
-// linear [row][64 B]; bank conflicts of the ds_read_b128 fragment reads are removed by permuting
-// the 16-byte k-chunks of every row on the SOURCE side (lane loads chunk slot^S[q]) and applying
-// the same involution on the read: q = (row>>2)&3 for pixel rows, (row/NV)&3 for weight rows,
-// S = {0,2,3,1}, which makes the four lane groups of ds_read_b128 hit 16 distinct 16-byte slots.
-// Out-of-image taps load from a 64-byte zero page instead of being zero-filled in registers.
-template <typename T, int TP, int TC, int WP, int WC, int MODE>
-__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p, const char* __restrict__ zero_page) {
+// v2: both operands HBM -> LDS by DMA (pixel rows of TA*ES / TB*ES contiguous bytes, 4-stage ring, counted
+// vmcnt), k-contiguous fragments by ds_read_b64_tr_b16 (bf16: the hardware transposes a [4 pixels][16 channels]
+// block per 16-lane group; probe: profiles/r1_tr_b16_probe.txt) or by ds_read_b32 (f32, one k element per lane).
+// Bank conflicts: 16-byte units of pixel row r are permuted with
+//   bf16: unit pair (32 B = the 16 channels one lane group reads) index ^= (r&3) | ((r>>3)&1)<<2
+//   f32 : 64-byte granule index ^= (r>>2)&1
+// applied on the DMA source side and on the read side alike.
+__device__ __forceinline__ unsigned udiv_rcp(unsigned m, unsigned d, float rcp) {
+    unsigned q = (unsigned)((float)m * rcp);
+    int r = (int)(m - q * d);
+    if (r < 0) { --q; r += (int)d; }
+    if (r >= (int)d) ++q;
+    return q;
+}
+
+template <typename T> __device__ __forceinline__ int wg_swz(int unit, int row, int units_per_row);
+template <> __device__ __forceinline__ int wg_swz<bf16_t>(int unit, int row, int upr) {
+    const int key = ((row & 3) | (((row >> 3) & 1) << 2)) & (upr / 2 - 1);
+    return (((unit >> 1) ^ key) << 1) | (unit & 1);
+}
+template <> __device__ __forceinline__ int wg_swz<float>(int unit, int row, int upr) {
+    return unit ^ ((((row >> 2) & 1) << 2) & (upr - 1));
+}
+
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+
+template <typename T, int TA, int TB, int NST>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgK p) {
     constexpr int ES = sizeof(T);
-    constexpr int KE = 64 / ES;
-    constexpr int CE = 16 / ES;
-    constexpr int WTP = TP / WP, WTC = TC / WC;
-    constexpr int FM = WTC / 16, FN = WTP / 16;
-    constexpr int NV = FM * 4;
-    constexpr int XI = TP / 64, WI = (TC + 63) / 64;
-    constexpr int BUF = (TP + TC) * 64;
-    static_assert(WP * WC == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    constexpr int KP = 64 / ES;                  // pixels per k-step (32 bf16 / 16 f32)
+    constexpr int RBA = TA * ES, RBB = TB * ES;  // bytes per pixel row of each tile
+    constexpr int UA = RBA / 16, UB = RBB / 16;  // 16-byte units per row
+    constexpr int NIA = KP * RBA / 1024, NIB = KP * RBB / 1024;   // DMA wave-instructions per tile
+    constexpr int IA = (NIA + 3) / 4, IB = (NIB + 3) / 4;         // ... per wave
+    constexpr int RPA = 1024 / RBA, RPB = 1024 / RBB;            // pixel rows per wave-instruction
+    constexpr int STAGE = KP * (RBA + RBB);
+    constexpr int LPW = IA + IB;
+    constexpr int WTA = TA / 2, WTB = TB / 2;
+    constexpr int FM = WTA / 16, FN = WTB / 16;
+    static_assert(NIA >= 2 && NIB >= 2, "tile too small");
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wp = wid / WC, wc = wid % WC;
+    const int wa = wid >> 1, wb = wid & 1;
     const int g = lane >> 4, pl = lane & 15;
-    const int m0 = blockIdx.x * TP;
-    const int c0 = blockIdx.y * TC;
-    const int ph = MODE ? (int)blockIdx.z : 0;
-    const int py = ph >> 1, px = ph & 1;
-    auto swz = [](int q) { return (0x1320 >> (4 * (q & 3))) & 3; };   // S = {0,2,3,1}
+    const int ta = blockIdx.x / p.tiles_b, tb = blockIdx.x - ta * p.tiles_b;
+    const int a0 = ta * TA, b0 = tb * TB;
+    const int tap = blockIdx.y;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int mbeg = blockIdx.z * p.mchunk;
+    const int mend = min(p.M, mbeg + p.mchunk);
+    const int nsteps = mend > mbeg ? (mend - mbeg + KP - 1) / KP : 0;
 
-    int kh0 = 0, kw0 = 0, nkh = p.KH, nkw = p.KW;
-    if (MODE) {
-        kh0 = (py + p.pad) & 1; kw0 = (px + p.pad) & 1;
-        nkh = p.KH > kh0 ? (p.KH - kh0 + 1) / 2 : 0;
-        nkw = p.KW > kw0 ? (p.KW - kw0 + 1) / 2 : 0;
-    }
-    const int cps = p.Cin / KE;
-    const int nsteps = nkh * nkw * cps;
+    const u32x4_t rp = make_srd(p.p, p.p_bytes);
+    const u32x4_t rq = make_srd(p.q, p.q_bytes);
+    const unsigned ppix = (unsigned)p.p_ld * ES, qpix = (unsigned)p.q_ld * ES;
+    const unsigned hw = (unsigned)(p.Hp * p.Wp);
 
-    const int lrow = tid >> 2, slot = tid & 3;
-    const int kcx = slot ^ swz(lrow >> 2);           // source k-chunk this lane fetches for pixel rows
-    const int kcw = slot ^ swz(lrow / NV);           // ... and for weight rows
-    int xn[XI], xby[XI], xbx[XI];
-    bool xv[XI];
+    // per-lane (row, unit) of each DMA instruction this wave issues
+    int prow[IA], qrow[IB];
+    unsigned pcol[IA], qcol[IB];
 #pragma unroll
-    for (int i = 0; i < XI; ++i) {
-        const int m = m0 + lrow + i * 64;
-        xv[i] = m < p.M;
-        const int mm = xv[i] ? m : 0;
-        const int n = mm / (p.Hq * p.Wq);
-        const int rem = mm - n * (p.Hq * p.Wq);
-        const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
-        xn[i] = n * p.Hi;
-        xby[i] = MODE ? qy : qy * p.stride;
-        xbx[i] = MODE ? qx : qx * p.stride;
+    for (int i = 0; i < IA; ++i) {
+        const int j = NIA >= 4 ? i * 4 + wid : (wid & (NIA - 1));
+        prow[i] = j * RPA + lane / UA;
+        pcol[i] = (unsigned)a0 * ES + (unsigned)wg_swz<T>(lane % UA, prow[i], UA) * 16u;
     }
-    const T* in = reinterpret_cast<const T*>(p.in);
-    const T* wt = reinterpret_cast<const T*>(p.wt);
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-
-    auto issue = [&](int s, int buf) {
-        const int tap = s / cps;
-        const int cch = s - tap * cps;
-        const int khi = tap / nkw, kwi = tap - khi * nkw;
-        const int kh = MODE ? kh0 + 2 * khi : khi;
-        const int kw = MODE ? kw0 + 2 * kwi : kwi;
-        int dy, dx;
-        if (MODE) { dy = (py + p.pad - kh) / 2; dx = (px + p.pad - kw) / 2; }
-        else if (p.flip) { dy = p.pad - kh; dx = p.pad - kw; }
-        else { dy = kh - p.pad; dx = kw - p.pad; }
-        char* sx = smem + buf * BUF;
-        char* sw = sx + TP * 64;
 #pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            const int iy = xby[i] + dy, ix = xbx[i] + dx;
-            const bool ok = xv[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            const char* src = ok ? reinterpret_cast<const char*>(in + ((long)(xn[i] + iy) * p.Wi + ix) * p.in_ld + cch * KE + kcx * CE)
-                                 : zero_page;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sx + (i * 4 + wid) * 1024), 16, 0, 0);
+    for (int i = 0; i < IB; ++i) {
+        const int j = NIB >= 4 ? i * 4 + wid : (wid & (NIB - 1));
+        qrow[i] = j * RPB + lane / UB;
+        qcol[i] = (unsigned)b0 * ES + (unsigned)wg_swz<T>(lane % UB, qrow[i], UB) * 16u;
+    }
+    auto issue = [&](int s, int stage) {
+        const int mb = mbeg + s * KP;
+        char* sp = smem + stage * STAGE;
+        char* sq = sp + KP * RBA;
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const int m = mb + prow[i];
+            const unsigned off = m < mend ? (unsigned)m * ppix + pcol[i] : OOB_OFF;
+            dma16(rp, sp + (NIA >= 4 ? i * 4 + wid : (wid & (NIA - 1))) * 1024, off, 0);
         }
 #pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            if (TC >= 64 || wid < TC / 16) {       // wave-uniform: a 32-row weight tile is filled by waves 0 and 1
-                const int row = lrow + i * 64;
-                const bool ok = c0 + row < p.Cout;
-                const char* src = ok ? reinterpret_cast<const char*>(wt + ((long)((c0 + row) * p.KH + kh) * p.KW + kw) * p.Cin + cch * KE + kcw * CE)
-                                     : zero_page;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sw + (i * 4 + wid) * 1024), 16, 0, 0);
+        for (int i = 0; i < IB; ++i) {
+            const int m = mb + qrow[i];
+            unsigned off = OOB_OFF;
+            if (m < mend) {
+                const unsigned n = udiv_rcp((unsigned)m, hw, p.rcp_hw);
+                const unsigned rem = (unsigned)m - n * hw;
+                const unsigned y = udiv_rcp(rem, (unsigned)p.Wp, p.rcp_w);
+                const unsigned x = rem - y * (unsigned)p.Wp;
+                const int iy = (int)y * p.stride - p.pad + kh, ix = (int)x * p.stride - p.pad + kw;
+                if ((unsigned)iy < (unsigned)p.Hq && (unsigned)ix < (unsigned)p.Wq)
+                    off = (unsigned)(((int)n * p.Hq + iy) * p.Wq + ix) * qpix + qcol[i];
+            }
+            dma16(rq, sq + (NIB >= 4 ? i * 4 + wid : (wid & (NIB - 1))) * 1024, off, 0);
+        }
+    };
+
+    // fragment read offsets (bytes within a stage)
+    // bf16: lane t=pl of a 16-lane group addresses pixel row 8g + (pl>>2) (+4 for the second half), channels 4*(pl&3)..+3
+    // f32 : lane reads pixel rows 4g + s (s < 4), channel pl
+    int aoff[FM][ES == 2 ? 2 : 4], boff[FN][ES == 2 ? 2 : 4];
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+        if (ES == 2) {
+            const int c = wa * WTA + a * 16 + 4 * (pl & 3);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = 8 * g + (pl >> 2) + 4 * h;
+                aoff[a][h] = r * RBA + wg_swz<T>(c >> 3, r, UA) * 16 + (c & 7) * 2;
+            }
+        } else {
+            const int c = wa * WTA + a * 16 + pl;
+#pragma unroll
+            for (int s = 0; s < (ES == 2 ? 2 : 4); ++s) {
+                const int r = 4 * g + s;
+                aoff[a][s] = r * RBA + wg_swz<T>(c >> 2, r, UA) * 16 + (c & 3) * 4;
             }
         }
+    }
+#pragma unroll
+    for (int b = 0; b < FN; ++b) {
+        if (ES == 2) {
+            const int c = wb * WTB + b * 16 + 4 * (pl & 3);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = 8 * g + (pl >> 2) + 4 * h;
+                boff[b][h] = KP * RBA + r * RBB + wg_swz<T>(c >> 3, r, UB) * 16 + (c & 7) * 2;
+            }
+        } else {
+            const int c = wb * WTB + b * 16 + pl;
+#pragma unroll
+            for (int s = 0; s < (ES == 2 ? 2 : 4); ++s) {
+                const int r = 4 * g + s;
+                boff[b][s] = KP * RBA + r * RBB + wg_swz<T>(c >> 2, r, UB) * 16 + (c & 3) * 4;
+            }
+        }
+    }
+    auto frag = [&](const char* sb, const int* off) -> uint4 {
+        if (ES == 2) {
+            typedef __attribute__((address_space(3))) v4i16_t* lp_t;
+            const v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(sb + off[0]));
+            const v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(sb + off[1]));
+            const uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+            return make_uint4(l.x, l.y, h.x, h.y);
+        }
+        return make_uint4(*reinterpret_cast<const uint32_t*>(sb + off[0]), *reinterpret_cast<const uint32_t*>(sb + off[1]),
+                          *reinterpret_cast<const uint32_t*>(sb + off[ES == 2 ? 0 : 2]), *reinterpret_cast<const uint32_t*>(sb + off[ES == 2 ? 1 : 3]));
     };
 
     f32x4 acc[FM][FN];
@@ -495,134 +744,58 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p, const char
 #pragma unroll
         for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int rslot = (g ^ swz(pl >> 2)) * 16;       // both fragment kinds: (row>>2)&3 resp. (row/NV)&3 equals pl>>2
     if (nsteps > 0) {
-        issue(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < NST - 1; ++st)
+            if (st < nsteps) issue(st, st);
         for (int s = 0; s < nsteps; ++s) {
-            if (s + 1 < nsteps) issue(s + 1, (s + 1) & 1);
-            const char* sx = smem + (s & 1) * BUF;
-            const char* sw = sx + TP * 64;
+            if (s + NST - 2 <= nsteps - 1) wait_vmcnt<(NST - 2) * LPW>();
+            else wait_vmcnt<0>();
+            raw_barrier();
+            if (s + NST - 1 < nsteps) issue(s + NST - 1, (s + NST - 1) & (NST - 1));
+            const char* sb = smem + (s & (NST - 1)) * STAGE;
             uint4 af[FM], bf[FN];
 #pragma unroll
-            for (int a = 0; a < FM; ++a) {
-                const int row = wc * WTC + (pl >> 2) * NV + a * 4 + (pl & 3);
-                af[a] = *reinterpret_cast<const uint4*>(sw + row * 64 + rslot);
-            }
+            for (int a = 0; a < FM; ++a) af[a] = frag(sb, aoff[a]);
 #pragma unroll
-            for (int b = 0; b < FN; ++b)
-                bf[b] = *reinterpret_cast<const uint4*>(sx + (wp * WTP + b * 16 + pl) * 64 + rslot);
+            for (int b = 0; b < FN; ++b) bf[b] = frag(sb, boff[b]);
 #pragma unroll
             for (int a = 0; a < FM; ++a)
 #pragma unroll
                 for (int b = 0; b < FN; ++b) Mma<T>::run(af[a], bf[b], acc[a][b]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed in the other buffer
-            __syncthreads();
         }
-    }
-
-    const int cb = c0 + wc * WTC + g * NV;
-    float sc[NV], sh[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        sc[j] = p.scale ? p.scale[cb + j] : 1.f;
-        sh[j] = p.shift ? p.shift[cb + j] : 0.f;
-    }
-    float s1[NV], s2[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    T* out = reinterpret_cast<T*>(p.out);
-    const T* res = reinterpret_cast<const T*>(p.res);
-#pragma unroll
-    for (int b = 0; b < FN; ++b) {
-        const int m = m0 + wp * WTP + b * 16 + pl;
-        float v[NV];
+        const long taps = (long)p.KH * p.KW;
 #pragma unroll
         for (int a = 0; a < FM; ++a)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][b][r];
-        if (p.stats) {
+            for (int r = 0; r < 4; ++r) {
+                const int ia = a0 + wa * WTA + a * 16 + 4 * g + r;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
-        }
-        if (m < p.M) {
-            long opix = m;
-            if (MODE) {
-                const int n = m / (p.Hq * p.Wq);
-                const int rem = m - n * (p.Hq * p.Wq);
-                const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
-                opix = ((long)n * p.Ho + 2 * qy + py) * p.Wo + 2 * qx + px;
-            }
-#pragma unroll
-            for (int j = 0; j < NV; ++j) v[j] = v[j] * sc[j] + sh[j];
-            if (res) {
-#pragma unroll
-                for (int j = 0; j < NV; j += CE) {
-                    float rv[CE];
-                    Vec16<T>::load(res + opix * p.res_ld + cb + j, rv);
-#pragma unroll
-                    for (int e = 0; e < CE; ++e) v[j + e] += rv[e];
+                for (int b = 0; b < FN; ++b) {
+                    const int ib = b0 + wb * WTB + b * 16 + pl;
+                    if (ia < p.A && ib < p.B) atomicAdd(p.dw + (ia * taps + tap) * p.B + ib, acc[a][b][r]);
                 }
             }
-            if (p.relu) {
-#pragma unroll
-                for (int j = 0; j < NV; ++j) v[j] = fmaxf(v[j], 0.f);
-            }
-#pragma unroll
-            for (int j = 0; j < NV; j += CE) Vec16<T>::store(out + opix * p.out_ld + cb + j, v + j);
-        }
-    }
-    if (p.stats) {
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                s1[j] += __shfl_xor(s1[j], o, 64);
-                s2[j] += __shfl_xor(s2[j], o, 64);
-            }
-        }
-        if (pl == 0) {
-            const long nsl = (long)gridDim.x * WP, sl = (long)blockIdx.x * WP + wp;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) *reinterpret_cast<float2*>(p.stats + ((cb + j) * nsl + sl) * 2) = make_float2(s1[j], s2[j]);
-        }
     }
 }
 
-// 64-byte zero page per device for the out-of-image taps of the DMA kernels (allocated on first use,
-// never freed: the only piece of library-owned device memory)
-const char* zero_page_for_current_device() {
-    static const char* pages[64] = {nullptr};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!pages[dev]) {
-        void* ptr = nullptr;
-        if (hipMalloc(&ptr, 256) != hipSuccess) return nullptr;
-        if (hipMemset(ptr, 0, 256) != hipSuccess) return nullptr;
-        pages[dev] = (const char*)ptr;
-    }
-    return pages[dev];
+bool env_flag(const char* name) {
+    const char* e = getenv(name);
+    return e && e[0] == '1';
 }
-
-bool use_v1_conv() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MSC_CONV_V1"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
+bool use_v1_conv() { static int v = -1; if (v < 0) v = env_flag("MSC_CONV_V1") ? 1 : 0; return v == 1; }
+bool use_v1_wgrad() { static int v = -1; if (v < 0) v = env_flag("MSC_WGRAD_V1") ? 1 : 0; return v == 1; }
 
 template <typename T, int TP, int TC, int WP, int WC>
 int launch_conv(const ConvK& k, int mode, hipStream_t st) {
     dim3 grid(ceil_div(k.M, TP), ceil_div(k.Cout, TC), mode ? 4 : 1);
-    if (use_v1_conv()) {
+    if (use_v1_conv() || k.in_bytes == 0) {
         if (mode) hipLaunchKernelGGL((conv_igemm_kernel<T, TP, TC, WP, WC, 1>), grid, dim3(256), 0, st, k);
         else hipLaunchKernelGGL((conv_igemm_kernel<T, TP, TC, WP, WC, 0>), grid, dim3(256), 0, st, k);
         return msc_check_launch("conv_igemm");
     }
-    const char* zp = zero_page_for_current_device();
-    if (!zp) return msc_fail(MSC_ERR_HIP, "conv_igemm: cannot allocate the zero page");
-    if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1>), grid, dim3(256), 0, st, k, zp);
-    else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0>), grid, dim3(256), 0, st, k, zp);
+    if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1, 4>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, 4>), grid, dim3(256), 0, st, k);
     return msc_check_launch("conv_igemm_dma");
 }
 
@@ -650,6 +823,12 @@ int conv_dispatch(const ConvK& k, int mode, hipStream_t st) {
     if (tc == 64 && tp == 128) return launch_conv<T, 128, 64, 4, 1>(k, mode, st);
     if (tc == 64) return launch_conv<T, 64, 64, 2, 2>(k, mode, st);
     return launch_conv<T, 256, 32, 4, 1>(k, mode, st);
+}
+
+template <typename T, int TA, int TB>
+void launch_wgrad(const WgK& k, dim3 grid, hipStream_t st) {
+    if (use_v1_wgrad() || k.p_bytes == 0) hipLaunchKernelGGL((conv_wgrad_kernel<T, TA, TB>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, TA, TB, 4>), grid, dim3(256), 0, st, k);
 }
 
 }  // namespace
@@ -686,6 +865,12 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
     const long m = (long)d->N * k->Hq * k->Wq;
     if (m <= 0 || m > 0x7fffffffL) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: bad pixel count %ld", m);
     k->M = (int)m;
+    // extents for the DMA kernel's buffer descriptors; 0 = too large for 31-bit offsets -> v1 kernel
+    const long in_b = (((long)d->N * d->Hi * d->Wi - 1) * d->in_ld + d->Cin) * es;
+    const long wt_b = (long)d->Cout * d->KH * d->KW * d->Cin * es;
+    const bool fits = in_b < 0x7fffffffL && wt_b < 0x7fffffffL;
+    k->in_bytes = fits ? (unsigned)in_b : 0;
+    k->wt_bytes = fits ? (unsigned)wt_b : 0;
     return MSC_OK;
 }
 
@@ -723,6 +908,14 @@ extern "C" int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream) {
     const long m = (long)d->N * d->Hp * d->Wp;
     if (m <= 0 || m > 0x7fffffffL) return msc_fail(MSC_ERR_ARG, "msc_conv_wgrad: bad pixel count %ld", m);
     k.M = (int)m;
+    const long p_b = ((m - 1) * d->p_ld + d->A) * es;
+    const long q_b = (((long)d->N * d->Hq * d->Wq - 1) * d->q_ld + d->B) * es;
+    // the float-reciprocal pixel decode of the DMA kernel is exact below 2^24 pixels
+    const bool fits = p_b < 0x7fffffffL && q_b < 0x7fffffffL && m < (1L << 24);
+    k.p_bytes = fits ? (unsigned)p_b : 0;
+    k.q_bytes = fits ? (unsigned)q_b : 0;
+    k.rcp_hw = 1.0f / (float)(d->Hp * d->Wp);
+    k.rcp_w = 1.0f / (float)d->Wp;
     const int kp = 64 / es;
     const bool big = (d->A % 128 == 0) && (d->B % 128 == 0);
     const int ta = big ? 128 : (d->A % 64 == 0 ? 64 : 32), tbs = big ? 128 : (d->B % 64 == 0 ? 64 : 32);
@@ -738,20 +931,18 @@ extern "C" int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream) {
     k.mchunk = mchunk; k.tiles_b = d->B / tbs;
     dim3 grid((d->A / ta) * (d->B / tbs), d->KH * d->KW, splits);
     hipStream_t st = (hipStream_t)stream;
-#define WG_LAUNCH(T, TA, TB) hipLaunchKernelGGL((conv_wgrad_kernel<T, TA, TB>), grid, dim3(256), 0, st, k)
     if (d->dtype == MSC_BF16) {
-        if (big) WG_LAUNCH(bf16_t, 128, 128);
-        else if (ta == 64 && tbs == 64) WG_LAUNCH(bf16_t, 64, 64);
-        else if (ta == 64) WG_LAUNCH(bf16_t, 64, 32);
-        else if (tbs == 64) WG_LAUNCH(bf16_t, 32, 64);
-        else WG_LAUNCH(bf16_t, 32, 32);
+        if (big) launch_wgrad<bf16_t, 128, 128>(k, grid, st);
+        else if (ta == 64 && tbs == 64) launch_wgrad<bf16_t, 64, 64>(k, grid, st);
+        else if (ta == 64) launch_wgrad<bf16_t, 64, 32>(k, grid, st);
+        else if (tbs == 64) launch_wgrad<bf16_t, 32, 64>(k, grid, st);
+        else launch_wgrad<bf16_t, 32, 32>(k, grid, st);
     } else {
-        if (big) WG_LAUNCH(float, 128, 128);
-        else if (ta == 64 && tbs == 64) WG_LAUNCH(float, 64, 64);
-        else if (ta == 64) WG_LAUNCH(float, 64, 32);
-        else if (tbs == 64) WG_LAUNCH(float, 32, 64);
-        else WG_LAUNCH(float, 32, 32);
+        if (big) launch_wgrad<float, 128, 128>(k, grid, st);
+        else if (ta == 64 && tbs == 64) launch_wgrad<float, 64, 64>(k, grid, st);
+        else if (ta == 64) launch_wgrad<float, 64, 32>(k, grid, st);
+        else if (tbs == 64) launch_wgrad<float, 32, 64>(k, grid, st);
+        else launch_wgrad<float, 32, 32>(k, grid, st);
     }
-#undef WG_LAUNCH
     return msc_check_launch("conv_wgrad");
 }
