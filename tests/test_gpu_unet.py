@@ -100,13 +100,14 @@ def test_train_step_fp32_matches_reference_golden(golden_dir, depth):
     assert close(grads['encoder.layer2.0.conv1.weight'][:4, :8], g['g_l2_conv1'])
     assert np.allclose(net.encoder.bn1.running_mean.cpu().numpy(), g['rm_bn1'], atol=1e-5)
     assert np.allclose(net.encoder.bn1.running_var.cpu().numpy(), g['rv_bn1'], atol=1e-5)
-    # every gradient against the oracle
+    # every gradient against the oracle (tensor-wise relative L2 error; see the conditioning note above)
     ref.train()
     lr = losses_ref.mixed_dice_ce(ref(x), tgt)
     lr.backward()
     for n_, p in ref.named_parameters():
         if n_ in grads and p.grad is not None:
-            assert close(grads[n_], p.grad.numpy(), rel=2.5 * base), n_
+            err = (grads[n_] - p.grad).norm().item() / (p.grad.norm().item() + 1e-12)
+            assert err < 2.5 * base, (n_, err)
 
 
 def test_autograd_node_drives_reference_style_loop():
