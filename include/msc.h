@@ -73,6 +73,17 @@ int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream);
  * src/unet_models.py:360) -> [64][7][8][4] (kh, kw padded to 8, ci padded to 4); msc_stem_unpack_grad is its adjoint. */
 int msc_pack_cast(const float* src, void* dst, int dtype, int64_t n, void* stream);
 int msc_pack_transpose(const float* src, void* dst, int dtype, int A, int T, int B, void* stream);
+/* the same for MANY tensors in one launch: block b handles items[block_item[b]], piece block_local[b]
+ * (kind 0: 2048-element piece of a cast; kind 1: one 32x32 tile of tap t of a transpose, local index
+ * = (t*ceil(A/32) + a_tile)*ceil(B/32) + b_tile).  All three tables live in device memory. */
+typedef struct msc_pack_item {
+    const float* src;
+    void* dst;
+    int32_t kind, A, T, B;
+    int64_t n;
+} msc_pack_item;
+int msc_pack_multi(const msc_pack_item* items, const int32_t* block_item, const int32_t* block_local, int nblocks,
+                   int dtype, void* stream);
 int msc_stem_pack(const float* w, void* dst, int dtype, int cout, void* stream);
 int msc_stem_unpack_grad(const float* dpacked, float* dw, int cout, void* stream);
 
@@ -100,7 +111,7 @@ int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_t res_ld, v
 /* backward of out = relu?(bn(y) (+res)):  dh = dout * [out>0] (if relu);
  * reduce: partial[C][msc_bn_bwd_blocks()][2] = (sum dh, sum dh*y) (deterministic, no atomics);  finalize: dgamma, dbeta (accumulated into fp32 grads) and
  * per-channel coefficients coef[3][C];  apply: dy = coef0*dh + coef1*y + coef2 ; dres (optional) = dh (or += if dres_acc). */
-int msc_bn_bwd_blocks(int64_t pixels, int C);
+int msc_bn_bwd_blocks(int64_t pixels, int C, int dtype);
 int msc_bn_bwd_reduce(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
                       int relu, float* partials, int dtype, int64_t pixels, int C, void* stream);
 int msc_bn_bwd_finalize(const float* partials, int blocks, int C, int64_t count, const float* gamma,
@@ -114,7 +125,7 @@ int msc_relu_bwd(const void* dy, int64_t dy_ld, const void* y, int64_t y_ld, voi
                  int accumulate, int dtype, int64_t pixels, int C, void* stream);
 /* per-channel bias gradient: db[c] += sum_pixels dy[p][c]  (conv bias of ConvRelu / ConvTranspose2d);
  * workspace: msc_bias_grad_workspace_bytes() bytes */
-int64_t msc_bias_grad_workspace_bytes(int64_t pixels, int C);
+int64_t msc_bias_grad_workspace_bytes(int64_t pixels, int C, int dtype);
 int msc_bias_grad(const void* dy, int64_t dy_ld, float* db, void* workspace, int dtype, int64_t pixels, int C, void* stream);
 
 /* final 1x1 conv 32 -> 2 with bias (src/unet_models.py:383,403; dropout p = 0) fused with the channel softmax

@@ -52,6 +52,7 @@ SIGNATURES = {
     'msc_conv_wgrad': (_i, [C.POINTER(WgradDesc), _vp]),
     'msc_pack_cast': (_i, [_vp, _vp, _i, _i64, _vp]),
     'msc_pack_transpose': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'msc_pack_multi': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'msc_stem_pack': (_i, [_vp, _vp, _i, _i, _vp]),
     'msc_stem_unpack_grad': (_i, [_vp, _vp, _i, _vp]),
     'msc_stem_prepare': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -60,12 +61,12 @@ SIGNATURES = {
     'msc_bn_finalize': (_i, [_vp, _i, _i, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'msc_bn_fold': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
     'msc_bn_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i64, _i, _vp]),
-    'msc_bn_bwd_blocks': (_i, [_i64, _i]),
+    'msc_bn_bwd_blocks': (_i, [_i64, _i, _i]),
     'msc_bn_bwd_reduce': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _i64, _i, _vp]),
     'msc_bn_bwd_finalize': (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'msc_bn_bwd_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _i64, _vp, _i64, _i, _i, _i64, _i, _vp]),
     'msc_relu_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i64, _i, _vp]),
-    'msc_bias_grad_workspace_bytes': (_i64, [_i64, _i]),
+    'msc_bias_grad_workspace_bytes': (_i64, [_i64, _i, _i]),
     'msc_bias_grad': (_i, [_vp, _i64, _vp, _vp, _i, _i64, _i, _vp]),
     'msc_final_fwd': (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'msc_final_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

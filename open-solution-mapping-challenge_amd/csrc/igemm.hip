@@ -801,11 +801,18 @@ int launch_conv(const ConvK& k, int mode, hipStream_t st) {
 
 // tile choice: TC follows Cout (128 / 64 / 32); the pixel tile shrinks when the launch would not
 // fill the 256 CUs.
+int tile_policy() { static int v = -1; if (v < 0) { const char* e = getenv("MSC_TILE_POLICY"); v = e ? atoi(e) : 0; } return v; }
+
 void pick_tile(int M, int Cout, int* tp, int* tc) {
     if (Cout % 128 == 0) {
         *tc = 128;
         *tp = ((long)ceil_div(M, 128) * (Cout / 128) >= 512) ? 128 : 64;
-        if (*tp == 64) *tc = 64;
+        if (*tp == 64) {
+            *tc = 64;
+            // policy 1: mid-size layers take 128x64 tiles (one block per CU, 8 MFMAs per wave per k-step)
+            // instead of twice as many 64x64 tiles (4 MFMAs per wave per k-step)
+            if (tile_policy() == 1 && (long)ceil_div(M, 128) * (Cout / 64) >= 256) *tp = 128;
+        }
     } else if (Cout % 64 == 0) {
         *tc = 64;
         *tp = ((long)ceil_div(M, 128) * (Cout / 64) >= 512) ? 128 : 64;
@@ -917,12 +924,20 @@ extern "C" int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream) {
     k.rcp_hw = 1.0f / (float)(d->Hp * d->Wp);
     k.rcp_w = 1.0f / (float)d->Wp;
     const int kp = 64 / es;
-    const bool big = (d->A % 128 == 0) && (d->B % 128 == 0);
+    // Tile and split-K choice.  Every split adds one fp32-atomic pass over dW and a pipeline fill, so a block
+    // should run >= 24 k-steps; within that, prefer the largest tile that still gives >= 384 blocks.
+    const int ksteps = ceil_div(k.M, kp);
+    const int max_splits = ksteps / 24 > 1 ? ksteps / 24 : 1;
+    bool big = (d->A % 128 == 0) && (d->B % 128 == 0);
+    if (big) {
+        const int tiles128 = (d->A / 128) * (d->B / 128) * d->KH * d->KW;
+        int sp = ceil_div(768, tiles128);
+        if (sp > max_splits) sp = max_splits;
+        if ((long)tiles128 * sp < 384) big = false;     // not enough parallelism: 64x64 tiles instead
+    }
     const int ta = big ? 128 : (d->A % 64 == 0 ? 64 : 32), tbs = big ? 128 : (d->B % 64 == 0 ? 64 : 32);
     const int tiles = (d->A / ta) * (d->B / tbs) * d->KH * d->KW;
-    // split the pixel (K) dimension until ~4 blocks per CU are in flight, at least 8 k-steps each
-    int splits = ceil_div(1024, tiles);
-    const int max_splits = ceil_div(k.M, 8 * kp);
+    int splits = ceil_div(768, tiles);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     int mchunk = ceil_div(k.M, splits);

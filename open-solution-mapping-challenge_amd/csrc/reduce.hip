@@ -11,20 +11,20 @@
 
 namespace {
 
-constexpr int RED_PIX = 128;   // pixels per block
+constexpr int RED_PIX_MAX = 128;   // pixels per block (halved, down to the row-lane count, until ~1024 blocks exist)
 
 // K = 2: (sum dh, sum dh*y) with dh = dout*[out>0] (BatchNorm backward);  K = 1: sum d (bias gradient)
 template <typename T, int K>
 __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ dout, long dout_ld, const T* __restrict__ out, long out_ld,
                                                         const T* __restrict__ y, long y_ld, int relu, float* __restrict__ partials,
-                                                        long pixels, int C, int cols, int S) {
+                                                        long pixels, int C, int cols, int S, int ppb) {
     constexpr int CE = Vec16<T>::N;
     __shared__ float red[256 * K * CE];
     const int tid = threadIdx.x;
     const int col = tid % cols, r = tid / cols, R = 256 / cols;
     const int vc = blockIdx.y * cols + col;
-    const long p0 = (long)blockIdx.x * RED_PIX;
-    const long p1 = min(pixels, p0 + RED_PIX);
+    const long p0 = (long)blockIdx.x * ppb;
+    const long p1 = min(pixels, p0 + ppb);
     float s1[CE], s2[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -150,18 +150,28 @@ __global__ __launch_bounds__(256) void bias_finalize_kernel(const float* __restr
     if (lane == 0) db[c] += (float)s1;
 }
 
+// launch geometry shared by the reduce launches and the workspace-size queries
+struct RedGeom { int cols, chunks, ppb, S; };
+bool red_geom(long pixels, int C, int ce, RedGeom* g) {
+    const int cv = C / ce;
+    int cols = 64;
+    while (cols > cv) cols >>= 1;                 // 4..64, power of two
+    if (cols < 1 || cv % cols || C % ce) return false;
+    const int rows = 256 / cols;
+    int ppb = RED_PIX_MAX;
+    while (ppb > rows && ppb > 16 && (long)ceil_div(pixels, ppb) * (cv / cols) < 1024) ppb >>= 1;
+    g->cols = cols; g->chunks = cv / cols; g->ppb = ppb; g->S = ceil_div(pixels, ppb);
+    return true;
+}
+
 template <typename T, int K>
 int launch_colreduce(const void* dout, long dout_ld, const void* out, long out_ld, const void* y, long y_ld, int relu,
                      float* partials, long pixels, int C, hipStream_t st) {
-    constexpr int CE = Vec16<T>::N;
-    const int cv = C / CE;
-    int cols = 64;
-    while (cols > cv) cols >>= 1;                 // 4..64, power of two
-    if (cols < 1 || cv % cols) return msc_fail(MSC_ERR_UNSUPPORTED, "column reduce: C=%d not supported", C);
-    const int S = ceil_div(pixels, RED_PIX);
-    dim3 grid(S, cv / cols);
+    RedGeom g;
+    if (!red_geom(pixels, C, Vec16<T>::N, &g)) return msc_fail(MSC_ERR_UNSUPPORTED, "column reduce: C=%d not supported", C);
+    dim3 grid(g.S, g.chunks);
     hipLaunchKernelGGL((colreduce_kernel<T, K>), grid, dim3(256), 0, st, (const T*)dout, dout_ld, (const T*)out, out_ld, (const T*)y, y_ld,
-                       relu, partials, pixels, C, cols, S);
+                       relu, partials, pixels, C, g.cols, g.S, g.ppb);
     return msc_check_launch("colreduce");
 }
 
@@ -179,7 +189,11 @@ extern "C" int msc_bn_finalize(const float* partials, int slices, int C, int64_t
     return msc_check_launch("msc_bn_finalize");
 }
 
-extern "C" int msc_bn_bwd_blocks(int64_t pixels, int C) { (void)C; return ceil_div(pixels, RED_PIX); }
+extern "C" int msc_bn_bwd_blocks(int64_t pixels, int C, int dtype) {
+    RedGeom g;
+    if (pixels <= 0 || !red_geom(pixels, C, dtype == MSC_BF16 ? 8 : 4, &g)) return -1;
+    return g.S;
+}
 
 extern "C" int msc_bn_bwd_reduce(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
                                  int relu, float* partials, int dtype, int64_t pixels, int C, void* stream) {
@@ -199,9 +213,10 @@ extern "C" int msc_bn_bwd_finalize(const float* partials, int blocks, int C, int
     return msc_check_launch("msc_bn_bwd_finalize");
 }
 
-extern "C" int64_t msc_bias_grad_workspace_bytes(int64_t pixels, int C) {
-    if (pixels <= 0 || C <= 0) return 0;
-    return (int64_t)ceil_div(pixels, RED_PIX) * C * (int64_t)sizeof(float);
+extern "C" int64_t msc_bias_grad_workspace_bytes(int64_t pixels, int C, int dtype) {
+    RedGeom g;
+    if (pixels <= 0 || C <= 0 || !red_geom(pixels, C, dtype == MSC_BF16 ? 8 : 4, &g)) return 0;
+    return (int64_t)g.S * C * (int64_t)sizeof(float);
 }
 
 extern "C" int msc_bias_grad(const void* dy, int64_t dy_ld, float* db, void* workspace, int dtype, int64_t pixels, int C, void* stream) {
@@ -212,6 +227,8 @@ extern "C" int msc_bias_grad(const void* dy, int64_t dy_ld, float* db, void* wor
     int rc = dtype == MSC_BF16 ? launch_colreduce<bf16_t, 1>(dy, dy_ld, nullptr, 0, nullptr, 0, 0, (float*)workspace, pixels, C, st)
                                : launch_colreduce<float, 1>(dy, dy_ld, nullptr, 0, nullptr, 0, 0, (float*)workspace, pixels, C, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(bias_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, ceil_div(pixels, RED_PIX), C, db);
+    RedGeom g;
+    red_geom(pixels, C, dtype == MSC_BF16 ? 8 : 4, &g);
+    hipLaunchKernelGGL(bias_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, g.S, C, db);
     return msc_check_launch("msc_bias_grad");
 }

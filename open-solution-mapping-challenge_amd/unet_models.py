@@ -309,10 +309,21 @@ class UNetResNet(nn.Module):
         return out
 
     def _build_pack(self):
-        """Allocate compute copies of the weights and the launch list that refreshes them."""
+        """Allocate compute copies of the weights and the launch list that refreshes them: ONE msc_pack_multi
+        launch over a device-resident table (plus the stem's own layout change)."""
+        import numpy as np
         lib = _lib.load()
         dev = self._flat[0].device
-        pk = {'ops': [], 'w': {}, 'wt': {}}
+        pk = {'ops': [], 'w': {}, 'wt': {}, 'keep': []}
+        items, blk_item, blk_local = [], [], []
+
+        def add(kind, src, dst, a, t, b, n):
+            idx = len(items)
+            items.append((src.data_ptr(), dst.data_ptr(), kind, a, t, b, n))
+            nb = (n + 2047) // 2048 if kind == 0 else t * ((a + 31) // 32) * ((b + 31) // 32)
+            blk_item.append(np.full(nb, idx, np.int32))
+            blk_local.append(np.arange(nb, dtype=np.int32))
+
         for name, m, kind in self._conv_list():
             w = m.weight
             if kind == 'stem':
@@ -325,15 +336,23 @@ class UNetResNet(nn.Module):
             direct = w if self._dt == F32 else None
             if direct is None:
                 direct = torch.empty(n, dtype=self._tdtype, device=dev)
-                pk['ops'].append((lib.msc_pack_cast, (w.data_ptr(), direct.data_ptr(), self._dt, n)))
-            trans = None
-            if True:
-                trans = torch.empty(n, dtype=self._tdtype, device=dev)
-                pk['ops'].append((lib.msc_pack_transpose, (w.data_ptr(), trans.data_ptr(), self._dt, a, kh * kw, b)))
+                add(0, w, direct, a, kh * kw, b, n)
+            trans = torch.empty(n, dtype=self._tdtype, device=dev)
+            add(1, w, trans, a, kh * kw, b, n)
             if kind == 'conv':       # master [Cout][..][Cin]: forward uses direct, dgrad the transpose
                 pk['w'][name], pk['wt'][name] = direct, trans
             else:                    # master [Cin][..][Cout]: forward uses the transpose, dgrad direct
                 pk['w'][name], pk['wt'][name] = trans, direct
+        rec = np.zeros(len(items), dtype=np.dtype({'names': ['src', 'dst', 'kind', 'A', 'T', 'B', 'n'],
+                                                   'formats': ['<u8', '<u8', '<i4', '<i4', '<i4', '<i4', '<i8'],
+                                                   'offsets': [0, 8, 16, 20, 24, 28, 32], 'itemsize': 40}))
+        for i, it in enumerate(items):
+            rec[i] = it
+        t_items = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+        t_bi = torch.from_numpy(np.concatenate(blk_item)).to(dev)
+        t_bl = torch.from_numpy(np.concatenate(blk_local)).to(dev)
+        pk['keep'] += [t_items, t_bi, t_bl]
+        pk['ops'].append((lib.msc_pack_multi, (t_items.data_ptr(), t_bi.data_ptr(), t_bl.data_ptr(), int(t_bi.numel()), self._dt)))
         return pk
 
     def _refresh_weights(self, stream):
@@ -486,7 +505,7 @@ class _Builder:
 
     def bias_ws(self, pixels, C):
         """shared scratch for msc_bias_grad (launches are stream-ordered, so one buffer serves all)"""
-        need = self.lib.msc_bias_grad_workspace_bytes(pixels, C) // 4
+        need = self.lib.msc_bias_grad_workspace_bytes(pixels, C, self.dt) // 4
         if getattr(self, '_bias_ws', None) is None or self._bias_ws.numel() < need:
             self._bias_ws = self.vec(max(need, 1 << 20))
         return self._bias_ws.data_ptr()
@@ -598,7 +617,7 @@ class _Builder:
         net, lib, P, bwd = self.net, self.lib, self.prog, self.prog.bwd
         cout = conv.out_channels
         dout = self.grad_of(out)
-        blocks = lib.msc_bn_bwd_blocks(count, cout)
+        blocks = lib.msc_bn_bwd_blocks(count, cout, self.dt)
         part = self.vec(blocks * cout * 2)
         coef = self.vec(3 * cout)
         self.emit(bwd, lib.msc_bn_bwd_reduce, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, int(relu), part.data_ptr(),

@@ -108,6 +108,20 @@ def pack_transpose(src, dst, dtype, A, T, B):
     _arr(dst, A * T * B).reshape(B, T, A)[...] = _arr(src, A * T * B).reshape(A, T, B).transpose(2, 1, 0)
 
 
+def pack_multi(items, block_item, block_local, nblocks, dtype):
+    import ctypes as C
+    bi = _arr(block_item, nblocks, np.int32)
+    raw = np.ctypeslib.as_array((C.c_uint8 * (40 * (int(bi.max()) + 1))).from_address(int(items)))
+    rec = raw.view(np.dtype({'names': ['src', 'dst', 'kind', 'A', 'T', 'B', 'n'],
+                             'formats': ['<u8', '<u8', '<i4', '<i4', '<i4', '<i4', '<i8'], 'offsets': [0, 8, 16, 20, 24, 28, 32],
+                             'itemsize': 40}))
+    for it in rec:
+        if it['kind'] == 0:
+            pack_cast(int(it['src']), int(it['dst']), dtype, int(it['n']))
+        else:
+            pack_transpose(int(it['src']), int(it['dst']), dtype, int(it['A']), int(it['T']), int(it['B']))
+
+
 def stem_pack(w, dst, dtype, cout):
     ww = _arr(w, cout * 147).reshape(cout, 3, 7, 7)
     out = _arr(dst, cout * 7 * 32).reshape(cout, 7, 8, 4)
@@ -187,7 +201,8 @@ def bn_bwd_reduce(dout, dout_ld, out, out_ld, y, y_ld, relu, partials, dtype, pi
     if relu:
         d = d * (_rows(out, pixels, Cc, out_ld) > 0)
     yy = _rows(y, pixels, Cc, y_ld).astype(np.float64)
-    nb = (pixels + 127) // 128
+    from mapping_challenge_amd import _lib
+    nb = _lib.load().msc_bn_bwd_blocks(pixels, Cc, dtype)
     p = _arr(partials, nb * Cc * 2).reshape(Cc, nb, 2)
     p[...] = 0
     p[:, 0, 0] = d.sum(0)
@@ -259,7 +274,7 @@ def conv_stats_slices(dref):
 
 
 TABLE = {'msc_conv_igemm': conv_igemm, 'msc_conv_wgrad': conv_wgrad, 'msc_pack_cast': pack_cast,
-         'msc_pack_transpose': pack_transpose, 'msc_stem_pack': stem_pack, 'msc_stem_unpack_grad': stem_unpack_grad,
+         'msc_pack_transpose': pack_transpose, 'msc_pack_multi': pack_multi, 'msc_stem_pack': stem_pack, 'msc_stem_unpack_grad': stem_unpack_grad,
          'msc_stem_prepare': stem_prepare, 'msc_maxpool2_fwd': maxpool2_fwd, 'msc_maxpool2_bwd': maxpool2_bwd,
          'msc_bn_finalize': bn_finalize, 'msc_bn_fold': bn_fold, 'msc_bn_apply': bn_apply,
          'msc_bn_bwd_reduce': bn_bwd_reduce, 'msc_bn_bwd_finalize': bn_bwd_finalize, 'msc_bn_bwd_apply': bn_bwd_apply,
