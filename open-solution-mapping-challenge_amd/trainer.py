@@ -113,6 +113,37 @@ class HipAdam:
         return {'m': self.m, 'v': self.v, 'steps': self.steps, 'lr': self.lr}
 
 
+def ddp_plan(prog, flat_grads, nchunks=4):
+    """Cut the backward launch list into `nchunks` pieces and find, after each piece, the suffix of the flat
+    gradient buffer that is final (parameters are laid out in forward order, backward finishes them from the
+    tail): [(launch_end, grad_lo, grad_hi) ...] with grad_lo None when nothing new completed.  The gradient
+    all-reduce of a piece is issued as soon as its launches are enqueued, so RCCL overlaps the rest of backward."""
+    base, n = flat_grads.data_ptr(), flat_grads.numel()
+    last = {}
+    for idx, ptr in prog.grad_writes:
+        off = (ptr - base) // 4
+        last[off] = max(last.get(off, -1), idx)
+    offs = sorted(last)
+    total = len(prog.bwd)
+    plan, done_from = [], n
+    for c in range(nchunks):
+        end = total * (c + 1) // nchunks
+        s = n
+        for off in reversed(offs):
+            if last[off] < end:
+                s = off
+            else:
+                break
+        if c == nchunks - 1:
+            s = 0
+        if s < done_from:
+            plan.append((end, s, done_from))
+            done_from = s
+        else:
+            plan.append((end, None, None))
+    return plan
+
+
 class TrainStep:
     """forward -> loss -> backward -> (all-reduce) -> Adam for a fixed batch shape; optionally captured
     into ONE hipGraph so that the ~1.2k launches of a step cost no host time on replay."""
@@ -136,10 +167,32 @@ class TrainStep:
         prog = net.train_forward(self.x)
         self.prog = prog
         loss_forward_backward(prog.logits, self.t, self.spec, prog.dlogits, self.loss, self.sums, self.world)
-        net.train_backward(prog)
         if self.world is not None and self.world.size > 1:
-            self.world.all_reduce_grads(net.flat_grads)
+            self._backward_overlapped(prog)
+        else:
+            net.train_backward(prog)
         self.opt.step()
+
+    def _backward_overlapped(self, prog):
+        """backward in pieces; each piece's finished gradient range goes to RCCL (async, its own stream) while the
+        next piece computes"""
+        import torch.distributed as dist
+        from .unet_models import _Program
+        net = self.net
+        flat_g = net.flat_grads
+        stream = torch.cuda.current_stream(flat_g.device).cuda_stream
+        if getattr(prog, '_ddp_plan', None) is None:
+            prog._ddp_plan = ddp_plan(prog, flat_g)
+        flat_g.zero_()
+        prog.stem_dw.zero_()
+        works, beg = [], 0
+        for end, lo, hi in prog._ddp_plan:
+            _Program.run(prog.bwd[beg:end], stream)
+            beg = end
+            if lo is not None:
+                works.append(dist.all_reduce(flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.world.group, async_op=True))
+        for w in works:
+            w.wait()
 
     def __call__(self, x, target):
         if self.x is None or self.x.shape != x.shape or self.t.shape != target.shape:

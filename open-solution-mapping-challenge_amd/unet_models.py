@@ -482,6 +482,7 @@ class _Builder:
         self.prog = _Program()
         self.prog.training = training
         self.prog.fold, self.prog.fold_version = [], -1
+        self.prog.grad_writes = []     # (index into bwd, device address of the gradient it writes)
         self.ops = []                 # backward emitters, forward order
         self.gbuf = {}                # id(buffer) -> grad buffer
         self.gwritten = set()         # (id(gbuf), c0, C) already written in this backward
@@ -502,6 +503,13 @@ class _Builder:
 
     def act(self, H, W, C):
         return Act(self.buf(H, W, C))
+
+    def g(self, param):
+        """gradient address of `param`; records which backward launch (the next one emitted) writes it, so the
+        data-parallel step knows when a suffix of the flat gradient buffer is final (trainer.ddp_plan)"""
+        ptr = self.net._g(param)
+        self.prog.grad_writes.append((len(self.prog.bwd), ptr))
+        return ptr
 
     def bias_ws(self, pixels, C):
         """shared scratch for msc_bias_grad (launches are stream-ordered, so one buffer serves all)"""
@@ -623,7 +631,7 @@ class _Builder:
         self.emit(bwd, lib.msc_bn_bwd_reduce, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, int(relu), part.data_ptr(),
                   self.dt, count, cout)
         self.emit(bwd, lib.msc_bn_bwd_finalize, part.data_ptr(), blocks, cout, count, bn.weight.data_ptr(),
-                  mean.data_ptr(), invstd.data_ptr(), net._g(bn.weight), net._g(bn.bias), coef.data_ptr())
+                  mean.data_ptr(), invstd.data_ptr(), self.g(bn.weight), self.g(bn.bias), coef.data_ptr())
         dres_ptr, dres_ld, dres_acc = None, 0, 0
         if res is not None:
             gres = self.grad_of(res)
@@ -635,9 +643,9 @@ class _Builder:
         dy = y
         if stem is not None:
             self.wgrad(bwd, dy, x, P.stem_dw.data_ptr(), 7, 1, 2, 0, q_hw=stem, q_ld=4, B=32)
-            self.emit(bwd, lib.msc_stem_unpack_grad, P.stem_dw.data_ptr(), net._g(conv.weight), 64)
+            self.emit(bwd, lib.msc_stem_unpack_grad, P.stem_dw.data_ptr(), self.g(conv.weight), 64)
             return                                    # the network input needs no gradient
-        self.wgrad(bwd, dy, x, net._g(conv.weight), geo['KH'], geo['KW'], geo['stride'], geo['pad'])
+        self.wgrad(bwd, dy, x, self.g(conv.weight), geo['KH'], geo['KW'], geo['stride'], geo['pad'])
         gx = self.grad_of(x)
         acc = self.grad_acc(x)
         wt = net._pack['wt'][name]
@@ -660,8 +668,8 @@ class _Builder:
         count = out.pixels
         if not masked:   # dmask = dout * [out > 0], in place: `out` has exactly one consumer
             self.emit(bwd, lib.msc_relu_bwd, dout.ptr, dout.ld, out.ptr, out.ld, dout.ptr, dout.ld, 0, self.dt, count, out.C)
-        self.emit(bwd, lib.msc_bias_grad, dout.ptr, dout.ld, net._g(conv.bias), self.bias_ws(count, out.C), self.dt, count, out.C)
-        self.wgrad(bwd, dout, x, net._g(conv.weight), 3, 3, 1, 1)
+        self.emit(bwd, lib.msc_bias_grad, dout.ptr, dout.ld, self.g(conv.bias), self.bias_ws(count, out.C), self.dt, count, out.C)
+        self.wgrad(bwd, dout, x, self.g(conv.weight), 3, 3, 1, 1)
         gx = self.grad_of(x)
         acc = self.grad_acc(x)
         self.conv(bwd, dout, net._pack['wt'][name], gx, KH=3, KW=3, stride=1, pad=1, flip=1, res=gx if acc else None)
@@ -679,9 +687,9 @@ class _Builder:
         count = out.pixels
         dm = self.act(out.H, out.W, out.C)           # compact masked gradient (dout may be a slice of a concat)
         self.emit(bwd, lib.msc_relu_bwd, dout.ptr, dout.ld, out.ptr, out.ld, dm.ptr, dm.ld, 0, self.dt, count, out.C)
-        self.emit(bwd, lib.msc_bias_grad, dm.ptr, dm.ld, net._g(deconv.bias), self.bias_ws(count, out.C), self.dt, count, out.C)
+        self.emit(bwd, lib.msc_bias_grad, dm.ptr, dm.ld, self.g(deconv.bias), self.bias_ws(count, out.C), self.dt, count, out.C)
         # dW[ci][kh][kw][co] = sum_coarse x[c][ci] * dm[2c-1+k][co]
-        self.wgrad(bwd, x, dm, net._g(deconv.weight), 4, 4, 2, 1)
+        self.wgrad(bwd, x, dm, self.g(deconv.weight), 4, 4, 2, 1)
         gx = self.grad_of(x)
         acc = self.grad_acc(x)
         self.conv(bwd, dm, net._pack['wt'][name], gx, KH=4, KW=4, stride=2, pad=1, res=gx if acc else None)
@@ -783,7 +791,7 @@ class _Builder:
             self.grad_acc(d0)
             # final 1x1 backward also applies dec0's ReLU mask, so dec0's backward skips it
             self.emit(P.bwd, lib.msc_final_bwd, P.dlogits.data_ptr(), d0.ptr, d0.ld, fin.weight.data_ptr(), gd0.ptr, gd0.ld,
-                      net._g(fin.weight), net._g(fin.bias), self.dt, N, H, W, nf)
+                      self.g(fin.weight), self.g(fin.bias), self.dt, N, H, W, nf)
             self._conv_relu_bwd('dec0.conv', x, net.dec0.conv, d0, masked=True)
             for op in reversed(self.ops):
                 op()

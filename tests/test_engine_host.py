@@ -74,3 +74,28 @@ def test_rejects_unsupported_configurations():
     net._host_interpreter = True
     with pytest.raises(ValueError, match='divisible by 64'):
         net.eval()(torch.zeros(1, 3, 300, 300))       # 300x300 is not a legal network input
+
+
+def test_ddp_plan_only_releases_finished_gradient_ranges(interpreted):
+    """the data-parallel step all-reduces a suffix of the flat gradient buffer after each quarter of backward: every
+    parameter inside a released range must have no later writer, and the ranges must tile the whole buffer"""
+    from mapping_challenge_amd.trainer import ddp_plan
+    ref, net = build(34)
+    net.train()
+    prog = net.train_forward(unet_ref.synthetic_batch(1, 64, 64))
+    flat_g = net.flat_grads
+    plan = ddp_plan(prog, flat_g, nchunks=4)
+    base = flat_g.data_ptr()
+    covered = []
+    for end, lo, hi in plan:
+        if lo is None:
+            continue
+        covered.append((lo, hi))
+        for idx, ptr in prog.grad_writes:
+            off = (ptr - base) // 4
+            if lo <= off < hi:
+                assert idx < end, (idx, end, off)
+    covered.sort()
+    assert covered[0][0] == 0 and covered[-1][1] == flat_g.numel()
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    assert len(covered) >= 3          # the overlap is real: gradients are released in several pieces

@@ -169,3 +169,37 @@ def test_bf16_train_step_runs_and_reduces_loss():
     tgt = losses_ref.synthetic_target(4, 64, 64)[:, :1].contiguous().cuda()
     losses = [step(x, tgt).item() for _ in range(8)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+def test_rccl_world1_overlapped_backward_equals_plain():
+    """RCCL smoke (one GPU is all gpurun exposes): process group of size 1 on backend nccl; the piecewise backward
+    with asynchronous per-piece all-reduce must give the gradients of the plain backward"""
+    import os
+    import torch.distributed as dist
+    from mapping_challenge_amd.distributed import World
+    from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(29600 + os.getpid() % 1000))
+        dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        world = World()
+        ref, net = build(34, 'fp32')
+        net.train()
+        x = unet_ref.synthetic_batch(2, 64, 64).cuda()
+        tgt = losses_ref.synthetic_target(2, 64, 64).cuda()
+        step = TrainStep(net, LossSpec.plain_ce(), HipAdam(net, lr=0.0), world=world)
+        step._setup(x, tgt[:, :1].contiguous())
+        step.x.copy_(x); step.t.copy_(tgt[:, :1])
+        prog = net.train_forward(step.x)
+        from mapping_challenge_amd.trainer import loss_forward_backward
+        loss_forward_backward(prog.logits, step.t, step.spec, prog.dlogits, step.loss, step.sums, world)
+        net.train_backward(prog)
+        plain = net.flat_grads.clone()
+        step._backward_overlapped(prog)
+        torch.cuda.synchronize()
+        scale = plain.abs().max().item()
+        assert (net.flat_grads - plain).abs().max().item() <= 1e-5 * scale
+        world.sync_model(net)
+    finally:
+        dist.destroy_process_group()
