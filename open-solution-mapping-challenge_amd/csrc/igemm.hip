@@ -295,21 +295,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
 }
 
 // ------------------------------------------------------------------------------------------------ v2 (DMA)
-// LDS image per stage: [TP pixel rows][64 B] then [TC weight rows][64 B], linear.  Row r keeps its four
-// 16-byte k-chunks permuted: slot = chunk ^ S[q], q = (r>>2)&3 for pixel rows and (r/NV)&3 for weight rows,
-// S = {0,2,3,1}: the four lane groups of ds_read_b128 ({0-3,12-15,20-27}, ...) then hit 16 distinct slots.
-template <typename T, int TP, int TC, int WP, int WC, int MODE, int NST>
-__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
+// K step = KB bytes per row: 128 B (one full cache line per row) whenever Cin*sizeof(T) is a multiple of 128,
+// else 64 B.  Measured LDS-DMA fill rate with the operand's 512-byte row pitch (profiles/r1_dma_fill_probe.txt):
+// 64-byte row segments 9-16 TB/s, 128-byte segments 28-31 TB/s -- the 64-byte form bounded the whole kernel.
+// LDS image per stage: [TP pixel rows][KB] then [TC weight rows][KB], linear (DMA destination = wave base +
+// lane*16).  Bank conflicts of the ds_read_b128 fragment reads are removed by permuting the 16-byte chunks of a
+// row on the SOURCE side and applying the same involution on the read:
+//   KB = 64 : slot = chunk ^ S[q],  S = {0,2,3,1},  q = (row>>2)&3 (pixel rows) | (row/NV)&3 (weight rows)
+//   KB = 128: slot = chunk ^ q,     q = (row>>1)&7 (pixel rows) | ((row/NV)&3)<<1 | (row>>1)&1 (weight rows)
+// both keys reduce to a function of the fragment lane (pl) only, so the four lane groups of ds_read_b128
+// ({0-3,12-15,20-27}, ...) hit 16 distinct 16-byte slots.
+template <int KB> __device__ __forceinline__ int swz_x(int row) {
+    return KB == 64 ? ((0x1320 >> (4 * ((row >> 2) & 3))) & 3) : ((row >> 1) & 7);
+}
+template <int KB, int NV> __device__ __forceinline__ int swz_w(int row) {
+    return KB == 64 ? ((0x1320 >> (4 * ((row / NV) & 3))) & 3) : ((((row / NV) & 3) << 1) | ((row >> 1) & 1));
+}
+template <int KB> __device__ __forceinline__ int swz_frag(int pl) {      // key of both fragment kinds for lane pl
+    return KB == 64 ? ((0x1320 >> (4 * ((pl >> 2) & 3))) & 3) : ((pl >> 1) & 7);
+}
+
+template <typename T, int TP, int TC, int WP, int WC, int MODE, int NST, int KB>
+__global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
     constexpr int ES = sizeof(T);
-    constexpr int KE = 64 / ES;
+    constexpr int NW = WP * WC;                  // waves per block
+    constexpr int KE = KB / ES;                  // K elements per step
+    constexpr int KSUB = KB / 64;                // MFMA sub-steps per K step
+    constexpr int LPR = KB / 16;                 // lanes (16-byte chunks) per row
+    constexpr int RPI = 64 / LPR;                // rows per DMA wave-instruction
     constexpr int WTP = TP / WP, WTC = TC / WC;
     constexpr int FM = WTC / 16, FN = WTP / 16;
     constexpr int NV = FM * 4;
-    constexpr int XI = TP / 64, WI = (TC + 63) / 64;
-    constexpr int STAGE = (TP + TC) * 64;
-    constexpr int LPW = XI + WI;                 // DMA instructions per wave per stage (uniform over waves)
-    static_assert(WP * WC == 4, "4 waves");
-    static_assert(NST >= 3 && (NST & (NST - 1)) == 0, "power-of-two ring");
+    constexpr int NIX = TP / RPI, NIW = TC / RPI;                 // DMA wave-instructions per tile
+    constexpr int XI = (NIX + NW - 1) / NW, WI = (NIW + NW - 1) / NW;   // ... per wave (short tiles are fetched redundantly)
+    constexpr int STAGE = (TP + TC) * KB;
+    constexpr int LPW = XI + WI;                 // DMA instructions per wave per stage, uniform over waves
+    static_assert(NIX % NW == 0 || NIX < NW, "pixel tile / wave count");
+    static_assert(NST * STAGE <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
 
     const int tid = threadIdx.x;
@@ -321,7 +343,6 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
     const int c0 = blockIdx.y * TC;
     const int ph = MODE ? (int)blockIdx.z : 0;
     const int py = ph >> 1, px = ph & 1;
-    auto swz = [](int q) { return (0x1320 >> (4 * (q & 3))) & 3; };   // S = {0,2,3,1}
 
     int kh0 = 0, kw0 = 0, nkh = p.KH, nkw = p.KW;
     if (MODE) {
@@ -335,14 +356,18 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
     const u32x4_t rx = make_srd(p.in, p.in_bytes);
     const u32x4_t rw = make_srd(p.wt, p.wt_bytes);
 
-    const int lrow = tid >> 2, slot = tid & 3;
-    const unsigned kcx = (unsigned)(slot ^ swz(lrow >> 2)) * 16u;     // source k-chunk (bytes) fetched for pixel rows
-    const unsigned kcw = (unsigned)(slot ^ swz(lrow / NV)) * 16u;     // ... and for weight rows
+    // ---- DMA lanes: instruction j (of this wave: j = i*NW + wid) covers tile rows j*RPI .. +RPI-1
+    const int lr = lane / LPR, slot = lane % LPR;
+    const unsigned pix_bytes = (unsigned)p.in_ld * ES;
+    const unsigned tap_bytes = (unsigned)p.Cin * ES;
     int xn[XI], xby[XI], xbx[XI];
+    unsigned xkc[XI];
     bool xv[XI];
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-        const int m = m0 + lrow + i * 64;
+        const int j = NIX >= NW ? i * NW + wid : wid % NIX;
+        const int row = j * RPI + lr;
+        const int m = m0 + row;
         xv[i] = m < p.M;
         const int mm = xv[i] ? m : 0;
         const int n = mm / (p.Hq * p.Wq);
@@ -351,19 +376,19 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
         xn[i] = n * p.Hi;
         xby[i] = MODE ? qy : qy * p.stride;
         xbx[i] = MODE ? qx : qx * p.stride;
+        xkc[i] = (unsigned)(slot ^ swz_x<KB>(row)) * 16u;
     }
-    const unsigned pix_bytes = (unsigned)p.in_ld * ES;
-    const unsigned tap_bytes = (unsigned)p.Cin * ES;
     unsigned wrow[WI];
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-        const int row = (lrow + i * 64) & (TC - 1);        // a 32-row weight tile is fetched twice (waves 2,3 repeat 0,1)
+        const int j = NIW >= NW ? i * NW + wid : wid % NIW;
+        const int row = j * RPI + lr;
         const int co = c0 + row;
-        wrow[i] = co < p.Cout ? (unsigned)co * (unsigned)(p.KH * p.KW) * tap_bytes + kcw : OOB_OFF;
+        wrow[i] = co < p.Cout ? (unsigned)co * (unsigned)(p.KH * p.KW) * tap_bytes + (unsigned)(slot ^ swz_w<KB, NV>(row)) * 16u : OOB_OFF;
     }
 
     // ---- issue iterator: (tap, k-chunk) of the next stage to fetch; per-lane offsets refreshed once per tap
-    int itap = 0, icch = 0;
+    int itap = 0, icch = 0, istage = 0;
     unsigned xoff[XI], woff[WI];
     auto set_tap = [&](int tap) {
         const int khi = tap / nkw, kwi = tap - khi * nkw;
@@ -377,22 +402,23 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
         for (int i = 0; i < XI; ++i) {
             const int iy = xby[i] + dy, ix = xbx[i] + dx;
             const bool ok = xv[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            xoff[i] = ok ? (unsigned)((xn[i] + iy) * p.Wi + ix) * pix_bytes + kcx : OOB_OFF;
+            xoff[i] = ok ? (unsigned)((xn[i] + iy) * p.Wi + ix) * pix_bytes + xkc[i] : OOB_OFF;
         }
         const unsigned toff = (unsigned)(kh * p.KW + kw) * tap_bytes;
 #pragma unroll
         for (int i = 0; i < WI; ++i) woff[i] = wrow[i] == OOB_OFF ? OOB_OFF : wrow[i] + toff;
     };
-    auto issue = [&](int stage) {
+    auto issue = [&]() {
         if (icch == 0) set_tap(itap);
-        const int soff = icch * 64;
-        char* sx = smem + stage * STAGE;
-        char* sw = sx + TP * 64;
+        const int soff = icch * KB;
+        char* sx = smem + istage * STAGE;
+        char* sw = sx + TP * KB;
 #pragma unroll
-        for (int i = 0; i < XI; ++i) dma16(rx, sx + (i * 4 + wid) * 1024, xoff[i], soff);
+        for (int i = 0; i < XI; ++i) dma16(rx, sx + (NIX >= NW ? i * NW + wid : wid % NIX) * 1024, xoff[i], soff);
 #pragma unroll
-        for (int i = 0; i < WI; ++i) dma16(rw, sw + (i * 4 + (TC >= 64 ? wid : (wid & (TC / 16 - 1)))) * 1024, woff[i], soff);
+        for (int i = 0; i < WI; ++i) dma16(rw, sw + (NIW >= NW ? i * NW + wid : wid % NIW) * 1024, woff[i], soff);
         if (++icch == cps) { icch = 0; ++itap; }
+        if (++istage == NST) istage = 0;
     };
 
     f32x4 acc[FM][FN];
@@ -401,34 +427,40 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
 #pragma unroll
         for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // fragment read offsets within a stage (both kinds: the swizzle key equals pl>>2)
-    const int rslot = (g ^ swz(pl >> 2)) * 16;
+    // fragment read offsets within a stage for MFMA sub-step 0 (sub-step kk: chunk index + 4*kk before the swizzle)
+    const int key = swz_frag<KB>(pl);
     int aoff[FM], boff[FN];
 #pragma unroll
-    for (int a = 0; a < FM; ++a) aoff[a] = TP * 64 + (wc * WTC + (pl >> 2) * NV + a * 4 + (pl & 3)) * 64 + rslot;
+    for (int a = 0; a < FM; ++a) aoff[a] = TP * KB + (wc * WTC + (pl >> 2) * NV + a * 4 + (pl & 3)) * KB;
 #pragma unroll
-    for (int b = 0; b < FN; ++b) boff[b] = (wp * WTP + b * 16 + pl) * 64 + rslot;
+    for (int b = 0; b < FN; ++b) boff[b] = (wp * WTP + b * 16 + pl) * KB;
 
     if (nsteps > 0) {
 #pragma unroll
         for (int st = 0; st < NST - 1; ++st)
-            if (st < nsteps) issue(st);
+            if (st < nsteps) issue();
+        int cstage = 0;
         for (int s = 0; s < nsteps; ++s) {
             // stage s must have landed; stages s+1 .. s+NST-2 may stay in flight
             if (s + NST - 2 <= nsteps - 1) wait_vmcnt<(NST - 2) * LPW>();
             else wait_vmcnt<0>();
             raw_barrier();                       // everyone's DMA of stage s is in LDS, everyone is done with stage s-1
-            if (s + NST - 1 < nsteps) issue((s + NST - 1) & (NST - 1));
-            const char* sb = smem + (s & (NST - 1)) * STAGE;
-            uint4 af[FM], bf[FN];
+            if (s + NST - 1 < nsteps) issue();
+            const char* sb = smem + cstage * STAGE;
 #pragma unroll
-            for (int a = 0; a < FM; ++a) af[a] = *reinterpret_cast<const uint4*>(sb + aoff[a]);
+            for (int kk = 0; kk < KSUB; ++kk) {
+                const int so = ((kk * 4 + g) ^ key) * 16;
+                uint4 af[FM], bf[FN];
 #pragma unroll
-            for (int b = 0; b < FN; ++b) bf[b] = *reinterpret_cast<const uint4*>(sb + boff[b]);
+                for (int a = 0; a < FM; ++a) af[a] = *reinterpret_cast<const uint4*>(sb + aoff[a] + so);
 #pragma unroll
-            for (int a = 0; a < FM; ++a)
+                for (int b = 0; b < FN; ++b) bf[b] = *reinterpret_cast<const uint4*>(sb + boff[b] + so);
 #pragma unroll
-                for (int b = 0; b < FN; ++b) Mma<T>::run(af[a], bf[b], acc[a][b]);
+                for (int a = 0; a < FM; ++a)
+#pragma unroll
+                    for (int b = 0; b < FN; ++b) Mma<T>::run(af[a], bf[b], acc[a][b]);
+            }
+            if (++cstage == NST) cstage = 0;
         }
     }
     conv_epilogue<T, FM, FN, WTP, WP, MODE>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px);
@@ -785,51 +817,68 @@ bool env_flag(const char* name) {
 }
 bool use_v1_conv() { static int v = -1; if (v < 0) v = env_flag("MSC_CONV_V1") ? 1 : 0; return v == 1; }
 bool use_v1_wgrad() { static int v = -1; if (v < 0) v = env_flag("MSC_WGRAD_V1") ? 1 : 0; return v == 1; }
+bool env_flag_cached_kb64() { static int v = -1; if (v < 0) v = env_flag("MSC_CONV_KB64") ? 1 : 0; return v == 1; }
 
-template <typename T, int TP, int TC, int WP, int WC>
+// One tile configuration = (pixel rows, channels, waves along pixels, waves along channels, ring depth at KB=128,
+// ring depth at KB=64).  LDS = NST*(TP+TC)*KB.
+template <typename T, int TP, int TC, int WP, int WC, int NST128, int NST64>
 int launch_conv(const ConvK& k, int mode, hipStream_t st) {
     dim3 grid(ceil_div(k.M, TP), ceil_div(k.Cout, TC), mode ? 4 : 1);
+    constexpr int NT = WP * WC * 64;
     if (use_v1_conv() || k.in_bytes == 0) {
-        if (mode) hipLaunchKernelGGL((conv_igemm_kernel<T, TP, TC, WP, WC, 1>), grid, dim3(256), 0, st, k);
-        else hipLaunchKernelGGL((conv_igemm_kernel<T, TP, TC, WP, WC, 0>), grid, dim3(256), 0, st, k);
+        if (WP * WC != 4) return msc_fail(MSC_ERR_UNSUPPORTED, "conv_igemm: v1 kernel has no 8-wave form");
+        if constexpr (WP * WC == 4) {
+            if (mode) hipLaunchKernelGGL((conv_igemm_kernel<T, TP, TC, WP, WC, 1>), grid, dim3(256), 0, st, k);
+            else hipLaunchKernelGGL((conv_igemm_kernel<T, TP, TC, WP, WC, 0>), grid, dim3(256), 0, st, k);
+        }
         return msc_check_launch("conv_igemm");
     }
-    if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1, 4>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, 4>), grid, dim3(256), 0, st, k);
+    const bool kb128 = ((long)k.Cin * (long)sizeof(T)) % 128 == 0 && !env_flag_cached_kb64();
+    if (kb128) {
+        if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1, NST128, 128>), grid, dim3(NT), 0, st, k);
+        else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, NST128, 128>), grid, dim3(NT), 0, st, k);
+    } else {
+        if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1, NST64, 64>), grid, dim3(NT), 0, st, k);
+        else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, NST64, 64>), grid, dim3(NT), 0, st, k);
+    }
     return msc_check_launch("conv_igemm_dma");
 }
 
-// tile choice: TC follows Cout (128 / 64 / 32); the pixel tile shrinks when the launch would not
-// fill the 256 CUs.
 int tile_policy() { static int v = -1; if (v < 0) { const char* e = getenv("MSC_TILE_POLICY"); v = e ? atoi(e) : 0; } return v; }
 
-void pick_tile(int M, int Cout, int* tp, int* tc) {
+// Tile choice.  The kernel is bounded by the L2->LDS fill rate on small tiles (flop per fetched byte =
+// TP*TC/(TP+TC) per 2 bytes), so take the largest tile that still gives every CU a block:
+//   Cout % 128 == 0:  256x128 (8 waves) if >= 512 blocks, else 128x128 if >= 256, else 64x64
+//   Cout %  64 == 0:  128x64 if >= 256 blocks, else 64x64          Cout % 32 == 0: 256x32
+// returns a config id; tp/tc/wp are what msc_conv_stats_slices needs
+enum { CFG_256x128, CFG_128x128, CFG_128x64, CFG_64x64, CFG_256x32 };
+int pick_tile(int M, int Cout, int* tp, int* tc, int* wp) {
+    int cfg;
     if (Cout % 128 == 0) {
-        *tc = 128;
-        *tp = ((long)ceil_div(M, 128) * (Cout / 128) >= 512) ? 128 : 64;
-        if (*tp == 64) {
-            *tc = 64;
-            // policy 1: mid-size layers take 128x64 tiles (one block per CU, 8 MFMAs per wave per k-step)
-            // instead of twice as many 64x64 tiles (4 MFMAs per wave per k-step)
-            if (tile_policy() == 1 && (long)ceil_div(M, 128) * (Cout / 64) >= 256) *tp = 128;
-        }
+        const long b128 = (long)ceil_div(M, 128) * (Cout / 128);
+        if (tile_policy() != 2 && (long)ceil_div(M, 256) * (Cout / 128) >= 512) cfg = CFG_256x128;
+        else if (b128 >= 256) cfg = CFG_128x128;
+        else cfg = CFG_64x64;
     } else if (Cout % 64 == 0) {
-        *tc = 64;
-        *tp = ((long)ceil_div(M, 128) * (Cout / 64) >= 512) ? 128 : 64;
+        cfg = ((long)ceil_div(M, 128) * (Cout / 64) >= 256) ? CFG_128x64 : CFG_64x64;
     } else {
-        *tc = 32;
-        *tp = 256;
+        cfg = CFG_256x32;
     }
+    static const int TPs[] = {256, 128, 128, 64, 256}, TCs[] = {128, 128, 64, 64, 32}, WPs[] = {4, 2, 4, 2, 4};
+    *tp = TPs[cfg]; *tc = TCs[cfg]; *wp = WPs[cfg];
+    return cfg;
 }
 
 template <typename T>
 int conv_dispatch(const ConvK& k, int mode, hipStream_t st) {
-    int tp, tc;
-    pick_tile(k.M, k.Cout, &tp, &tc);
-    if (tc == 128) return launch_conv<T, 128, 128, 2, 2>(k, mode, st);
-    if (tc == 64 && tp == 128) return launch_conv<T, 128, 64, 4, 1>(k, mode, st);
-    if (tc == 64) return launch_conv<T, 64, 64, 2, 2>(k, mode, st);
-    return launch_conv<T, 256, 32, 4, 1>(k, mode, st);
+    int tp, tc, wp;
+    switch (pick_tile(k.M, k.Cout, &tp, &tc, &wp)) {
+        case CFG_256x128: return launch_conv<T, 256, 128, 4, 2, 3, 4>(k, mode, st);   // 144 KB / 96 KB of LDS, 1 block (8 waves) per CU
+        case CFG_128x128: return launch_conv<T, 128, 128, 2, 2, 4, 4>(k, mode, st);   // 128 KB / 64 KB
+        case CFG_128x64:  return launch_conv<T, 128, 64, 4, 1, 4, 4>(k, mode, st);    //  96 KB / 48 KB
+        case CFG_64x64:   return launch_conv<T, 64, 64, 2, 2, 4, 4>(k, mode, st);     //  64 KB / 32 KB
+        default:          return launch_conv<T, 256, 32, 4, 1, 4, 4>(k, mode, st);    // 144 KB / 72 KB
+    }
 }
 
 template <typename T, int TA, int TB>
@@ -884,10 +933,9 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
 extern "C" int msc_conv_stats_slices(const msc_conv_desc* d) {
     ConvK k;
     if (conv_fill(d, &k) != MSC_OK) return -1;
-    int tp, tc;
-    pick_tile(k.M, k.Cout, &tp, &tc);
-    const int wpx = (tc == 128 || (tc == 64 && tp == 64)) ? 2 : 4;
-    return ceil_div(k.M, tp) * wpx;
+    int tp, tc, wp;
+    pick_tile(k.M, k.Cout, &tp, &tc, &wp);
+    return ceil_div(k.M, tp) * wp;
 }
 
 extern "C" int msc_conv_igemm(const msc_conv_desc* d, void* stream) {
