@@ -51,9 +51,13 @@ typedef struct msc_conv_desc {
     int64_t in_ld, out_ld, res_ld;
     int32_t dtype, mode;
     int32_t N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, flip, relu;
+    int32_t cfg;   /* 0 = heuristic kernel configuration, 1..msc_conv_num_cfgs() = explicit (tile, K-step, ring depth) */
 } msc_conv_desc;
 int msc_conv_igemm(const msc_conv_desc* d, void* stream);
-int msc_conv_stats_slices(const msc_conv_desc* d);
+int msc_conv_stats_slices(const msc_conv_desc* d);   /* depends on d->cfg */
+/* configurations of the conv kernel that are valid for a descriptor (for per-layer timing by the caller) */
+int msc_conv_num_cfgs(void);
+int msc_conv_cfg_ok(const msc_conv_desc* d, int cfg);
 
 /* weight gradient (autograd of the same modules; reference: loss.backward(), src/steps/pytorch/models.py:110)
  *   dw[a][kh][kw][b] += sum_m p[m][a] * q[(y*stride-pad+kh, x*stride-pad+kw)][b]    (fp32 atomics, dw pre-zeroed)
@@ -65,6 +69,8 @@ typedef struct msc_wgrad_desc {
     int64_t p_ld, q_ld;
     int32_t dtype;
     int32_t N, Hp, Wp, A, Hq, Wq, B, KH, KW, stride, pad;
+    int32_t cfg;   /* 0 = heuristic; 1 + tile*4 + split: tile 0 = 128x128 when divisible / 1 = 64x64 at most, split = index of
+                      the target block count {256, 512, 1024, 2048} the pixel dimension is split for */
 } msc_wgrad_desc;
 int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream);
 

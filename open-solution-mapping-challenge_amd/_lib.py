@@ -24,7 +24,7 @@ class ConvDesc(C.Structure):
                 ('dtype', C.c_int32), ('mode', C.c_int32),
                 ('N', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32), ('Cin', C.c_int32),
                 ('Ho', C.c_int32), ('Wo', C.c_int32), ('Cout', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32),
-                ('stride', C.c_int32), ('pad', C.c_int32), ('flip', C.c_int32), ('relu', C.c_int32)]
+                ('stride', C.c_int32), ('pad', C.c_int32), ('flip', C.c_int32), ('relu', C.c_int32), ('cfg', C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -32,7 +32,7 @@ class WgradDesc(C.Structure):
                 ('p_ld', C.c_int64), ('q_ld', C.c_int64), ('dtype', C.c_int32),
                 ('N', C.c_int32), ('Hp', C.c_int32), ('Wp', C.c_int32), ('A', C.c_int32),
                 ('Hq', C.c_int32), ('Wq', C.c_int32), ('B', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32),
-                ('stride', C.c_int32), ('pad', C.c_int32)]
+                ('stride', C.c_int32), ('pad', C.c_int32), ('cfg', C.c_int32)]
 
 
 class LossCfg(C.Structure):
@@ -49,6 +49,8 @@ SIGNATURES = {
     'msc_abi_version': (_i, []),
     'msc_conv_igemm': (_i, [C.POINTER(ConvDesc), _vp]),
     'msc_conv_stats_slices': (_i, [C.POINTER(ConvDesc)]),
+    'msc_conv_num_cfgs': (_i, []),
+    'msc_conv_cfg_ok': (_i, [C.POINTER(ConvDesc), _i]),
     'msc_conv_wgrad': (_i, [C.POINTER(WgradDesc), _vp]),
     'msc_pack_cast': (_i, [_vp, _vp, _i, _i64, _vp]),
     'msc_pack_transpose': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

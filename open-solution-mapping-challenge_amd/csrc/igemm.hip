@@ -817,67 +817,86 @@ bool env_flag(const char* name) {
 }
 bool use_v1_conv() { static int v = -1; if (v < 0) v = env_flag("MSC_CONV_V1") ? 1 : 0; return v == 1; }
 bool use_v1_wgrad() { static int v = -1; if (v < 0) v = env_flag("MSC_WGRAD_V1") ? 1 : 0; return v == 1; }
-bool env_flag_cached_kb64() { static int v = -1; if (v < 0) v = env_flag("MSC_CONV_KB64") ? 1 : 0; return v == 1; }
 
-// One tile configuration = (pixel rows, channels, waves along pixels, waves along channels, ring depth at KB=128,
-// ring depth at KB=64).  LDS = NST*(TP+TC)*KB.
-template <typename T, int TP, int TC, int WP, int WC, int NST128, int NST64>
-int launch_conv(const ConvK& k, int mode, hipStream_t st) {
+// ---- kernel configurations.  A configuration = (pixel rows, channels, waves along pixels, waves along channels,
+// bytes of K per row and step, ring depth); LDS = NST*(TP+TC)*KB.  Which one is fastest depends on the layer
+// (fill-rate-bound small layers want occupancy, large ones want big tiles and full-line K steps), so besides the
+// heuristic (cfg 0) the caller may pick one explicitly -- UNetResNet times the valid ones per layer when it builds
+// a program (msc_conv_cfg_ok enumerates them).
+struct ConvCfg { int tp, tc, wp, wc, kb, nst; };
+constexpr int N_CONV_CFG = 10;
+static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
+    {0, 0, 0, 0, 0, 0},
+    {256, 128, 4, 2, 128, 3},   //  1: 144 KB, 8 waves, 1 block/CU
+    {256, 128, 4, 2, 64, 4},    //  2:  96 KB, 8 waves
+    {128, 128, 2, 2, 128, 4},   //  3: 128 KB
+    {128, 128, 2, 2, 64, 4},    //  4:  64 KB, 2 blocks/CU
+    {128, 64, 4, 1, 128, 3},    //  5:  72 KB, 2 blocks/CU
+    {128, 64, 4, 1, 64, 4},     //  6:  48 KB, 3 blocks/CU
+    {64, 64, 2, 2, 128, 4},     //  7:  64 KB
+    {64, 64, 2, 2, 64, 4},      //  8:  32 KB
+    {256, 32, 4, 1, 128, 3},    //  9: 108 KB
+    {256, 32, 4, 1, 64, 4},     // 10:  72 KB
+};
+
+template <typename T, int TP, int TC, int WP, int WC, int KB, int NST>
+int launch_dma(const ConvK& k, int mode, hipStream_t st) {
     dim3 grid(ceil_div(k.M, TP), ceil_div(k.Cout, TC), mode ? 4 : 1);
     constexpr int NT = WP * WC * 64;
-    if (use_v1_conv() || k.in_bytes == 0) {
-        if (WP * WC != 4) return msc_fail(MSC_ERR_UNSUPPORTED, "conv_igemm: v1 kernel has no 8-wave form");
-        if constexpr (WP * WC == 4) {
-            if (mode) hipLaunchKernelGGL((conv_igemm_kernel<T, TP, TC, WP, WC, 1>), grid, dim3(256), 0, st, k);
-            else hipLaunchKernelGGL((conv_igemm_kernel<T, TP, TC, WP, WC, 0>), grid, dim3(256), 0, st, k);
-        }
-        return msc_check_launch("conv_igemm");
-    }
-    const bool kb128 = ((long)k.Cin * (long)sizeof(T)) % 128 == 0 && !env_flag_cached_kb64();
-    if (kb128) {
-        if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1, NST128, 128>), grid, dim3(NT), 0, st, k);
-        else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, NST128, 128>), grid, dim3(NT), 0, st, k);
-    } else {
-        if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1, NST64, 64>), grid, dim3(NT), 0, st, k);
-        else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, NST64, 64>), grid, dim3(NT), 0, st, k);
-    }
+    if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1, NST, KB>), grid, dim3(NT), 0, st, k);
+    else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, NST, KB>), grid, dim3(NT), 0, st, k);
     return msc_check_launch("conv_igemm_dma");
 }
 
-int tile_policy() { static int v = -1; if (v < 0) { const char* e = getenv("MSC_TILE_POLICY"); v = e ? atoi(e) : 0; } return v; }
+template <typename T, int TP, int TC, int WP, int WC>
+int launch_v1(const ConvK& k, int mode, hipStream_t st) {
+    dim3 grid(ceil_div(k.M, TP), ceil_div(k.Cout, TC), mode ? 4 : 1);
+    if (mode) hipLaunchKernelGGL((conv_igemm_kernel<T, TP, TC, WP, WC, 1>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((conv_igemm_kernel<T, TP, TC, WP, WC, 0>), grid, dim3(256), 0, st, k);
+    return msc_check_launch("conv_igemm");
+}
 
-// Tile choice.  The kernel is bounded by the L2->LDS fill rate on small tiles (flop per fetched byte =
-// TP*TC/(TP+TC) per 2 bytes), so take the largest tile that still gives every CU a block:
-//   Cout % 128 == 0:  256x128 (8 waves) if >= 512 blocks, else 128x128 if >= 256, else 64x64
-//   Cout %  64 == 0:  128x64 if >= 256 blocks, else 64x64          Cout % 32 == 0: 256x32
-// returns a config id; tp/tc/wp are what msc_conv_stats_slices needs
-enum { CFG_256x128, CFG_128x128, CFG_128x64, CFG_64x64, CFG_256x32 };
-int pick_tile(int M, int Cout, int* tp, int* tc, int* wp) {
-    int cfg;
+bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
+    if (cfg < 1 || cfg > N_CONV_CFG) return false;
+    const ConvCfg& c = CONV_CFGS[cfg];
+    if (k.Cout % c.tc) return false;
+    if (c.tc == 32 && k.Cout % 64 == 0) return false;        // a 32-channel tile only for the 32-channel layers
+    if (((long)k.Cin * es) % c.kb) return false;
+    return k.in_bytes != 0;
+}
+
+// heuristic: largest tile that still gives every CU a block; 64-byte K steps (best on average over the network)
+int pick_cfg(const ConvK& k) {
+    const int M = k.M, Cout = k.Cout;
     if (Cout % 128 == 0) {
-        const long b128 = (long)ceil_div(M, 128) * (Cout / 128);
-        if (tile_policy() != 2 && (long)ceil_div(M, 256) * (Cout / 128) >= 512) cfg = CFG_256x128;
-        else if (b128 >= 256) cfg = CFG_128x128;
-        else cfg = CFG_64x64;
-    } else if (Cout % 64 == 0) {
-        cfg = ((long)ceil_div(M, 128) * (Cout / 64) >= 256) ? CFG_128x64 : CFG_64x64;
-    } else {
-        cfg = CFG_256x32;
+        if ((long)ceil_div(M, 256) * (Cout / 128) >= 512) return 2;
+        if ((long)ceil_div(M, 128) * (Cout / 128) >= 512) return 4;
+        return 8;
     }
-    static const int TPs[] = {256, 128, 128, 64, 256}, TCs[] = {128, 128, 64, 64, 32}, WPs[] = {4, 2, 4, 2, 4};
-    *tp = TPs[cfg]; *tc = TCs[cfg]; *wp = WPs[cfg];
-    return cfg;
+    if (Cout % 64 == 0) return ((long)ceil_div(M, 128) * (Cout / 64) >= 512) ? 6 : 8;
+    return 10;
 }
 
 template <typename T>
-int conv_dispatch(const ConvK& k, int mode, hipStream_t st) {
-    int tp, tc, wp;
-    switch (pick_tile(k.M, k.Cout, &tp, &tc, &wp)) {
-        case CFG_256x128: return launch_conv<T, 256, 128, 4, 2, 3, 4>(k, mode, st);   // 144 KB / 96 KB of LDS, 1 block (8 waves) per CU
-        case CFG_128x128: return launch_conv<T, 128, 128, 2, 2, 4, 4>(k, mode, st);   // 128 KB / 64 KB
-        case CFG_128x64:  return launch_conv<T, 128, 64, 4, 1, 4, 4>(k, mode, st);    //  96 KB / 48 KB
-        case CFG_64x64:   return launch_conv<T, 64, 64, 2, 2, 4, 4>(k, mode, st);     //  64 KB / 32 KB
-        default:          return launch_conv<T, 256, 32, 4, 1, 4, 4>(k, mode, st);    // 144 KB / 72 KB
+int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
+    if (use_v1_conv() || k.in_bytes == 0) {      // register-staged fallback (also for operands beyond 2 GiB)
+        if (k.Cout % 128 == 0) return launch_v1<T, 128, 128, 2, 2>(k, mode, st);
+        if (k.Cout % 64 == 0) return launch_v1<T, 64, 64, 2, 2>(k, mode, st);
+        return launch_v1<T, 256, 32, 4, 1>(k, mode, st);
+    }
+    if (cfg == 0) cfg = pick_cfg(k);
+    if (!conv_cfg_ok(k, (int)sizeof(T), cfg)) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: configuration %d is not valid for this layer", cfg);
+    switch (cfg) {
+        case 1: return launch_dma<T, 256, 128, 4, 2, 128, 3>(k, mode, st);
+        case 2: return launch_dma<T, 256, 128, 4, 2, 64, 4>(k, mode, st);
+        case 3: return launch_dma<T, 128, 128, 2, 2, 128, 4>(k, mode, st);
+        case 4: return launch_dma<T, 128, 128, 2, 2, 64, 4>(k, mode, st);
+        case 5: return launch_dma<T, 128, 64, 4, 1, 128, 3>(k, mode, st);
+        case 6: return launch_dma<T, 128, 64, 4, 1, 64, 4>(k, mode, st);
+        case 7: return launch_dma<T, 64, 64, 2, 2, 128, 4>(k, mode, st);
+        case 8: return launch_dma<T, 64, 64, 2, 2, 64, 4>(k, mode, st);
+        case 9: return launch_dma<T, 256, 32, 4, 1, 128, 3>(k, mode, st);
+        default: return launch_dma<T, 256, 32, 4, 1, 64, 4>(k, mode, st);
     }
 }
 
@@ -933,9 +952,22 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
 extern "C" int msc_conv_stats_slices(const msc_conv_desc* d) {
     ConvK k;
     if (conv_fill(d, &k) != MSC_OK) return -1;
-    int tp, tc, wp;
-    pick_tile(k.M, k.Cout, &tp, &tc, &wp);
-    return ceil_div(k.M, tp) * wp;
+    int cfg = d->cfg;
+    if (use_v1_conv() || k.in_bytes == 0) {
+        const int tp = k.Cout % 128 == 0 ? 128 : (k.Cout % 64 == 0 ? 64 : 256), wp = k.Cout % 64 == 0 ? 2 : 4;
+        return ceil_div(k.M, tp) * wp;
+    }
+    if (cfg == 0) cfg = pick_cfg(k);
+    if (!conv_cfg_ok(k, d->dtype == MSC_BF16 ? 2 : 4, cfg)) return -1;
+    return ceil_div(k.M, CONV_CFGS[cfg].tp) * CONV_CFGS[cfg].wp;
+}
+
+extern "C" int msc_conv_num_cfgs(void) { return N_CONV_CFG; }
+
+extern "C" int msc_conv_cfg_ok(const msc_conv_desc* d, int cfg) {
+    ConvK k;
+    if (conv_fill(d, &k) != MSC_OK) return 0;
+    return conv_cfg_ok(k, d->dtype == MSC_BF16 ? 2 : 4, cfg) ? 1 : 0;
 }
 
 extern "C" int msc_conv_igemm(const msc_conv_desc* d, void* stream) {
@@ -943,8 +975,8 @@ extern "C" int msc_conv_igemm(const msc_conv_desc* d, void* stream) {
     int rc = conv_fill(d, &k);
     if (rc != MSC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (d->dtype == MSC_BF16) return conv_dispatch<bf16_t>(k, d->mode, st);
-    return conv_dispatch<float>(k, d->mode, st);
+    if (d->dtype == MSC_BF16) return conv_dispatch<bf16_t>(k, d->mode, d->cfg, st);
+    return conv_dispatch<float>(k, d->mode, d->cfg, st);
 }
 
 extern "C" int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream) {
@@ -976,8 +1008,15 @@ extern "C" int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream) {
     // should run >= 24 k-steps; within that, prefer the largest tile that still gives >= 384 blocks.
     const int ksteps = ceil_div(k.M, kp);
     const int max_splits = ksteps / 24 > 1 ? ksteps / 24 : 1;
+    // cfg 0: heuristic; else 1 + tsel*4 + ssel with tsel 0 = 128x128 tiles when possible, 1 = 64x64 at most,
+    // ssel = index into the target block counts below
+    static const int TARGETS[4] = {256, 512, 1024, 2048};
+    if (d->cfg < 0 || d->cfg > 8) return msc_fail(MSC_ERR_ARG, "msc_conv_wgrad: cfg %d", d->cfg);
+    const int target = d->cfg ? TARGETS[(d->cfg - 1) & 3] : 768;
     bool big = (d->A % 128 == 0) && (d->B % 128 == 0);
-    if (big) {
+    if (d->cfg) {
+        if ((d->cfg - 1) >> 2) big = false;
+    } else if (big) {
         const int tiles128 = (d->A / 128) * (d->B / 128) * d->KH * d->KW;
         int sp = ceil_div(768, tiles128);
         if (sp > max_splits) sp = max_splits;
@@ -985,7 +1024,7 @@ extern "C" int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream) {
     }
     const int ta = big ? 128 : (d->A % 64 == 0 ? 64 : 32), tbs = big ? 128 : (d->B % 64 == 0 ? 64 : 32);
     const int tiles = (d->A / ta) * (d->B / tbs) * d->KH * d->KW;
-    int splits = ceil_div(768, tiles);
+    int splits = ceil_div(target, tiles);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     int mchunk = ceil_div(k.M, splits);

@@ -31,7 +31,7 @@ def _nhwc(t):
     return t.stride(2)
 
 
-def conv_igemm(x, w, out, stride=1, pad=0, mode=0, flip=0, relu=False, scale=None, shift=None, res=None, stats=None):
+def conv_igemm(x, w, out, stride=1, pad=0, mode=0, flip=0, relu=False, scale=None, shift=None, res=None, stats=None, cfg=0):
     """w: [Cout, KH, KW, Cin] in x.dtype.  mode 0: gather conv; mode 1: transposed (stride 2)."""
     d = ConvDesc()
     d.in_, d.wt, d.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
@@ -45,29 +45,41 @@ def conv_igemm(x, w, out, stride=1, pad=0, mode=0, flip=0, relu=False, scale=Non
     d.N, d.Hi, d.Wi, d.Cin = x.shape
     _, d.Ho, d.Wo, d.Cout = out.shape
     d.KH, d.KW = w.shape[1], w.shape[2]
-    d.stride, d.pad, d.flip, d.relu = stride, pad, int(flip), int(relu)
+    d.stride, d.pad, d.flip, d.relu, d.cfg = stride, pad, int(flip), int(relu), int(cfg)
     _lib.check(_lib.load().msc_conv_igemm(C.byref(d), _stream(x)), 'msc_conv_igemm')
     return out
 
 
-def conv_stats_slices(x, w, out, stride=1, pad=0):
+def conv_valid_cfgs(x, w, out, stride=1, pad=0, mode=0):
+    """explicit kernel configurations usable for this layer (0 = heuristic is always valid)"""
+    d = ConvDesc()
+    d.in_, d.wt, d.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.in_ld, d.out_ld, d.dtype, d.mode = _nhwc(x), _nhwc(out), _dt(x), mode
+    d.N, d.Hi, d.Wi, d.Cin = x.shape
+    _, d.Ho, d.Wo, d.Cout = out.shape
+    d.KH, d.KW, d.stride, d.pad = w.shape[1], w.shape[2], stride, pad
+    lib = _lib.load()
+    return [c for c in range(1, lib.msc_conv_num_cfgs() + 1) if lib.msc_conv_cfg_ok(C.byref(d), c)]
+
+
+def conv_stats_slices(x, w, out, stride=1, pad=0, cfg=0):
     d = ConvDesc()
     d.in_, d.wt, d.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.in_ld, d.out_ld, d.dtype, d.mode = _nhwc(x), _nhwc(out), _dt(x), 0
     d.N, d.Hi, d.Wi, d.Cin = x.shape
     _, d.Ho, d.Wo, d.Cout = out.shape
-    d.KH, d.KW, d.stride, d.pad = w.shape[1], w.shape[2], stride, pad
+    d.KH, d.KW, d.stride, d.pad, d.cfg = w.shape[1], w.shape[2], stride, pad, int(cfg)
     return _lib.load().msc_conv_stats_slices(C.byref(d))
 
 
-def conv_wgrad(p, q, dw, KH, KW, stride=1, pad=0):
+def conv_wgrad(p, q, dw, KH, KW, stride=1, pad=0, cfg=0):
     """dw f32 [A, KH, KW, B] += sum_m p[m][a] * q[gather(m)][b]"""
     d = WgradDesc()
     d.p, d.q, d.dw = p.data_ptr(), q.data_ptr(), dw.data_ptr()
     d.p_ld, d.q_ld, d.dtype = _nhwc(p), _nhwc(q), _dt(p)
     d.N, d.Hp, d.Wp, d.A = p.shape
     _, d.Hq, d.Wq, d.B = q.shape
-    d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+    d.KH, d.KW, d.stride, d.pad, d.cfg = KH, KW, stride, pad, int(cfg)
     _lib.check(_lib.load().msc_conv_wgrad(C.byref(d), _stream(p)), 'msc_conv_wgrad')
     return dw
 

@@ -169,7 +169,7 @@ class UNetResNet(nn.Module):
     """
 
     def __init__(self, encoder_depth, num_classes, num_filters=32, dropout_2d=0.2, pretrained=False,
-                 is_deconv=False, compute_dtype='bf16'):
+                 is_deconv=False, compute_dtype='bf16', autotune=None):
         super().__init__()
         if encoder_depth not in _ENC:
             raise NotImplementedError('only 34, 101, 152 version of Resnet are implemented')
@@ -201,6 +201,9 @@ class UNetResNet(nn.Module):
         self.dec0 = _ConvReluParams(nf, nf)
         self.final = nn.Conv2d(nf, num_classes, kernel_size=1)
         self.set_compute_dtype(compute_dtype)
+        # time the valid kernel configurations of every conv / wgrad launch when a program is built (MSC_AUTOTUNE=0 disables)
+        import os as _os
+        self.autotune = (_os.environ.get('MSC_AUTOTUNE', '1') != '0') if autotune is None else bool(autotune)
         self._programs = {}
         self._flat = None
         self._version = 0          # bumped whenever master weights change -> packed copies are stale
@@ -473,6 +476,9 @@ UNetResNet._grad_views = _grad_views
 
 
 # ----------------------------------------------------------------------------- program builder
+_TUNE_CACHE = {}
+
+
 class _Builder:
     def __init__(self, net, N, H, W, training, device):
         self.net, self.N, self.H, self.W, self.training, self.dev = net, N, H, W, training, device
@@ -549,7 +555,7 @@ class _Builder:
         lst.append((fn, args))
 
     def conv_desc(self, x, wt, out, KH, KW, stride, pad, mode=0, flip=0, relu=0, scale=None, shift=None, res=None,
-                  stats=None, in_hw=None, in_ld=None, cin=None, out_hw=None):
+                  stats=None, in_hw=None, in_ld=None, cin=None, out_hw=None, want_stats=False):
         d = ConvDesc()
         d.in_, d.wt, d.out = x.ptr, wt.data_ptr(), out.ptr
         d.res = res.ptr if res is not None else None
@@ -564,7 +570,9 @@ class _Builder:
         d.Ho, d.Wo = out_hw if out_hw is not None else (out.H, out.W)
         d.Cout = out.C
         d.KH, d.KW, d.stride, d.pad, d.flip, d.relu = KH, KW, stride, pad, flip, relu
+        d.cfg = 0
         self.prog.keep.append(d)
+        self.tune_conv(d, want_stats)
         return d
 
     def conv(self, lst, *a, **k):
@@ -582,8 +590,67 @@ class _Builder:
         d.Hq, d.Wq = q_hw if q_hw is not None else (q.H, q.W)
         d.B = B if B is not None else q.C
         d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+        d.cfg = 0
         self.prog.keep.append(d)
+        self.tune_wgrad(d)
         self.emit(lst, self.lib.msc_conv_wgrad, C.byref(d))
+
+    # ---- per-layer kernel configuration (like cuDNN's benchmark mode): time the valid configurations once per
+    # distinct layer shape on the real buffers and keep the fastest; results are cached process-wide
+    def _time(self, fn, dref, reps=3):
+        stream = _stream_of(self.dev)
+        if fn(dref, stream) != 0:
+            return None
+        best = 1e30
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn(dref, stream)
+            b.record()
+            b.synchronize()
+            best = min(best, a.elapsed_time(b))
+        return best
+
+    def tune_conv(self, d, want_stats):
+        if not self.net.autotune or self.dev.type != 'cuda':
+            return
+        key = ('c', self.dt, d.mode, d.flip, d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad,
+               bool(d.res), want_stats, d.in_ld, d.out_ld, bool(d.relu))
+        cache = _TUNE_CACHE
+        if key not in cache:
+            lib = self.lib
+            best, best_t = 0, 1e30
+            for c in range(1, lib.msc_conv_num_cfgs() + 1):
+                if not lib.msc_conv_cfg_ok(C.byref(d), c):
+                    continue
+                d.cfg = c
+                if want_stats:
+                    need = lib.msc_conv_stats_slices(C.byref(d)) * d.Cout * 2
+                    if getattr(self, '_tune_stats', None) is None or self._tune_stats.numel() < need:
+                        self._tune_stats = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=self.dev)
+                    d.stats = self._tune_stats.data_ptr()
+                t = self._time(lib.msc_conv_igemm, C.byref(d))
+                if t is not None and t < best_t:
+                    best, best_t = c, t
+            d.stats = None
+            cache[key] = best
+        d.cfg = cache[key]
+
+    def tune_wgrad(self, d):
+        if not self.net.autotune or self.dev.type != 'cuda':
+            return
+        key = ('w', self.dt, d.N, d.Hp, d.Wp, d.A, d.Hq, d.Wq, d.B, d.KH, d.KW, d.stride, d.pad, d.p_ld, d.q_ld)
+        cache = _TUNE_CACHE
+        if key not in cache:
+            big_ok = d.A % 128 == 0 and d.B % 128 == 0
+            best, best_t = 0, 1e30
+            for c in range(1 if big_ok else 5, 9):
+                d.cfg = c
+                t = self._time(self.lib.msc_conv_wgrad, C.byref(d))
+                if t is not None and t < best_t:
+                    best, best_t = c, t
+            cache[key] = best
+        d.cfg = cache[key]
 
     # ---- layers -------------------------------------------------------------------------------
     def conv_bn(self, name, x, conv, bn, stride, relu, out, res=None, stem=None):
@@ -605,7 +672,7 @@ class _Builder:
             self.conv(fwd, x, w, out, relu=int(relu), scale=scale, shift=shift, res=res, **geo)
             return
         y = self.act(out.H, out.W, cout)
-        d = self.conv_desc(x, w, y, **geo)
+        d = self.conv_desc(x, w, y, want_stats=True, **geo)
         slices = lib.msc_conv_stats_slices(C.byref(d))
         if slices <= 0:
             _lib.check(-1, 'msc_conv_stats_slices')

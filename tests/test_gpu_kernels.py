@@ -206,3 +206,45 @@ def test_loss_kernels_match_oracle_and_golden(golden_dir):
         loss_forward_backward(logits.cuda(), t.cuda(), spec, d, loss, sums)
         assert abs(loss.item() - float(g['loss_' + name])) < 2e-5
         assert np.allclose(d.cpu().numpy(), g['dlogits_' + name], atol=2e-8, rtol=1e-4)
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('cin,cout,k,stride,hw,n', [(128, 128, 3, 1, 20, 3), (64, 256, 1, 1, 16, 4), (32, 32, 3, 1, 24, 2), (64, 64, 3, 2, 18, 2)])
+def test_every_kernel_configuration_is_correct(dtype, cin, cout, k, stride, hw, n):
+    """the per-layer autotuner may pick any valid configuration: each must give the same convolution (incl. BN partial
+    statistics and the transposed mode), and each wgrad configuration the same weight gradient"""
+    from mapping_challenge_amd import ops
+    pad = k // 2
+    x = rnd((n, cin, hw, hw), dtype, 1)
+    w = rnd((cout, cin, k, k), dtype, 2, (2.0 / (cin * k * k)) ** 0.5)
+    ref = F.conv2d(x, w, stride=stride, padding=pad)
+    ho = ref.shape[2]
+    xd = nhwc(x, dtype)
+    wk = w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    out = torch.empty((n, ho, ho, cout), dtype=dtype, device='cuda')
+    cfgs = ops.conv_valid_cfgs(xd, wk, out, stride, pad)
+    assert cfgs
+    for c in cfgs:
+        out.zero_()
+        slices = ops.conv_stats_slices(xd, wk, out, stride, pad, cfg=c)
+        stats = torch.zeros((cout, slices, 2), dtype=torch.float32, device='cuda')
+        ops.conv_igemm(xd, wk, out, stride=stride, pad=pad, stats=stats, cfg=c)
+        assert torch.allclose(to_nchw(out), ref, **tol(dtype)), c
+        assert torch.allclose(stats.sum(1)[:, 0].cpu(), ref.sum((0, 2, 3)), rtol=2e-3, atol=5e-2), c
+    if stride == 1 and k == 3:      # transposed mode with the same operands: ConvTranspose2d(k3,s2,p1,output_padding=1)
+        wt = rnd((cin, cout, 4, 4), dtype, 3, 0.05)
+        reft = F.conv_transpose2d(x, wt, stride=2, padding=1)
+        wkt = ops.pack_transpose(wt.permute(0, 2, 3, 1).contiguous().view(cin, 16, cout).cuda(), dtype).view(cout, 4, 4, cin)
+        outt = torch.empty((n, 2 * hw, 2 * hw, cout), dtype=dtype, device='cuda')
+        for c in ops.conv_valid_cfgs(xd, wkt, outt, 2, 1, mode=1):
+            outt.zero_()
+            ops.conv_igemm(xd, wkt, outt, stride=2, pad=1, mode=1, cfg=c)
+            assert torch.allclose(to_nchw(outt), reft, **tol(dtype)), c
+    dy = rnd(tuple(ref.shape), dtype, 4)
+    wv = w.clone().requires_grad_(True)
+    F.conv2d(x, wv, stride=stride, padding=pad).backward(dy)
+    gref = wv.grad.permute(0, 2, 3, 1)
+    for c in range(1 if (cin % 128 == 0 and cout % 128 == 0) else 5, 9):
+        dw = torch.zeros((cout, k, k, cin), dtype=torch.float32, device='cuda')
+        ops.conv_wgrad(nhwc(dy, dtype), xd, dw, k, k, stride=stride, pad=pad, cfg=c)
+        assert (dw.cpu() - gref).abs().max().item() / gref.abs().max().item() < (2e-5 if dtype == torch.float32 else 1e-2), c

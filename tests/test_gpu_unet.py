@@ -191,12 +191,17 @@ def test_rccl_world1_overlapped_backward_equals_plain():
         step = TrainStep(net, LossSpec.plain_ce(), HipAdam(net, lr=0.0), world=world)
         step._setup(x, tgt[:, :1].contiguous())
         step.x.copy_(x); step.t.copy_(tgt[:, :1])
-        prog = net.train_forward(step.x)
         from mapping_challenge_amd.trainer import loss_forward_backward
-        loss_forward_backward(prog.logits, step.t, step.spec, prog.dlogits, step.loss, step.sums, world)
-        net.train_backward(prog)
+
+        def fwd_loss():
+            prog = net.train_forward(step.x)
+            loss_forward_backward(prog.logits, step.t, step.spec, prog.dlogits, step.loss, step.sums, world)
+            return prog
+        # backward consumes its saved activations in place (dy overwrites y), so each backward needs its own forward;
+        # momentum 0.1 running statistics are the only state a forward changes and they do not enter the gradients
+        net.train_backward(fwd_loss())
         plain = net.flat_grads.clone()
-        step._backward_overlapped(prog)
+        step._backward_overlapped(fwd_loss())
         torch.cuda.synchronize()
         scale = plain.abs().max().item()
         assert (net.flat_grads - plain).abs().max().item() <= 1e-5 * scale
