@@ -187,7 +187,7 @@ class TrainStep:
         prog.stem_dw.zero_()
         works, beg = [], 0
         for end, lo, hi in prog._ddp_plan:
-            _Program.run(prog.bwd[beg:end], stream)
+            _Program.run_backward(prog.bwd[beg:end], flat_g.device)     # joins its side stream before returning
             beg = end
             if lo is not None:
                 works.append(dist.all_reduce(flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.world.group, async_op=True))
@@ -229,7 +229,7 @@ class TrainStep:
         loss_forward_backward(prog.logits, self.t, self.spec, prog.dlogits, self.loss, self.sums, None)
         net._flat[1].zero_()
         prog.stem_dw.zero_()
-        _Program.run(prog.bwd, stream)
+        _Program.run_backward(prog.bwd, self.x.device)
         lib = _lib.load()
         o = self.opt
         p, gr = net.flat_params, net.flat_grads

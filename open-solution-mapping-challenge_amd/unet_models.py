@@ -139,6 +139,18 @@ def _stream_of(device):
     return torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0
 
 
+import os as _os_env
+_OVERLAP_WGRAD = _os_env.environ.get('MSC_OVERLAP_WGRAD', '1') != '0'
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 class _Program:
     """Static launch list for one (N,H,W,dtype,training) configuration."""
 
@@ -156,6 +168,40 @@ class _Program:
             rc = fn(*args, stream)
             if rc != 0:
                 _lib.check(rc, fn.__name__)
+
+    SIDE = ('msc_conv_wgrad', 'msc_stem_unpack_grad')
+
+    @staticmethod
+    def run_backward(launches, device):
+        """Backward launch list with the weight-gradient kernels on a second HIP stream.  A wgrad only reads buffers
+        that are final once it is reached in list order (dy, the layer input) and atomically adds into its own slice
+        of the flat gradient buffer, so it can run beside the rest of the backward chain (BN backward -> dgrad -> ...),
+        which on the small layers of the encoder leaves most CUs idle.  The side stream waits for everything launched
+        so far before each wgrad and is joined at the end; under hipGraph capture this becomes graph edges."""
+        if device.type != 'cuda' or not _OVERLAP_WGRAD:
+            return _Program.run(launches, _stream_of(device))
+        main = torch.cuda.current_stream(device)
+        side = _side_stream(device)
+        mh, sh = main.cuda_stream, side.cuda_stream
+        used, fresh = False, True
+        for fn, args in launches:
+            if fn.__name__ in _Program.SIDE:
+                if fresh:                          # main-stream work was issued since the last fork point
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    fresh = False
+                rc = fn(*args, sh)
+                used = True
+            else:
+                rc = fn(*args, mh)
+                fresh = True
+            if rc != 0:
+                _lib.check(rc, fn.__name__)
+        if used:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            main.wait_event(ev)
 
 
 # ----------------------------------------------------------------------------- the network
@@ -410,7 +456,7 @@ class UNetResNet(nn.Module):
         if dlogits.data_ptr() != prog.dlogits.data_ptr():
             prog.dlogits.copy_(dlogits)
         prog.stem_dw.zero_()
-        _Program.run(prog.bwd, stream)
+        _Program.run_backward(prog.bwd, dlogits.device)
 
     def forward(self, x):
         if self.training and torch.is_grad_enabled():
