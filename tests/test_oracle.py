@@ -182,3 +182,16 @@ def test_reference_dense_crf_runs_on_oracle_shim():
     a = pp.dense_crf(img, probs, iterations=3)
     b = crf_ref.dense_crf(img, probs, post_ref_mean(), post_ref_std(), iterations=3)
     assert np.allclose(a, b, atol=1e-6)
+
+
+def test_c_restatement_of_post_chain_matches_numpy_oracle():
+    """oracle/post_ref.c (the C port timed as CPU baseline) against oracle/post_ref.py, incl. empty and full masks"""
+    from oracle import post_ref_c
+    probs = list(post_ref.synthetic_probs(3, 96, 80, seed=11, smooth=3.0))
+    probs.append(np.stack([np.ones((96, 80), np.float32), np.zeros((96, 80), np.float32)]))
+    for p in probs:
+        for k in (0, 2, 3):
+            lab, sc = post_ref_c.postprocess(p, (112, 100), k)
+            lab2, sc2 = post_ref.postprocess(p, (112, 100), 0, k)
+            assert (lab == lab2).all()
+            assert all(np.allclose(a, b, rtol=1e-12) for a, b in zip(sc, sc2))
