@@ -255,9 +255,13 @@ def main():
             dom = max(fam.items(), key=lambda kv: kv[1]['ms'])
             peak = PEAK_BF16 if args.dtype == 'bf16' else PEAK_F32
             ach = conv['flops'] / (conv['ms'] * 1e-3) if conv['ms'] else 0.0
+            traffic = None
+            pmc_file = os.path.join(ROOT, 'profiles', 'pmc_traffic_%s_r%d.json' % (args.workload, enc))
+            if os.path.exists(pmc_file):      # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_summary.py)
+                traffic = json.load(open(pmc_file)).get('hbm_bytes_per_launch')
             result['roofline'] = {
                 'kernel': 'conv_igemm_dma_kernel (implicit-GEMM conv / dgrad / deconv, %d launches per step, per-layer autotuned tile)' % round(conv['launches']),
-                'bound': 'mfma', 'achieved': ach / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+                'bound': 'mfma', 'achieved': ach / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
                 'avg_launch_us': 1e3 * conv['ms'] / max(conv['launches'], 1),
                 'algorithmic_gflop_per_step': conv['flops'] / 1e9,
                 'wgrad': {'achieved': (wg['flops'] / (wg['ms'] * 1e-3) / 1e12) if wg['ms'] else None, 'ms_per_step': wg['ms'],

@@ -13,7 +13,12 @@ bench) timeout 900 python bench.py --workload infer --steps 10 --warmup 3 > gpur
        timeout 900 python bench.py --workload post --steps 10 --warmup 3 > gpurun_out/bench_post.log 2>&1; echo "bench post rc=$?"; tail -3 gpurun_out/bench_post.log
        timeout 1200 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_train.log 2>&1; echo "bench train rc=$?"; tail -3 gpurun_out/bench_train.log;;
 prof)  cd /tmp; export TMPDIR=/tmp
-       timeout 1200 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_train" -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_train.log" 2>&1; echo "prof rc=$?"
+       timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_train" -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_train.log" 2>&1; echo "prof rc=$?"
        cd "$GRAFT_REPO_ROOT";;
+pmc)   cd /tmp; export TMPDIR=/tmp
+       for c in FETCH_SIZE WRITE_SIZE; do
+         timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c" -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-breakdown > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log" 2>&1; echo "pmc $c rc=$?"
+       done
+       cd "$GRAFT_REPO_ROOT"; python tools/pmc_summary.py gpurun_out gpurun_out/pmc_traffic.json > gpurun_out/pmc_summary.txt 2>&1; head -12 gpurun_out/pmc_summary.txt;;
 esac
 done
