@@ -525,12 +525,32 @@ UNetResNet._grad_views = _grad_views
 
 # ----------------------------------------------------------------------------- program builder
 _TUNE_CACHE = {}
+_TUNE_FILE = _os_env.environ.get('MSC_TUNE_CACHE')      # optional JSON file: reuse per-layer choices across processes
+
+
+def _tune_load():
+    if _TUNE_FILE and _os_env.path.exists(_TUNE_FILE) and not _TUNE_CACHE:
+        import json
+        with open(_TUNE_FILE) as f:
+            for k, v in json.load(f).items():
+                _TUNE_CACHE[k] = v
+
+
+def _tune_save():
+    if _TUNE_FILE:
+        import json
+        tmp = _TUNE_FILE + '.tmp'
+        with open(tmp, 'w') as f:
+            json.dump(_TUNE_CACHE, f)
+        _os_env.replace(tmp, _TUNE_FILE)
 
 
 class _Builder:
     def __init__(self, net, N, H, W, training, device):
         self.net, self.N, self.H, self.W, self.training, self.dev = net, N, H, W, training, device
         self.lib = _lib.load()
+        _tune_load()
+        self._tuned_new = False
         self.dt, self.tdtype = net._dt, net._tdtype
         self.es = 2 if self.dt == BF16 else 4
         self.prog = _Program()
@@ -662,8 +682,8 @@ class _Builder:
     def tune_conv(self, d, want_stats):
         if not self.net.autotune or self.dev.type != 'cuda':
             return
-        key = ('c', self.dt, d.mode, d.flip, d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad,
-               bool(d.res), want_stats, d.in_ld, d.out_ld, bool(d.relu))
+        key = repr(('c', self.dt, d.mode, d.flip, d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad,
+                    bool(d.res), want_stats, d.in_ld, d.out_ld, bool(d.relu)))
         cache = _TUNE_CACHE
         if key not in cache:
             lib = self.lib
@@ -682,12 +702,13 @@ class _Builder:
                     best, best_t = c, t
             d.stats = None
             cache[key] = best
+            self._tuned_new = True
         d.cfg = cache[key]
 
     def tune_wgrad(self, d):
         if not self.net.autotune or self.dev.type != 'cuda':
             return
-        key = ('w', self.dt, d.N, d.Hp, d.Wp, d.A, d.Hq, d.Wq, d.B, d.KH, d.KW, d.stride, d.pad, d.p_ld, d.q_ld)
+        key = repr(('w', self.dt, d.N, d.Hp, d.Wp, d.A, d.Hq, d.Wq, d.B, d.KH, d.KW, d.stride, d.pad, d.p_ld, d.q_ld))
         cache = _TUNE_CACHE
         if key not in cache:
             big_ok = d.A % 128 == 0 and d.B % 128 == 0
@@ -698,6 +719,7 @@ class _Builder:
                 if t is not None and t < best_t:
                     best, best_t = c, t
             cache[key] = best
+            self._tuned_new = True
         d.cfg = cache[key]
 
     # ---- layers -------------------------------------------------------------------------------
@@ -912,4 +934,6 @@ class _Builder:
                 op()
         P.keep += [xp]
         P.acts = {'c1': s1, 'd0': d0, 'cat2': cat2, 'cat3': cat3, 'cat4': cat4, 'cat5': cat5}
+        if self._tuned_new:
+            _tune_save()
         return P

@@ -3,6 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
+export MSC_TUNE_CACHE="${GRAFT_REPO_ROOT:-.}/gpurun_out/tune_cache.json"
 STAGES="${1:-probe tests smoke bench}"
 for s in $STAGES; do
 case $s in
@@ -12,10 +13,12 @@ smoke) timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; 
 bench) timeout 900 python bench.py --workload infer --steps 10 --warmup 3 > gpurun_out/bench_infer.log 2>&1; echo "bench infer rc=$?"; tail -3 gpurun_out/bench_infer.log
        timeout 900 python bench.py --workload post --steps 10 --warmup 3 > gpurun_out/bench_post.log 2>&1; echo "bench post rc=$?"; tail -3 gpurun_out/bench_post.log
        timeout 1200 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_train.log 2>&1; echo "bench train rc=$?"; tail -3 gpurun_out/bench_train.log;;
-prof)  cd /tmp; export TMPDIR=/tmp
+prof)  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1   # fills the tune cache so the profile holds no tuning launches
+       cd /tmp; export TMPDIR=/tmp
        timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_train" -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_train.log" 2>&1; echo "prof rc=$?"
        cd "$GRAFT_REPO_ROOT";;
-pmc)   cd /tmp; export TMPDIR=/tmp
+pmc)   python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
+       cd /tmp; export TMPDIR=/tmp
        for c in FETCH_SIZE WRITE_SIZE; do
          timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c" -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-breakdown > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log" 2>&1; echo "pmc $c rc=$?"
        done
