@@ -48,6 +48,8 @@ struct ConvK {
     int N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, flip, relu;
     int M, Hq, Wq;
     unsigned in_bytes, wt_bytes;     // extents for the buffer descriptors of the DMA kernel
+    int ntc;                         // channel tiles (DMA kernel: 1-D grid of ntm*ntc blocks, XCD-aware order)
+    int xcd_order;                   // 1: XCD-aware tile order, 0: pixel tile fastest (for A/B measurements)
 };
 
 template <typename T> struct Mma;
@@ -96,7 +98,8 @@ __device__ __forceinline__ void dma16(u32x4_t srd, char* lds_wave_base, unsigned
 
 // shared epilogue: lane holds NV consecutive channels cb.. of pixel rows (b*16+pl), b < FN
 template <typename T, int FM, int FN, int WTP, int WP, int MODE>
-__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][FN], int m0, int wp, int cb, int pl, int py, int px) {
+__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][FN], int m0, int wp, int cb, int pl, int py, int px,
+                                              int mtile, int ntm) {
     constexpr int NV = FM * 4;
     constexpr int CE = 16 / (int)sizeof(T);
     float sc[NV], sh[NV];
@@ -160,7 +163,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
         }
         if (pl == 0) {
             // layout [Cout][slices][2]: msc_bn_finalize gives each channel one wavefront over its slices
-            const long nsl = (long)gridDim.x * WP, sl = (long)blockIdx.x * WP + wp;
+            const long nsl = (long)ntm * WP, sl = (long)mtile * WP + wp;
 #pragma unroll
             for (int j = 0; j < NV; ++j) *reinterpret_cast<float2*>(p.stats + ((cb + j) * nsl + sl) * 2) = make_float2(s1[j], s2[j]);
         }
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
             __syncthreads();
         }
     }
-    conv_epilogue<T, FM, FN, WTP, WP, MODE>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px);
+    conv_epilogue<T, FM, FN, WTP, WP, MODE>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------ v2 (DMA)
@@ -339,8 +342,17 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wid / WC, wc = wid % WC;
     const int g = lane >> 4, pl = lane & 15;
-    const int m0 = blockIdx.x * TP;
-    const int c0 = blockIdx.y * TC;
+    // XCD-aware tile order: workgroup b runs on XCD b%8 (observed dispatch order; only speed depends on it).  Each
+    // XCD gets a contiguous run of tiles with the channel tile varying fastest, so the blocks that re-read one pixel
+    // tile (one per channel tile) and one weight tile share that XCD's L2 close in time.
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, wq = nwg >> 3, wr = nwg & 7;
+    const int wgid = (xcd < wr ? xcd * (wq + 1) : wr * (wq + 1) + (xcd - wr) * wq) + (orig >> 3);
+    const int ntm_ = nwg / p.ntc;
+    const int mtile = p.xcd_order ? wgid / p.ntc : orig % ntm_;
+    const int ctile = p.xcd_order ? wgid - mtile * p.ntc : orig / ntm_;
+    const int m0 = mtile * TP;
+    const int c0 = ctile * TC;
     const int ph = MODE ? (int)blockIdx.z : 0;
     const int py = ph >> 1, px = ph & 1;
 
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
             if (++cstage == NST) cstage = 0;
         }
     }
-    conv_epilogue<T, FM, FN, WTP, WP, MODE>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px);
+    conv_epilogue<T, FM, FN, WTP, WP, MODE>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px, mtile, nwg / p.ntc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -816,6 +828,7 @@ bool env_flag(const char* name) {
     return e && e[0] == '1';
 }
 bool use_v1_conv() { static int v = -1; if (v < 0) v = env_flag("MSC_CONV_V1") ? 1 : 0; return v == 1; }
+bool xcd_order_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("MSC_XCD_ORDER"); v = (e && e[0] == '0') ? 0 : 1; } return v == 1; }
 bool use_v1_wgrad() { static int v = -1; if (v < 0) v = env_flag("MSC_WGRAD_V1") ? 1 : 0; return v == 1; }
 
 // ---- kernel configurations.  A configuration = (pixel rows, channels, waves along pixels, waves along channels,
@@ -840,8 +853,11 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
 };
 
 template <typename T, int TP, int TC, int WP, int WC, int KB, int NST>
-int launch_dma(const ConvK& k, int mode, hipStream_t st) {
-    dim3 grid(ceil_div(k.M, TP), ceil_div(k.Cout, TC), mode ? 4 : 1);
+int launch_dma(const ConvK& k0, int mode, hipStream_t st) {
+    ConvK k = k0;
+    k.ntc = ceil_div(k.Cout, TC);
+    k.xcd_order = xcd_order_enabled() ? 1 : 0;
+    dim3 grid(ceil_div(k.M, TP) * k.ntc, 1, mode ? 4 : 1);
     constexpr int NT = WP * WC * 64;
     if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1, NST, KB>), grid, dim3(NT), 0, st, k);
     else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, NST, KB>), grid, dim3(NT), 0, st, k);
