@@ -1,0 +1,82 @@
+"""GPU: BASELINE.json's full-size configurations through size-independent properties (the CPU oracle needs minutes
+per batch at these sizes): determinism, batch independence, fp32-mode vs bf16-mode agreement on the device, training
+invariants, and idempotence / ordering properties of the labelling chain."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_ref, losses_ref, post_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def make(depth, dtype):
+    from mapping_challenge_amd.unet_models import UNetResNet
+    net = UNetResNet(depth, 2, num_filters=32, dropout_2d=0.0, pretrained=True, is_deconv=True, compute_dtype=dtype)
+    net.load_state_dict(unet_ref.seeded_state_dict(net))
+    net.flatten_parameters('cuda')
+    return net
+
+
+def test_config2_resnet34_bf16_batch32_256_inference_properties():
+    x = unet_ref.synthetic_batch(32, 256, 256, seed=9).cuda()
+    bf, fp = make(34, 'bf16'), make(34, 'fp32')
+    p1 = bf.predict_proba(x).clone()
+    p2 = bf.predict_proba(x).clone()
+    assert torch.equal(p1, p2)                                    # deterministic: no atomics on the inference path
+    assert torch.isfinite(p1).all() and (p1.sum(1) - 1).abs().max().item() < 1e-5
+    # batch independence: image 5 alone == image 5 inside the batch of 32 (tile shapes differ with the batch size)
+    alone = bf.predict_proba(x[5:6]).clone()
+    assert (alone[0] - p1[5]).abs().max().item() < 2e-2
+    # bf16 mode against the exact-fp32 mode of the same engine (which the small-size tests hold to 1e-4 of the reference)
+    pf = fp.predict_proba(x)
+    assert (pf - p1).abs().max().item() < 0.2
+    assert ((pf[:, 1] > 0.5) == (p1[:, 1] > 0.5)).float().mean().item() > 0.97
+
+
+def test_config3_resnet101_bf16_batch32_train_step_properties():
+    from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
+    arch = {'weighted_cross_entropy': {'w0': 50, 'sigma': 10, 'imsize': (256, 256)},
+            'loss_weights': {'dice_mask': 0.2, 'bce_mask': 1.0}, 'dice': {'smooth': 1, 'dice_activation': 'softmax'}}
+    net = make(101, 'bf16')
+    net.train()
+    x = unet_ref.synthetic_batch(32, 256, 256, seed=3).cuda()
+    t4 = losses_ref.synthetic_target(4, 256, 256)
+    tgt = t4.repeat(8, 1, 1, 1).cuda()
+    step = TrainStep(net, LossSpec.mixed(arch), HipAdam(net, lr=5e-4, weight_decay=1e-4), use_graph=True)
+    before = net.flat_params.clone()
+    losses = [step(x, tgt).item() for _ in range(6)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]            # it learns the fixed batch
+    g = net.flat_grads
+    assert torch.isfinite(g).all() and g.abs().max().item() > 0
+    delta = (net.flat_params - before).abs()
+    assert delta.max().item() <= 6 * 5e-4 * 1.05 + 1e-6                   # Adam moves a weight by at most lr per step
+    assert (delta > 0).float().mean().item() > 0.99                       # every parameter received a gradient
+    # the loss the fused kernels report equals the oracle's loss on the engine's own logits
+    prog = step.prog
+    ref_loss = losses_ref.mixed_dice_ce(prog.logits.float().cpu(), tgt.cpu()).item()
+    from mapping_challenge_amd.trainer import loss_forward_backward
+    l2 = torch.zeros(1, device='cuda'); s2 = torch.zeros(4, dtype=torch.float64, device='cuda'); d2 = torch.empty_like(prog.logits)
+    loss_forward_backward(prog.logits, tgt, step.spec, d2, l2, s2)
+    assert abs(l2.item() - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
+
+
+def test_config4_postprocessing_256_batch64_properties():
+    from mapping_challenge_amd import postprocessing as post
+    probs = torch.from_numpy(post_ref.synthetic_probs(64, 256, 256, seed=77)).cuda()
+    out = post.postprocess_batch(probs, (300, 300), 0, 2)
+    out2 = post.postprocess_batch(probs, (300, 300), 0, 2)
+    assert len(out) == 64
+    for (lab, sc), (lab2, sc2) in zip(out, out2):
+        assert (lab == lab2).all() and lab.dtype == np.int32 and lab.shape == (2, 300, 300)       # deterministic
+        for l, s in zip(lab, sc):
+            ids = np.unique(l[l > 0])
+            assert (ids == np.arange(1, len(ids) + 1)).all() and len(s) == len(ids)                # labels 1..n, one score each
+            assert all(np.isfinite(v) and v > 0 for v in s)
+        assert (lab[0] > 0).sum() + (lab[1] > 0).sum() > 0
+        # borders of the resized map are 0 (scipy 'constant' edge rule) -> after the 2x2 dilation only row/col 0 can stay empty
+        assert (lab[:, 0, :] == 0).all() and (lab[:, :, 0] == 0).all()
+    # labelling is idempotent on an undilated label image: label(labels > 0) == labels
+    und = post.postprocess_batch(probs[:8], (300, 300), 0, 0)
+    for lab, _ in und:
+        assert (post.label_multilayer_image(lab > 0) == lab).all()
