@@ -204,6 +204,15 @@ int64_t msc_crf_workspace_bytes(int B, int H, int W, int radius);
 int msc_dense_crf(const float* probs, const uint8_t* rgb, float* out, void* workspace, int B, int H, int W,
                   float sxy_g, float compat_g, float sxy_b, float srgb, float compat_b, int iterations, void* stream);
 
+/* ---------------------------------------------------------------- test-time augmentation --------
+ * src/loaders.py:401-517 on the device.  specs[v]: bit 0 ud flip, bit 1 lr flip (ud wins, like the reference's elif
+ * chain), bits 2-3 rotation/90 counter-clockwise.  transform: x f32 [N,C,H,W] -> out [V,N,C,H,W] (variant v of every
+ * image); aggregate: preds [V,N,C,H,W] -> out [N,C,H,W], inverse transform then method 0 mean / 1 gmean / 2 max / 3 min
+ * (TestTimeAugmentationAggregator.agg_method).  specs is a device array; any_quarter_turn tells whether H == W is needed. */
+int msc_tta_transform(const float* x, float* out, const int32_t* specs, int N, int C, int H, int W, int V, int any_quarter_turn, void* stream);
+int msc_tta_aggregate(const float* preds, float* out, const int32_t* specs, int N, int C, int H, int W, int V, int method,
+                      int any_quarter_turn, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,8 @@ SIGNATURES = {
     'msc_add_dropped': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'msc_build_score': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'msc_crf_workspace_bytes': (_i64, [_i, _i, _i, _i]),
+    'msc_tta_transform': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'msc_tta_aggregate': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'msc_dense_crf': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _f, _f, _i, _vp]),
 }
 

@@ -331,6 +331,65 @@ __global__ void crf_iter_kernel(const float* __restrict__ probs, const uint8_t* 
     }
 }
 
+// ------------------------------------------------------------------ test-time augmentation (src/loaders.py:401-517)
+// spec bits: 0 = ud flip, 1 = lr flip (the reference's elif chain: ud wins), 2-3 = rotation / 90 (counter-clockwise,
+// as skimage.rotate / np.rot90).  transformed = rot90^k(flip(image)).
+__device__ __forceinline__ void tta_src_of(int i, int j, int spec, int H, int W, int* y, int* x) {
+    const int k = (spec >> 2) & 3;
+    int yy, xx;                                  // position before the rotation
+    if (k == 0) { yy = i; xx = j; }
+    else if (k == 1) { yy = j; xx = W - 1 - i; }
+    else if (k == 2) { yy = H - 1 - i; xx = W - 1 - j; }
+    else { yy = H - 1 - j; xx = i; }
+    if (spec & 1) yy = H - 1 - yy;
+    else if (spec & 2) xx = W - 1 - xx;
+    *y = yy; *x = xx;
+}
+__device__ __forceinline__ void tta_dst_of(int y, int x, int spec, int H, int W, int* i, int* j) {
+    if (spec & 1) y = H - 1 - y;
+    else if (spec & 2) x = W - 1 - x;
+    const int k = (spec >> 2) & 3;
+    if (k == 0) { *i = y; *j = x; }
+    else if (k == 1) { *i = W - 1 - x; *j = y; }
+    else if (k == 2) { *i = H - 1 - y; *j = W - 1 - x; }
+    else { *i = x; *j = H - 1 - y; }
+}
+__global__ void tta_transform_kernel(const float* __restrict__ x, float* __restrict__ out, long planes, int H, int W,
+                                     const int32_t* __restrict__ specs, int V) {
+    const long HW = (long)H * W, total = (long)V * planes * HW;
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(t % W), i = (int)((t / W) % H);
+        const long pl = (t / HW) % planes;
+        const int v = (int)(t / (HW * planes));
+        int y, xx;
+        tta_src_of(i, j, specs[v], H, W, &y, &xx);
+        out[t] = x[pl * HW + (long)y * W + xx];
+    }
+}
+__global__ void tta_aggregate_kernel(const float* __restrict__ preds, float* __restrict__ out, long planes, int H, int W,
+                                     const int32_t* __restrict__ specs, int V, int method) {
+    const long HW = (long)H * W, total = planes * HW;
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(t % W), y = (int)((t / W) % H);
+        const long pl = t / HW;
+        double acc = method == 2 ? -1e300 : (method == 3 ? 1e300 : 0.0);
+        for (int v = 0; v < V; ++v) {
+            int i, j;
+            tta_dst_of(y, x, specs[v], H, W, &i, &j);
+            const float p = preds[((long)v * planes + pl) * HW + (long)i * W + j];
+            if (method == 0) acc += (double)p;                       // mean
+            else if (method == 1) acc += (double)logf(p);            // gmean = exp(mean(log p))
+            else if (method == 2) acc = fmax(acc, (double)p);        // max
+            else acc = fmin(acc, (double)p);                         // min
+        }
+        float r;
+        if (method == 0) r = (float)(acc / V);
+        else if (method == 1) r = expf((float)(acc / V));
+        else r = (float)acc;
+        out[t] = r;
+    }
+}
+
 inline dim3 plane_grid(long HW, int B) {
     long bx = (HW + 255) / 256;
     if (bx > 1024) bx = 1024;
@@ -483,4 +542,27 @@ extern "C" int msc_dense_crf(const float* probs, const uint8_t* rgb, float* out,
         cur = dst;
     }
     return msc_check_launch("msc_dense_crf");
+}
+
+static int tta_check(const char* name, const void* a, const void* b, const int32_t* specs, int N, int C, int H, int W, int V, const int32_t* host_specs) {
+    if (!a || !b || !specs || N <= 0 || C <= 0 || H <= 0 || W <= 0 || V <= 0) return msc_fail(MSC_ERR_ARG, "%s: bad argument", name);
+    (void)host_specs;
+    return MSC_OK;
+}
+
+extern "C" int msc_tta_transform(const float* x, float* out, const int32_t* specs, int N, int C, int H, int W, int V, int any_quarter_turn, void* stream) {
+    int rc = tta_check("msc_tta_transform", x, out, specs, N, C, H, W, V, nullptr);
+    if (rc) return rc;
+    if (any_quarter_turn && H != W) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_tta_transform: 90/270 degree rotations need square images");
+    hipLaunchKernelGGL(tta_transform_kernel, dim3(flat_grid((long)V * N * C * H * W)), dim3(256), 0, (hipStream_t)stream, x, out, (long)N * C, H, W, specs, V);
+    return msc_check_launch("msc_tta_transform");
+}
+
+extern "C" int msc_tta_aggregate(const float* preds, float* out, const int32_t* specs, int N, int C, int H, int W, int V, int method, int any_quarter_turn, void* stream) {
+    int rc = tta_check("msc_tta_aggregate", preds, out, specs, N, C, H, W, V, nullptr);
+    if (rc) return rc;
+    if (method < 0 || method > 3) return msc_fail(MSC_ERR_ARG, "msc_tta_aggregate: method %d (0 mean, 1 gmean, 2 max, 3 min)", method);
+    if (any_quarter_turn && H != W) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_tta_aggregate: 90/270 degree rotations need square images");
+    hipLaunchKernelGGL(tta_aggregate_kernel, dim3(flat_grid((long)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, preds, out, (long)N * C, H, W, specs, V, method);
+    return msc_check_launch("msc_tta_aggregate");
 }

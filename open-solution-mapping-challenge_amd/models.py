@@ -122,6 +122,21 @@ class BasePyTorchUNet(BaseTransformer):
     def transform(self, datagen, validation_datagen=None, *args, **kwargs):
         return self._transform(datagen, validation_datagen)
 
+    def transform_tta(self, datagen, tta_transformations, method='gmean'):
+        """`unet_tta` in one transformer (src/pipelines.py:94-143, src/loaders.py:401-517): every batch is expanded to its
+        TTA variants on the device, predicted, un-transformed and aggregated; returns the same dict as transform()."""
+        from . import tta
+        specs = tta.tta_specs(**dict(tta_transformations))
+        dev = self._device()
+        batch_gen, steps = datagen
+        outs = []
+        for batch_id, data in enumerate(batch_gen):
+            X = data[0] if isinstance(data, (list, tuple)) else data
+            outs.append(tta.predict_tta(self.model, X.to(dev, non_blocking=True), specs, method).cpu().numpy())
+            if batch_id == steps:
+                break
+        return {'{}_prediction'.format(self.output_names[0]): np.vstack(outs)}
+
     def transform_device(self, datagen):
         """generator of cuda f32 [n,2,H,W] probability batches (stays on the device for postprocess_batch)"""
         for p in self._forward_probs(datagen):

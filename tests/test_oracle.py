@@ -195,3 +195,23 @@ def test_c_restatement_of_post_chain_matches_numpy_oracle():
             lab2, sc2 = post_ref.postprocess(p, (112, 100), 0, k)
             assert (lab == lab2).all()
             assert all(np.allclose(a, b, rtol=1e-12) for a, b in zip(sc, sc2))
+
+
+@needs_ref
+def test_oracle_tta_equals_reference_functions():
+    from oracle import tta_ref
+    ld = ref_import.ref('loaders')
+    rng = np.random.default_rng(0)
+    gen = ld.TestTimeAugmentationGenerator(flip_ud=True, flip_lr=True, rotation=True, color_shift_runs=False)
+    _, params, _ = gen._get_tta_data(0, {'x': 1})
+    specs = tta_ref.tta_specs(True, True, True)
+    assert params == specs
+    img = rng.random((32, 32, 3)).astype(np.float32)
+    preds = [rng.random((2, 32, 32)).astype(np.float32) for _ in specs]
+    for sp, pr in zip(specs, preds):
+        assert np.array_equal(ld.test_time_augmentation_transform(img, sp), tta_ref.transform(img.transpose(2, 0, 1), sp).transpose(1, 2, 0))
+        assert np.array_equal(ld.test_time_augmentation_inverse_transform(pr, sp), tta_ref.inverse_transform(pr, sp))
+    for m in ('mean', 'gmean', 'max', 'min'):
+        agg = ld.TestTimeAugmentationAggregator(m, 1)
+        a = ld.aggregate_augmentations(0, preds, specs, [0] * len(specs), agg.agg_method)
+        assert np.allclose(a, tta_ref.aggregate(preds, specs, m), rtol=1e-6)
