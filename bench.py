@@ -89,6 +89,9 @@ def family_times(launches, stream, repeats=2):
                 f['flops'] += conv_flops(args[0]._obj) / repeats
             elif name == 'msc_conv_wgrad':
                 f['flops'] += wgrad_flops(args[0]._obj) / repeats
+            elif name == 'msc_wgrad_group_run':
+                f['flops'] += sum(wgrad_flops(d) for d in args[0].descs) / repeats
+                f['launches'] += (len(args[0].descs) - 1.0) / repeats      # counted as layers, not kernel launches
     return fam
 
 
@@ -250,7 +253,10 @@ def main():
             if args.dump_launches:
                 dump_launches(launches, stream, args.dump_launches)
             conv = fam.get('msc_conv_igemm', {'ms': 0, 'launches': 0, 'flops': 0})
-            wg = fam.get('msc_conv_wgrad', {'ms': 0, 'launches': 0, 'flops': 0})
+            wg = {'ms': 0.0, 'launches': 0.0, 'flops': 0.0}
+            for name in ('msc_conv_wgrad', 'msc_wgrad_group_run'):
+                for key in wg:
+                    wg[key] += fam.get(name, {}).get(key, 0.0)
             total_ms = sum(f['ms'] for f in fam.values())
             dom = max(fam.items(), key=lambda kv: kv[1]['ms'])
             peak = PEAK_BF16 if args.dtype == 'bf16' else PEAK_F32
@@ -265,7 +271,7 @@ def main():
                 'avg_launch_us': 1e3 * conv['ms'] / max(conv['launches'], 1),
                 'algorithmic_gflop_per_step': conv['flops'] / 1e9,
                 'wgrad': {'achieved': (wg['flops'] / (wg['ms'] * 1e-3) / 1e12) if wg['ms'] else None, 'ms_per_step': wg['ms'],
-                          'launches': round(wg['launches'])},
+                          'layers': round(wg['launches'])},
                 'dominant_family': dom[0], 'family_ms_per_step': {k: round(v['ms'], 3) for k, v in sorted(fam.items())},
                 'sum_kernel_ms_per_step': total_ms,
                 'whole_step_frac_of_mfma_peak': (conv['flops'] + wg['flops']) * (args.steps / dt) / peak}

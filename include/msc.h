@@ -69,10 +69,25 @@ typedef struct msc_wgrad_desc {
     int64_t p_ld, q_ld;
     int32_t dtype;
     int32_t N, Hp, Wp, A, Hq, Wq, B, KH, KW, stride, pad;
-    int32_t cfg;   /* 0 = heuristic; 1 + tile*4 + split: tile 0 = 128x128 when divisible / 1 = 64x64 at most, split = index of
-                      the target block count {256, 512, 1024, 2048} the pixel dimension is split for */
+    int32_t cfg;   /* 0 = heuristic; 1..msc_conv_wgrad_num_cfgs(): 1 + tile*5 + split, tile 0 = 128x128 when divisible /
+                      1 = 64x64 at most / 2 = 32x64 at most, split = index of the target block count
+                      {256, 512, 1024, 2048, none} the pixel dimension is split for */
 } msc_wgrad_desc;
 int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream);
+int msc_conv_wgrad_num_cfgs(void);
+
+/* Several weight gradients in one launch per tile shape.  The layers of a ResNet stage (src/unet_models.py:365-368:
+ * torchvision layer1..4) are individually too small to fill 256 CUs; their weight gradients depend only on saved
+ * activations and on gradients that stay live until the end of backward, so the caller may defer and batch them.
+ * steps_per_block > 0: every block runs about that many k-steps (32 bf16 / 16 f32 pixels each) and tiles are capped
+ * at tile_cap (128/64/32) -- the policy for grouped launches; steps_per_block == 0: each descriptor's own cfg.
+ * The descriptors are copied to the device at creation; the group stays valid until destroyed and may be run any
+ * number of times (also inside a hipGraph capture). */
+typedef struct msc_wgrad_group msc_wgrad_group;
+int msc_wgrad_group_create(const msc_wgrad_desc* descs, int n, int steps_per_block, int tile_cap, msc_wgrad_group** out);
+int msc_wgrad_group_run(const msc_wgrad_group* g, void* stream);
+int msc_wgrad_group_launches(const msc_wgrad_group* g);
+void msc_wgrad_group_destroy(msc_wgrad_group* g);
 
 /* fp32 master weight -> compute copy.  msc_pack_cast: same layout.  msc_pack_transpose: [A][T][B] -> [B][T][A]
  * (data-gradient / ConvTranspose2d operand).  msc_stem_pack: conv1 weight [64][3][7][7] (torch layout,
@@ -119,12 +134,13 @@ int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_t res_ld, v
  * per-channel coefficients coef[3][C];  apply: dy = coef0*dh + coef1*y + coef2 ; dres (optional) = dh (or += if dres_acc). */
 int msc_bn_bwd_blocks(int64_t pixels, int C, int dtype);
 int msc_bn_bwd_reduce(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
-                      int relu, float* partials, int dtype, int64_t pixels, int C, void* stream);
+                      int relu, const float* scale, const float* shift, float* partials, int dtype, int64_t pixels, int C,
+                      void* stream);
 int msc_bn_bwd_finalize(const float* partials, int blocks, int C, int64_t count, const float* gamma,
                         const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef, void* stream);
 int msc_bn_bwd_apply(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
-                     int relu, const float* coef, void* dy, int64_t dy_ld, void* dres, int64_t dres_ld, int dres_acc,
-                     int dtype, int64_t pixels, int C, void* stream);
+                     int relu, const float* scale, const float* shift, const float* coef, void* dy, int64_t dy_ld,
+                     void* dres, int64_t dres_ld, int dres_acc, int dtype, int64_t pixels, int C, void* stream);
 
 /* ReLU backward for the decoder (ConvRelu / deconv+ReLU): dx = dy*[y>0], optionally dx += */
 int msc_relu_bwd(const void* dy, int64_t dy_ld, const void* y, int64_t y_ld, void* dx, int64_t dx_ld,

@@ -52,6 +52,11 @@ SIGNATURES = {
     'msc_conv_num_cfgs': (_i, []),
     'msc_conv_cfg_ok': (_i, [C.POINTER(ConvDesc), _i]),
     'msc_conv_wgrad': (_i, [C.POINTER(WgradDesc), _vp]),
+    'msc_conv_wgrad_num_cfgs': (_i, []),
+    'msc_wgrad_group_create': (_i, [C.POINTER(WgradDesc), _i, _i, _i, C.POINTER(_vp)]),
+    'msc_wgrad_group_run': (_i, [_vp, _vp]),
+    'msc_wgrad_group_launches': (_i, [_vp]),
+    'msc_wgrad_group_destroy': (None, [_vp]),
     'msc_pack_cast': (_i, [_vp, _vp, _i, _i64, _vp]),
     'msc_pack_transpose': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'msc_pack_multi': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
@@ -64,9 +69,9 @@ SIGNATURES = {
     'msc_bn_fold': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
     'msc_bn_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i64, _i, _vp]),
     'msc_bn_bwd_blocks': (_i, [_i64, _i, _i]),
-    'msc_bn_bwd_reduce': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _i64, _i, _vp]),
+    'msc_bn_bwd_reduce': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i, _i64, _i, _vp]),
     'msc_bn_bwd_finalize': (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'msc_bn_bwd_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _i64, _vp, _i64, _i, _i, _i64, _i, _vp]),
+    'msc_bn_bwd_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i64, _i, _vp]),
     'msc_relu_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i64, _i, _vp]),
     'msc_bias_grad_workspace_bytes': (_i64, [_i64, _i, _i]),
     'msc_bias_grad': (_i, [_vp, _i64, _vp, _vp, _i, _i64, _i, _vp]),

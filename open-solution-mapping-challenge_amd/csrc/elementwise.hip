@@ -177,7 +177,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ y, long y_ld, const T* __r
         float v[CE], r[CE];
         Vec16<T>::load(y + pix * y_ld + c, v);
 #pragma unroll
-        for (int e = 0; e < CE; ++e) v[e] = v[e] * scale[c + e] + shift[c + e];
+        for (int e = 0; e < CE; ++e) v[e] = fmaf(v[e], scale[c + e], shift[c + e]);
         if (res) {
             Vec16<T>::load(res + pix * res_ld + c, r);
 #pragma unroll
@@ -193,7 +193,8 @@ __global__ void bn_apply_kernel(const T* __restrict__ y, long y_ld, const T* __r
 
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, long dout_ld, const T* __restrict__ out, long out_ld,
-                                    const T* __restrict__ y, long y_ld, int relu, const float* __restrict__ coef,
+                                    const T* __restrict__ y, long y_ld, int relu, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, const float* __restrict__ coef,
                                     T* __restrict__ dy, long dy_ld, T* __restrict__ dres, long dres_ld, int dres_acc,
                                     long pixels, int C) {
     constexpr int CE = Vec16<T>::N;
@@ -205,10 +206,13 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, long dout_ld, co
         float d[CE], o[CE], yy[CE], r[CE];
         Vec16<T>::load(dout + pix * dout_ld + c, d);
         Vec16<T>::load(y + pix * y_ld + c, yy);
-        if (relu) {
+        if (relu == 1) {
             Vec16<T>::load(out + pix * out_ld + c, o);
 #pragma unroll
             for (int e = 0; e < CE; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+        } else if (relu == 2) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) d[e] = fmaf(yy[e], scale[c + e], shift[c + e]) > 0.f ? d[e] : 0.f;
         }
         if (dres) {
             if (dres_acc) {
@@ -526,15 +530,16 @@ extern "C" int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_
 }
 
 extern "C" int msc_bn_bwd_apply(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
-                                int relu, const float* coef, void* dy, int64_t dy_ld, void* dres, int64_t dres_ld, int dres_acc,
-                                int dtype, int64_t pixels, int C, void* stream) {
+                                int relu, const float* scale, const float* shift, const float* coef, void* dy, int64_t dy_ld,
+                                void* dres, int64_t dres_ld, int dres_acc, int dtype, int64_t pixels, int C, void* stream) {
     DT_CHECK("msc_bn_bwd_apply", dtype);
     VEC_CHECK("msc_bn_bwd_apply", dtype, C);
-    if (!dout || !y || !coef || !dy || (relu && !out)) return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_apply: null pointer");
+    if (!dout || !y || !coef || !dy || relu < 0 || relu > 2 || (relu == 1 && !out) || (relu == 2 && (!scale || !shift)))
+        return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_apply: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const long total = pixels * (C / (dtype == MSC_BF16 ? 8 : 4));
-    if (dtype == MSC_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)dout, (long)dout_ld, (const bf16_t*)out, (long)out_ld, (const bf16_t*)y, (long)y_ld, relu, coef, (bf16_t*)dy, (long)dy_ld, (bf16_t*)dres, (long)dres_ld, dres_acc, (long)pixels, C);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const float*)dout, (long)dout_ld, (const float*)out, (long)out_ld, (const float*)y, (long)y_ld, relu, coef, (float*)dy, (long)dy_ld, (float*)dres, (long)dres_ld, dres_acc, (long)pixels, C);
+    if (dtype == MSC_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)dout, (long)dout_ld, (const bf16_t*)out, (long)out_ld, (const bf16_t*)y, (long)y_ld, relu, scale, shift, coef, (bf16_t*)dy, (long)dy_ld, (bf16_t*)dres, (long)dres_ld, dres_acc, (long)pixels, C);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const float*)dout, (long)dout_ld, (const float*)out, (long)out_ld, (const float*)y, (long)y_ld, relu, scale, shift, coef, (float*)dy, (long)dy_ld, (float*)dres, (long)dres_ld, dres_acc, (long)pixels, C);
     return msc_check_launch("msc_bn_bwd_apply");
 }
 

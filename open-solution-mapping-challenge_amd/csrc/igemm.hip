@@ -36,6 +36,9 @@
 //                 on the fragment reads.
 #include <stdlib.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 #include "msc_internal.h"
 
@@ -484,18 +487,38 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
 //   convT wgrad: P = X  (a = cin, coarse grid), Q = dOut (b = cout, fine grid), stride 2
 // GEMM K = pixels, the strided dimension of NHWC: both operands are staged pixel-major in LDS and the
 // k-contiguous MFMA fragments are produced by a transposing LDS read.
+constexpr int WGRAD_NS = 5, WGRAD_NCFG = 3 * WGRAD_NS;
+
 struct WgK {
     const char* p; const char* q; float* dw;
     long p_ld, q_ld;
     int N, Hp, Wp, A, Hq, Wq, B, KH, KW, stride, pad;
     int M, mchunk, tiles_b;
+    int ntiles, ntaps, xcd_order;    // 1-D grid of ntiles*ntaps*splits blocks; split slowest, channel tile fastest
+    int nblocks;                     // ntiles*ntaps*splits
     unsigned p_bytes, q_bytes;
     float rcp_hw, rcp_w;
 };
 
+// Blocks that share a pixel range (one split) share P/Q: give each XCD (block b runs on XCD b % 8) a contiguous
+// run of the split-major order so that range stays in one L2 instead of all eight.
+__device__ __forceinline__ void wgrad_block(const WgK& p, int orig, int nwg, int& tile, int& tap, int& split) {
+    int wgid = orig;
+    if (p.xcd_order) {
+        const int xcd = orig & 7, wq = nwg >> 3, wr = nwg & 7;
+        wgid = (xcd < wr ? xcd * (wq + 1) : wr * (wq + 1) + (xcd - wr) * wq) + (orig >> 3);
+    }
+    const int per = p.ntiles * p.ntaps;
+    split = wgid / per;
+    const int r = wgid - split * per;
+    tap = r / p.ntiles;
+    tile = r - tap * p.ntiles;
+}
+
 // v1: register staging, element-wise (ds_read_u16) gather of the fragments
 template <typename T, int TA, int TB>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgK p) {
+    const int orig = blockIdx.x, nwg = gridDim.x;
     constexpr int ES = sizeof(T);
     constexpr int KP = 64 / ES;      // pixels per k-step
     constexpr int CE = 16 / ES;
@@ -511,11 +534,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgK p) {
     const int lane = tid & 63, wid = tid >> 6;
     const int wa = wid >> 1, wb = wid & 1;
     const int g = lane >> 4, pl = lane & 15;
-    const int ta = blockIdx.x / p.tiles_b, tb = blockIdx.x - ta * p.tiles_b;
+    int tile, tap, split;
+    wgrad_block(p, orig, nwg, tile, tap, split);
+    const int ta = tile / p.tiles_b, tb = tile - ta * p.tiles_b;
     const int a0 = ta * TA, b0 = tb * TB;
-    const int tap = blockIdx.y;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
-    const int mbeg = blockIdx.z * p.mchunk;
+    const int mbeg = split * p.mchunk;
     const int mend = min(p.M, mbeg + p.mchunk);
     const int nsteps = mend > mbeg ? (mend - mbeg + KP - 1) / KP : 0;
 
@@ -655,7 +679,7 @@ template <> __device__ __forceinline__ int wg_swz<float>(int unit, int row, int 
 typedef short v4i16_t __attribute__((ext_vector_type(4)));
 
 template <typename T, int TA, int TB, int NST>
-__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgK p) {
+__device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, const int nwg) {
     constexpr int ES = sizeof(T);
     constexpr int KP = 64 / ES;                  // pixels per k-step (32 bf16 / 16 f32)
     constexpr int RBA = TA * ES, RBB = TB * ES;  // bytes per pixel row of each tile
@@ -675,11 +699,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgK p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wid >> 1, wb = wid & 1;
     const int g = lane >> 4, pl = lane & 15;
-    const int ta = blockIdx.x / p.tiles_b, tb = blockIdx.x - ta * p.tiles_b;
+    int tile, tap, split;
+    wgrad_block(p, orig, nwg, tile, tap, split);
+    const int ta = tile / p.tiles_b, tb = tile - ta * p.tiles_b;
     const int a0 = ta * TA, b0 = tb * TB;
-    const int tap = blockIdx.y;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
-    const int mbeg = blockIdx.z * p.mchunk;
+    const int mbeg = split * p.mchunk;
     const int mend = min(p.M, mbeg + p.mchunk);
     const int nsteps = mend > mbeg ? (mend - mbeg + KP - 1) / KP : 0;
 
@@ -823,6 +848,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgK p) {
     }
 }
 
+template <typename T, int TA, int TB, int NST>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgK p) {
+    wgrad_dma_body<T, TA, TB, NST>(p, blockIdx.x, gridDim.x);
+}
+
+// Several weight-gradient problems of one tile shape in a single launch (msc_wgrad_group_*): the layers of a
+// ResNet stage are too small to fill 256 CUs one at a time, together they do.  `starts` are the first block of
+// each problem (multiples of 8, so a problem's XCD-local order is the same as in a launch of its own).
+template <typename T, int TA, int TB, int NST>
+__global__ __launch_bounds__(256) void conv_wgrad_group_kernel(const WgK* __restrict__ tab, const int* __restrict__ starts, int n) {
+    const int b = blockIdx.x;
+    int i = 0;
+    while (i + 1 < n && starts[i + 1] <= b) ++i;
+    WgK p;
+    const int* src = reinterpret_cast<const int*>(tab + i);
+    int* dst = reinterpret_cast<int*>(&p);
+#pragma unroll
+    for (unsigned j = 0; j < sizeof(WgK) / 4; ++j) dst[j] = __builtin_amdgcn_readfirstlane(src[j]);
+    const int orig = b - __builtin_amdgcn_readfirstlane(starts[i]);
+    if (orig >= p.nblocks) return;
+    wgrad_dma_body<T, TA, TB, NST>(p, orig, p.nblocks);
+}
+
 bool env_flag(const char* name) {
     const char* e = getenv(name);
     return e && e[0] == '1';
@@ -916,11 +964,6 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
     }
 }
 
-template <typename T, int TA, int TB>
-void launch_wgrad(const WgK& k, dim3 grid, hipStream_t st) {
-    if (use_v1_wgrad() || k.p_bytes == 0) hipLaunchKernelGGL((conv_wgrad_kernel<T, TA, TB>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, TA, TB, 4>), grid, dim3(256), 0, st, k);
-}
 
 }  // namespace
 
@@ -995,7 +1038,15 @@ extern "C" int msc_conv_igemm(const msc_conv_desc* d, void* stream) {
     return conv_dispatch<float>(k, d->mode, d->cfg, st);
 }
 
-extern "C" int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream) {
+extern "C" int msc_conv_wgrad_num_cfgs(void) { return WGRAD_NCFG; }
+
+namespace {
+
+struct WgPlan { WgK k; int dtype, ta, tb; bool dma; };
+
+// Validates a descriptor and fixes tile shape and split-K.  steps_per_block > 0 (grouped launches: other problems
+// fill the chip, so a block just runs that many k-steps) overrides the per-launch policy selected by d->cfg.
+int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPlan* out) {
     if (!d || !d->p || !d->q || !d->dw) return msc_fail(MSC_ERR_ARG, "msc_conv_wgrad: null pointer");
     if (d->dtype != MSC_BF16 && d->dtype != MSC_F32) return msc_fail(MSC_ERR_ARG, "msc_conv_wgrad: dtype %d", d->dtype);
     const int es = d->dtype == MSC_BF16 ? 2 : 4;
@@ -1004,7 +1055,7 @@ extern "C" int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream) {
                       (d->KW == 1 && d->pad == 0 && (d->stride * d->q_ld * es) % 16 == 0 && ((int64_t)d->Wq * d->q_ld * es) % 16 == 0);
     if ((d->p_ld * es) % 16 || !q_ok || (((uintptr_t)d->p | (uintptr_t)d->q) & 15))
         return msc_fail(MSC_ERR_ARG, "msc_conv_wgrad: operands must keep 16-byte alignment");
-    WgK k;
+    WgK& k = out->k;
     k.p = (const char*)d->p; k.q = (const char*)d->q; k.dw = d->dw; k.p_ld = d->p_ld; k.q_ld = d->q_ld;
     k.N = d->N; k.Hp = d->Hp; k.Wp = d->Wp; k.A = d->A; k.Hq = d->Hq; k.Wq = d->Wq; k.B = d->B;
     k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad;
@@ -1020,47 +1071,161 @@ extern "C" int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream) {
     k.rcp_hw = 1.0f / (float)(d->Hp * d->Wp);
     k.rcp_w = 1.0f / (float)d->Wp;
     const int kp = 64 / es;
-    // Tile and split-K choice.  Every split adds one fp32-atomic pass over dW and a pipeline fill, so a block
-    // should run >= 24 k-steps; within that, prefer the largest tile that still gives >= 384 blocks.
     const int ksteps = ceil_div(k.M, kp);
-    const int max_splits = ksteps / 24 > 1 ? ksteps / 24 : 1;
-    // cfg 0: heuristic; else 1 + tsel*4 + ssel with tsel 0 = 128x128 tiles when possible, 1 = 64x64 at most,
-    // ssel = index into the target block counts below
-    static const int TARGETS[4] = {256, 512, 1024, 2048};
-    if (d->cfg < 0 || d->cfg > 8) return msc_fail(MSC_ERR_ARG, "msc_conv_wgrad: cfg %d", d->cfg);
-    const int target = d->cfg ? TARGETS[(d->cfg - 1) & 3] : 768;
     bool big = (d->A % 128 == 0) && (d->B % 128 == 0);
-    if (d->cfg) {
-        if ((d->cfg - 1) >> 2) big = false;
-    } else if (big) {
-        const int tiles128 = (d->A / 128) * (d->B / 128) * d->KH * d->KW;
-        int sp = ceil_div(768, tiles128);
-        if (sp > max_splits) sp = max_splits;
-        if ((long)tiles128 * sp < 384) big = false;     // not enough parallelism: 64x64 tiles instead
+    int tsel = 0, splits;
+    if (steps_per_block > 0) {
+        if (tile_cap < 128) big = false;
+        if (tile_cap < 64) tsel = 2;
+        splits = ceil_div(ksteps, steps_per_block);
+    } else {
+        // Tile and split-K choice.  Every split adds one fp32-atomic pass over dW and a pipeline fill, so a block
+        // should run >= 24 k-steps; within that, prefer the largest tile that still gives >= 384 blocks.
+        const int max_splits = ksteps / 24 > 1 ? ksteps / 24 : 1;
+        // cfg 0: heuristic; else 1 + tsel*5 + ssel with tsel 0 = 128x128 tiles when possible, 1 = 64x64 at most,
+        // 2 = 32 output channels x 64 at most; ssel = index into the target block counts below (last: no split-K)
+        static const int TARGETS[WGRAD_NS] = {256, 512, 1024, 2048, 1};
+        if (d->cfg < 0 || d->cfg > WGRAD_NCFG) return msc_fail(MSC_ERR_ARG, "msc_conv_wgrad: cfg %d", d->cfg);
+        tsel = d->cfg ? (d->cfg - 1) / WGRAD_NS : 0;
+        const int target = d->cfg ? TARGETS[(d->cfg - 1) % WGRAD_NS] : 768;
+        if (d->cfg) {
+            if (tsel) big = false;
+        } else if (big) {
+            const int tiles128 = (d->A / 128) * (d->B / 128) * d->KH * d->KW;
+            int sp = ceil_div(768, tiles128);
+            if (sp > max_splits) sp = max_splits;
+            if ((long)tiles128 * sp < 384) big = false;     // not enough parallelism: 64x64 tiles instead
+        }
+        const int ta0 = big ? 128 : (d->A % 64 == 0 && tsel != 2 ? 64 : 32), tb0 = big ? 128 : (d->B % 64 == 0 ? 64 : 32);
+        splits = ceil_div(target, (d->A / ta0) * (d->B / tb0) * d->KH * d->KW);
+        if (splits > max_splits) splits = max_splits;
     }
-    const int ta = big ? 128 : (d->A % 64 == 0 ? 64 : 32), tbs = big ? 128 : (d->B % 64 == 0 ? 64 : 32);
-    const int tiles = (d->A / ta) * (d->B / tbs) * d->KH * d->KW;
-    int splits = ceil_div(target, tiles);
-    if (splits > max_splits) splits = max_splits;
+    const int ta = big ? 128 : (d->A % 64 == 0 && tsel != 2 ? 64 : 32), tbs = big ? 128 : (d->B % 64 == 0 ? 64 : 32);
     if (splits < 1) splits = 1;
     int mchunk = ceil_div(k.M, splits);
     mchunk = ceil_div(mchunk, kp) * kp;
     splits = ceil_div(k.M, mchunk);
     k.mchunk = mchunk; k.tiles_b = d->B / tbs;
-    dim3 grid((d->A / ta) * (d->B / tbs), d->KH * d->KW, splits);
-    hipStream_t st = (hipStream_t)stream;
-    if (d->dtype == MSC_BF16) {
-        if (big) launch_wgrad<bf16_t, 128, 128>(k, grid, st);
-        else if (ta == 64 && tbs == 64) launch_wgrad<bf16_t, 64, 64>(k, grid, st);
-        else if (ta == 64) launch_wgrad<bf16_t, 64, 32>(k, grid, st);
-        else if (tbs == 64) launch_wgrad<bf16_t, 32, 64>(k, grid, st);
-        else launch_wgrad<bf16_t, 32, 32>(k, grid, st);
-    } else {
-        if (big) launch_wgrad<float, 128, 128>(k, grid, st);
-        else if (ta == 64 && tbs == 64) launch_wgrad<float, 64, 64>(k, grid, st);
-        else if (ta == 64) launch_wgrad<float, 64, 32>(k, grid, st);
-        else if (tbs == 64) launch_wgrad<float, 32, 64>(k, grid, st);
-        else launch_wgrad<float, 32, 32>(k, grid, st);
+    k.ntiles = (d->A / ta) * (d->B / tbs); k.ntaps = d->KH * d->KW; k.xcd_order = xcd_order_enabled() ? 1 : 0;
+    k.nblocks = k.ntiles * k.ntaps * splits;
+    out->dtype = d->dtype; out->ta = ta; out->tb = tbs;
+    out->dma = !use_v1_wgrad() && k.p_bytes != 0;
+    return MSC_OK;
+}
+
+// calls f.template operator()<T, TA, TB>() for the plan's (dtype, tile)
+template <typename F>
+void wgrad_tile_dispatch(int dtype, int ta, int tb, F&& f) {
+#define MSC_WG_CASE(T) \
+    if (ta == 128) f.template operator()<T, 128, 128>(); \
+    else if (ta == 64 && tb == 64) f.template operator()<T, 64, 64>(); \
+    else if (ta == 64) f.template operator()<T, 64, 32>(); \
+    else if (tb == 64) f.template operator()<T, 32, 64>(); \
+    else f.template operator()<T, 32, 32>();
+    if (dtype == MSC_BF16) { MSC_WG_CASE(bf16_t) } else { MSC_WG_CASE(float) }
+#undef MSC_WG_CASE
+}
+
+struct WgLaunchOne {
+    const WgK& k; bool dma; hipStream_t st;
+    template <typename T, int TA, int TB> void operator()() const {
+        if (dma) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, TA, TB, 4>), dim3(k.nblocks), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<T, TA, TB>), dim3(k.nblocks), dim3(256), 0, st, k);
     }
+};
+
+struct WgLaunchGroup {
+    const WgK* tab; const int* starts; int n, blocks; hipStream_t st;
+    template <typename T, int TA, int TB> void operator()() const {
+        hipLaunchKernelGGL((conv_wgrad_group_kernel<T, TA, TB, 4>), dim3(blocks), dim3(256), 0, st, tab, starts, n);
+    }
+};
+
+}  // namespace
+
+extern "C" int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream) {
+    WgPlan pl;
+    int rc = wgrad_plan(d, 0, 128, &pl);
+    if (rc != MSC_OK) return rc;
+    wgrad_tile_dispatch(pl.dtype, pl.ta, pl.tb, WgLaunchOne{pl.k, pl.dma, (hipStream_t)stream});
     return msc_check_launch("conv_wgrad");
+}
+
+// ---- grouped weight gradients ---------------------------------------------------------------------
+struct msc_wgrad_group {
+    struct Bucket { int dtype, ta, tb, n, blocks; WgK* tab; int* starts; };
+    std::vector<Bucket> buckets;      // DMA-kernel problems by (dtype, tile): one launch each
+    std::vector<WgPlan> singles;      // problems the DMA kernel cannot take (>= 2 GiB operands): launched one by one
+    void* dev = nullptr;              // one allocation behind every table
+};
+
+extern "C" int msc_wgrad_group_create(const msc_wgrad_desc* descs, int n, int steps_per_block, int tile_cap, msc_wgrad_group** out) {
+    if (!descs || n <= 0 || !out) return msc_fail(MSC_ERR_ARG, "msc_wgrad_group_create: bad argument");
+    std::vector<WgPlan> plans(n);
+    for (int i = 0; i < n; ++i) {
+        int rc = wgrad_plan(&descs[i], steps_per_block, tile_cap > 0 ? tile_cap : 128, &plans[i]);
+        if (rc != MSC_OK) return rc;
+    }
+    msc_wgrad_group* g = new msc_wgrad_group;
+    // the longest-running blocks first: the launch ends when its slowest block does
+    std::stable_sort(plans.begin(), plans.end(), [](const WgPlan& a, const WgPlan& b) { return a.k.mchunk > b.k.mchunk; });
+    std::vector<std::vector<int>> members;
+    for (int i = 0; i < n; ++i) {
+        const WgPlan& p = plans[i];
+        if (!p.dma) { g->singles.push_back(p); continue; }
+        size_t b = 0;
+        for (; b < g->buckets.size(); ++b)
+            if (g->buckets[b].dtype == p.dtype && g->buckets[b].ta == p.ta && g->buckets[b].tb == p.tb) break;
+        if (b == g->buckets.size()) { g->buckets.push_back({p.dtype, p.ta, p.tb, 0, 0, nullptr, nullptr}); members.emplace_back(); }
+        members[b].push_back(i);
+    }
+    size_t bytes = 0;
+    for (size_t b = 0; b < g->buckets.size(); ++b) bytes += members[b].size() * (sizeof(WgK) + 16) + 256;
+    if (bytes) {
+        if (hipMalloc(&g->dev, bytes) != hipSuccess) { delete g; return msc_fail(MSC_ERR_HIP, "msc_wgrad_group_create: hipMalloc(%zu)", bytes); }
+        std::vector<char> host(bytes, 0);
+        size_t off = 0;
+        for (size_t b = 0; b < g->buckets.size(); ++b) {
+            auto& bk = g->buckets[b];
+            bk.n = (int)members[b].size();
+            bk.tab = reinterpret_cast<WgK*>((char*)g->dev + off);
+            WgK* ht = reinterpret_cast<WgK*>(host.data() + off);
+            off += (size_t)bk.n * sizeof(WgK);
+            bk.starts = reinterpret_cast<int*>((char*)g->dev + off);
+            int* hs = reinterpret_cast<int*>(host.data() + off);
+            off = (off + (size_t)bk.n * sizeof(int) + 255) & ~(size_t)255;
+            int start = 0;
+            for (int j = 0; j < bk.n; ++j) {
+                ht[j] = plans[members[b][j]].k;
+                hs[j] = start;
+                start += (ht[j].nblocks + 7) & ~7;
+            }
+            bk.blocks = start;
+        }
+        if (hipMemcpy(g->dev, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(g->dev); delete g;
+            return msc_fail(MSC_ERR_HIP, "msc_wgrad_group_create: hipMemcpy");
+        }
+    }
+    *out = g;
+    return MSC_OK;
+}
+
+extern "C" int msc_wgrad_group_run(const msc_wgrad_group* g, void* stream) {
+    if (!g) return msc_fail(MSC_ERR_ARG, "msc_wgrad_group_run: null group");
+    hipStream_t st = (hipStream_t)stream;
+    for (const auto& bk : g->buckets)
+        wgrad_tile_dispatch(bk.dtype, bk.ta, bk.tb, WgLaunchGroup{bk.tab, bk.starts, bk.n, bk.blocks, st});
+    for (const auto& p : g->singles) wgrad_tile_dispatch(p.dtype, p.ta, p.tb, WgLaunchOne{p.k, p.dma, st});
+    return msc_check_launch("wgrad_group");
+}
+
+extern "C" int msc_wgrad_group_launches(const msc_wgrad_group* g) {
+    return g ? (int)(g->buckets.size() + g->singles.size()) : -1;
+}
+
+extern "C" void msc_wgrad_group_destroy(msc_wgrad_group* g) {
+    if (!g) return;
+    if (g->dev) (void)hipFree(g->dev);
+    delete g;
 }

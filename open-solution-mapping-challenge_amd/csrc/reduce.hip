@@ -16,7 +16,8 @@ constexpr int RED_PIX_MAX = 128;   // pixels per block (halved, down to the row-
 // K = 2: (sum dh, sum dh*y) with dh = dout*[out>0] (BatchNorm backward);  K = 1: sum d (bias gradient)
 template <typename T, int K>
 __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ dout, long dout_ld, const T* __restrict__ out, long out_ld,
-                                                        const T* __restrict__ y, long y_ld, int relu, float* __restrict__ partials,
+                                                        const T* __restrict__ y, long y_ld, int relu, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, float* __restrict__ partials,
                                                         long pixels, int C, int cols, int S, int ppb) {
     constexpr int CE = Vec16<T>::N;
     __shared__ float red[256 * K * CE];
@@ -30,10 +31,15 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ do
     for (int e = 0; e < CE; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     const bool live = vc * CE < C;
     if (live) {
+        float sc[CE], sh[CE];
+        if (K == 2 && relu == 2) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { sc[e] = scale[vc * CE + e]; sh[e] = shift[vc * CE + e]; }
+        }
         for (long p = p0 + r; p < p1; p += R) {
             float d[CE];
             Vec16<T>::load(dout + p * dout_ld + vc * CE, d);
-            if (relu) {
+            if (relu == 1) {
                 float o[CE];
                 Vec16<T>::load(out + p * out_ld + vc * CE, o);
 #pragma unroll
@@ -42,6 +48,10 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ do
             if (K == 2) {
                 float yy[CE];
                 Vec16<T>::load(y + p * y_ld + vc * CE, yy);
+                if (relu == 2) {            // the forward's pre-activation, recomputed instead of reading `out`
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) d[e] = fmaf(yy[e], sc[e], sh[e]) > 0.f ? d[e] : 0.f;
+                }
 #pragma unroll
                 for (int e = 0; e < CE; ++e) s2[e] += d[e] * yy[e];
             }
@@ -166,12 +176,12 @@ bool red_geom(long pixels, int C, int ce, RedGeom* g) {
 
 template <typename T, int K>
 int launch_colreduce(const void* dout, long dout_ld, const void* out, long out_ld, const void* y, long y_ld, int relu,
-                     float* partials, long pixels, int C, hipStream_t st) {
+                     const float* scale, const float* shift, float* partials, long pixels, int C, hipStream_t st) {
     RedGeom g;
     if (!red_geom(pixels, C, Vec16<T>::N, &g)) return msc_fail(MSC_ERR_UNSUPPORTED, "column reduce: C=%d not supported", C);
     dim3 grid(g.S, g.chunks);
     hipLaunchKernelGGL((colreduce_kernel<T, K>), grid, dim3(256), 0, st, (const T*)dout, dout_ld, (const T*)out, out_ld, (const T*)y, y_ld,
-                       relu, partials, pixels, C, g.cols, g.S, g.ppb);
+                       relu, scale, shift, partials, pixels, C, g.cols, g.S, g.ppb);
     return msc_check_launch("colreduce");
 }
 
@@ -196,13 +206,15 @@ extern "C" int msc_bn_bwd_blocks(int64_t pixels, int C, int dtype) {
 }
 
 extern "C" int msc_bn_bwd_reduce(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
-                                 int relu, float* partials, int dtype, int64_t pixels, int C, void* stream) {
+                                 int relu, const float* scale, const float* shift, float* partials, int dtype, int64_t pixels, int C,
+                                 void* stream) {
     DT_CHECK("msc_bn_bwd_reduce", dtype);
-    if (!dout || !y || !partials || (relu && !out) || pixels <= 0) return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_reduce: bad argument");
+    if (!dout || !y || !partials || relu < 0 || relu > 2 || (relu == 1 && !out) || (relu == 2 && (!scale || !shift)) || pixels <= 0)
+        return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_reduce: bad argument");
     if (C % (dtype == MSC_BF16 ? 32 : 16)) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bn_bwd_reduce: C=%d must be a multiple of %d", C, dtype == MSC_BF16 ? 32 : 16);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MSC_BF16) return launch_colreduce<bf16_t, 2>(dout, dout_ld, out, out_ld, y, y_ld, relu, partials, pixels, C, st);
-    return launch_colreduce<float, 2>(dout, dout_ld, out, out_ld, y, y_ld, relu, partials, pixels, C, st);
+    if (dtype == MSC_BF16) return launch_colreduce<bf16_t, 2>(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, partials, pixels, C, st);
+    return launch_colreduce<float, 2>(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, partials, pixels, C, st);
 }
 
 extern "C" int msc_bn_bwd_finalize(const float* partials, int blocks, int C, int64_t count, const float* gamma,
@@ -224,8 +236,8 @@ extern "C" int msc_bias_grad(const void* dy, int64_t dy_ld, float* db, void* wor
     if (!dy || !db || !workspace || pixels <= 0) return msc_fail(MSC_ERR_ARG, "msc_bias_grad: bad argument");
     if (C % (dtype == MSC_BF16 ? 32 : 16)) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bias_grad: C=%d must be a multiple of %d", C, dtype == MSC_BF16 ? 32 : 16);
     hipStream_t st = (hipStream_t)stream;
-    int rc = dtype == MSC_BF16 ? launch_colreduce<bf16_t, 1>(dy, dy_ld, nullptr, 0, nullptr, 0, 0, (float*)workspace, pixels, C, st)
-                               : launch_colreduce<float, 1>(dy, dy_ld, nullptr, 0, nullptr, 0, 0, (float*)workspace, pixels, C, st);
+    int rc = dtype == MSC_BF16 ? launch_colreduce<bf16_t, 1>(dy, dy_ld, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, (float*)workspace, pixels, C, st)
+                               : launch_colreduce<float, 1>(dy, dy_ld, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, (float*)workspace, pixels, C, st);
     if (rc) return rc;
     RedGeom g;
     red_geom(pixels, C, dtype == MSC_BF16 ? 8 : 4, &g);

@@ -84,6 +84,32 @@ def conv_wgrad(p, q, dw, KH, KW, stride=1, pad=0, cfg=0):
     return dw
 
 
+def _wgrad_desc(p, q, dw, KH, KW, stride, pad, cfg=0):
+    d = WgradDesc()
+    d.p, d.q, d.dw = p.data_ptr(), q.data_ptr(), dw.data_ptr()
+    d.p_ld, d.q_ld, d.dtype = _nhwc(p), _nhwc(q), _dt(p)
+    d.N, d.Hp, d.Wp, d.A = p.shape
+    _, d.Hq, d.Wq, d.B = q.shape
+    d.KH, d.KW, d.stride, d.pad, d.cfg = KH, KW, stride, pad, int(cfg)
+    return d
+
+
+def conv_wgrad_group(problems, steps_per_block=64, tile_cap=128, runs=1):
+    """problems: [(p, q, dw, KH, KW, stride, pad)]; all weight gradients in one launch per tile shape.
+    Returns the number of kernel launches one run takes."""
+    lib = _lib.load()
+    arr = (WgradDesc * len(problems))(*[_wgrad_desc(*pr) for pr in problems])
+    h = C.c_void_p()
+    _lib.check(lib.msc_wgrad_group_create(arr, len(problems), steps_per_block, tile_cap, C.byref(h)), 'msc_wgrad_group_create')
+    try:
+        for _ in range(runs):
+            _lib.check(lib.msc_wgrad_group_run(h, _stream(problems[0][0])), 'msc_wgrad_group_run')
+        return lib.msc_wgrad_group_launches(h)
+    finally:
+        torch.cuda.synchronize()
+        lib.msc_wgrad_group_destroy(h)
+
+
 def pack_transpose(src, dtype):
     """f32 [A, T, B] -> dtype [B, T, A]"""
     A, T, B = src.shape

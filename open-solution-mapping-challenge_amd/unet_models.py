@@ -158,11 +158,21 @@ class _Program:
 
     def __init__(self):
         self.fwd, self.bwd, self.keep = [], [], []
+        self.groups = []        # msc_wgrad_group handles owned by this program
         self.x_in = None        # f32 NCHW input staging buffer
         self.logits = None      # f32 NCHW
         self.probs = None       # f32 NCHW (eval)
         self.dlogits = None     # f32 NCHW (train)
         self.bytes = 0
+
+    def __del__(self):
+        try:
+            lib = _lib.load()
+            for h in self.groups:
+                lib.msc_wgrad_group_destroy(h)
+        except Exception:
+            pass
+        self.groups = []
 
     @staticmethod
     def run(launches, stream):
@@ -171,7 +181,7 @@ class _Program:
             if rc != 0:
                 _lib.check(rc, fn.__name__)
 
-    SIDE = ('msc_conv_wgrad', 'msc_stem_unpack_grad')
+    SIDE = ('msc_conv_wgrad', 'msc_wgrad_group_run', 'msc_stem_unpack_grad')
 
     @staticmethod
     def run_backward(launches, device):
@@ -526,14 +536,20 @@ UNetResNet._grad_views = _grad_views
 # ----------------------------------------------------------------------------- program builder
 _TUNE_CACHE = {}
 _TUNE_FILE = _os_env.environ.get('MSC_TUNE_CACHE')      # optional JSON file: reuse per-layer choices across processes
+# per-layer choices measured on MI355X for the BASELINE.json configurations, shipped with the package (like a
+# MIOpen perf-db); shapes not in it are timed on first use.  MSC_TUNE_DB=0 ignores it.
+_TUNE_DB = _os_env.path.join(_os_env.path.dirname(_os_env.path.abspath(__file__)), 'tune', 'gfx950.json')
 
 
 def _tune_load():
-    if _TUNE_FILE and _os_env.path.exists(_TUNE_FILE) and not _TUNE_CACHE:
-        import json
-        with open(_TUNE_FILE) as f:
-            for k, v in json.load(f).items():
-                _TUNE_CACHE[k] = v
+    if _TUNE_CACHE:
+        return
+    import json
+    files = [_TUNE_DB] if _os_env.environ.get('MSC_TUNE_DB', '1') != '0' else []
+    for path in files + ([_TUNE_FILE] if _TUNE_FILE else []):
+        if _os_env.path.exists(path):
+            with open(path) as f:
+                _TUNE_CACHE.update(json.load(f))
 
 
 def _tune_save():
@@ -543,6 +559,10 @@ def _tune_save():
         with open(tmp, 'w') as f:
             json.dump(_TUNE_CACHE, f)
         _os_env.replace(tmp, _TUNE_FILE)
+
+
+class _GroupHandle(C.c_void_p):
+    """msc_wgrad_group* plus the descriptors it was made from (for FLOP accounting in bench.py)"""
 
 
 class _Builder:
@@ -561,6 +581,13 @@ class _Builder:
         self.gbuf = {}                # id(buffer) -> grad buffer
         self.gwritten = set()         # (id(gbuf), c0, C) already written in this backward
         self.slices = {}              # id(buffer) -> set of (c0, C)
+        # Weight gradients are deferred and launched MSC_WGRAD_GROUP (default 24) at a time (msc_wgrad_group_*): one layer of the
+        # encoder cannot fill 256 CUs, a dozen can.  0/1 = one launch per layer (the CPU interpreter always does that).
+        env = _os_env.environ
+        self.group_max = int(env.get('MSC_WGRAD_GROUP', '24')) if (training and device.type == 'cuda') else 0
+        self.group_steps = int(env.get('MSC_WGRAD_GROUP_STEPS', '64'))
+        self.group_tile = int(env.get('MSC_WGRAD_GROUP_TILE', '128'))
+        self.pending = []             # deferred (WgradDesc, gradient address or None)
 
     # ---- memory
     def buf(self, H, W, C, dtype=None):
@@ -660,8 +687,31 @@ class _Builder:
         d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
         d.cfg = 0
         self.prog.keep.append(d)
+        if self.group_max > 1:
+            gw = None
+            writes = self.prog.grad_writes
+            if writes and writes[-1] == (len(self.prog.bwd), d.dw):      # recorded by g(): moves to the group launch
+                gw = writes.pop()[1]
+            self.pending.append((d, gw))
+            if len(self.pending) >= self.group_max:
+                self.flush_wgrads()
+            return
         self.tune_wgrad(d)
         self.emit(lst, self.lib.msc_conv_wgrad, C.byref(d))
+
+    def flush_wgrads(self):
+        if not self.pending:
+            return
+        n = len(self.pending)
+        arr = (WgradDesc * n)(*[d for d, _ in self.pending])
+        h = _GroupHandle()
+        _lib.check(self.lib.msc_wgrad_group_create(arr, n, self.group_steps, self.group_tile, C.byref(h)), 'msc_wgrad_group_create')
+        h.descs = [d for d, _ in self.pending]
+        self.prog.groups.append(h)
+        idx = len(self.prog.bwd)
+        self.emit(self.prog.bwd, self.lib.msc_wgrad_group_run, h)
+        self.prog.grad_writes += [(idx, gw) for _, gw in self.pending if gw is not None]
+        self.pending = []
 
     # ---- per-layer kernel configuration (like cuDNN's benchmark mode): time the valid configurations once per
     # distinct layer shape on the real buffers and keep the fastest; results are cached process-wide
@@ -685,8 +735,8 @@ class _Builder:
         key = repr(('c', self.dt, d.mode, d.flip, d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad,
                     bool(d.res), want_stats, d.in_ld, d.out_ld, bool(d.relu)))
         cache = _TUNE_CACHE
-        if key not in cache:
-            lib = self.lib
+        lib = self.lib
+        if key not in cache or (cache[key] and not lib.msc_conv_cfg_ok(C.byref(d), int(cache[key]))):
             best, best_t = 0, 1e30
             for c in range(1, lib.msc_conv_num_cfgs() + 1):
                 if not lib.msc_conv_cfg_ok(C.byref(d), c):
@@ -708,12 +758,13 @@ class _Builder:
     def tune_wgrad(self, d):
         if not self.net.autotune or self.dev.type != 'cuda':
             return
-        key = repr(('w', self.dt, d.N, d.Hp, d.Wp, d.A, d.Hq, d.Wq, d.B, d.KH, d.KW, d.stride, d.pad, d.p_ld, d.q_ld))
+        key = repr(('w2', self.dt, d.N, d.Hp, d.Wp, d.A, d.Hq, d.Wq, d.B, d.KH, d.KW, d.stride, d.pad, d.p_ld, d.q_ld))
         cache = _TUNE_CACHE
-        if key not in cache:
-            big_ok = d.A % 128 == 0 and d.B % 128 == 0
+        big_ok = d.A % 128 == 0 and d.B % 128 == 0
+        ncfg = self.lib.msc_conv_wgrad_num_cfgs()
+        if key not in cache or not (0 <= int(cache[key]) <= ncfg):
             best, best_t = 0, 1e30
-            for c in range(1 if big_ok else 5, 9):
+            for c in range(1 if big_ok else 6, ncfg + 1):
                 d.cfg = c
                 t = self._time(self.lib.msc_conv_wgrad, C.byref(d))
                 if t is not None and t < best_t:
@@ -756,17 +807,20 @@ class _Builder:
                   scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr())
         self.emit(fwd, lib.msc_bn_apply, y.ptr, y.ld, res.ptr if res is not None else None, res.ld if res is not None else 0,
                   out.ptr, out.ld, scale.data_ptr(), shift.data_ptr(), int(relu), self.dt, count, cout)
-        self.ops.append(lambda: self._conv_bn_bwd(name, x, conv, bn, geo, relu, out, res, y, mean, invstd, count, stem))
+        self.ops.append(lambda: self._conv_bn_bwd(name, x, conv, bn, geo, relu, out, res, y, mean, invstd, count, stem, scale, shift))
 
-    def _conv_bn_bwd(self, name, x, conv, bn, geo, relu, out, res, y, mean, invstd, count, stem):
+    def _conv_bn_bwd(self, name, x, conv, bn, geo, relu, out, res, y, mean, invstd, count, stem, scale, shift):
         net, lib, P, bwd = self.net, self.lib, self.prog, self.prog.bwd
         cout = conv.out_channels
         dout = self.grad_of(out)
         blocks = lib.msc_bn_bwd_blocks(count, cout, self.dt)
         part = self.vec(blocks * cout * 2)
         coef = self.vec(3 * cout)
-        self.emit(bwd, lib.msc_bn_bwd_reduce, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, int(relu), part.data_ptr(),
-                  self.dt, count, cout)
+        # ReLU mask: without a residual the pre-activation is scale*y + shift, recomputed from the y both kernels read
+        # anyway (mode 2) instead of reading `out` (mode 1)
+        mask = 0 if not relu else (1 if res is not None else 2)
+        self.emit(bwd, lib.msc_bn_bwd_reduce, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, mask, scale.data_ptr(),
+                  shift.data_ptr(), part.data_ptr(), self.dt, count, cout)
         self.emit(bwd, lib.msc_bn_bwd_finalize, part.data_ptr(), blocks, cout, count, bn.weight.data_ptr(),
                   mean.data_ptr(), invstd.data_ptr(), self.g(bn.weight), self.g(bn.bias), coef.data_ptr())
         dres_ptr, dres_ld, dres_acc = None, 0, 0
@@ -775,11 +829,12 @@ class _Builder:
             dres_acc = self.grad_acc(res)
             dres_ptr, dres_ld = gres.ptr, gres.ld
         # dy overwrites y in place (each element is read, then written, by the same lane)
-        self.emit(bwd, lib.msc_bn_bwd_apply, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, int(relu), coef.data_ptr(),
-                  y.ptr, y.ld, dres_ptr, dres_ld, dres_acc, self.dt, count, cout)
+        self.emit(bwd, lib.msc_bn_bwd_apply, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, mask, scale.data_ptr(),
+                  shift.data_ptr(), coef.data_ptr(), y.ptr, y.ld, dres_ptr, dres_ld, dres_acc, self.dt, count, cout)
         dy = y
         if stem is not None:
             self.wgrad(bwd, dy, x, P.stem_dw.data_ptr(), 7, 1, 2, 0, q_hw=stem, q_ld=4, B=32)
+            self.flush_wgrads()
             self.emit(bwd, lib.msc_stem_unpack_grad, P.stem_dw.data_ptr(), self.g(conv.weight), 64)
             return                                    # the network input needs no gradient
         self.wgrad(bwd, dy, x, self.g(conv.weight), geo['KH'], geo['KW'], geo['stride'], geo['pad'])
@@ -932,6 +987,7 @@ class _Builder:
             self._conv_relu_bwd('dec0.conv', x, net.dec0.conv, d0, masked=True)
             for op in reversed(self.ops):
                 op()
+            self.flush_wgrads()
         P.keep += [xp]
         P.acts = {'c1': s1, 'd0': d0, 'cat2': cat2, 'cat3': cat3, 'cat4': cat4, 'cat5': cat5}
         if self._tuned_new:

@@ -23,5 +23,13 @@ pmc)   python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > g
          timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c" -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-breakdown > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log" 2>&1; echo "pmc $c rc=$?"
        done
        cd "$GRAFT_REPO_ROOT"; python tools/pmc_summary.py gpurun_out gpurun_out/pmc_traffic.json > gpurun_out/pmc_summary.txt 2>&1; head -12 gpurun_out/pmc_summary.txt;;
+ktests) timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_unet.py -m gpu -q -rf --tb=short -p no:cacheprovider > gpurun_out/pytest_k.log 2>&1; echo "pytest rc=$?"; tail -15 gpurun_out/pytest_k.log;;
+ab)    # A/B of environment switches on the train step: AB="NAME=VAL,NAME2=VAL2 NAME=VAL ..." (one run per word)
+       python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
+       for cfg in $AB; do
+         tag=$(echo "$cfg" | tr ',=' '__')
+         ( IFS=,; for kv in $cfg; do export "$kv"; done; timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline $ABFLAGS > "gpurun_out/ab_$tag.log" 2>&1 )
+         echo "$cfg: $(grep -o '"ms_per_step": [0-9.]*' "gpurun_out/ab_$tag.log" | head -1) $(grep -o '"wgrad": {[^}]*}' "gpurun_out/ab_$tag.log" | head -1)"
+       done;;
 esac
 done

@@ -244,7 +244,34 @@ def test_every_kernel_configuration_is_correct(dtype, cin, cout, k, stride, hw, 
     wv = w.clone().requires_grad_(True)
     F.conv2d(x, wv, stride=stride, padding=pad).backward(dy)
     gref = wv.grad.permute(0, 2, 3, 1)
-    for c in range(1 if (cin % 128 == 0 and cout % 128 == 0) else 5, 9):
+    from mapping_challenge_amd import _lib
+    for c in range(1 if (cin % 128 == 0 and cout % 128 == 0) else 6, _lib.load().msc_conv_wgrad_num_cfgs() + 1):
         dw = torch.zeros((cout, k, k, cin), dtype=torch.float32, device='cuda')
         ops.conv_wgrad(nhwc(dy, dtype), xd, dw, k, k, stride=stride, pad=pad, cfg=c)
         assert (dw.cpu() - gref).abs().max().item() / gref.abs().max().item() < (2e-5 if dtype == torch.float32 else 1e-2), c
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('steps,cap', [(64, 128), (4, 64), (1, 32), (0, 128)])
+def test_grouped_weight_gradients_equal_separate_ones(dtype, steps, cap):
+    """msc_wgrad_group_*: layers of different shapes (several tile buckets, 1x1 / 3x3 / strided, ragged pixel counts) in one
+    launch per bucket; each gradient equals torch's, also when the group is run twice into the same buffers (+=)"""
+    from mapping_challenge_amd import ops
+    shapes = [(128, 128, 3, 1, 20, 3), (64, 256, 1, 1, 16, 4), (32, 32, 3, 1, 24, 2), (64, 64, 3, 2, 18, 2), (256, 128, 1, 1, 9, 3),
+              (128, 256, 3, 1, 7, 1), (32, 96, 1, 2, 10, 2)]
+    problems, refs = [], []
+    for i, (cin, cout, k, stride, hw, n) in enumerate(shapes):
+        pad = k // 2
+        x = rnd((n, cin, hw, hw), dtype, 10 + i)
+        wv = rnd((cout, cin, k, k), dtype, 30 + i, 0.05).requires_grad_(True)
+        y = F.conv2d(x, wv, stride=stride, padding=pad)
+        dy = rnd(tuple(y.shape), dtype, 50 + i)
+        y.backward(dy)
+        refs.append(wv.grad.permute(0, 2, 3, 1))
+        dw = torch.zeros((cout, k, k, cin), dtype=torch.float32, device='cuda')
+        problems.append((nhwc(dy, dtype), nhwc(x, dtype), dw, k, k, stride, pad))
+    launches = ops.conv_wgrad_group(problems, steps, cap, runs=2)
+    assert 1 <= launches <= 5
+    for pr, gref in zip(problems, refs):
+        err = (pr[2].cpu() / 2 - gref).abs().max().item() / gref.abs().max().item()
+        assert err < (2e-5 if dtype == torch.float32 else 1e-2), (pr[2].shape, err)
