@@ -581,10 +581,13 @@ class _Builder:
         self.gbuf = {}                # id(buffer) -> grad buffer
         self.gwritten = set()         # (id(gbuf), c0, C) already written in this backward
         self.slices = {}              # id(buffer) -> set of (c0, C)
-        # Weight gradients are deferred and launched MSC_WGRAD_GROUP (default 24) at a time (msc_wgrad_group_*): one layer of the
-        # encoder cannot fill 256 CUs, a dozen can.  0/1 = one launch per layer (the CPU interpreter always does that).
+        # Weight gradients are deferred and launched MSC_WGRAD_GROUP at a time (msc_wgrad_group_*): one layer of the
+        # encoder cannot fill 256 CUs, a dozen can.  Default: all of them at the end of backward in a single process;
+        # 24 under torch.distributed, so that gradient buckets still complete while backward runs (trainer.ddp_plan).
+        # 0/1 = one launch per layer (the CPU interpreter always does that).
         env = _os_env.environ
-        self.group_max = int(env.get('MSC_WGRAD_GROUP', '24')) if (training and device.type == 'cuda') else 0
+        multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        self.group_max = int(env.get('MSC_WGRAD_GROUP', '24' if multi else '1000')) if (training and device.type == 'cuda') else 0
         self.group_steps = int(env.get('MSC_WGRAD_GROUP_STEPS', '64'))
         self.group_tile = int(env.get('MSC_WGRAD_GROUP_TILE', '128'))
         self.pending = []             # deferred (WgradDesc, gradient address or None)
