@@ -885,7 +885,7 @@ bool use_v1_wgrad() { static int v = -1; if (v < 0) v = env_flag("MSC_WGRAD_V1")
 // heuristic (cfg 0) the caller may pick one explicitly -- UNetResNet times the valid ones per layer when it builds
 // a program (msc_conv_cfg_ok enumerates them).
 struct ConvCfg { int tp, tc, wp, wc, kb, nst; };
-constexpr int N_CONV_CFG = 10;
+constexpr int N_CONV_CFG = 14;
 static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {0, 0, 0, 0, 0, 0},
     {256, 128, 4, 2, 128, 3},   //  1: 144 KB, 8 waves, 1 block/CU
@@ -898,6 +898,12 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {64, 64, 2, 2, 64, 4},      //  8:  32 KB
     {256, 32, 4, 1, 128, 3},    //  9: 108 KB
     {256, 32, 4, 1, 64, 4},     // 10:  72 KB
+    // 8-wave variants of the mid-size tiles for the 16x16 / 32x32 feature maps of layer3/layer2, where one block per
+    // CU is all the layer offers: twice the waves per block to hide the L2 -> LDS latency
+    {128, 64, 4, 2, 128, 4},    // 11:  96 KB, 8 waves
+    {128, 128, 4, 2, 128, 3},   // 12:  96 KB, 8 waves
+    {64, 128, 2, 2, 128, 4},    // 13:  96 KB
+    {64, 128, 2, 4, 128, 4},    // 14:  96 KB, 8 waves
 };
 
 template <typename T, int TP, int TC, int WP, int WC, int KB, int NST>
@@ -960,7 +966,11 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
         case 7: return launch_dma<T, 64, 64, 2, 2, 128, 4>(k, mode, st);
         case 8: return launch_dma<T, 64, 64, 2, 2, 64, 4>(k, mode, st);
         case 9: return launch_dma<T, 256, 32, 4, 1, 128, 3>(k, mode, st);
-        default: return launch_dma<T, 256, 32, 4, 1, 64, 4>(k, mode, st);
+        case 10: return launch_dma<T, 256, 32, 4, 1, 64, 4>(k, mode, st);
+        case 11: return launch_dma<T, 128, 64, 4, 2, 128, 4>(k, mode, st);
+        case 12: return launch_dma<T, 128, 128, 4, 2, 128, 3>(k, mode, st);
+        case 13: return launch_dma<T, 64, 128, 2, 2, 128, 4>(k, mode, st);
+        default: return launch_dma<T, 64, 128, 2, 4, 128, 4>(k, mode, st);
     }
 }
 

@@ -28,7 +28,7 @@ ab)    # A/B of environment switches on the train step: AB="NAME=VAL,NAME2=VAL2 
        python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
        for cfg in $AB; do
          tag=$(echo "$cfg" | tr ',=' '__')
-         ( IFS=,; for kv in $cfg; do export "$kv"; done; timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline $ABFLAGS > "gpurun_out/ab_$tag.log" 2>&1 )
+         ( IFS=,; for kv in $cfg; do export "$kv"; done; unset IFS; timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline $ABFLAGS > "gpurun_out/ab_$tag.log" 2>&1 )
          echo "$cfg: $(grep -o '"ms_per_step": [0-9.]*' "gpurun_out/ab_$tag.log" | head -1) $(grep -o '"wgrad": {[^}]*}' "gpurun_out/ab_$tag.log" | head -1)"
        done;;
 esac
