@@ -1,6 +1,6 @@
 """Benchmark of the U-Net hot path on MI355X (contract: see the task statement / DESIGN.md section 5).
 
-    python bench.py --gpus N --steps K --warmup W [--workload train|infer|post] [--encoder 101] [--dtype bf16]
+    python bench.py --gpus N --steps K --warmup W [--workload train|infer|post|annot] [--encoder 101] [--dtype bf16]
 
 One "step" = one pass of the hot path over one synthetic batch resident in HBM:
   train (default, BASELINE.json metric / configs[2]): ResNet101-U-Net forward + mixed weighted-CE/Dice loss + backward +
@@ -165,12 +165,27 @@ def cpu_baseline_post(probs, target, dilate, budget_s=15.0):
             'sample': 'oracle/post_ref.c (plain C, -O2, single thread) resize+threshold+label+dilate+score on %d masks' % k}
 
 
+def cpu_baseline_annot(layers, budget_s=15.0):
+    """the reference's loop (decompose -> encode -> toBbox per instance, src/utils.py:61-127) on the numpy restatement of
+    the pycocotools arithmetic, one thread, image by image until the budget is spent"""
+    from oracle import annot_ref
+    t0, k = time.time(), 0
+    while time.time() - t0 < budget_s and k < len(layers) // 2:
+        pair = layers[2 * k:2 * k + 2]
+        scores = [[1.0] * int(l.max()) for l in pair]
+        annot_ref.create_annotations([k], [(pair, scores)], [100, 100], [1, 1])
+        k += 1
+    dt = time.time() - t0
+    return {'value': k / dt, 'unit': 'img/s', 'cores': 1, 'kind': 'port',
+            'sample': 'oracle/annot_ref.py (numpy restatement of src/utils.py:61-127 + maskApi.c) on %d images of 2 layers' % k}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='train', choices=['train', 'infer', 'post'])
+    ap.add_argument('--workload', default='train', choices=['train', 'infer', 'post', 'annot'])
     ap.add_argument('--encoder', type=int, default=None)
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--size', type=int, default=256)
@@ -277,6 +292,29 @@ def main():
                 'whole_step_frac_of_mfma_peak': (conv['flops'] + wg['flops']) * (args.steps / dt) / peak}
         if world.rank == 0 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline_train(enc, hw) if args.workload == 'train' else cpu_baseline_infer(enc, hw)
+    elif args.workload == 'annot':
+        # labelled 300x300 layers (2 per image, on the device) -> COCO RLE strings + boxes on the host
+        from mapping_challenge_amd import postprocessing as post, utils
+        from oracle import post_ref
+        batch = args.batch or 64
+        probs_h = post_ref.synthetic_probs(batch, 256, 256, seed=1234 + world.rank)
+        res = post.postprocess_batch(torch.from_numpy(probs_h).to(dev), (300, 300), 0, 2)
+        layers_h = np.concatenate([labels for labels, _ in res]).astype(np.int32)
+        layers = torch.from_numpy(layers_h).to(dev)
+        enc = utils.encode_labels(layers)
+        n_inst = sum(len(e) for e in enc)
+        dt = timed(lambda: utils.encode_labels(layers))
+        value = batch * world.size * args.steps / dt
+        bytes_per_img = 2 * 300 * 300 * 4 * 4.0      # label read + transpose write/read + scan flags, per image (2 layers)
+        result.update(metric='annotation encoding images/sec (instances of 2 layers of 300x300 labels -> COCO RLE + bbox)', unit='img/s',
+                      value=value, ms_per_step=1e3 * dt / args.steps, dtype='i32/u8',
+                      config={'workload': 'RLE + bbox encoding of %d images x 2 label layers (300x300), %d instances per step' % (batch, n_inst),
+                              'ms_per_img': 1e3 / value * world.size},
+                      roofline={'bound': 'hbm', 'achieved': value * bytes_per_img / 1e9 / world.size, 'peak': PEAK_HBM / 1e9, 'unit': 'GB/s',
+                                'frac': value * bytes_per_img / world.size / PEAK_HBM, 'traffic': None,
+                                'note': 'two synchronous calls (sizes return to the host) + D2H of table and strings; latency bound'})
+        if world.rank == 0 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline_annot(layers_h)
     else:
         from mapping_challenge_amd import postprocessing as post
         from oracle import post_ref

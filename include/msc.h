@@ -229,6 +229,22 @@ int msc_tta_transform(const float* x, float* out, const int32_t* specs, int N, i
 int msc_tta_aggregate(const float* preds, float* out, const int32_t* specs, int N, int C, int H, int W, int V, int method,
                       int any_quarter_turn, void* stream);
 
+/* ---------------------------------------------------------------- annotation encoding ------------
+ * src/utils.py:61-127 (decompose -> rle_from_binary -> bounding_box_from_rle, i.e. pycocotools 2.0.0 maskApi.c
+ * rleEncode / rleToString / rleToBbox) for every instance of every layer in two calls, both synchronous on `stream`
+ * (they return counts the caller sizes the next buffer with):
+ *   msc_rle_segments: labels i32 [layers,H,W] (0 = background, instance ids < 2^24) -> column-major runs of equal
+ *     label, kept in `ws` (msc_rle_segments_workspace bytes); *nseg = number of runs.
+ *   msc_rle_encode: runs -> instances sorted by (layer, label).  *table -> i32 [n_inst][8] = layer, label, string
+ *     begin, string end (byte offsets into *chars), xs, ys, xe, ye (inclusive box; COCO bbox = [xs, ys, xe-xs+1,
+ *     ye-ys+1]); *chars -> the concatenated COCO count strings.  Both point into `ws` (device memory,
+ *     msc_rle_encode_workspace(nseg) bytes).  Instance ids with no pixel do not appear. */
+int64_t msc_rle_segments_workspace(int layers, int H, int W);
+int msc_rle_segments(const int32_t* labels, int layers, int H, int W, void* ws, int64_t ws_bytes, int32_t* nseg, void* stream);
+int64_t msc_rle_encode_workspace(int nseg);
+int msc_rle_encode(const void* seg_ws, int layers, int H, int W, int nseg, void* ws, int64_t ws_bytes, int32_t* n_inst,
+                   int64_t* n_chars, const int32_t** table, const char** chars, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

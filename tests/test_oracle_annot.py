@@ -1,0 +1,93 @@
+"""CPU: the annotation-encoding oracle (oracle/annot_ref.py) against (a) the known-answer examples of the published
+algorithm (maskApi.h documents `M=[0 0 1 1 1 0 1] -> [2 3 1 1]` and `M=[1 1 1 1 1 1 0] -> [0 6 1]`), (b) the
+reference's own src/utils.py run through the pycocotools shim, (c) the golden fixture that code generated,
+(d) round trips.  pycocotools itself is not installed: parity with the real library is unpinned (annot_ref header)."""
+import json
+import logging
+import os
+
+import numpy as np
+import pytest
+
+from oracle import annot_ref, ref_import
+
+needs_ref = pytest.mark.skipif(not ref_import.available(), reason='/root/reference not present')
+
+
+def golden_predictions():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_golden_annot', os.path.join(os.path.dirname(__file__), 'golden', 'make_golden_annot.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.synthetic_predictions()
+
+
+def test_known_answers_of_the_published_algorithm():
+    # column vectors: h = 7, w = 1, so column-major order is the listed order
+    assert annot_ref.rle_encode(np.array([0, 0, 1, 1, 1, 0, 1], np.uint8)[:, None]) == [2, 3, 1, 1]
+    assert annot_ref.rle_encode(np.array([1, 1, 1, 1, 1, 1, 0], np.uint8)[:, None]) == [0, 6, 1]
+    # column-major: a 2x2 mask [[0,1],[1,1]] reads 0,1,1,1
+    assert annot_ref.rle_encode(np.array([[0, 1], [1, 1]], np.uint8)) == [1, 3]
+    # string coding by hand: 67 = 0b10_00011 -> chars (3|0x20)+48='S', 2+48='2'; deltas from the 4th count on
+    assert annot_ref.rle_to_string([67, 5, 7, 5, 7, 5, 7, 5]) == b'S25700000'
+    # a negative delta: 3 - 5 = -2 -> 0b11110 (sign bit 0x10 set, x becomes -1 -> stop) -> 30+48 = 'N'
+    assert annot_ref.rle_to_string([1, 5, 1, 3]) == b'151N'
+    assert annot_ref.rle_from_string(b'151N') == [1, 5, 1, 3]
+
+
+def test_round_trips_and_bbox_on_random_masks():
+    rng = np.random.default_rng(5)
+    for h, w in ((1, 1), (1, 9), (9, 1), (7, 5), (40, 33)):
+        for dens in (0.0, 0.1, 0.5, 0.95, 1.0):
+            m = (rng.random((h, w)) < dens).astype(np.uint8)
+            c = annot_ref.rle_encode(m)
+            assert c == annot_ref.rle_encode_fast(m) and sum(c) == h * w
+            s = annot_ref.rle_to_string(c)
+            assert all(48 <= ch < 112 for ch in s)
+            assert annot_ref.rle_from_string(s) == c
+            assert (annot_ref.rle_decode(c, h, w) == m).all()
+            bb = annot_ref.rle_to_bbox(c, h, w)
+            if m.any():
+                ys, xs = np.nonzero(m)
+                assert bb == [xs.min(), ys.min(), xs.max() - xs.min() + 1, ys.max() - ys.min() + 1]
+            else:
+                assert bb == [0, 0, 0, 0]
+    # 0/255 masks (what decompose produces) encode like 0/1 masks
+    m = (rng.random((12, 12)) < 0.4).astype(np.uint8)
+    assert annot_ref.rle_encode(m * 255) == annot_ref.rle_encode(m)
+
+
+def test_create_annotations_matches_golden(golden_dir):
+    gold = json.load(open(os.path.join(golden_dir, 'annot.json')))
+    preds = golden_predictions()
+    ann = annot_ref.create_annotations(range(100, 100 + len(preds)), preds, [None, 100], [1, 1])
+    assert len(ann) == len(gold) == 39
+    for a, g in zip(ann, gold):
+        assert a['image_id'] == g['image_id'] and a['category_id'] == g['category_id'] and a['segmentation'] == g['segmentation']
+        assert [float(v) for v in a['bbox']] == g['bbox'] and float(a['score']) == g['score']
+    # every string decodes back to the instance it came from
+    k = 0
+    for (labels, scores) in preds:
+        for i, _ in zip(range(1, int(labels[1].max()) + 1), scores[1]):
+            seg = gold[k]['segmentation']
+            assert (annot_ref.rle_decode(annot_ref.rle_from_string(seg['counts']), *seg['size']) == (labels[1] == i)).all()
+            k += 1
+    assert k == len(gold)
+
+
+@needs_ref
+def test_restatement_equals_reference_utils():
+    import pandas as pd
+    utils = ref_import.ref('utils')
+    preds = golden_predictions()
+    lab = preds[3][0][1]
+    ref_masks, my_masks = utils.decompose(lab), annot_ref.decompose(lab)
+    assert len(ref_masks) == len(my_masks) == 5 and all((a == b).all() for a, b in zip(ref_masks, my_masks))
+    assert len(utils.decompose(np.zeros((4, 4), np.int32))) == 1
+    for m in my_masks:
+        r = utils.rle_from_binary(m.astype('uint8'))
+        assert r == annot_ref.rle_from_binary(m.astype('uint8'))
+        assert list(utils.bounding_box_from_rle(r)) == annot_ref.bounding_box_from_rle(r)
+    meta = pd.DataFrame({'ImageId': list(range(100, 100 + len(preds)))})
+    ref_ann = utils.create_annotations(meta, preds, logging.getLogger('t'), [None, 100], [1, 1])
+    assert ref_ann == annot_ref.create_annotations(meta['ImageId'].values, preds, [None, 100], [1, 1])
