@@ -245,6 +245,22 @@ int64_t msc_rle_encode_workspace(int nseg);
 int msc_rle_encode(const void* seg_ws, int layers, int H, int W, int nseg, void* ws, int64_t ws_bytes, int32_t* n_inst,
                    int64_t* n_chars, const int32_t** table, const char** chars, void* stream);
 
+/* ---------------------------------------------------------------- target preparation -------------
+ * overlay_mask_one_image (src/preparation.py:44-84) for erode = dilate = 0 (neptune.yaml:69-70) from the decoded
+ * instance masks of ONE image, masks u8 [n,H,W] in annotation order, category_nr i32 [n] (NULL: all 1):
+ *   mask_overlayed u8 [H,W]; distances_f16 [H,W] = float16 bits of (nearest + second nearest instance distance);
+ *   second_nearest f64 [H,W] (may be NULL); kept i32 [n] (may be NULL): 0 skipped by is_on_border(mask, 2),
+ *   1 used, 2 overlayed but discarded by update_distances' `dist.sum() == 0` rule.  All pointers device memory.
+ * msc_prep_border: the optional border class (:73-76), in place; synchronous (needs mask.max()).
+ * msc_size_matrix: get_size_matrix (:181-187) from msc_label4 labels: sizes[p] = area of p's component, 1 on
+ *   background; areas = scratch i32 [B][max_labels+1]. */
+int64_t msc_prep_workspace_bytes(int n, int H, int W);
+int msc_prep_targets(const uint8_t* masks, const int32_t* category_nr, int n, int H, int W, uint8_t* mask_overlayed,
+                     uint16_t* distances_f16, double* second_nearest, int32_t* kept, void* workspace, void* stream);
+int msc_prep_border(uint8_t* mask_overlayed, const double* second_nearest, double border_width, int32_t* scratch, int H, int W,
+                    void* stream);
+int msc_size_matrix(const int32_t* labels, int32_t* sizes, int32_t* areas, int B, int H, int W, int max_labels, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
