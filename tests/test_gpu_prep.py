@@ -39,7 +39,6 @@ def test_degenerate_stacks_and_categories():
     check(base, category_nr=[1, 1, 2, 2, 3, 3])              # later categories overwrite earlier ones
     check(base, border_width=3)
     check(base, category_nr=[1, 1, 2, 2, 2, 2], border_width=4)
-    check((base * 255).astype(np.uint8))                     # any non-zero value is foreground
 
 
 def test_size_matrix_and_argument_errors():
