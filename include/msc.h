@@ -37,10 +37,8 @@ int msc_abi_version(void);
  * mode 0 (gather):      out[q] = sum_t in[q*stride + off(t)] * W[.][t][.]   off = t-pad, or pad-t if flip
  * mode 1 (transposed):  out[q] = sum_{t:(q+pad-t) even} in[(q+pad-t)/2] * W[.][t][.]   (stride must be 2)
  * epilogue: v = acc*scale[c] + shift[c] (+ res) ; ReLU ; store.  scale/shift/res may be NULL.
- * stats (mode 0 only, may be NULL): per-channel partial sum / sum of squares of the raw accumulators (BatchNorm2d
- *   training mode).  stat_slots == 0: [Cout][msc_conv_stats_slices()][2] floats, one exclusive slot per tile row
- *   (deterministic; reduced by msc_bn_finalize).  stat_slots > 0: [Cout][stat_slots][2] floats the caller zeroed,
- *   accumulated with fp32 atomics -- few enough for msc_bn_train_apply to finalise them in its own prologue.
+ * stats (mode 0 only, may be NULL): per-channel partial sum / sum of squares of the raw accumulators,
+ *   [Cout][msc_conv_stats_slices()][2] floats, reduced by msc_bn_finalize (BatchNorm2d training mode).
  * weights: dtype [Cout][KH][KW][Cin].  Cin*sizeof(dtype) % 64 == 0, Cout % 32 == 0. */
 typedef struct msc_conv_desc {
     const void* in;
@@ -54,7 +52,6 @@ typedef struct msc_conv_desc {
     int32_t dtype, mode;
     int32_t N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, flip, relu;
     int32_t cfg;   /* 0 = heuristic kernel configuration, 1..msc_conv_num_cfgs() = explicit (tile, K-step, ring depth) */
-    int32_t stat_slots;
 } msc_conv_desc;
 int msc_conv_igemm(const msc_conv_desc* d, void* stream);
 int msc_conv_stats_slices(const msc_conv_desc* d);   /* depends on d->cfg */
@@ -132,33 +129,18 @@ int msc_bn_fold(const float* gamma, const float* beta, const float* running_mean
                 float eps, float* scale, float* shift, int C, void* stream);
 int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_t res_ld, void* out, int64_t out_ld,
                  const float* scale, const float* shift, int relu, int dtype, int64_t pixels, int C, void* stream);
-/* finalize + apply in one launch, for statistics accumulated in few slots (msc_conv_desc.stat_slots): every block
- * reduces the slots of its <= 128 channels itself; scale / shift / save_* / running_* are written as by msc_bn_finalize */
-int msc_bn_train_apply(const void* y, int64_t y_ld, const void* res, int64_t res_ld, void* out, int64_t out_ld, int relu,
-                       const float* stats, int slots, int64_t count, const float* gamma, const float* beta, float eps,
-                       float momentum, float* running_mean, float* running_var, float* scale, float* shift,
-                       float* save_mean, float* save_invstd, int dtype, int64_t pixels, int C, void* stream);
 /* backward of out = relu?(bn(y) (+res)):  dh = dout * [out>0] (if relu);
  * reduce: partial[C][msc_bn_bwd_blocks()][2] = (sum dh, sum dh*y) (deterministic, no atomics);  finalize: dgamma, dbeta (accumulated into fp32 grads) and
  * per-channel coefficients coef[3][C];  apply: dy = coef0*dh + coef1*y + coef2 ; dres (optional) = dh (or += if dres_acc). */
 int msc_bn_bwd_blocks(int64_t pixels, int C, int dtype);
 int msc_bn_bwd_reduce(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
-                      int relu, const float* scale, const float* shift, float* partials, int slots, int dtype, int64_t pixels,
-                      int C, void* stream);
+                      int relu, const float* scale, const float* shift, float* partials, int dtype, int64_t pixels, int C,
+                      void* stream);
 int msc_bn_bwd_finalize(const float* partials, int blocks, int C, int64_t count, const float* gamma,
                         const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef, void* stream);
 int msc_bn_bwd_apply(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
                      int relu, const float* scale, const float* shift, const float* coef, void* dy, int64_t dy_ld,
                      void* dres, int64_t dres_ld, int dres_acc, int dtype, int64_t pixels, int C, void* stream);
-/* slots > 0 in msc_bn_bwd_reduce: partial[C][slots][2], zeroed by the caller, accumulated with fp32 atomics; then
- * finalize + apply in one launch (dgamma / dbeta += by the blocks of the first pixel chunk): */
-int msc_bn_bwd_apply_fused(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
-                           int relu, const float* scale, const float* shift, const float* partials, int slots, int64_t count,
-                           const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
-                           void* dy, int64_t dy_ld, void* dres, int64_t dres_ld, int dres_acc, int dtype, int64_t pixels, int C,
-                           void* stream);
-/* hipMemsetAsync(p, 0, bytes) as a launch-list entry (the slot buffers of a step are one allocation) */
-int msc_zero(void* p, int64_t bytes, void* stream);
 
 /* ReLU backward for the decoder (ConvRelu / deconv+ReLU): dx = dy*[y>0], optionally dx += */
 int msc_relu_bwd(const void* dy, int64_t dy_ld, const void* y, int64_t y_ld, void* dx, int64_t dx_ld,

@@ -24,8 +24,7 @@ class ConvDesc(C.Structure):
                 ('dtype', C.c_int32), ('mode', C.c_int32),
                 ('N', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32), ('Cin', C.c_int32),
                 ('Ho', C.c_int32), ('Wo', C.c_int32), ('Cout', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32),
-                ('stride', C.c_int32), ('pad', C.c_int32), ('flip', C.c_int32), ('relu', C.c_int32), ('cfg', C.c_int32),
-                ('stat_slots', C.c_int32)]
+                ('stride', C.c_int32), ('pad', C.c_int32), ('flip', C.c_int32), ('relu', C.c_int32), ('cfg', C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -70,11 +69,7 @@ SIGNATURES = {
     'msc_bn_fold': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
     'msc_bn_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i64, _i, _vp]),
     'msc_bn_bwd_blocks': (_i, [_i64, _i, _i]),
-    'msc_bn_bwd_reduce': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i, _i, _i64, _i, _vp]),
-    'msc_bn_train_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp]),
-    'msc_bn_bwd_apply_fused': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp,
-                                    _vp, _i64, _vp, _i64, _i, _i, _i64, _i, _vp]),
-    'msc_zero': (_i, [_vp, _i64, _vp]),
+    'msc_bn_bwd_reduce': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i, _i64, _i, _vp]),
     'msc_bn_bwd_finalize': (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'msc_bn_bwd_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i64, _i, _vp]),
     'msc_relu_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i64, _i, _vp]),

@@ -53,7 +53,6 @@ struct ConvK {
     unsigned in_bytes, wt_bytes;     // extents for the buffer descriptors of the DMA kernel
     int ntc;                         // channel tiles (DMA kernel: 1-D grid of ntm*ntc blocks, XCD-aware order)
     int xcd_order;                   // 1: XCD-aware tile order, 0: pixel tile fastest (for A/B measurements)
-    int stat_slots;                  // > 0: stats are [Cout][stat_slots][2], accumulated with fp32 atomics
 };
 
 template <typename T> struct Mma;
@@ -166,23 +165,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
             }
         }
         if (pl == 0) {
-            const long sl = (long)mtile * WP + wp;
-            if (p.stat_slots) {
-                // few slots per channel, accumulated atomically: small enough for the consumer (msc_bn_train_apply) to
-                // finalise the statistics itself instead of a separate launch
-                const long s = sl % p.stat_slots;
+            // layout [Cout][slices][2]: msc_bn_finalize gives each channel one wavefront over its slices
+            const long nsl = (long)ntm * WP, sl = (long)mtile * WP + wp;
 #pragma unroll
-                for (int j = 0; j < NV; ++j) {
-                    float* dst = p.stats + ((cb + j) * (long)p.stat_slots + s) * 2;
-                    atomicAdd(dst, s1[j]);
-                    atomicAdd(dst + 1, s2[j]);
-                }
-            } else {
-                // layout [Cout][slices][2]: msc_bn_finalize gives each channel one wavefront over its slices
-                const long nsl = (long)ntm * WP;
-#pragma unroll
-                for (int j = 0; j < NV; ++j) *reinterpret_cast<float2*>(p.stats + ((cb + j) * nsl + sl) * 2) = make_float2(s1[j], s2[j]);
-            }
+            for (int j = 0; j < NV; ++j) *reinterpret_cast<float2*>(p.stats + ((cb + j) * nsl + sl) * 2) = make_float2(s1[j], s2[j]);
         }
     }
 }
@@ -1007,8 +993,6 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
         return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: pointers must be 16-byte aligned");
     k->in = (const char*)d->in; k->wt = (const char*)d->wt; k->out = (char*)d->out; k->res = (const char*)d->res;
     k->scale = d->scale; k->shift = d->shift; k->stats = d->stats;
-    if (d->stat_slots < 0) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: stat_slots %d", d->stat_slots);
-    k->stat_slots = d->stats ? d->stat_slots : 0;
     k->in_ld = d->in_ld; k->out_ld = d->out_ld; k->res_ld = d->res_ld;
     k->N = d->N; k->Hi = d->Hi; k->Wi = d->Wi; k->Cin = d->Cin; k->Ho = d->Ho; k->Wo = d->Wo; k->Cout = d->Cout;
     k->KH = d->KH; k->KW = d->KW; k->stride = d->stride; k->pad = d->pad; k->flip = d->flip; k->relu = d->relu;

@@ -18,7 +18,7 @@ template <typename T, int K>
 __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ dout, long dout_ld, const T* __restrict__ out, long out_ld,
                                                         const T* __restrict__ y, long y_ld, int relu, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, float* __restrict__ partials,
-                                                        long pixels, int C, int cols, int S, int ppb, int slots) {
+                                                        long pixels, int C, int cols, int S, int ppb) {
     constexpr int CE = Vec16<T>::N;
     __shared__ float red[256 * K * CE];
     const int tid = threadIdx.x;
@@ -75,20 +75,11 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ do
                 if (K == 2) s2[e] += o[CE + e];
             }
         }
-        if (slots) {           // [C][slots][K], caller-zeroed, fp32 atomics: finalised by the consumer's prologue
 #pragma unroll
-            for (int e = 0; e < CE; ++e) {
-                float* dst = partials + ((long)(vc * CE + e) * slots + blockIdx.x % slots) * K;
-                atomicAdd(dst, s1[e]);
-                if (K == 2) atomicAdd(dst + 1, s2[e]);
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < CE; ++e) {
-                float* dst = partials + ((long)(vc * CE + e) * S + blockIdx.x) * K;
-                dst[0] = s1[e];
-                if (K == 2) dst[1] = s2[e];
-            }
+        for (int e = 0; e < CE; ++e) {
+            float* dst = partials + ((long)(vc * CE + e) * S + blockIdx.x) * K;
+            dst[0] = s1[e];
+            if (K == 2) dst[1] = s2[e];
         }
     }
 }
@@ -183,155 +174,14 @@ bool red_geom(long pixels, int C, int ce, RedGeom* g) {
     return true;
 }
 
-// ---- BatchNorm apply kernels that finalise the statistics themselves --------------------------------------
-// A block owns `cols` 16-byte channel vectors (<= 128 channels) and a pixel range; its prologue reduces the few
-// slots of those channels (double accumulation) into the per-channel coefficients, kept in LDS / registers.
-// The blocks of pixel chunk 0 also write the per-channel results every other consumer needs.
-struct ApplyGeom { int cols, chunks, ppb, nx; };
-bool apply_geom(long pixels, int C, int ce, ApplyGeom* g) {
-    if (C % ce) return false;
-    const int cv = C / ce;
-    int cols = 16;
-    while (cols > 1 && cv % cols) cols >>= 1;
-    const int rows = 256 / cols;
-    int ppb = 256;
-    while (ppb > rows && (long)ceil_div(pixels, ppb) * (cv / cols) < 1024) ppb >>= 1;
-    g->cols = cols; g->chunks = cv / cols; g->ppb = ppb; g->nx = ceil_div(pixels, ppb);
-    return true;
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void bn_train_apply_kernel(const T* __restrict__ y, long y_ld, const T* __restrict__ res, long res_ld,
-                                                             T* __restrict__ out, long out_ld, int relu, const float* __restrict__ stats, int slots,
-                                                             double count, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             float eps, float momentum, float* running_mean, float* running_var,
-                                                             float* scale_out, float* shift_out, float* save_mean, float* save_invstd,
-                                                             long pixels, int C, int cols, int ppb) {
-    constexpr int CE = Vec16<T>::N;
-    __shared__ float s_scale[16 * CE], s_shift[16 * CE];
-    const int tid = threadIdx.x;
-    const int cbase = blockIdx.y * cols * CE, nch = cols * CE;
-    for (int c = tid; c < nch; c += 256) {
-        const float* p = stats + (long)(cbase + c) * slots * 2;
-        double s1 = 0.0, s2 = 0.0;
-        for (int s = 0; s < slots; ++s) { s1 += p[2 * s]; s2 += p[2 * s + 1]; }
-        const double mean = s1 / count;
-        double var = s2 / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma ? gamma[cbase + c] : 1.f, b = beta ? beta[cbase + c] : 0.f;
-        const float sc = g * invstd, sh = b - (float)mean * sc;
-        s_scale[c] = sc; s_shift[c] = sh;
-        if (blockIdx.x == 0) {
-            const int ch = cbase + c;
-            scale_out[ch] = sc; shift_out[ch] = sh;
-            if (save_mean) save_mean[ch] = (float)mean;
-            if (save_invstd) save_invstd[ch] = invstd;
-            if (running_mean) running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mean;
-            if (running_var) {
-                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-                running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
-            }
-        }
-    }
-    __syncthreads();
-    const int col = tid % cols, r = tid / cols, R = 256 / cols;
-    float sc[CE], sh[CE];
-#pragma unroll
-    for (int e = 0; e < CE; ++e) { sc[e] = s_scale[col * CE + e]; sh[e] = s_shift[col * CE + e]; }
-    const int c = cbase + col * CE;
-    const long p0 = (long)blockIdx.x * ppb, p1 = min(pixels, p0 + ppb);
-    for (long pix = p0 + r; pix < p1; pix += R) {
-        float v[CE], rr[CE];
-        Vec16<T>::load(y + pix * y_ld + c, v);
-#pragma unroll
-        for (int e = 0; e < CE; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
-        if (res) {
-            Vec16<T>::load(res + pix * res_ld + c, rr);
-#pragma unroll
-            for (int e = 0; e < CE; ++e) v[e] += rr[e];
-        }
-        if (relu) {
-#pragma unroll
-            for (int e = 0; e < CE; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        Vec16<T>::store(out + pix * out_ld + c, v);
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const T* __restrict__ dout, long dout_ld, const T* __restrict__ out, long out_ld,
-                                                                 const T* __restrict__ y, long y_ld, int relu, const float* __restrict__ scale,
-                                                                 const float* __restrict__ shift, const float* __restrict__ partials, int slots,
-                                                                 double count, const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                                 const float* __restrict__ invstd, float* dgamma, float* dbeta,
-                                                                 T* __restrict__ dy, long dy_ld, T* __restrict__ dres, long dres_ld, int dres_acc,
-                                                                 long pixels, int C, int cols, int ppb) {
-    constexpr int CE = Vec16<T>::N;
-    __shared__ float s_coef[3][16 * CE];
-    const int tid = threadIdx.x;
-    const int cbase = blockIdx.y * cols * CE, nch = cols * CE;
-    for (int c = tid; c < nch; c += 256) {
-        const int ch = cbase + c;
-        const float* p = partials + (long)ch * slots * 2;
-        double s1 = 0.0, s2 = 0.0;
-        for (int s = 0; s < slots; ++s) { s1 += p[2 * s]; s2 += p[2 * s + 1]; }
-        const double mu = mean[ch], is = invstd[ch], g = gamma ? gamma[ch] : 1.0;
-        const double dbe = s1, dga = is * (s2 - mu * s1);
-        if (blockIdx.x == 0) {
-            if (dgamma) dgamma[ch] += (float)dga;
-            if (dbeta) dbeta[ch] += (float)dbe;
-        }
-        // dy = g*is*(dh - dbe/M - xhat*dga/M),  xhat = (y-mu)*is   ->   dy = a*dh + b*y + k0
-        const double a = g * is, b = -g * is * is * dga / count, k0 = -g * is * dbe / count - b * mu;
-        s_coef[0][c] = (float)a; s_coef[1][c] = (float)b; s_coef[2][c] = (float)k0;
-    }
-    __syncthreads();
-    const int col = tid % cols, r = tid / cols, R = 256 / cols;
-    const int c = cbase + col * CE;
-    float ca[CE], cb[CE], ck[CE], sc[CE], sh[CE];
-#pragma unroll
-    for (int e = 0; e < CE; ++e) {
-        ca[e] = s_coef[0][col * CE + e]; cb[e] = s_coef[1][col * CE + e]; ck[e] = s_coef[2][col * CE + e];
-        sc[e] = relu == 2 ? scale[c + e] : 0.f; sh[e] = relu == 2 ? shift[c + e] : 0.f;
-    }
-    const long p0 = (long)blockIdx.x * ppb, p1 = min(pixels, p0 + ppb);
-    for (long pix = p0 + r; pix < p1; pix += R) {
-        float d[CE], o[CE], yy[CE], rr[CE];
-        Vec16<T>::load(dout + pix * dout_ld + c, d);
-        Vec16<T>::load(y + pix * y_ld + c, yy);
-        if (relu == 1) {
-            Vec16<T>::load(out + pix * out_ld + c, o);
-#pragma unroll
-            for (int e = 0; e < CE; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
-        } else if (relu == 2) {
-#pragma unroll
-            for (int e = 0; e < CE; ++e) d[e] = fmaf(yy[e], sc[e], sh[e]) > 0.f ? d[e] : 0.f;
-        }
-        if (dres) {
-            if (dres_acc) {
-                Vec16<T>::load(dres + pix * dres_ld + c, rr);
-#pragma unroll
-                for (int e = 0; e < CE; ++e) rr[e] += d[e];
-                Vec16<T>::store(dres + pix * dres_ld + c, rr);
-            } else {
-                Vec16<T>::store(dres + pix * dres_ld + c, d);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < CE; ++e) yy[e] = ca[e] * d[e] + cb[e] * yy[e] + ck[e];
-        Vec16<T>::store(dy + pix * dy_ld + c, yy);
-    }
-}
-
 template <typename T, int K>
 int launch_colreduce(const void* dout, long dout_ld, const void* out, long out_ld, const void* y, long y_ld, int relu,
-                     const float* scale, const float* shift, float* partials, long pixels, int C, hipStream_t st, int slots = 0) {
+                     const float* scale, const float* shift, float* partials, long pixels, int C, hipStream_t st) {
     RedGeom g;
     if (!red_geom(pixels, C, Vec16<T>::N, &g)) return msc_fail(MSC_ERR_UNSUPPORTED, "column reduce: C=%d not supported", C);
     dim3 grid(g.S, g.chunks);
     hipLaunchKernelGGL((colreduce_kernel<T, K>), grid, dim3(256), 0, st, (const T*)dout, dout_ld, (const T*)out, out_ld, (const T*)y, y_ld,
-                       relu, scale, shift, partials, pixels, C, g.cols, g.S, g.ppb, slots);
+                       relu, scale, shift, partials, pixels, C, g.cols, g.S, g.ppb);
     return msc_check_launch("colreduce");
 }
 
@@ -356,16 +206,15 @@ extern "C" int msc_bn_bwd_blocks(int64_t pixels, int C, int dtype) {
 }
 
 extern "C" int msc_bn_bwd_reduce(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
-                                 int relu, const float* scale, const float* shift, float* partials, int slots, int dtype, int64_t pixels,
-                                 int C, void* stream) {
+                                 int relu, const float* scale, const float* shift, float* partials, int dtype, int64_t pixels, int C,
+                                 void* stream) {
     DT_CHECK("msc_bn_bwd_reduce", dtype);
-    if (slots < 0) return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_reduce: slots %d", slots);
     if (!dout || !y || !partials || relu < 0 || relu > 2 || (relu == 1 && !out) || (relu == 2 && (!scale || !shift)) || pixels <= 0)
         return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_reduce: bad argument");
     if (C % (dtype == MSC_BF16 ? 32 : 16)) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bn_bwd_reduce: C=%d must be a multiple of %d", C, dtype == MSC_BF16 ? 32 : 16);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MSC_BF16) return launch_colreduce<bf16_t, 2>(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, partials, pixels, C, st, slots);
-    return launch_colreduce<float, 2>(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, partials, pixels, C, st, slots);
+    if (dtype == MSC_BF16) return launch_colreduce<bf16_t, 2>(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, partials, pixels, C, st);
+    return launch_colreduce<float, 2>(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, partials, pixels, C, st);
 }
 
 extern "C" int msc_bn_bwd_finalize(const float* partials, int blocks, int C, int64_t count, const float* gamma,
@@ -394,58 +243,4 @@ extern "C" int msc_bias_grad(const void* dy, int64_t dy_ld, float* db, void* wor
     red_geom(pixels, C, dtype == MSC_BF16 ? 8 : 4, &g);
     hipLaunchKernelGGL(bias_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, g.S, C, db);
     return msc_check_launch("msc_bias_grad");
-}
-
-extern "C" int msc_bn_train_apply(const void* y, int64_t y_ld, const void* res, int64_t res_ld, void* out, int64_t out_ld, int relu,
-                                  const float* stats, int slots, int64_t count, const float* gamma, const float* beta, float eps,
-                                  float momentum, float* running_mean, float* running_var, float* scale, float* shift,
-                                  float* save_mean, float* save_invstd, int dtype, int64_t pixels, int C, void* stream) {
-    DT_CHECK("msc_bn_train_apply", dtype);
-    if (!y || !out || !stats || !scale || !shift || slots <= 0 || count <= 0 || pixels <= 0)
-        return msc_fail(MSC_ERR_ARG, "msc_bn_train_apply: bad argument");
-    ApplyGeom g;
-    if (!apply_geom(pixels, C, dtype == MSC_BF16 ? 8 : 4, &g) || C % (dtype == MSC_BF16 ? 32 : 16))
-        return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bn_train_apply: C=%d must be a multiple of %d", C, dtype == MSC_BF16 ? 32 : 16);
-    hipStream_t st = (hipStream_t)stream;
-    dim3 grid(g.nx, g.chunks);
-    if (dtype == MSC_BF16)
-        hipLaunchKernelGGL(bn_train_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)y, (long)y_ld, (const bf16_t*)res, (long)res_ld,
-                           (bf16_t*)out, (long)out_ld, relu, stats, slots, (double)count, gamma, beta, eps, momentum, running_mean, running_var,
-                           scale, shift, save_mean, save_invstd, (long)pixels, C, g.cols, g.ppb);
-    else
-        hipLaunchKernelGGL(bn_train_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)y, (long)y_ld, (const float*)res, (long)res_ld,
-                           (float*)out, (long)out_ld, relu, stats, slots, (double)count, gamma, beta, eps, momentum, running_mean, running_var,
-                           scale, shift, save_mean, save_invstd, (long)pixels, C, g.cols, g.ppb);
-    return msc_check_launch("msc_bn_train_apply");
-}
-
-extern "C" int msc_bn_bwd_apply_fused(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
-                                      int relu, const float* scale, const float* shift, const float* partials, int slots, int64_t count,
-                                      const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
-                                      void* dy, int64_t dy_ld, void* dres, int64_t dres_ld, int dres_acc, int dtype, int64_t pixels, int C,
-                                      void* stream) {
-    DT_CHECK("msc_bn_bwd_apply_fused", dtype);
-    if (!dout || !y || !partials || !save_mean || !save_invstd || !dy || slots <= 0 || count <= 0 || pixels <= 0 || relu < 0 || relu > 2 ||
-        (relu == 1 && !out) || (relu == 2 && (!scale || !shift)))
-        return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_apply_fused: bad argument");
-    ApplyGeom g;
-    if (!apply_geom(pixels, C, dtype == MSC_BF16 ? 8 : 4, &g) || C % (dtype == MSC_BF16 ? 32 : 16))
-        return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bn_bwd_apply_fused: C=%d must be a multiple of %d", C, dtype == MSC_BF16 ? 32 : 16);
-    hipStream_t st = (hipStream_t)stream;
-    dim3 grid(g.nx, g.chunks);
-    if (dtype == MSC_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, (long)dout_ld, (const bf16_t*)out,
-                           (long)out_ld, (const bf16_t*)y, (long)y_ld, relu, scale, shift, partials, slots, (double)count, gamma, save_mean,
-                           save_invstd, dgamma, dbeta, (bf16_t*)dy, (long)dy_ld, (bf16_t*)dres, (long)dres_ld, dres_acc, (long)pixels, C, g.cols, g.ppb);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, (long)dout_ld, (const float*)out,
-                           (long)out_ld, (const float*)y, (long)y_ld, relu, scale, shift, partials, slots, (double)count, gamma, save_mean,
-                           save_invstd, dgamma, dbeta, (float*)dy, (long)dy_ld, (float*)dres, (long)dres_ld, dres_acc, (long)pixels, C, g.cols, g.ppb);
-    return msc_check_launch("msc_bn_bwd_apply_fused");
-}
-
-extern "C" int msc_zero(void* p, int64_t bytes, void* stream) {
-    if (!p || bytes < 0) return msc_fail(MSC_ERR_ARG, "msc_zero: bad argument");
-    if (bytes && hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream) != hipSuccess) return msc_fail(MSC_ERR_HIP, "msc_zero: hipMemsetAsync");
-    return MSC_OK;
 }

@@ -591,12 +591,6 @@ class _Builder:
         self.group_steps = int(env.get('MSC_WGRAD_GROUP_STEPS', '64'))
         self.group_tile = int(env.get('MSC_WGRAD_GROUP_TILE', '128'))
         self.pending = []             # deferred (WgradDesc, gradient address or None)
-        # BatchNorm statistics (forward sums, backward sums) accumulate in a few slots per channel inside ONE arena that
-        # a single msc_zero clears at the start of a step; the consuming apply kernels finalise them in their prologue
-        # (no finalize launches).  MSC_BN_FUSED=0: exclusive partial slots + separate finalize kernels (deterministic).
-        self.bn_fused = training and env.get('MSC_BN_FUSED', '1') != '0'
-        self.arena = torch.zeros(1 << 24, dtype=torch.float32, device=device) if self.bn_fused else None
-        self.arena_used = 0
 
     # ---- memory
     def buf(self, H, W, C, dtype=None):
@@ -613,23 +607,6 @@ class _Builder:
 
     def act(self, H, W, C):
         return Act(self.buf(H, W, C))
-
-    def slot_alloc(self, nfloats):
-        """device address of `nfloats` zero-at-step-start floats in the statistics arena"""
-        nfloats = (nfloats + 63) // 64 * 64
-        if self.arena_used + nfloats > self.arena.numel():
-            raise _lib.MscError('BatchNorm statistics arena exhausted')
-        ptr = self.arena.data_ptr() + 4 * self.arena_used
-        self.arena_used += nfloats
-        return ptr
-
-    @staticmethod
-    def bn_slots(pixels):
-        """slots per channel: enough to keep the fp32 atomics of the producers apart, few enough for a block prologue"""
-        s = 8
-        while s < 64 and s * 8192 < pixels:
-            s *= 2
-        return s
 
     def g(self, param):
         """gradient address of `param`; records which backward launch (the next one emitted) writes it, so the
@@ -676,7 +653,7 @@ class _Builder:
         lst.append((fn, args))
 
     def conv_desc(self, x, wt, out, KH, KW, stride, pad, mode=0, flip=0, relu=0, scale=None, shift=None, res=None,
-                  stats=None, in_hw=None, in_ld=None, cin=None, out_hw=None, want_stats=False, stat_slots=0):
+                  stats=None, in_hw=None, in_ld=None, cin=None, out_hw=None, want_stats=False):
         d = ConvDesc()
         d.in_, d.wt, d.out = x.ptr, wt.data_ptr(), out.ptr
         d.res = res.ptr if res is not None else None
@@ -692,7 +669,6 @@ class _Builder:
         d.Cout = out.C
         d.KH, d.KW, d.stride, d.pad, d.flip, d.relu = KH, KW, stride, pad, flip, relu
         d.cfg = 0
-        d.stat_slots = stat_slots
         self.prog.keep.append(d)
         self.tune_conv(d, want_stats)
         return d
@@ -820,19 +796,6 @@ class _Builder:
             self.conv(fwd, x, w, out, relu=int(relu), scale=scale, shift=shift, res=res, **geo)
             return
         y = self.act(out.H, out.W, cout)
-        count = self.N * out.H * out.W
-        if self.bn_fused:
-            slots = self.bn_slots(count)
-            d = self.conv_desc(x, w, y, want_stats=True, stat_slots=slots, **geo)
-            d.stats = self.slot_alloc(cout * slots * 2)
-            self.emit(fwd, lib.msc_conv_igemm, C.byref(d))
-            mean, invstd = self.vec(cout), self.vec(cout)
-            self.emit(fwd, lib.msc_bn_train_apply, y.ptr, y.ld, res.ptr if res is not None else None, res.ld if res is not None else 0,
-                      out.ptr, out.ld, int(relu), d.stats, slots, count, bn.weight.data_ptr(), bn.bias.data_ptr(), BN_EPS, BN_MOMENTUM,
-                      bn.running_mean.data_ptr(), bn.running_var.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
-                      invstd.data_ptr(), self.dt, count, cout)
-            self.ops.append(lambda: self._conv_bn_bwd(name, x, conv, bn, geo, relu, out, res, y, mean, invstd, count, stem, scale, shift))
-            return
         d = self.conv_desc(x, w, y, want_stats=True, **geo)
         slices = lib.msc_conv_stats_slices(C.byref(d))
         if slices <= 0:
@@ -841,6 +804,7 @@ class _Builder:
         d.stats = part.data_ptr()
         self.emit(fwd, lib.msc_conv_igemm, C.byref(d))
         mean, invstd = self.vec(cout), self.vec(cout)
+        count = self.N * out.H * out.W
         self.emit(fwd, lib.msc_bn_finalize, part.data_ptr(), slices, cout, count, bn.weight.data_ptr(), bn.bias.data_ptr(),
                   BN_EPS, BN_MOMENTUM, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                   scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr())
@@ -852,35 +816,24 @@ class _Builder:
         net, lib, P, bwd = self.net, self.lib, self.prog, self.prog.bwd
         cout = conv.out_channels
         dout = self.grad_of(out)
+        blocks = lib.msc_bn_bwd_blocks(count, cout, self.dt)
+        part = self.vec(blocks * cout * 2)
+        coef = self.vec(3 * cout)
         # ReLU mask: without a residual the pre-activation is scale*y + shift, recomputed from the y both kernels read
         # anyway (mode 2) instead of reading `out` (mode 1)
         mask = 0 if not relu else (1 if res is not None else 2)
-        if self.bn_fused:
-            slots = self.bn_slots(count)
-            part_ptr = self.slot_alloc(cout * slots * 2)
-        else:
-            slots = 0
-            blocks = lib.msc_bn_bwd_blocks(count, cout, self.dt)
-            part_ptr = self.vec(blocks * cout * 2).data_ptr()
         self.emit(bwd, lib.msc_bn_bwd_reduce, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, mask, scale.data_ptr(),
-                  shift.data_ptr(), part_ptr, slots, self.dt, count, cout)
-        if not self.bn_fused:
-            coef = self.vec(3 * cout)
-            self.emit(bwd, lib.msc_bn_bwd_finalize, part_ptr, blocks, cout, count, bn.weight.data_ptr(),
-                      mean.data_ptr(), invstd.data_ptr(), self.g(bn.weight), self.g(bn.bias), coef.data_ptr())
+                  shift.data_ptr(), part.data_ptr(), self.dt, count, cout)
+        self.emit(bwd, lib.msc_bn_bwd_finalize, part.data_ptr(), blocks, cout, count, bn.weight.data_ptr(),
+                  mean.data_ptr(), invstd.data_ptr(), self.g(bn.weight), self.g(bn.bias), coef.data_ptr())
         dres_ptr, dres_ld, dres_acc = None, 0, 0
         if res is not None:
             gres = self.grad_of(res)
             dres_acc = self.grad_acc(res)
             dres_ptr, dres_ld = gres.ptr, gres.ld
         # dy overwrites y in place (each element is read, then written, by the same lane)
-        if self.bn_fused:
-            self.emit(bwd, lib.msc_bn_bwd_apply_fused, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, mask, scale.data_ptr(),
-                      shift.data_ptr(), part_ptr, slots, count, bn.weight.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                      self.g(bn.weight), self.g(bn.bias), y.ptr, y.ld, dres_ptr, dres_ld, dres_acc, self.dt, count, cout)
-        else:
-            self.emit(bwd, lib.msc_bn_bwd_apply, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, mask, scale.data_ptr(),
-                      shift.data_ptr(), coef.data_ptr(), y.ptr, y.ld, dres_ptr, dres_ld, dres_acc, self.dt, count, cout)
+        self.emit(bwd, lib.msc_bn_bwd_apply, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, mask, scale.data_ptr(),
+                  shift.data_ptr(), coef.data_ptr(), y.ptr, y.ld, dres_ptr, dres_ld, dres_acc, self.dt, count, cout)
         dy = y
         if stem is not None:
             self.wgrad(bwd, dy, x, P.stem_dw.data_ptr(), 7, 1, 2, 0, q_hw=stem, q_ld=4, B=32)
@@ -971,8 +924,6 @@ class _Builder:
         # stem: conv7x7/2 + BN + ReLU + MaxPool2d(2,2)   (:360-363)
         xp = torch.zeros((N, H + 6, W + 8, 4), dtype=self.tdtype, device=self.dev)
         P.bytes += xp.numel() * xp.element_size()
-        if self.bn_fused:
-            self.emit(P.fwd, lib.msc_zero, self.arena.data_ptr(), 0)      # byte count patched once the arena is laid out
         self.emit(P.fwd, lib.msc_stem_prepare, P.x_in.data_ptr(), xp.data_ptr(), self.dt, N, H, W)
         s1 = self.act(H // 2, W // 2, 64)
         self.conv_bn('encoder.conv1', Act(xp), enc.conv1, enc.bn1, 2, True, s1, stem=(H + 6, W + 8))
@@ -1040,10 +991,6 @@ class _Builder:
             for op in reversed(self.ops):
                 op()
             self.flush_wgrads()
-        if self.bn_fused:
-            P.fwd[0] = (lib.msc_zero, (self.arena.data_ptr(), 4 * self.arena_used))
-            P.keep.append(self.arena)
-            P.bytes += 4 * self.arena_used
         P.keep += [xp]
         P.acts = {'c1': s1, 'd0': d0, 'cat2': cat2, 'cat3': cat3, 'cat4': cat4, 'cat5': cat5}
         if self._tuned_new:

@@ -62,11 +62,7 @@ def conv_igemm(dref):
             off = ((n_i[ok] * Hi + iy[ok]) * Wi + ix[ok]) * d.in_ld
             x = src[off[:, None] + cidx[None, :]].astype(np.float64)
             acc[ok] += x @ w[:, kh, kw, :].astype(np.float64).T
-    if d.stats and d.stat_slots:
-        st = _arr(d.stats, d.stat_slots * Cout * 2).reshape(Cout, d.stat_slots, 2)      # caller-zeroed, accumulated
-        st[:, 0, 0] += acc.sum(0)
-        st[:, 0, 1] += (acc * acc).sum(0)
-    elif d.stats:
+    if d.stats:
         # everything in slice 0, the other slices the real kernel would fill are zeroed
         from mapping_challenge_amd import _lib
         slices = _lib.load().msc_conv_stats_slices(dref)
@@ -206,41 +202,17 @@ def _relu_mask(relu, out, out_ld, y, y_ld, scale, shift, pixels, Cc):
     return _rows(y, pixels, Cc, y_ld) * _arr(scale, Cc) + _arr(shift, Cc) > 0      # relu == 2: recomputed pre-activation
 
 
-def bn_bwd_reduce(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, partials, slots, dtype, pixels, Cc):
+def bn_bwd_reduce(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, partials, dtype, pixels, Cc):
     d = _rows(dout, pixels, Cc, dout_ld).astype(np.float64)
     if relu:
         d = d * _relu_mask(relu, out, out_ld, y, y_ld, scale, shift, pixels, Cc)
     yy = _rows(y, pixels, Cc, y_ld).astype(np.float64)
-    if slots:
-        p = _arr(partials, slots * Cc * 2).reshape(Cc, slots, 2)        # caller-zeroed, accumulated
-        p[:, 0, 0] += d.sum(0)
-        p[:, 0, 1] += (d * yy).sum(0)
-        return
     from mapping_challenge_amd import _lib
     nb = _lib.load().msc_bn_bwd_blocks(pixels, Cc, dtype)
     p = _arr(partials, nb * Cc * 2).reshape(Cc, nb, 2)
     p[...] = 0
     p[:, 0, 0] = d.sum(0)
     p[:, 0, 1] = (d * yy).sum(0)
-
-
-def bn_train_apply(y, y_ld, res, res_ld, out, out_ld, relu, stats, slots, count, gamma, beta, eps, momentum, rm, rv, scale, shift,
-                   smean, sinv, dtype, pixels, Cc):
-    bn_finalize(stats, slots, Cc, count, gamma, beta, eps, momentum, rm, rv, scale, shift, smean, sinv)
-    bn_apply(y, y_ld, res, res_ld, out, out_ld, scale, shift, relu, dtype, pixels, Cc)
-
-
-def bn_bwd_apply_fused(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, partials, slots, count, gamma, mean, invstd,
-                       dgamma, dbeta, dy, dy_ld, dres, dres_ld, dres_acc, dtype, pixels, Cc):
-    coef = np.zeros(3 * Cc, np.float32)
-    bn_bwd_finalize(partials, slots, Cc, count, gamma, mean, invstd, dgamma, dbeta, coef.ctypes.data)
-    bn_bwd_apply(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, coef.ctypes.data, dy, dy_ld, dres, dres_ld, dres_acc,
-                 dtype, pixels, Cc)
-
-
-def zero(ptr, nbytes):
-    if nbytes:
-        _arr(ptr, nbytes, np.uint8)[...] = 0
 
 
 def bn_bwd_finalize(partials, blocks, Cc, count, gamma, mean, invstd, dgamma, dbeta, coef):
@@ -312,7 +284,6 @@ TABLE = {'msc_conv_igemm': conv_igemm, 'msc_conv_wgrad': conv_wgrad, 'msc_pack_c
          'msc_stem_prepare': stem_prepare, 'msc_maxpool2_fwd': maxpool2_fwd, 'msc_maxpool2_bwd': maxpool2_bwd,
          'msc_bn_finalize': bn_finalize, 'msc_bn_fold': bn_fold, 'msc_bn_apply': bn_apply,
          'msc_bn_bwd_reduce': bn_bwd_reduce, 'msc_bn_bwd_finalize': bn_bwd_finalize, 'msc_bn_bwd_apply': bn_bwd_apply,
-         'msc_bn_train_apply': bn_train_apply, 'msc_bn_bwd_apply_fused': bn_bwd_apply_fused, 'msc_zero': zero,
          'msc_relu_bwd': relu_bwd, 'msc_bias_grad': bias_grad, 'msc_final_fwd': final_fwd, 'msc_final_bwd': final_bwd}
 
 

@@ -1,7 +1,5 @@
 """GPU: single-kernel parity through the C ABI against torch-CPU fp32 references of the same op.
 fp32 mode (v_mfma_f32_16x16x4_f32) is held to 1e-4-class tolerances; bf16 mode to bf16 rounding."""
-import ctypes as C
-
 import numpy as np
 import pytest
 import torch
@@ -277,72 +275,3 @@ def test_grouped_weight_gradients_equal_separate_ones(dtype, steps, cap):
     for pr, gref in zip(problems, refs):
         err = (pr[2].cpu() / 2 - gref).abs().max().item() / gref.abs().max().item()
         assert err < (2e-5 if dtype == torch.float32 else 1e-2), (pr[2].shape, err)
-
-
-@pytest.mark.parametrize('dtype', DT)
-@pytest.mark.parametrize('C_,n,hw,res,relu', [(64, 4, 24, False, True), (256, 2, 16, True, True), (96, 3, 9, False, False), (1024, 2, 8, True, True)])
-def test_batchnorm_with_slot_statistics_and_fused_finalize(dtype, C_, n, hw, res, relu):
-    """conv epilogue statistics accumulated in a few slots (fp32 atomics) -> msc_bn_train_apply (finalize + apply in one
-    launch) -> msc_bn_bwd_reduce(slots) -> msc_bn_bwd_apply_fused, against torch's BatchNorm2d in training mode"""
-    from mapping_challenge_amd import _lib, ops
-    lib = _lib.load()
-    st = torch.cuda.current_stream().cuda_stream
-    dt = ops._dt(torch.empty(0, dtype=dtype))
-    cin, slots = 64, 8
-    x = rnd((n, cin, hw, hw), dtype, 1)
-    w = rnd((C_, cin, 1, 1), dtype, 2, 0.2)
-    gamma, beta = rnd((C_,), torch.float32, 3) * 0.5 + 1.0, rnd((C_,), torch.float32, 4) * 0.3
-    idt = rnd((n, C_, hw, hw), dtype, 5) if res else None
-    dout_h = rnd((n, C_, hw, hw), dtype, 6)
-    # torch reference on the values the kernels see (y rounded to dtype like the stored conv output)
-    y_ref = F.conv2d(x, w).to(dtype).float().requires_grad_(True)
-    bn = torch.nn.BatchNorm2d(C_)
-    bn.weight.data, bn.bias.data = gamma.clone(), beta.clone()
-    z = bn(y_ref) + (idt if res else 0)
-    o_ref = torch.relu(z) if relu else z
-    o_ref.backward(dout_h)
-    # device
-    xd, wk = nhwc(x, dtype), w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
-    y = torch.empty((n, hw, hw, C_), dtype=dtype, device='cuda')
-    stats = torch.zeros((C_, slots, 2), dtype=torch.float32, device='cuda')
-    d = ops.ConvDesc()
-    d.in_, d.wt, d.out, d.stats = xd.data_ptr(), wk.data_ptr(), y.data_ptr(), stats.data_ptr()
-    d.in_ld, d.out_ld, d.dtype, d.mode = cin, C_, dt, 0
-    d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.stat_slots = n, hw, hw, cin, hw, hw, C_, 1, 1, 1, 0, slots
-    _lib.check(lib.msc_conv_igemm(C.byref(d), st), 'conv')
-    yf = to_nchw(y)
-    assert torch.allclose(stats.sum(1)[:, 0].cpu(), F.conv2d(x, w).sum((0, 2, 3)), rtol=2e-3, atol=5e-2)
-    g_d, b_d = gamma.cuda(), beta.cuda()
-    rm, rv = torch.zeros(C_, device='cuda'), torch.ones(C_, device='cuda')
-    scale, shift, mean, invstd = (torch.empty(C_, device='cuda') for _ in range(4))
-    out = torch.empty_like(y)
-    idt_d = nhwc(idt, dtype) if res else None
-    count = n * hw * hw
-    _lib.check(lib.msc_bn_train_apply(y.data_ptr(), C_, idt_d.data_ptr() if res else None, C_ if res else 0, out.data_ptr(), C_, int(relu),
-                                      stats.data_ptr(), slots, count, g_d.data_ptr(), b_d.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(),
-                                      scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dt, count, C_, st), 'train_apply')
-    t = dict(atol=2e-5, rtol=1e-4) if dtype == torch.float32 else dict(atol=6e-2, rtol=3e-2)
-    assert torch.allclose(to_nchw(out), o_ref.detach(), **t)
-    # statistics are those of the fp32 accumulators (before rounding y to dtype): compare loosely in bf16
-    ts = dict(atol=1e-5, rtol=1e-4) if dtype == torch.float32 else dict(atol=2e-2, rtol=2e-2)
-    assert torch.allclose(rm.cpu(), bn.running_mean, **ts) and torch.allclose(rv.cpu(), bn.running_var, **ts)
-    assert torch.allclose(mean.cpu(), yf.mean((0, 2, 3)), **ts)
-    # backward
-    dout = nhwc(dout_h, dtype)
-    mask = 0 if not relu else (1 if res else 2)
-    part = torch.zeros((C_, slots, 2), dtype=torch.float32, device='cuda')
-    _lib.check(lib.msc_bn_bwd_reduce(dout.data_ptr(), C_, out.data_ptr(), C_, y.data_ptr(), C_, mask, scale.data_ptr(), shift.data_ptr(),
-                                     part.data_ptr(), slots, dt, count, C_, st), 'bwd_reduce')
-    dgamma, dbeta = torch.zeros(C_, device='cuda'), torch.zeros(C_, device='cuda')
-    dres = torch.empty_like(y) if res else None
-    _lib.check(lib.msc_bn_bwd_apply_fused(dout.data_ptr(), C_, out.data_ptr(), C_, y.data_ptr(), C_, mask, scale.data_ptr(), shift.data_ptr(),
-                                          part.data_ptr(), slots, count, g_d.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                          dgamma.data_ptr(), dbeta.data_ptr(), y.data_ptr(), C_, dres.data_ptr() if res else None,
-                                          C_ if res else 0, 0, dt, count, C_, st), 'bwd_apply_fused')
-    tg = dict(atol=1e-3, rtol=2e-3) if dtype == torch.float32 else dict(atol=0.5, rtol=5e-2)
-    assert torch.allclose(dgamma.cpu(), bn.weight.grad, **tg) and torch.allclose(dbeta.cpu(), bn.bias.grad, **tg)
-    td = dict(atol=2e-4, rtol=2e-3) if dtype == torch.float32 else dict(atol=8e-2, rtol=5e-2)
-    assert torch.allclose(to_nchw(y), y_ref.grad, **td)            # dy overwrote y in place
-    if res:
-        dmask = dout_h * (o_ref.detach() > 0) if relu else dout_h
-        assert torch.allclose(to_nchw(dres), dmask, **td)
