@@ -47,24 +47,37 @@ class LossSpec:
                    w0=wce['w0'], sigma=wce['sigma'], imsize=tuple(wce['imsize']))
 
 
-def loss_forward_backward(logits, target, spec, dlogits, loss_out, sums, world=None, grad_scale=1.0):
-    """Fused loss: fills `dlogits` (f32 NCHW) and `loss_out` (f32[1]); `sums` f64[4] scratch.
-    With `world` (a torch.distributed process group wrapper) the sums are all-reduced first."""
+def loss_sums(logits, target, spec, sums):
+    """phase 1 of the fused loss: the four f64 sums of this rank's batch"""
+    import ctypes as C
     N, Cc, H, W = logits.shape
     if Cc != 2:
         raise ValueError('loss kernels implement the 2-class head')
-    tc = target.shape[1]
     stream = torch.cuda.current_stream(logits.device).cuda_stream
-    lib = _lib.load()
+    _lib.check(_lib.load().msc_loss_sums(logits.data_ptr(), target.data_ptr(), target.shape[1], C.byref(spec.cfg), sums.data_ptr(),
+                                         N, H, W, stream), 'msc_loss_sums')
+
+
+def loss_grad(logits, target, spec, dlogits, loss_out, sums, total_pixels, grad_scale=1.0):
+    """phase 2: loss value and dlogits from the (all-reduced) sums; total_pixels = pixels of the GLOBAL batch"""
     import ctypes as C
-    _lib.check(lib.msc_loss_sums(logits.data_ptr(), target.data_ptr(), tc, C.byref(spec.cfg), sums.data_ptr(), N, H, W, stream),
-               'msc_loss_sums')
+    N, _, H, W = logits.shape
+    stream = torch.cuda.current_stream(logits.device).cuda_stream
+    _lib.check(_lib.load().msc_loss_grad(logits.data_ptr(), target.data_ptr(), target.shape[1], C.byref(spec.cfg), sums.data_ptr(),
+                                         float(total_pixels), float(grad_scale), loss_out.data_ptr(), dlogits.data_ptr(), N, H, W, stream),
+               'msc_loss_grad')
+
+
+def loss_forward_backward(logits, target, spec, dlogits, loss_out, sums, world=None, grad_scale=1.0):
+    """Fused loss: fills `dlogits` (f32 NCHW) and `loss_out` (f32[1]); `sums` f64[4] scratch.
+    With `world` (a torch.distributed process group wrapper) the sums are all-reduced first."""
+    N, _, H, W = logits.shape
+    loss_sums(logits, target, spec, sums)
     total = float(N * H * W)
     if world is not None and world.size > 1:
         world.all_reduce(sums)
         total *= world.size
-    _lib.check(lib.msc_loss_grad(logits.data_ptr(), target.data_ptr(), tc, C.byref(spec.cfg), sums.data_ptr(), total,
-                                 float(grad_scale), loss_out.data_ptr(), dlogits.data_ptr(), N, H, W, stream), 'msc_loss_grad')
+    loss_grad(logits, target, spec, dlogits, loss_out, sums, total, grad_scale)
 
 
 class HipAdam:
@@ -145,13 +158,17 @@ def ddp_plan(prog, flat_grads, nchunks=4):
 
 
 class TrainStep:
-    """forward -> loss -> backward -> (all-reduce) -> Adam for a fixed batch shape; optionally captured
-    into ONE hipGraph so that the ~1.2k launches of a step cost no host time on replay."""
+    """forward -> loss -> backward -> (all-reduce) -> Adam for a fixed batch shape.  use_graph: the ~1.1k launches of
+    a step are captured so that they cost no host time on replay -- ONE hipGraph in a single process; with
+    collectives, a handful of graphs (forward + loss sums | loss gradient + backward piece 1 | piece 2.. | Adam) with the
+    RCCL calls issued eagerly between them, so the gradient all-reduce of a piece still overlaps the next pieces."""
 
-    def __init__(self, net, spec, optimizer, world=None, use_graph=False):
+    def __init__(self, net, spec, optimizer, world=None, use_graph=False, force_collectives=False):
         self.net, self.spec, self.opt, self.world = net, spec, optimizer, world
-        self.use_graph = use_graph and (world is None or world.size == 1)
+        self.dist = world is not None and (world.size > 1 or force_collectives)     # force: exercise RCCL with one rank
+        self.use_graph = use_graph
         self.graph = None
+        self.pieces = None
         self.x = self.t = self.loss = self.sums = None
         self.prog = None
 
@@ -167,7 +184,7 @@ class TrainStep:
         prog = net.train_forward(self.x)
         self.prog = prog
         loss_forward_backward(prog.logits, self.t, self.spec, prog.dlogits, self.loss, self.sums, self.world)
-        if self.world is not None and self.world.size > 1:
+        if self.dist:
             self._backward_overlapped(prog)
         else:
             net.train_backward(prog)
@@ -203,19 +220,85 @@ class TrainStep:
         if not self.use_graph:
             self._body()
             return self.loss
-        if self.graph is None:
+        if self.graph is None and self.pieces is None:
             # the first step runs eagerly (builds the program, allocates, packs) and IS this call's step;
             # capturing afterwards does not execute anything, replays start with the next call
             self._body()
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._body_captured()
-            self.graph = g
+            if self.dist:
+                self._capture_pieces()
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._body_captured()
+                self.graph = g
             return self.loss
-        self.graph.replay()
+        if self.pieces is not None:
+            self._replay_pieces()
+        else:
+            self.graph.replay()
         self.opt.steps += 1
         return self.loss
+
+    # ---- piecewise capture: graphs around the collectives ----------------------------------------------
+    def _capture_pieces(self):
+        from .unet_models import _Program
+        net, prog, dev = self.net, self.prog, self.x.device
+        N, _, H, W = prog.logits.shape
+        total = float(N * H * W) * (self.world.size if self.world.size > 1 else 1)
+        flat_g = net.flat_grads
+        if getattr(prog, '_ddp_plan', None) is None:
+            prog._ddp_plan = ddp_plan(prog, flat_g)
+
+        def capture(fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn(torch.cuda.current_stream(dev).cuda_stream)
+            return g
+
+        def forward(stream):
+            _Program.run(net._pack['ops'], stream)
+            prog.x_in.copy_(self.x)
+            _Program.run(prog.fwd, stream)
+            loss_sums(prog.logits, self.t, self.spec, self.sums)
+
+        def piece(beg, end, first):
+            def fn(stream):
+                if first:
+                    loss_grad(prog.logits, self.t, self.spec, prog.dlogits, self.loss, self.sums, total)
+                    flat_g.zero_()
+                    prog.stem_dw.zero_()
+                _Program.run_backward(prog.bwd[beg:end], dev)
+            return fn
+
+        def adam(stream):
+            o, lib = self.opt, _lib.load()
+            p = net.flat_params
+            _lib.check(lib.msc_adam_tick(o.state.data_ptr(), stream), 'msc_adam_tick')
+            _lib.check(lib.msc_adam_step(p.data_ptr(), flat_g.data_ptr(), o.m.data_ptr(), o.v.data_ptr(), p.numel(), o.lr, o.betas[0],
+                                         o.betas[1], o.eps, o.weight_decay, 0, 1.0, o.state.data_ptr(), stream), 'msc_adam_step')
+
+        pieces, beg = [], 0
+        for end, lo, hi in prog._ddp_plan:
+            pieces.append((capture(piece(beg, end, beg == 0)), lo, hi))
+            beg = end
+        self.pieces = (capture(forward), pieces, capture(adam))
+        net._packed_version = -1
+
+    def _replay_pieces(self):
+        import torch.distributed as dist
+        fwd, pieces, adam = self.pieces
+        flat_g = self.net.flat_grads
+        fwd.replay()
+        self.world.all_reduce(self.sums)
+        works = []
+        for g, lo, hi in pieces:
+            g.replay()
+            if lo is not None:
+                works.append(dist.all_reduce(flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.world.group, async_op=True))
+        for w in works:
+            w.wait()
+        adam.replay()
 
     def _body_captured(self):
         # same as _body, but the weight repack after Adam is part of the graph so replays stay consistent

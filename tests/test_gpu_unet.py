@@ -208,3 +208,36 @@ def test_rccl_world1_overlapped_backward_equals_plain():
         world.sync_model(net)
     finally:
         dist.destroy_process_group()
+
+
+def test_rccl_world1_piecewise_graph_step_equals_eager():
+    """the multi-GPU training step (graphs around eager RCCL collectives) on a process group of size 1: the same loss
+    trajectory and parameters as the plain eager step"""
+    import os
+    import torch.distributed as dist
+    from mapping_challenge_amd.distributed import World
+    from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(29600 + os.getpid() % 1000))
+        dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        arch = {'weighted_cross_entropy': {'w0': 50, 'sigma': 10, 'imsize': (256, 256)},
+                'loss_weights': {'dice_mask': 0.2, 'bce_mask': 1.0}, 'dice': {'smooth': 1, 'dice_activation': 'softmax'}}
+        x = unet_ref.synthetic_batch(2, 64, 64).cuda()
+        tgt = losses_ref.synthetic_target(2, 64, 64).cuda()
+        out = {}
+        for mode in ('eager', 'pieces'):
+            ref, net = build(34, 'fp32')
+            net.train()
+            kw = dict(world=World(), use_graph=True, force_collectives=True) if mode == 'pieces' else {}
+            step = TrainStep(net, LossSpec.mixed(arch), HipAdam(net, lr=5e-4, weight_decay=1e-4), **kw)
+            losses = [step(x, tgt).item() for _ in range(4)]
+            if mode == 'pieces':
+                assert step.pieces is not None and len(step.pieces[1]) == 4
+            out[mode] = (losses, net.flat_params.clone())
+        assert np.allclose(out['eager'][0], out['pieces'][0], rtol=2e-3)
+        assert (out['eager'][1] - out['pieces'][1]).abs().mean().item() < 2e-5
+        assert out['pieces'][0][-1] < out['pieces'][0][0]
+    finally:
+        dist.destroy_process_group()
