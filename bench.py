@@ -240,8 +240,18 @@ def main():
             tgt = losses_ref.synthetic_target(min(batch, 4), hw, hw, seed=world.rank)
             tgt = tgt.repeat((batch + tgt.shape[0] - 1) // tgt.shape[0], 1, 1, 1)[:batch].contiguous().to(dev)
             net.train()
+            # MSC_FORCE_COLLECTIVES=1: run the multi-GPU step -- piecewise graphs + RCCL calls on a process group of one
+            # rank -- on a single GPU, to measure what it costs over the one-graph step
+            force = os.environ.get('MSC_FORCE_COLLECTIVES') == '1' and world.size == 1
+            if force:
+                import torch.distributed as dist
+                if not dist.is_initialized():
+                    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+                    os.environ.setdefault('MASTER_PORT', '29533')
+                    dist.init_process_group('nccl', rank=0, world_size=1)
             step = TrainStep(net, LossSpec.mixed(ARCH), HipAdam(net, lr=5e-4, weight_decay=1e-4), world=world,
-                             use_graph=not args.no_graph)
+                             use_graph=not args.no_graph,
+                             force_collectives=force)
             dt = timed(lambda: step(x, tgt))
             prog = step.prog
             loss = float(step.loss.item())
