@@ -300,7 +300,7 @@ def main():
                 'dominant_family': dom[0], 'family_ms_per_step': {k: round(v['ms'], 3) for k, v in sorted(fam.items())},
                 'sum_kernel_ms_per_step': total_ms,
                 'whole_step_frac_of_mfma_peak': (conv['flops'] + wg['flops']) * (args.steps / dt) / peak}
-        if world.rank == 0 and not args.no_cpu_baseline:
+        if world.rank == 0 and world.size == 1 and not args.no_cpu_baseline:      # reported at N=1 only
             result['cpu_baseline'] = cpu_baseline_train(enc, hw) if args.workload == 'train' else cpu_baseline_infer(enc, hw)
     elif args.workload == 'annot':
         # labelled 300x300 layers (2 per image, on the device) -> COCO RLE strings + boxes on the host
@@ -323,7 +323,7 @@ def main():
                       roofline={'bound': 'hbm', 'achieved': value * bytes_per_img / 1e9 / world.size, 'peak': PEAK_HBM / 1e9, 'unit': 'GB/s',
                                 'frac': value * bytes_per_img / world.size / PEAK_HBM, 'traffic': None,
                                 'note': 'two synchronous calls (sizes return to the host) + D2H of table and strings; latency bound'})
-        if world.rank == 0 and not args.no_cpu_baseline:
+        if world.rank == 0 and world.size == 1 and not args.no_cpu_baseline:      # reported at N=1 only
             result['cpu_baseline'] = cpu_baseline_annot(layers_h)
     else:
         from mapping_challenge_amd import postprocessing as post
@@ -341,7 +341,7 @@ def main():
                       roofline={'bound': 'hbm', 'achieved': value * bytes_per_img / 1e9 / world.size, 'peak': PEAK_HBM / 1e9, 'unit': 'GB/s',
                                 'frac': value * bytes_per_img / world.size / PEAK_HBM, 'traffic': None,
                                 'note': 'whole chain incl. the final D2H of labels; latency/launch bound'})
-        if world.rank == 0 and not args.no_cpu_baseline:
+        if world.rank == 0 and world.size == 1 and not args.no_cpu_baseline:      # reported at N=1 only
             result['cpu_baseline'] = cpu_baseline_post(probs_h, (300, 300), 2)
     if world.rank == 0:
         print(json.dumps(result))
