@@ -11,7 +11,8 @@
 
 namespace {
 
-constexpr int RED_PIX_MAX = 128;   // pixels per block (halved, down to the row-lane count, until ~1024 blocks exist)
+constexpr int RED_PIX = 128;       // pixels per block: halved (down to the row-lane count) until ~1024 blocks exist,
+                                   // doubled (up to 2048) while more than 4096 would: the finalize pass reads one partial per block
 
 // K = 2: (sum dh, sum dh*y) with dh = dout*[out>0] (BatchNorm backward);  K = 1: sum d (bias gradient)
 template <typename T, int K>
@@ -168,8 +169,9 @@ bool red_geom(long pixels, int C, int ce, RedGeom* g) {
     while (cols > cv) cols >>= 1;                 // 4..64, power of two
     if (cols < 1 || cv % cols || C % ce) return false;
     const int rows = 256 / cols;
-    int ppb = RED_PIX_MAX;
+    int ppb = RED_PIX;
     while (ppb > rows && ppb > 16 && (long)ceil_div(pixels, ppb) * (cv / cols) < 1024) ppb >>= 1;
+    while (ppb < 2048 && (long)ceil_div(pixels, ppb) * (cv / cols) > 4096) ppb <<= 1;
     g->cols = cols; g->chunks = cv / cols; g->ppb = ppb; g->S = ceil_div(pixels, ppb);
     return true;
 }
