@@ -51,7 +51,7 @@ struct ConvK {
     int N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, flip, relu;
     int M, Hq, Wq;
     unsigned in_bytes, wt_bytes;     // extents for the buffer descriptors of the DMA kernel
-    int ntc, ntm;                    // channel / pixel tiles (DMA kernel: ntm*ntc tiles walked by a 1-D persistent grid, XCD-aware order)
+    int ntc;                         // channel tiles (DMA kernel: 1-D grid of ntm*ntc blocks, XCD-aware order)
     int xcd_order;                   // 1: XCD-aware tile order, 0: pixel tile fastest (for A/B measurements)
 };
 
@@ -91,9 +91,7 @@ __device__ __forceinline__ u32x4_t make_srd(const void* base, unsigned bytes) {
     return r;
 }
 __device__ __forceinline__ void dma16(u32x4_t srd, char* lds_wave_base, unsigned voff, int soff) {
-    // wave-uniform by construction; readfirstlane keeps it in an SGPR where the compiler cannot prove that
-    const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)lds_wave_base);
-    soff = __builtin_amdgcn_readfirstlane(soff);
+    const unsigned lds_addr = (unsigned)(size_t)(lds_ptr_t)lds_wave_base;
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
@@ -323,7 +321,6 @@ template <int KB> __device__ __forceinline__ int swz_frag(int pl) {      // key 
     return KB == 64 ? ((0x1320 >> (4 * ((pl >> 2) & 3))) & 3) : ((pl >> 1) & 7);
 }
 
-// One tile per block (the large-tile configurations: their register budget has no room for the tile loop below).
 template <typename T, int TP, int TC, int WP, int WC, int MODE, int NST, int KB>
 __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
     constexpr int ES = sizeof(T);
@@ -482,206 +479,6 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
         }
     }
     conv_epilogue<T, FM, FN, WTP, WP, MODE>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px, mtile, nwg / p.ntc);
-}
-
-// The same pipeline with persistent blocks (the small-tile configurations).
-template <typename T, int TP, int TC, int WP, int WC, int MODE, int NST, int KB>
-__global__ __launch_bounds__(WP * WC * 64) void conv_igemm_persist_kernel(ConvK p) {
-    constexpr bool PERSIST = true;
-    constexpr int ES = sizeof(T);
-    constexpr int NW = WP * WC;                  // waves per block
-    constexpr int KE = KB / ES;                  // K elements per step
-    constexpr int KSUB = KB / 64;                // MFMA sub-steps per K step
-    constexpr int LPR = KB / 16;                 // lanes (16-byte chunks) per row
-    constexpr int RPI = 64 / LPR;                // rows per DMA wave-instruction
-    constexpr int WTP = TP / WP, WTC = TC / WC;
-    constexpr int FM = WTC / 16, FN = WTP / 16;
-    constexpr int NV = FM * 4;
-    constexpr int NIX = TP / RPI, NIW = TC / RPI;                 // DMA wave-instructions per tile
-    constexpr int XI = (NIX + NW - 1) / NW, WI = (NIW + NW - 1) / NW;   // ... per wave (short tiles are fetched redundantly)
-    constexpr int STAGE = (TP + TC) * KB;
-    constexpr int LPW = XI + WI;                 // DMA instructions per wave per stage, uniform over waves
-    static_assert(NIX % NW == 0 || NIX < NW, "pixel tile / wave count");
-    static_assert(NST * STAGE <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wp = wid / WC, wc = wid % WC;
-    const int g = lane >> 4, pl = lane & 15;
-    // XCD-aware tile order: workgroup b runs on XCD b%8 (observed dispatch order; only speed depends on it).  Each
-    // XCD gets a contiguous run of tiles with the channel tile varying fastest, so the blocks that re-read one pixel
-    // tile (one per channel tile) and one weight tile share that XCD's L2 close in time.
-    // PERSIST (the small-tile configurations; the others cannot afford the registers): the grid holds at most as many
-    // blocks as fit on the chip (a multiple of 8); block b walks tiles b, b + gridDim.x, ... and its DMA ring runs ahead
-    // across tile boundaries, so the fill latency and the epilogue of one tile hide behind the loads of the next (the
-    // 8192-pixel layers are a few k-steps per tile).  Otherwise one tile per block.
-    const int ntiles = p.ntm * p.ntc;
-    const int tstep = PERSIST ? (int)gridDim.x : ntiles;
-    auto tile_of = [&](int t, int& mtile, int& ctile) {
-        if (p.xcd_order) {
-            const int xcd = t & 7, wq = ntiles >> 3, wr = ntiles & 7;
-            const int wgid = (xcd < wr ? xcd * (wq + 1) : wr * (wq + 1) + (xcd - wr) * wq) + (t >> 3);
-            mtile = wgid / p.ntc;
-            ctile = wgid - mtile * p.ntc;
-        } else {
-            mtile = t % p.ntm;
-            ctile = t / p.ntm;
-        }
-    };
-    const int ph = MODE ? (int)blockIdx.z : 0;
-    const int py = ph >> 1, px = ph & 1;
-
-    int kh0 = 0, kw0 = 0, nkh = p.KH, nkw = p.KW;
-    if (MODE) {
-        kh0 = (py + p.pad) & 1; kw0 = (px + p.pad) & 1;
-        nkh = p.KH > kh0 ? (p.KH - kh0 + 1) / 2 : 0;
-        nkw = p.KW > kw0 ? (p.KW - kw0 + 1) / 2 : 0;
-    }
-    const int cps = p.Cin / KE;
-    const int nsteps = nkh * nkw * cps;
-
-    const u32x4_t rx = make_srd(p.in, p.in_bytes);
-    const u32x4_t rw = make_srd(p.wt, p.wt_bytes);
-
-    // ---- DMA lanes: instruction j (of this wave: j = i*NW + wid) covers tile rows j*RPI .. +RPI-1
-    const int lr = lane / LPR, slot = lane % LPR;
-    const unsigned pix_bytes = (unsigned)p.in_ld * ES;
-    const unsigned tap_bytes = (unsigned)p.Cin * ES;
-    int xn[XI], xby[XI], xbx[XI];
-    unsigned xkc[XI];
-    bool xv[XI];
-    unsigned wrow[WI];
-    auto decode = [&](int t) {        // per-lane rows of the tile the ring fetches next
-        int mtile, ctile;
-        tile_of(t, mtile, ctile);
-        const int m0 = mtile * TP, c0 = ctile * TC;
-#pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            const int j = NIX >= NW ? i * NW + wid : wid % NIX;
-            const int row = j * RPI + lr;
-            const int m = m0 + row;
-            xv[i] = m < p.M;
-            const int mm = xv[i] ? m : 0;
-            const int n = mm / (p.Hq * p.Wq);
-            const int rem = mm - n * (p.Hq * p.Wq);
-            const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
-            xn[i] = n * p.Hi;
-            xby[i] = MODE ? qy : qy * p.stride;
-            xbx[i] = MODE ? qx : qx * p.stride;
-            xkc[i] = (unsigned)(slot ^ swz_x<KB>(row)) * 16u;
-        }
-#pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const int j = NIW >= NW ? i * NW + wid : wid % NIW;
-            const int row = j * RPI + lr;
-            const int co = c0 + row;
-            wrow[i] = co < p.Cout ? (unsigned)co * (unsigned)(p.KH * p.KW) * tap_bytes + (unsigned)(slot ^ swz_w<KB, NV>(row)) * 16u : OOB_OFF;
-        }
-    };
-    int itile = blockIdx.x;
-    decode(itile);
-
-    // ---- issue iterator: (tap, k-chunk) of the next stage to fetch; per-lane offsets refreshed once per tap
-    int itap = 0, icch = 0, istage = 0;
-    unsigned xoff[XI], woff[WI];
-    auto set_tap = [&](int tap) {
-        const int khi = tap / nkw, kwi = tap - khi * nkw;
-        const int kh = MODE ? kh0 + 2 * khi : khi;
-        const int kw = MODE ? kw0 + 2 * kwi : kwi;
-        int dy, dx;
-        if (MODE) { dy = (py + p.pad - kh) / 2; dx = (px + p.pad - kw) / 2; }
-        else if (p.flip) { dy = p.pad - kh; dx = p.pad - kw; }
-        else { dy = kh - p.pad; dx = kw - p.pad; }
-#pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            const int iy = xby[i] + dy, ix = xbx[i] + dx;
-            const bool ok = xv[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            xoff[i] = ok ? (unsigned)((xn[i] + iy) * p.Wi + ix) * pix_bytes + xkc[i] : OOB_OFF;
-        }
-        const unsigned toff = (unsigned)(kh * p.KW + kw) * tap_bytes;
-#pragma unroll
-        for (int i = 0; i < WI; ++i) woff[i] = wrow[i] == OOB_OFF ? OOB_OFF : wrow[i] + toff;
-    };
-    auto issue = [&]() {
-        if (icch == 0) set_tap(itap);
-        const int soff = icch * KB;
-        char* sx = smem + istage * STAGE;
-        char* sw = sx + TP * KB;
-#pragma unroll
-        for (int i = 0; i < XI; ++i) dma16(rx, sx + (NIX >= NW ? i * NW + wid : wid % NIX) * 1024, xoff[i], soff);
-#pragma unroll
-        for (int i = 0; i < WI; ++i) dma16(rw, sw + (NIW >= NW ? i * NW + wid : wid % NIW) * 1024, woff[i], soff);
-        if (++icch == cps) {
-            icch = 0;
-            ++itap;
-            if (PERSIST && itap == nkh * nkw) {  // next tile of this block
-                itap = 0;
-                itile += tstep;
-                if (itile < ntiles) decode(itile);
-            }
-        }
-        if (++istage == NST) istage = 0;
-    };
-
-    f32x4 acc[FM][FN];
-
-    // fragment read offsets within a stage for MFMA sub-step 0 (sub-step kk: chunk index + 4*kk before the swizzle)
-    const int key = swz_frag<KB>(pl);
-    int aoff[FM], boff[FN];
-#pragma unroll
-    for (int a = 0; a < FM; ++a) aoff[a] = TP * KB + (wc * WTC + (pl >> 2) * NV + a * 4 + (pl & 3)) * KB;
-#pragma unroll
-    for (int b = 0; b < FN; ++b) boff[b] = (wp * WTP + b * 16 + pl) * KB;
-
-    if (nsteps <= 0) return;
-    const int my_tiles = PERSIST ? (ntiles - (int)blockIdx.x + tstep - 1) / tstep : 1;
-    const int total = my_tiles * nsteps;         // k-steps this block runs, over all its tiles
-#pragma unroll
-    for (int st = 0; st < NST - 1; ++st)
-        if (st < total) issue();
-    auto run_tile = [&](const int t, const int gs0) {     // gs0: k-steps this block has run before this tile
-        int cstage = gs0 % NST;
-#pragma unroll
-        for (int a = 0; a < FM; ++a)
-#pragma unroll
-            for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < nsteps; ++s) {
-            const int gs = gs0 + s;
-            // stage gs must have landed; stages gs+1 .. gs+NST-2 may stay in flight.  The counter also holds the
-            // previous tile's epilogue stores: at most N operations outstanding still means at most N loads, and loads
-            // complete in order, so the guarantee stands (the wait is merely conservative right after an epilogue).
-            if (gs + NST - 2 <= total - 1) wait_vmcnt<(NST - 2) * LPW>();
-            else wait_vmcnt<0>();
-            raw_barrier();                       // everyone's DMA of stage gs is in LDS, everyone is done with stage gs-1
-            if (gs + NST - 1 < total) issue();
-            const char* sb = smem + cstage * STAGE;
-#pragma unroll
-            for (int kk = 0; kk < KSUB; ++kk) {
-                const int so = ((kk * 4 + g) ^ key) * 16;
-                uint4 af[FM], bf[FN];
-#pragma unroll
-                for (int a = 0; a < FM; ++a) af[a] = *reinterpret_cast<const uint4*>(sb + aoff[a] + so);
-#pragma unroll
-                for (int b = 0; b < FN; ++b) bf[b] = *reinterpret_cast<const uint4*>(sb + boff[b] + so);
-#pragma unroll
-                for (int a = 0; a < FM; ++a)
-#pragma unroll
-                    for (int b = 0; b < FN; ++b) Mma<T>::run(af[a], bf[b], acc[a][b]);
-            }
-            if (++cstage == NST) cstage = 0;
-        }
-        int mtile, ctile;
-        tile_of(t, mtile, ctile);
-        conv_epilogue<T, FM, FN, WTP, WP, MODE>(p, acc, mtile * TP, wp, ctile * TC + wc * WTC + g * NV, pl, py, px, mtile, p.ntm);
-    };
-    if constexpr (PERSIST) {
-        int gs0 = 0;
-        for (int t = blockIdx.x; t < ntiles; t += tstep, gs0 += nsteps) run_tile(t, gs0);
-    } else {
-        run_tile(blockIdx.x, 0);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1080,7 +877,6 @@ bool env_flag(const char* name) {
 }
 bool use_v1_conv() { static int v = -1; if (v < 0) v = env_flag("MSC_CONV_V1") ? 1 : 0; return v == 1; }
 bool xcd_order_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("MSC_XCD_ORDER"); v = (e && e[0] == '0') ? 0 : 1; } return v == 1; }
-bool persistent_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("MSC_PERSIST"); v = (e && e[0] == '0') ? 0 : 1; } return v == 1; }
 bool use_v1_wgrad() { static int v = -1; if (v < 0) v = env_flag("MSC_WGRAD_V1") ? 1 : 0; return v == 1; }
 
 // ---- kernel configurations.  A configuration = (pixel rows, channels, waves along pixels, waves along channels,
@@ -1112,38 +908,13 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
 
 template <typename T, int TP, int TC, int WP, int WC, int KB, int NST>
 int launch_dma(const ConvK& k0, int mode, hipStream_t st) {
-    constexpr bool PERSIST = TP * TC <= 64 * 64 || (WP * WC == 8 && TP * TC <= 128 * 64);
     ConvK k = k0;
     k.ntc = ceil_div(k.Cout, TC);
-    k.ntm = ceil_div(k.M, TP);
     k.xcd_order = xcd_order_enabled() ? 1 : 0;
+    dim3 grid(ceil_div(k.M, TP) * k.ntc, 1, mode ? 4 : 1);
     constexpr int NT = WP * WC * 64;
-    // resident capacity of the chip for this instantiation (blocks per CU x CUs), asked once
-    static int capacity[2] = {0, 0};
-    if constexpr (PERSIST) if (!capacity[mode ? 1 : 0]) {
-        int per_cu = 0, dev = 0;
-        hipDeviceProp_t prop;
-        hipError_t e = mode ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_igemm_persist_kernel<T, TP, TC, WP, WC, 1, NST, KB>, NT, 0)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_igemm_persist_kernel<T, TP, TC, WP, WC, 0, NST, KB>, NT, 0);
-        if (e != hipSuccess || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu < 1)
-            return msc_fail(MSC_ERR_HIP, "conv_igemm_dma: occupancy query failed");
-        capacity[mode ? 1 : 0] = per_cu * prop.multiProcessorCount;
-    }
-    const int ntiles = k.ntm * k.ntc;
-    int blocks = ntiles;
-    if (PERSIST && persistent_enabled()) {
-        int cap = capacity[mode ? 1 : 0] / (mode ? 4 : 1);       // the four phases of mode 1 share the chip
-        cap = cap >= 16 ? (cap & ~7) : 8;
-        if (blocks > cap) blocks = cap;
-    }
-    dim3 grid(blocks, 1, mode ? 4 : 1);
-    if constexpr (PERSIST) {
-        if (mode) hipLaunchKernelGGL((conv_igemm_persist_kernel<T, TP, TC, WP, WC, 1, NST, KB>), grid, dim3(NT), 0, st, k);
-        else hipLaunchKernelGGL((conv_igemm_persist_kernel<T, TP, TC, WP, WC, 0, NST, KB>), grid, dim3(NT), 0, st, k);
-    } else {
-        if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1, NST, KB>), grid, dim3(NT), 0, st, k);
-        else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, NST, KB>), grid, dim3(NT), 0, st, k);
-    }
+    if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1, NST, KB>), grid, dim3(NT), 0, st, k);
+    else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, NST, KB>), grid, dim3(NT), 0, st, k);
     return msc_check_launch("conv_igemm_dma");
 }
 

@@ -275,37 +275,3 @@ def test_grouped_weight_gradients_equal_separate_ones(dtype, steps, cap):
     for pr, gref in zip(problems, refs):
         err = (pr[2].cpu() / 2 - gref).abs().max().item() / gref.abs().max().item()
         assert err < (2e-5 if dtype == torch.float32 else 1e-2), (pr[2].shape, err)
-
-
-@pytest.mark.parametrize('dtype', DT)
-@pytest.mark.parametrize('cin,cout,k,stride,hw,n', [(64, 128, 1, 1, 128, 4), (64, 64, 3, 1, 96, 4), (128, 64, 3, 2, 128, 3)])
-def test_persistent_blocks_walk_many_tiles(dtype, cin, cout, k, stride, hw, n):
-    """layers with more tiles than the chip holds blocks: the small-tile configurations run persistent blocks whose DMA
-    ring crosses tile boundaries; every tile (incl. BN partial statistics and the transposed mode) must still be right"""
-    from mapping_challenge_amd import ops
-    pad = k // 2
-    x = rnd((n, cin, hw, hw), dtype, 1)
-    w = rnd((cout, cin, k, k), dtype, 2, (2.0 / (cin * k * k)) ** 0.5)
-    ref = F.conv2d(x, w, stride=stride, padding=pad)
-    ho = ref.shape[2]
-    xd = nhwc(x, dtype)
-    wk = w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
-    out = torch.empty((n, ho, ho, cout), dtype=dtype, device='cuda')
-    small = [c for c in ops.conv_valid_cfgs(xd, wk, out, stride, pad) if c in (7, 8, 11, 14)]
-    assert small
-    for c in small:
-        out.zero_()
-        slices = ops.conv_stats_slices(xd, wk, out, stride, pad, cfg=c)
-        stats = torch.zeros((cout, slices, 2), dtype=torch.float32, device='cuda')
-        ops.conv_igemm(xd, wk, out, stride=stride, pad=pad, stats=stats, cfg=c)
-        assert torch.allclose(to_nchw(out), ref, **tol(dtype)), c
-        assert torch.allclose(stats.sum(1)[:, 0].cpu(), ref.sum((0, 2, 3)), rtol=2e-3, atol=0.5), c
-    if stride == 1 and k == 3:
-        wt = rnd((cin, cout, 4, 4), dtype, 3, 0.05)
-        reft = F.conv_transpose2d(x, wt, stride=2, padding=1)
-        wkt = ops.pack_transpose(wt.permute(0, 2, 3, 1).contiguous().view(cin, 16, cout).cuda(), dtype).view(cout, 4, 4, cin)
-        outt = torch.empty((n, 2 * hw, 2 * hw, cout), dtype=dtype, device='cuda')
-        for c in [c for c in ops.conv_valid_cfgs(xd, wkt, outt, 2, 1, mode=1) if c in (7, 8, 11, 14)]:
-            outt.zero_()
-            ops.conv_igemm(xd, wkt, outt, stride=2, pad=1, mode=1, cfg=c)
-            assert torch.allclose(to_nchw(outt), reft, **tol(dtype)), c
