@@ -23,6 +23,15 @@ pmc)   python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > g
          timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c" -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-breakdown > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log" 2>&1; echo "pmc $c rc=$?"
        done
        cd "$GRAFT_REPO_ROOT"; python tools/pmc_summary.py gpurun_out gpurun_out/pmc_traffic.json > gpurun_out/pmc_summary.txt 2>&1; head -12 gpurun_out/pmc_summary.txt;;
+pmcsq) # SQ / LDS / L2 counters of the train step, one rocprofv3 pass per counter group (counter runs carry kernel-trace only)
+       python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
+       cd /tmp; export TMPDIR=/tmp
+       i=0
+       for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum"; do
+         i=$((i+1)); rm -rf "$GRAFT_REPO_ROOT/gpurun_out/pmcsq_$i"
+         timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmcsq_$i" -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-breakdown > "$GRAFT_REPO_ROOT/gpurun_out/pmcsq_$i.log" 2>&1; echo "pmcsq $i rc=$?"
+       done
+       cd "$GRAFT_REPO_ROOT"; python tools/pmc_sq_summary.py gpurun_out/pmcsq_1 gpurun_out/pmcsq_2 gpurun_out/pmcsq_3 > gpurun_out/pmcsq_summary.txt 2>&1; head -30 gpurun_out/pmcsq_summary.txt | cut -c1-260;;
 ktests) timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_unet.py -m gpu -q -rf --tb=short -p no:cacheprovider > gpurun_out/pytest_k.log 2>&1; echo "pytest rc=$?"; tail -15 gpurun_out/pytest_k.log;;
 ab)    # A/B of environment switches on the train step: AB="NAME=VAL,NAME2=VAL2 NAME=VAL ..." (one run per word)
        python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
