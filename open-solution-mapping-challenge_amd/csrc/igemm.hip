@@ -885,7 +885,7 @@ bool use_v1_wgrad() { static int v = -1; if (v < 0) v = env_flag("MSC_WGRAD_V1")
 // heuristic (cfg 0) the caller may pick one explicitly -- UNetResNet times the valid ones per layer when it builds
 // a program (msc_conv_cfg_ok enumerates them).
 struct ConvCfg { int tp, tc, wp, wc, kb, nst; };
-constexpr int N_CONV_CFG = 14;
+constexpr int N_CONV_CFG = 19;
 static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {0, 0, 0, 0, 0, 0},
     {256, 128, 4, 2, 128, 3},   //  1: 144 KB, 8 waves, 1 block/CU
@@ -904,6 +904,13 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {128, 128, 4, 2, 128, 3},   // 12:  96 KB, 8 waves
     {64, 128, 2, 2, 128, 4},    // 13:  96 KB
     {64, 128, 2, 4, 128, 4},    // 14:  96 KB, 8 waves
+    // deeper rings: the small layers are bound by the latency of the L2 -> LDS fill (SQ counters: waves parked 44 % of
+    // the time at 13 TB/s aggregate fill), i.e. by the bytes in flight per CU
+    {64, 128, 2, 4, 128, 6},    // 15: 144 KB, 8 waves
+    {128, 64, 4, 2, 128, 6},    // 16: 144 KB, 8 waves
+    {64, 64, 2, 2, 128, 5},     // 17:  80 KB, 2 blocks/CU
+    {128, 128, 4, 2, 128, 4},   // 18: 128 KB, 8 waves
+    {256, 128, 4, 2, 64, 6},    // 19: 144 KB, 8 waves
 };
 
 template <typename T, int TP, int TC, int WP, int WC, int KB, int NST>
@@ -970,7 +977,12 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
         case 11: return launch_dma<T, 128, 64, 4, 2, 128, 4>(k, mode, st);
         case 12: return launch_dma<T, 128, 128, 4, 2, 128, 3>(k, mode, st);
         case 13: return launch_dma<T, 64, 128, 2, 2, 128, 4>(k, mode, st);
-        default: return launch_dma<T, 64, 128, 2, 4, 128, 4>(k, mode, st);
+        case 14: return launch_dma<T, 64, 128, 2, 4, 128, 4>(k, mode, st);
+        case 15: return launch_dma<T, 64, 128, 2, 4, 128, 6>(k, mode, st);
+        case 16: return launch_dma<T, 128, 64, 4, 2, 128, 6>(k, mode, st);
+        case 17: return launch_dma<T, 64, 64, 2, 2, 128, 5>(k, mode, st);
+        case 18: return launch_dma<T, 128, 128, 4, 2, 128, 4>(k, mode, st);
+        default: return launch_dma<T, 256, 128, 4, 2, 64, 6>(k, mode, st);
     }
 }
 
