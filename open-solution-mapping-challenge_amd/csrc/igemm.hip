@@ -309,16 +309,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
 // row on the SOURCE side and applying the same involution on the read:
 //   KB = 64 : slot = chunk ^ S[q],  S = {0,2,3,1},  q = (row>>2)&3 (pixel rows) | (row/NV)&3 (weight rows)
 //   KB = 128: slot = chunk ^ q,     q = (row>>1)&7 (pixel rows) | ((row/NV)&3)<<1 | (row>>1)&1 (weight rows)
+//   KB = 256: slot = chunk ^ q,     q = row&15     (pixel rows) | ((row/NV)&3)<<2 | row&3      (weight rows)
+//             (a row is exactly the 64 banks, so the key alone has to spread the 16 lanes of a read)
 // both keys reduce to a function of the fragment lane (pl) only, so the four lane groups of ds_read_b128
 // ({0-3,12-15,20-27}, ...) hit 16 distinct 16-byte slots.
 template <int KB> __device__ __forceinline__ int swz_x(int row) {
-    return KB == 64 ? ((0x1320 >> (4 * ((row >> 2) & 3))) & 3) : ((row >> 1) & 7);
+    return KB == 64 ? ((0x1320 >> (4 * ((row >> 2) & 3))) & 3) : KB == 128 ? ((row >> 1) & 7) : (row & 15);
 }
 template <int KB, int NV> __device__ __forceinline__ int swz_w(int row) {
-    return KB == 64 ? ((0x1320 >> (4 * ((row / NV) & 3))) & 3) : ((((row / NV) & 3) << 1) | ((row >> 1) & 1));
+    return KB == 64 ? ((0x1320 >> (4 * ((row / NV) & 3))) & 3)
+         : KB == 128 ? ((((row / NV) & 3) << 1) | ((row >> 1) & 1)) : ((((row / NV) & 3) << 2) | (row & 3));
 }
 template <int KB> __device__ __forceinline__ int swz_frag(int pl) {      // key of both fragment kinds for lane pl
-    return KB == 64 ? ((0x1320 >> (4 * ((pl >> 2) & 3))) & 3) : ((pl >> 1) & 7);
+    return KB == 64 ? ((0x1320 >> (4 * ((pl >> 2) & 3))) & 3) : KB == 128 ? ((pl >> 1) & 7) : pl;
 }
 
 template <typename T, int TP, int TC, int WP, int WC, int MODE, int NST, int KB>
@@ -885,7 +888,7 @@ bool use_v1_wgrad() { static int v = -1; if (v < 0) v = env_flag("MSC_WGRAD_V1")
 // heuristic (cfg 0) the caller may pick one explicitly -- UNetResNet times the valid ones per layer when it builds
 // a program (msc_conv_cfg_ok enumerates them).
 struct ConvCfg { int tp, tc, wp, wc, kb, nst; };
-constexpr int N_CONV_CFG = 19;
+constexpr int N_CONV_CFG = 23;
 static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {0, 0, 0, 0, 0, 0},
     {256, 128, 4, 2, 128, 3},   //  1: 144 KB, 8 waves, 1 block/CU
@@ -911,6 +914,11 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {64, 64, 2, 2, 128, 5},     // 17:  80 KB, 2 blocks/CU
     {128, 128, 4, 2, 128, 4},   // 18: 128 KB, 8 waves
     {256, 128, 4, 2, 64, 6},    // 19: 144 KB, 8 waves
+    // 256-byte k-steps: 4 MFMA sub-steps (instead of 2) between two barriers
+    {64, 64, 2, 2, 256, 4},     // 20: 128 KB
+    {64, 128, 2, 4, 256, 3},    // 21: 144 KB, 8 waves
+    {128, 64, 4, 2, 256, 3},    // 22: 144 KB, 8 waves
+    {128, 128, 4, 2, 256, 2},   // 23: 128 KB, 8 waves
 };
 
 template <typename T, int TP, int TC, int WP, int WC, int KB, int NST>
@@ -982,7 +990,11 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
         case 16: return launch_dma<T, 128, 64, 4, 2, 128, 6>(k, mode, st);
         case 17: return launch_dma<T, 64, 64, 2, 2, 128, 5>(k, mode, st);
         case 18: return launch_dma<T, 128, 128, 4, 2, 128, 4>(k, mode, st);
-        default: return launch_dma<T, 256, 128, 4, 2, 64, 6>(k, mode, st);
+        case 19: return launch_dma<T, 256, 128, 4, 2, 64, 6>(k, mode, st);
+        case 20: return launch_dma<T, 64, 64, 2, 2, 256, 4>(k, mode, st);
+        case 21: return launch_dma<T, 64, 128, 2, 4, 256, 3>(k, mode, st);
+        case 22: return launch_dma<T, 128, 64, 4, 2, 256, 3>(k, mode, st);
+        default: return launch_dma<T, 128, 128, 4, 2, 256, 2>(k, mode, st);
     }
 }
 
