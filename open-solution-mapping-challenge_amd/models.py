@@ -21,6 +21,7 @@ import torch
 
 from . import _lib
 from .distributed import World
+from .postprocessing import _to_host
 from .steps import BaseTransformer
 from .trainer import HipAdam, LossSpec, TrainStep
 from .unet_models import UNetResNet
@@ -116,7 +117,7 @@ class BasePyTorchUNet(BaseTransformer):
                 break
 
     def _transform(self, datagen, validation_datagen=None):
-        outs = [p.cpu().numpy() for p in self._forward_probs(datagen)]
+        outs = [_to_host(p) for p in self._forward_probs(datagen)]
         return {'{}_prediction'.format(self.output_names[0]): np.vstack(outs)}
 
     def transform(self, datagen, validation_datagen=None, *args, **kwargs):
@@ -132,7 +133,7 @@ class BasePyTorchUNet(BaseTransformer):
         outs = []
         for batch_id, data in enumerate(batch_gen):
             X = data[0] if isinstance(data, (list, tuple)) else data
-            outs.append(tta.predict_tta(self.model, X.to(dev, non_blocking=True), specs, method).cpu().numpy())
+            outs.append(_to_host(tta.predict_tta(self.model, X.to(dev, non_blocking=True), specs, method)))
             if batch_id == steps:
                 break
         return {'{}_prediction'.format(self.output_names[0]): np.vstack(outs)}
@@ -188,7 +189,7 @@ class _StreamMixin:
 
     def _stream(self, datagen):
         for probs in self._forward_probs(datagen):
-            for image in probs.cpu().numpy():
+            for image in _to_host(probs):
                 yield image
 
 
