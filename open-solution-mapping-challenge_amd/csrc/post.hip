@@ -125,21 +125,40 @@ __device__ __forceinline__ void uf_union(int* L, int a, int b) {
     }
 }
 
-__global__ void ccl_init_kernel(const uint8_t* __restrict__ mask, int32_t* __restrict__ L, long HW) {
-    const long b = blockIdx.y;
-    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x)
-        L[b * HW + p] = mask[b * HW + p] ? (int)p : -1;
+// One wavefront per image row: every foreground pixel starts as a child of the first pixel of its horizontal run
+// (ballot of 64 pixels -> run starts -> highest start at or below the lane; the run open at a chunk boundary is
+// carried in a scalar), so the horizontal unions are done before any atomic is issued.
+__global__ __launch_bounds__(256) void ccl_init_kernel(const uint8_t* __restrict__ mask, int32_t* __restrict__ L, int H, int W, long rows) {
+    const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int y = (int)(row % H);
+    const uint8_t* m = mask + row * W;
+    int* l = L + row * W;
+    int carry = -1;                                   // start of the run that reaches the previous chunk's last pixel
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int x = x0 + lane;
+        const bool fg = x < W && m[x] != 0;
+        const unsigned long long f = __ballot(fg);
+        const unsigned long long starts = f & ~((f << 1) | (carry >= 0 ? 1ull : 0ull));
+        const unsigned long long below = starts & (~0ull >> (63 - lane));
+        const int sx = below ? x0 + 63 - __clzll((long long)below) : carry;
+        if (x < W) l[x] = fg ? y * W + sx : -1;
+        const int last = __shfl(fg ? sx : -1, 63, 64);
+        carry = (f >> 63) ? last : -1;
+    }
 }
+// vertical unions, once per pair of touching runs: at the first pixel where the two runs overlap
 __global__ void ccl_merge_kernel(const uint8_t* __restrict__ mask, int32_t* __restrict__ L, int H, int W) {
     const long HW = (long)H * W;
     const long b = blockIdx.y;
     const uint8_t* m = mask + b * HW;
     int* l = L + b * HW;
     for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
-        if (!m[p]) continue;
+        if (p < W || !m[p] || !m[p - W]) continue;
         const int x = (int)(p % W);
-        if (x > 0 && m[p - 1]) uf_union(l, (int)p, (int)p - 1);
-        if (p >= W && m[p - W]) uf_union(l, (int)p, (int)(p - W));
+        if (x > 0 && m[p - 1] && m[p - W - 1]) continue;
+        uf_union(l, (int)p, (int)(p - W));
     }
 }
 __global__ void ccl_compress_kernel(int32_t* __restrict__ L, long HW) {
@@ -475,7 +494,7 @@ extern "C" int msc_label4(const uint8_t* mask, int32_t* labels, int32_t* counts,
     const long HW = (long)H * W;
     const dim3 g = plane_grid(HW, B);
     int32_t* rank = (int32_t*)workspace;
-    hipLaunchKernelGGL(ccl_init_kernel, g, dim3(256), 0, st, mask, labels, HW);
+    hipLaunchKernelGGL(ccl_init_kernel, dim3(ceil_div((long)B * H, 4)), dim3(256), 0, st, mask, labels, H, W, (long)B * H);
     hipLaunchKernelGGL(ccl_merge_kernel, g, dim3(256), 0, st, mask, labels, H, W);
     hipLaunchKernelGGL(ccl_compress_kernel, g, dim3(256), 0, st, labels, HW);
     hipLaunchKernelGGL(ccl_rank_kernel, dim3(B), dim3(1024), 0, st, labels, rank, counts, HW);
