@@ -251,8 +251,9 @@ class TrainStep:
             prog._ddp_plan = ddp_plan(prog, flat_g)
 
         def capture(fn):
+            # thread_local: the RCCL watchdog thread of torch.distributed may poll events while we capture
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 fn(torch.cuda.current_stream(dev).cuda_stream)
             return g
 
