@@ -39,6 +39,10 @@ int msc_abi_version(void);
  * epilogue: v = acc*scale[c] + shift[c] (+ res) ; ReLU ; store.  scale/shift/res may be NULL.
  * stats (mode 0 only, may be NULL): per-channel partial sum / sum of squares of the raw accumulators,
  *   [Cout][msc_conv_stats_slices()][2] floats, reduced by msc_bn_finalize (BatchNorm2d training mode).
+ *   stats_kind 1 (data-gradient convs): the launch also reduces what msc_bn_bwd_reduce would read back -- the output
+ *   is the gradient w.r.t. a BatchNorm+ReLU layer's activation, stats_y that layer's pre-BN tensor (same shape as
+ *   out), scale/shift its forward coefficients (used for the ReLU mask only, NULL = no ReLU; no affine is applied):
+ *   stats[c][slice] = (sum dh, sum dh*y), dh = acc*[scale*y+shift > 0].  Same layout, feeds msc_bn_bwd_finalize.
  * weights: dtype [Cout][KH][KW][Cin].  Cin*sizeof(dtype) % 64 == 0, Cout % 32 == 0. */
 typedef struct msc_conv_desc {
     const void* in;
@@ -52,6 +56,9 @@ typedef struct msc_conv_desc {
     int32_t dtype, mode;
     int32_t N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, flip, relu;
     int32_t cfg;   /* 0 = heuristic kernel configuration, 1..msc_conv_num_cfgs() = explicit (tile, K-step, ring depth) */
+    int32_t stats_kind;
+    const void* stats_y;
+    int64_t stats_y_ld;
 } msc_conv_desc;
 int msc_conv_igemm(const msc_conv_desc* d, void* stream);
 int msc_conv_stats_slices(const msc_conv_desc* d);   /* depends on d->cfg */

@@ -47,6 +47,7 @@ namespace {
 struct ConvK {
     const char* in; const char* wt; char* out; const char* res;
     const float* scale; const float* shift; float* stats;
+    const char* sy; long sy_ld; int stats_kind;     // stats_kind 1: BatchNorm-backward sums against the tensor sy
     long in_ld, out_ld, res_ld;
     int N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, flip, relu;
     int M, Hq, Wq;
@@ -105,6 +106,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
                                               int mtile, int ntm) {
     constexpr int NV = FM * 4;
     constexpr int CE = 16 / (int)sizeof(T);
+    // stats_kind 1 (a data-gradient conv that also produces the BatchNorm-backward sums of the layer whose output
+    // gradient it writes): scale/shift are that layer's forward coefficients, used for the ReLU mask only
+    const bool bnb = p.stats && p.stats_kind == 1;
     float sc[NV], sh[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -124,9 +128,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
         for (int a = 0; a < FM; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][b][r];
-        if (p.stats) {
+        if (p.stats && !bnb) {
 #pragma unroll
             for (int j = 0; j < NV; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+        }
+        if (bnb && m < p.M) {          // (sum dh, sum dh*y), dh = dout * [scale*y + shift > 0] (no mask without scale)
+            const T* sy = reinterpret_cast<const T*>(p.sy);
+#pragma unroll
+            for (int j = 0; j < NV; j += CE) {
+                float yv[CE];
+                Vec16<T>::load(sy + (long)m * p.sy_ld + cb + j, yv);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) {
+                    const float dh = (!p.scale || fmaf(yv[e], sc[j + e], sh[j + e]) > 0.f) ? v[j + e] : 0.f;
+                    s1[j + e] += dh;
+                    s2[j + e] += dh * yv[e];
+                }
+            }
         }
         if (m < p.M) {
             long opix = m;
@@ -136,8 +154,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
                 const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
                 opix = ((long)n * p.Ho + 2 * qy + py) * p.Wo + 2 * qx + px;
             }
+            if (!bnb) {
 #pragma unroll
-            for (int j = 0; j < NV; ++j) v[j] = v[j] * sc[j] + sh[j];
+                for (int j = 0; j < NV; ++j) v[j] = v[j] * sc[j] + sh[j];
+            }
             if (res) {
 #pragma unroll
                 for (int j = 0; j < NV; j += CE) {
@@ -1017,6 +1037,10 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
         return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: pointers must be 16-byte aligned");
     k->in = (const char*)d->in; k->wt = (const char*)d->wt; k->out = (char*)d->out; k->res = (const char*)d->res;
     k->scale = d->scale; k->shift = d->shift; k->stats = d->stats;
+    k->sy = (const char*)d->stats_y; k->sy_ld = d->stats_y_ld; k->stats_kind = d->stats ? d->stats_kind : 0;
+    if (k->stats_kind < 0 || k->stats_kind > 1) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: stats_kind %d", d->stats_kind);
+    if (k->stats_kind == 1 && (!d->stats_y || d->res || d->relu || (d->stats_y_ld * es) % 16 || ((uintptr_t)d->stats_y & 15) || !d->scale != !d->shift))
+        return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: BatchNorm-backward statistics need stats_y (16-byte aligned), no residual, no ReLU");
     k->in_ld = d->in_ld; k->out_ld = d->out_ld; k->res_ld = d->res_ld;
     k->N = d->N; k->Hi = d->Hi; k->Wi = d->Wi; k->Cin = d->Cin; k->Ho = d->Ho; k->Wo = d->Wo; k->Cout = d->Cout;
     k->KH = d->KH; k->KW = d->KW; k->stride = d->stride; k->pad = d->pad; k->flip = d->flip; k->relu = d->relu;

@@ -591,6 +591,9 @@ class _Builder:
         self.group_steps = int(env.get('MSC_WGRAD_GROUP_STEPS', '64'))
         self.group_tile = int(env.get('MSC_WGRAD_GROUP_TILE', '128'))
         self.pending = []             # deferred (WgradDesc, gradient address or None)
+        self.gcount = {}              # activation slice -> number of launches that write its gradient
+        self.gwriter = {}             # activation slice -> ConvDesc of the (mode 0, no residual) dgrad conv that wrote it first
+        self.fuse_bn_bwd = _os_env.environ.get('MSC_FUSE_BN_BWD', '1') != '0'
 
     # ---- memory
     def buf(self, H, W, C, dtype=None):
@@ -640,6 +643,7 @@ class _Builder:
         """1 if the gradient slice was already written during this backward (-> accumulate), else
         marks it (and every registered sub-slice it covers) written and returns 0."""
         key = (id(a.buf), a.c0, a.C)
+        self.gcount[key] = self.gcount.get(key, 0) + 1
         if key in self.gwritten:
             return 1
         self.gwritten.add(key)
@@ -816,14 +820,29 @@ class _Builder:
         net, lib, P, bwd = self.net, self.lib, self.prog, self.prog.bwd
         cout = conv.out_channels
         dout = self.grad_of(out)
-        blocks = lib.msc_bn_bwd_blocks(count, cout, self.dt)
-        part = self.vec(blocks * cout * 2)
         coef = self.vec(3 * cout)
         # ReLU mask: without a residual the pre-activation is scale*y + shift, recomputed from the y both kernels read
         # anyway (mode 2) instead of reading `out` (mode 1)
         mask = 0 if not relu else (1 if res is not None else 2)
-        self.emit(bwd, lib.msc_bn_bwd_reduce, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, mask, scale.data_ptr(),
-                  shift.data_ptr(), part.data_ptr(), self.dt, count, cout)
+        gkey = (id(out.buf), out.c0, out.C)      # grad_acc() keys gradient slices by their activation
+        wd = self.gwriter.get(gkey) if (self.fuse_bn_bwd and mask != 1 and self.gcount.get(gkey, 0) == 1) else None
+        if wd is not None:
+            # dout has exactly one writer, a data-gradient conv that ran earlier in this backward: its epilogue also
+            # reduces (sum dh, sum dh*y) per tile, so the column-reduce pass over dout and y is not launched
+            wd.stats_kind, wd.stats_y, wd.stats_y_ld = 1, y.ptr, y.ld
+            wd.scale, wd.shift = (scale.data_ptr(), shift.data_ptr()) if mask == 2 else (None, None)
+            wd.stats = 1                     # any non-null value: the slice count depends on it being requested
+            blocks = lib.msc_conv_stats_slices(C.byref(wd))
+            if blocks <= 0:
+                _lib.check(-1, 'msc_conv_stats_slices')
+            part = self.vec(blocks * cout * 2)
+            wd.stats = part.data_ptr()
+        else:
+            blocks = lib.msc_bn_bwd_blocks(count, cout, self.dt)
+            part = self.vec(blocks * cout * 2)
+        if wd is None:
+            self.emit(bwd, lib.msc_bn_bwd_reduce, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, mask, scale.data_ptr(),
+                      shift.data_ptr(), part.data_ptr(), self.dt, count, cout)
         self.emit(bwd, lib.msc_bn_bwd_finalize, part.data_ptr(), blocks, cout, count, bn.weight.data_ptr(),
                   mean.data_ptr(), invstd.data_ptr(), self.g(bn.weight), self.g(bn.bias), coef.data_ptr())
         dres_ptr, dres_ld, dres_acc = None, 0, 0
@@ -846,7 +865,9 @@ class _Builder:
         wt = net._pack['wt'][name]
         k = geo['KH']
         if geo['stride'] == 1:
-            self.conv(bwd, dy, wt, gx, KH=k, KW=k, stride=1, pad=geo['pad'], flip=1, res=gx if acc else None)
+            d = self.conv(bwd, dy, wt, gx, KH=k, KW=k, stride=1, pad=geo['pad'], flip=1, res=gx if acc else None)
+            if not acc:
+                self.gwriter[(id(x.buf), x.c0, x.C)] = d
         else:
             self.conv(bwd, dy, wt, gx, KH=k, KW=k, stride=2, pad=geo['pad'], mode=1, res=gx if acc else None)
 

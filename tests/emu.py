@@ -62,7 +62,17 @@ def conv_igemm(dref):
             off = ((n_i[ok] * Hi + iy[ok]) * Wi + ix[ok]) * d.in_ld
             x = src[off[:, None] + cidx[None, :]].astype(np.float64)
             acc[ok] += x @ w[:, kh, kw, :].astype(np.float64).T
-    if d.stats:
+    if d.stats and d.stats_kind == 1:
+        from mapping_challenge_amd import _lib
+        slices = _lib.load().msc_conv_stats_slices(dref)
+        st = _arr(d.stats, slices * Cout * 2).reshape(Cout, slices, 2)
+        yy = _rows(d.stats_y, N * Ho * Wo, Cout, d.stats_y_ld).astype(np.float64)
+        dh = acc * (yy * _arr(d.scale, Cout) + _arr(d.shift, Cout) > 0) if d.scale else acc
+        st[...] = 0
+        st[:, 0, 0] = dh.sum(0)
+        st[:, 0, 1] = (dh * yy).sum(0)
+        scale, shift = 1.0, 0.0          # the coefficients only define the mask
+    elif d.stats:
         # everything in slice 0, the other slices the real kernel would fill are zeroed
         from mapping_challenge_amd import _lib
         slices = _lib.load().msc_conv_stats_slices(dref)

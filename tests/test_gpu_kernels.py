@@ -275,3 +275,43 @@ def test_grouped_weight_gradients_equal_separate_ones(dtype, steps, cap):
     for pr, gref in zip(problems, refs):
         err = (pr[2].cpu() / 2 - gref).abs().max().item() / gref.abs().max().item()
         assert err < (2e-5 if dtype == torch.float32 else 1e-2), (pr[2].shape, err)
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('cin,cout,k,hw,n,masked', [(128, 64, 1, 16, 3, True), (64, 64, 3, 20, 2, True), (256, 128, 1, 9, 2, False)])
+def test_conv_epilogue_batchnorm_backward_sums(dtype, cin, cout, k, hw, n, masked):
+    """stats_kind 1: a (data-gradient) conv also reduces (sum dh, sum dh*y), dh = out * [scale*y + shift > 0], per channel --
+    what msc_bn_bwd_reduce would compute from the stored tensors; every configuration"""
+    import ctypes as C
+    from mapping_challenge_amd import _lib, ops
+    lib = _lib.load()
+    pad = k // 2
+    x = rnd((n, cin, hw, hw), dtype, 1)
+    w = rnd((cout, cin, k, k), dtype, 2, (2.0 / (cin * k * k)) ** 0.5)
+    y = rnd((n, cout, hw, hw), dtype, 3)
+    scale, shift = rnd((cout,), torch.float32, 4), rnd((cout,), torch.float32, 5) * 0.3
+    ref = F.conv2d(x, w, padding=pad)
+    m = ((y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) > 0).float() if masked else torch.ones_like(y)
+    e1, e2 = (ref * m).sum((0, 2, 3)), (ref * m * y).sum((0, 2, 3))
+    xd, yd = nhwc(x, dtype), nhwc(y, dtype)
+    wk = w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    out = torch.empty((n, hw, hw, cout), dtype=dtype, device='cuda')
+    sc, sh = scale.cuda(), shift.cuda()
+    for c in ops.conv_valid_cfgs(xd, wk, out, 1, pad):
+        d = ops.ConvDesc()
+        d.in_, d.wt, d.out = xd.data_ptr(), wk.data_ptr(), out.data_ptr()
+        d.in_ld, d.out_ld, d.dtype, d.mode = cin, cout, ops._dt(xd), 0
+        d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.cfg = n, hw, hw, cin, hw, hw, cout, k, k, 1, pad, c
+        d.stats_kind, d.stats_y, d.stats_y_ld = 1, yd.data_ptr(), cout
+        if masked:
+            d.scale, d.shift = sc.data_ptr(), sh.data_ptr()
+        d.stats = 1
+        slices = lib.msc_conv_stats_slices(C.byref(d))
+        stats = torch.zeros((cout, slices, 2), dtype=torch.float32, device='cuda')
+        d.stats = stats.data_ptr()
+        out.zero_()
+        _lib.check(lib.msc_conv_igemm(C.byref(d), torch.cuda.current_stream().cuda_stream), 'conv')
+        assert torch.allclose(to_nchw(out), ref, **tol(dtype)), c          # the coefficients do not touch the output
+        s = stats.sum(1).cpu()
+        t = dict(rtol=2e-3, atol=5e-2) if dtype == torch.float32 else dict(rtol=2e-2, atol=0.5)
+        assert torch.allclose(s[:, 0], e1, **t) and torch.allclose(s[:, 1], e2, **t), c
