@@ -156,6 +156,9 @@ int msc_relu_bwd(const void* dy, int64_t dy_ld, const void* y, int64_t y_ld, voi
  * workspace: msc_bias_grad_workspace_bytes() bytes */
 int64_t msc_bias_grad_workspace_bytes(int64_t pixels, int C, int dtype);
 int msc_bias_grad(const void* dy, int64_t dy_ld, float* db, void* workspace, int dtype, int64_t pixels, int C, void* stream);
+/* both in one pass over the tensors: dx = dy*[y>0] (dx may alias dy) and db[c] += sum_pixels dx[p][c]; same workspace */
+int msc_relu_bias_grad(const void* dy, int64_t dy_ld, const void* y, int64_t y_ld, void* dx, int64_t dx_ld, float* db,
+                       void* workspace, int dtype, int64_t pixels, int C, void* stream);
 
 /* final 1x1 conv 32 -> 2 with bias (src/unet_models.py:383,403; dropout p = 0) fused with the channel softmax
  * the reference applies on the host afterwards (src/models.py:88-92, src/utils.py:231-273).

@@ -76,6 +76,7 @@ SIGNATURES = {
     'msc_relu_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i64, _i, _vp]),
     'msc_bias_grad_workspace_bytes': (_i64, [_i64, _i, _i]),
     'msc_bias_grad': (_i, [_vp, _i64, _vp, _vp, _i, _i64, _i, _vp]),
+    'msc_relu_bias_grad': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i64, _i, _vp]),
     'msc_final_fwd': (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'msc_final_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'msc_loss_sums': (_i, [_vp, _vp, _i, C.POINTER(LossCfg), _vp, _i, _i, _i, _vp]),

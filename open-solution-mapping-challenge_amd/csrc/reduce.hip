@@ -19,7 +19,7 @@ template <typename T, int K>
 __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ dout, long dout_ld, const T* __restrict__ out, long out_ld,
                                                         const T* __restrict__ y, long y_ld, int relu, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, float* __restrict__ partials,
-                                                        long pixels, int C, int cols, int S, int ppb) {
+                                                        long pixels, int C, int cols, int S, int ppb, T* __restrict__ dx, long dx_ld) {
     constexpr int CE = Vec16<T>::N;
     __shared__ float red[256 * K * CE];
     const int tid = threadIdx.x;
@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ do
 #pragma unroll
                 for (int e = 0; e < CE; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
             }
+            if (K == 1 && dx) Vec16<T>::store(dx + p * dx_ld + vc * CE, d);      // the masked gradient itself (ReLU backward)
             if (K == 2) {
                 float yy[CE];
                 Vec16<T>::load(y + p * y_ld + vc * CE, yy);
@@ -178,12 +179,13 @@ bool red_geom(long pixels, int C, int ce, RedGeom* g) {
 
 template <typename T, int K>
 int launch_colreduce(const void* dout, long dout_ld, const void* out, long out_ld, const void* y, long y_ld, int relu,
-                     const float* scale, const float* shift, float* partials, long pixels, int C, hipStream_t st) {
+                     const float* scale, const float* shift, float* partials, long pixels, int C, hipStream_t st,
+                     void* dx = nullptr, long dx_ld = 0) {
     RedGeom g;
     if (!red_geom(pixels, C, Vec16<T>::N, &g)) return msc_fail(MSC_ERR_UNSUPPORTED, "column reduce: C=%d not supported", C);
     dim3 grid(g.S, g.chunks);
     hipLaunchKernelGGL((colreduce_kernel<T, K>), grid, dim3(256), 0, st, (const T*)dout, dout_ld, (const T*)out, out_ld, (const T*)y, y_ld,
-                       relu, scale, shift, partials, pixels, C, g.cols, g.S, g.ppb);
+                       relu, scale, shift, partials, pixels, C, g.cols, g.S, g.ppb, (T*)dx, dx_ld);
     return msc_check_launch("colreduce");
 }
 
@@ -245,4 +247,19 @@ extern "C" int msc_bias_grad(const void* dy, int64_t dy_ld, float* db, void* wor
     red_geom(pixels, C, dtype == MSC_BF16 ? 8 : 4, &g);
     hipLaunchKernelGGL(bias_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, g.S, C, db);
     return msc_check_launch("msc_bias_grad");
+}
+
+extern "C" int msc_relu_bias_grad(const void* dy, int64_t dy_ld, const void* y, int64_t y_ld, void* dx, int64_t dx_ld, float* db,
+                                  void* workspace, int dtype, int64_t pixels, int C, void* stream) {
+    DT_CHECK("msc_relu_bias_grad", dtype);
+    if (!dy || !y || !dx || !db || !workspace || pixels <= 0) return msc_fail(MSC_ERR_ARG, "msc_relu_bias_grad: bad argument");
+    if (C % (dtype == MSC_BF16 ? 32 : 16)) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_relu_bias_grad: C=%d must be a multiple of %d", C, dtype == MSC_BF16 ? 32 : 16);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = dtype == MSC_BF16 ? launch_colreduce<bf16_t, 1>(dy, dy_ld, y, y_ld, nullptr, 0, 1, nullptr, nullptr, (float*)workspace, pixels, C, st, dx, dx_ld)
+                               : launch_colreduce<float, 1>(dy, dy_ld, y, y_ld, nullptr, 0, 1, nullptr, nullptr, (float*)workspace, pixels, C, st, dx, dx_ld);
+    if (rc) return rc;
+    RedGeom g;
+    red_geom(pixels, C, dtype == MSC_BF16 ? 8 : 4, &g);
+    hipLaunchKernelGGL(bias_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, g.S, C, db);
+    return msc_check_launch("msc_relu_bias_grad");
 }

@@ -882,9 +882,11 @@ class _Builder:
         net, lib, P, bwd = self.net, self.lib, self.prog, self.prog.bwd
         dout = self.grad_of(out)
         count = out.pixels
-        if not masked:   # dmask = dout * [out > 0], in place: `out` has exactly one consumer
-            self.emit(bwd, lib.msc_relu_bwd, dout.ptr, dout.ld, out.ptr, out.ld, dout.ptr, dout.ld, 0, self.dt, count, out.C)
-        self.emit(bwd, lib.msc_bias_grad, dout.ptr, dout.ld, self.g(conv.bias), self.bias_ws(count, out.C), self.dt, count, out.C)
+        if not masked:   # dmask = dout * [out > 0], in place (`out` has exactly one consumer), and the bias gradient in the same pass
+            self.emit(bwd, lib.msc_relu_bias_grad, dout.ptr, dout.ld, out.ptr, out.ld, dout.ptr, dout.ld, self.g(conv.bias),
+                      self.bias_ws(count, out.C), self.dt, count, out.C)
+        else:
+            self.emit(bwd, lib.msc_bias_grad, dout.ptr, dout.ld, self.g(conv.bias), self.bias_ws(count, out.C), self.dt, count, out.C)
         self.wgrad(bwd, dout, x, self.g(conv.weight), 3, 3, 1, 1)
         gx = self.grad_of(x)
         acc = self.grad_acc(x)
@@ -902,8 +904,8 @@ class _Builder:
         dout = self.grad_of(out)
         count = out.pixels
         dm = self.act(out.H, out.W, out.C)           # compact masked gradient (dout may be a slice of a concat)
-        self.emit(bwd, lib.msc_relu_bwd, dout.ptr, dout.ld, out.ptr, out.ld, dm.ptr, dm.ld, 0, self.dt, count, out.C)
-        self.emit(bwd, lib.msc_bias_grad, dm.ptr, dm.ld, self.g(deconv.bias), self.bias_ws(count, out.C), self.dt, count, out.C)
+        self.emit(bwd, lib.msc_relu_bias_grad, dout.ptr, dout.ld, out.ptr, out.ld, dm.ptr, dm.ld, self.g(deconv.bias),
+                  self.bias_ws(count, out.C), self.dt, count, out.C)
         # dW[ci][kh][kw][co] = sum_coarse x[c][ci] * dm[2c-1+k][co]
         self.wgrad(bwd, x, dm, self.g(deconv.weight), 4, 4, 2, 1)
         gx = self.grad_of(x)

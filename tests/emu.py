@@ -259,6 +259,11 @@ def relu_bwd(dy, dy_ld, y, y_ld, dx, dx_ld, accumulate, dtype, pixels, Cc):
     dst[...] = dst + d if accumulate else d
 
 
+def relu_bias_grad(dy, dy_ld, y, y_ld, dx, dx_ld, db, workspace, dtype, pixels, Cc):
+    relu_bwd(dy, dy_ld, y, y_ld, dx, dx_ld, 0, dtype, pixels, Cc)
+    bias_grad(dx, dx_ld, db, workspace, dtype, pixels, Cc)
+
+
 def bias_grad(dy, dy_ld, db, workspace, dtype, pixels, Cc):
     _arr(db, Cc)[...] += _rows(dy, pixels, Cc, dy_ld).astype(np.float64).sum(0)
 
@@ -294,7 +299,7 @@ TABLE = {'msc_conv_igemm': conv_igemm, 'msc_conv_wgrad': conv_wgrad, 'msc_pack_c
          'msc_stem_prepare': stem_prepare, 'msc_maxpool2_fwd': maxpool2_fwd, 'msc_maxpool2_bwd': maxpool2_bwd,
          'msc_bn_finalize': bn_finalize, 'msc_bn_fold': bn_fold, 'msc_bn_apply': bn_apply,
          'msc_bn_bwd_reduce': bn_bwd_reduce, 'msc_bn_bwd_finalize': bn_bwd_finalize, 'msc_bn_bwd_apply': bn_bwd_apply,
-         'msc_relu_bwd': relu_bwd, 'msc_bias_grad': bias_grad, 'msc_final_fwd': final_fwd, 'msc_final_bwd': final_bwd}
+         'msc_relu_bwd': relu_bwd, 'msc_bias_grad': bias_grad, 'msc_relu_bias_grad': relu_bias_grad, 'msc_final_fwd': final_fwd, 'msc_final_bwd': final_bwd}
 
 
 def run(launches, stream=None):
