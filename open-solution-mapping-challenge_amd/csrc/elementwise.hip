@@ -287,52 +287,6 @@ __global__ void final_fwd_kernel(const T* __restrict__ in, long in_ld, const flo
     }
 }
 
-// C == CC known at compile time (the network's 32 filters): the weight-gradient partial sums stay in registers over all
-// the pixels a lane visits and are reduced across the wavefront once, instead of 2*C wave reductions per pixel
-template <typename T, int CC>
-__global__ void final_bwd_fixed_kernel(const float* __restrict__ dlogits, const T* __restrict__ in, long in_ld,
-                                       const float* __restrict__ w, T* __restrict__ din, long din_ld,
-                                       float* __restrict__ dw, float* __restrict__ db, int N, long HW) {
-    constexpr int CE = Vec16<T>::N;
-    __shared__ float sw[2 * CC];
-    __shared__ float acc[2 * CC + 2];
-    for (int i = threadIdx.x; i < 2 * CC; i += blockDim.x) sw[i] = w[i];
-    for (int i = threadIdx.x; i < 2 * CC + 2; i += blockDim.x) acc[i] = 0.f;
-    __syncthreads();
-    const long total = (long)N * HW;
-    const int lane = threadIdx.x & 63;
-    float a0[CC], a1[CC], g0s = 0.f, g1s = 0.f;
-#pragma unroll
-    for (int c = 0; c < CC; ++c) { a0[c] = 0.f; a1[c] = 0.f; }
-    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
-        const long n = p / HW, hw = p - n * HW;
-        const float g0 = dlogits[(n * 2) * HW + hw], g1 = dlogits[(n * 2 + 1) * HW + hw];
-        g0s += g0; g1s += g1;
-#pragma unroll
-        for (int c = 0; c < CC; c += CE) {
-            float v[CE], d[CE];
-            Vec16<T>::load(in + p * in_ld + c, v);
-#pragma unroll
-            for (int e = 0; e < CE; ++e) {
-                d[e] = v[e] > 0.f ? g0 * sw[c + e] + g1 * sw[CC + c + e] : 0.f;      // dec0's ReLU (src/unet_models.py:401)
-                a0[c + e] = fmaf(g0, v[e], a0[c + e]);
-                a1[c + e] = fmaf(g1, v[e], a1[c + e]);
-            }
-            Vec16<T>::store(din + p * din_ld + c, d);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < CC; ++c) {
-        const float t0 = wave_sum(a0[c]), t1 = wave_sum(a1[c]);
-        if (lane == 0) { atomicAdd(&acc[c], t0); atomicAdd(&acc[CC + c], t1); }
-    }
-    g0s = wave_sum(g0s); g1s = wave_sum(g1s);
-    if (lane == 0) { atomicAdd(&acc[2 * CC], g0s); atomicAdd(&acc[2 * CC + 1], g1s); }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * CC; i += blockDim.x) atomicAdd(dw + i, acc[i]);
-    if (threadIdx.x < 2 && db) atomicAdd(db + threadIdx.x, acc[2 * CC + threadIdx.x]);
-}
-
 template <typename T>
 __global__ void final_bwd_kernel(const float* __restrict__ dlogits, const T* __restrict__ in, long in_ld,
                                  const float* __restrict__ w, T* __restrict__ din, long din_ld,
@@ -624,11 +578,6 @@ extern "C" int msc_final_bwd(const float* dlogits, const void* in, int64_t in_ld
     const size_t shm = (4 * C + 2) * sizeof(float);
     long blocks = ((long)N * hw + EW_THREADS - 1) / EW_THREADS;
     if (blocks > 1024) blocks = 1024;
-    if (C == 32) {
-        if (dtype == MSC_BF16) hipLaunchKernelGGL((final_bwd_fixed_kernel<bf16_t, 32>), dim3((int)blocks), dim3(EW_THREADS), 0, st, dlogits, (const bf16_t*)in, (long)in_ld, w, (bf16_t*)din, (long)din_ld, dw, db, N, hw);
-        else hipLaunchKernelGGL((final_bwd_fixed_kernel<float, 32>), dim3((int)blocks), dim3(EW_THREADS), 0, st, dlogits, (const float*)in, (long)in_ld, w, (float*)din, (long)din_ld, dw, db, N, hw);
-        return msc_check_launch("msc_final_bwd");
-    }
     if (dtype == MSC_BF16) hipLaunchKernelGGL(final_bwd_kernel<bf16_t>, dim3((int)blocks), dim3(EW_THREADS), shm, st, dlogits, (const bf16_t*)in, (long)in_ld, w, (bf16_t*)din, (long)din_ld, dw, db, N, hw, C);
     else hipLaunchKernelGGL(final_bwd_kernel<float>, dim3((int)blocks), dim3(EW_THREADS), shm, st, dlogits, (const float*)in, (long)in_ld, w, (float*)din, (long)din_ld, dw, db, N, hw, C);
     return msc_check_launch("msc_final_bwd");
