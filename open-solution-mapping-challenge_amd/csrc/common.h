@@ -56,14 +56,16 @@ template <> struct Vec16<float> {
         float4 t = *reinterpret_cast<const float4*>(p);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
+    static __device__ __forceinline__ void unpack(uint4 t, float* v) {      // a raw 16-byte load, converted later
+        v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+    }
     static __device__ __forceinline__ void store(float* p, const float* v) {
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     }
 };
 template <> struct Vec16<bf16_t> {
     static constexpr int N = 8;
-    static __device__ __forceinline__ void load(const bf16_t* p, float* v) {
-        uint4 t = *reinterpret_cast<const uint4*>(p);
+    static __device__ __forceinline__ void unpack(uint4 t, float* v) {
         uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -71,6 +73,7 @@ template <> struct Vec16<bf16_t> {
             v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
         }
     }
+    static __device__ __forceinline__ void load(const bf16_t* p, float* v) { unpack(*reinterpret_cast<const uint4*>(p), v); }
     static __device__ __forceinline__ void store(bf16_t* p, const float* v) {
         uint4 t;
         t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]);

@@ -120,6 +120,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
     for (int j = 0; j < NV; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
     T* out = reinterpret_cast<T*>(p.out);
     const T* res = reinterpret_cast<const T*>(p.res);
+    // the tensor the epilogue reads (residual / BatchNorm-backward y) is fetched for all fragments before the first use --
+    // nothing else is left to hide its latency behind -- where the wave tile is small enough to afford the registers
+    constexpr bool PRE = FN * (NV / CE) <= 2;
+    const T* side = bnb ? reinterpret_cast<const T*>(p.sy) : res;
+    const long side_ld = bnb ? p.sy_ld : p.res_ld;
+    uint4 pre[PRE ? FN : 1][PRE ? NV / CE : 1];
+    if (PRE && side) {
+#pragma unroll
+        for (int b = 0; b < FN; ++b) {
+            const int m = m0 + wp * WTP + b * 16 + pl;
+            if (m < p.M) {
+                long opix = m;
+                if (MODE) {
+                    const int n = m / (p.Hq * p.Wq);
+                    const int rem = m - n * (p.Hq * p.Wq);
+                    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+                    opix = ((long)n * p.Ho + 2 * qy + py) * p.Wo + 2 * qx + px;
+                }
+#pragma unroll
+                for (int j = 0; j < NV; j += CE) pre[PRE ? b : 0][PRE ? j / CE : 0] = *reinterpret_cast<const uint4*>(side + opix * side_ld + cb + j);
+            }
+        }
+    }
 #pragma unroll
     for (int b = 0; b < FN; ++b) {
         const int m = m0 + wp * WTP + b * 16 + pl;
@@ -133,11 +156,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
             for (int j = 0; j < NV; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
         }
         if (bnb && m < p.M) {          // (sum dh, sum dh*y), dh = dout * [scale*y + shift > 0] (no mask without scale)
-            const T* sy = reinterpret_cast<const T*>(p.sy);
 #pragma unroll
             for (int j = 0; j < NV; j += CE) {
                 float yv[CE];
-                Vec16<T>::load(sy + (long)m * p.sy_ld + cb + j, yv);
+                if (PRE) Vec16<T>::unpack(pre[PRE ? b : 0][PRE ? j / CE : 0], yv);
+                else Vec16<T>::load(side + (long)m * side_ld + cb + j, yv);
 #pragma unroll
                 for (int e = 0; e < CE; ++e) {
                     const float dh = (!p.scale || fmaf(yv[e], sc[j + e], sh[j + e]) > 0.f) ? v[j + e] : 0.f;
@@ -162,7 +185,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
 #pragma unroll
                 for (int j = 0; j < NV; j += CE) {
                     float rv[CE];
-                    Vec16<T>::load(res + opix * p.res_ld + cb + j, rv);
+                    if (PRE) Vec16<T>::unpack(pre[PRE ? b : 0][PRE ? j / CE : 0], rv);
+                    else Vec16<T>::load(res + opix * p.res_ld + cb + j, rv);
 #pragma unroll
                     for (int e = 0; e < CE; ++e) v[j + e] += rv[e];
                 }
