@@ -43,8 +43,6 @@ int msc_abi_version(void);
  *   is the gradient w.r.t. a BatchNorm+ReLU layer's activation, stats_y that layer's pre-BN tensor (same shape as
  *   out), scale/shift its forward coefficients (used for the ReLU mask only, NULL = no ReLU; no affine is applied):
  *   stats[c][slice] = (sum dh, sum dh*y), dh = acc*[scale*y+shift > 0].  Same layout, feeds msc_bn_bwd_finalize.
- *   stats_kind 2: the layer has a residual input, so its mask is [stats_mask > 0] (its stored output); `res` may
- *   be given (this launch is the last of several writers accumulating the gradient): dh = (acc+res)*[mask].
  * weights: dtype [Cout][KH][KW][Cin].  Cin*sizeof(dtype) % 64 == 0, Cout % 32 == 0. */
 typedef struct msc_conv_desc {
     const void* in;
@@ -61,8 +59,6 @@ typedef struct msc_conv_desc {
     int32_t stats_kind;
     const void* stats_y;
     int64_t stats_y_ld;
-    const void* stats_mask;
-    int64_t stats_mask_ld;
 } msc_conv_desc;
 int msc_conv_igemm(const msc_conv_desc* d, void* stream);
 int msc_conv_stats_slices(const msc_conv_desc* d);   /* depends on d->cfg */

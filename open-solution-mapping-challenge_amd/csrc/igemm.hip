@@ -47,8 +47,7 @@ namespace {
 struct ConvK {
     const char* in; const char* wt; char* out; const char* res;
     const float* scale; const float* shift; float* stats;
-    const char* sy; long sy_ld; int stats_kind;     // stats_kind 1/2: BatchNorm-backward sums against the tensor sy
-    const char* sm; long sm_ld;                     // stats_kind 2: ReLU mask = [sm > 0]
+    const char* sy; long sy_ld; int stats_kind;     // stats_kind 1: BatchNorm-backward sums against the tensor sy
     long in_ld, out_ld, res_ld;
     int N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, flip, relu;
     int M, Hq, Wq;
@@ -107,11 +106,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
                                               int mtile, int ntm) {
     constexpr int NV = FM * 4;
     constexpr int CE = 16 / (int)sizeof(T);
-    // stats_kind 1/2 (a data-gradient conv that also produces the BatchNorm-backward sums of the layer whose output
-    // gradient it completes): kind 1 -- scale/shift are that layer's forward coefficients, used for the ReLU mask only;
-    // kind 2 -- the mask is [sm > 0] (a layer with a residual input), and this launch may be the accumulating last writer
-    const bool bnb = p.stats && p.stats_kind != 0;
-    const bool mask_t = bnb && p.stats_kind == 2;
+    // stats_kind 1 (a data-gradient conv that also produces the BatchNorm-backward sums of the layer whose output
+    // gradient it writes): scale/shift are that layer's forward coefficients, used for the ReLU mask only
+    const bool bnb = p.stats && p.stats_kind == 1;
     float sc[NV], sh[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -158,6 +155,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
 #pragma unroll
             for (int j = 0; j < NV; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
         }
+        if (bnb && m < p.M) {          // (sum dh, sum dh*y), dh = dout * [scale*y + shift > 0] (no mask without scale)
+#pragma unroll
+            for (int j = 0; j < NV; j += CE) {
+                float yv[CE];
+                if (PRE) Vec16<T>::unpack(pre[PRE ? b : 0][PRE ? j / CE : 0], yv);
+                else Vec16<T>::load(side + (long)m * side_ld + cb + j, yv);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) {
+                    const float dh = (!p.scale || fmaf(yv[e], sc[j + e], sh[j + e]) > 0.f) ? v[j + e] : 0.f;
+                    s1[j + e] += dh;
+                    s2[j + e] += dh * yv[e];
+                }
+            }
+        }
         if (m < p.M) {
             long opix = m;
             if (MODE) {
@@ -174,26 +185,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
 #pragma unroll
                 for (int j = 0; j < NV; j += CE) {
                     float rv[CE];
-                    if (PRE && !bnb) Vec16<T>::unpack(pre[PRE ? b : 0][PRE ? j / CE : 0], rv);
+                    if (PRE) Vec16<T>::unpack(pre[PRE ? b : 0][PRE ? j / CE : 0], rv);
                     else Vec16<T>::load(res + opix * p.res_ld + cb + j, rv);
 #pragma unroll
                     for (int e = 0; e < CE; ++e) v[j + e] += rv[e];
-                }
-            }
-            if (bnb) {       // (sum dh, sum dh*y) of the finished gradient, dh = v * [mask]  (mode 0 only: opix == m)
-#pragma unroll
-                for (int j = 0; j < NV; j += CE) {
-                    float yv[CE], mv[CE];
-                    if (PRE) Vec16<T>::unpack(pre[PRE ? b : 0][PRE ? j / CE : 0], yv);
-                    else Vec16<T>::load(side + (long)m * side_ld + cb + j, yv);
-                    if (mask_t) Vec16<T>::load(reinterpret_cast<const T*>(p.sm) + (long)m * p.sm_ld + cb + j, mv);
-#pragma unroll
-                    for (int e = 0; e < CE; ++e) {
-                        const bool keep = mask_t ? mv[e] > 0.f : (!p.scale || fmaf(yv[e], sc[j + e], sh[j + e]) > 0.f);
-                        const float dh = keep ? v[j + e] : 0.f;
-                        s1[j + e] += dh;
-                        s2[j + e] += dh * yv[e];
-                    }
                 }
             }
             if (p.relu) {
@@ -1067,14 +1062,9 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
     k->in = (const char*)d->in; k->wt = (const char*)d->wt; k->out = (char*)d->out; k->res = (const char*)d->res;
     k->scale = d->scale; k->shift = d->shift; k->stats = d->stats;
     k->sy = (const char*)d->stats_y; k->sy_ld = d->stats_y_ld; k->stats_kind = d->stats ? d->stats_kind : 0;
-    k->sm = (const char*)d->stats_mask; k->sm_ld = d->stats_mask_ld;
-    if (k->stats_kind < 0 || k->stats_kind > 2) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: stats_kind %d", d->stats_kind);
-    if (k->stats_kind && (!d->stats_y || d->relu || (d->stats_y_ld * es) % 16 || ((uintptr_t)d->stats_y & 15)))
-        return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: BatchNorm-backward statistics need stats_y (16-byte aligned) and no ReLU");
-    if (k->stats_kind == 1 && (!d->scale != !d->shift))
-        return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: stats_kind 1: scale and shift go together");
-    if (k->stats_kind == 2 && (!d->stats_mask || d->scale || d->shift || (d->stats_mask_ld * es) % 16 || ((uintptr_t)d->stats_mask & 15)))
-        return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: stats_kind 2 needs stats_mask (16-byte aligned) and no scale/shift");
+    if (k->stats_kind < 0 || k->stats_kind > 1) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: stats_kind %d", d->stats_kind);
+    if (k->stats_kind == 1 && (!d->stats_y || d->res || d->relu || (d->stats_y_ld * es) % 16 || ((uintptr_t)d->stats_y & 15) || !d->scale != !d->shift))
+        return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: BatchNorm-backward statistics need stats_y (16-byte aligned), no residual, no ReLU");
     k->in_ld = d->in_ld; k->out_ld = d->out_ld; k->res_ld = d->res_ld;
     k->N = d->N; k->Hi = d->Hi; k->Wi = d->Wi; k->Cin = d->Cin; k->Ho = d->Ho; k->Wo = d->Wo; k->Cout = d->Cout;
     k->KH = d->KH; k->KW = d->KW; k->stride = d->stride; k->pad = d->pad; k->flip = d->flip; k->relu = d->relu;

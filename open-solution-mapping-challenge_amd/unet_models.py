@@ -591,8 +591,8 @@ class _Builder:
         self.group_steps = int(env.get('MSC_WGRAD_GROUP_STEPS', '64'))
         self.group_tile = int(env.get('MSC_WGRAD_GROUP_TILE', '128'))
         self.pending = []             # deferred (WgradDesc, gradient address or None)
-        self.glast = {}               # activation slice -> ConvDesc of the mode-0 dgrad conv that was the LAST launch to write
-                                      # its gradient so far (None: the last writer is something else)
+        self.gcount = {}              # activation slice -> number of launches that write its gradient
+        self.gwriter = {}             # activation slice -> ConvDesc of the (mode 0, no residual) dgrad conv that wrote it first
         self.fuse_bn_bwd = _os_env.environ.get('MSC_FUSE_BN_BWD', '1') != '0'
 
     # ---- memory
@@ -643,10 +643,7 @@ class _Builder:
         """1 if the gradient slice was already written during this backward (-> accumulate), else
         marks it (and every registered sub-slice it covers) written and returns 0."""
         key = (id(a.buf), a.c0, a.C)
-        self.glast[key] = None                       # the caller is the newest writer; conv writers register themselves after
-        for (c0, C) in self.slices.get(id(a.buf), ()):
-            if c0 >= a.c0 and c0 + C <= a.c0 + a.C:
-                self.glast[(id(a.buf), c0, C)] = None
+        self.gcount[key] = self.gcount.get(key, 0) + 1
         if key in self.gwritten:
             return 1
         self.gwritten.add(key)
@@ -828,17 +825,12 @@ class _Builder:
         # anyway (mode 2) instead of reading `out` (mode 1)
         mask = 0 if not relu else (1 if res is not None else 2)
         gkey = (id(out.buf), out.c0, out.C)      # grad_acc() keys gradient slices by their activation
-        wd = self.glast.get(gkey) if self.fuse_bn_bwd else None
+        wd = self.gwriter.get(gkey) if (self.fuse_bn_bwd and mask != 1 and self.gcount.get(gkey, 0) == 1) else None
         if wd is not None:
-            # the launch that completed dout earlier in this backward is a data-gradient conv: its epilogue also reduces
-            # (sum dh, sum dh*y) per tile (of acc + what earlier writers left, if it accumulates), so the column-reduce
-            # pass over dout, y and out is not launched
-            wd.stats_y, wd.stats_y_ld = y.ptr, y.ld
-            if mask == 1:
-                wd.stats_kind, wd.stats_mask, wd.stats_mask_ld = 2, out.ptr, out.ld
-            else:
-                wd.stats_kind = 1
-                wd.scale, wd.shift = (scale.data_ptr(), shift.data_ptr()) if mask == 2 else (None, None)
+            # dout has exactly one writer, a data-gradient conv that ran earlier in this backward: its epilogue also
+            # reduces (sum dh, sum dh*y) per tile, so the column-reduce pass over dout and y is not launched
+            wd.stats_kind, wd.stats_y, wd.stats_y_ld = 1, y.ptr, y.ld
+            wd.scale, wd.shift = (scale.data_ptr(), shift.data_ptr()) if mask == 2 else (None, None)
             wd.stats = 1                     # any non-null value: the slice count depends on it being requested
             blocks = lib.msc_conv_stats_slices(C.byref(wd))
             if blocks <= 0:
@@ -874,7 +866,8 @@ class _Builder:
         k = geo['KH']
         if geo['stride'] == 1:
             d = self.conv(bwd, dy, wt, gx, KH=k, KW=k, stride=1, pad=geo['pad'], flip=1, res=gx if acc else None)
-            self.glast[(id(x.buf), x.c0, x.C)] = d
+            if not acc:
+                self.gwriter[(id(x.buf), x.c0, x.C)] = d
         else:
             self.conv(bwd, dy, wt, gx, KH=k, KW=k, stride=2, pad=geo['pad'], mode=1, res=gx if acc else None)
 
