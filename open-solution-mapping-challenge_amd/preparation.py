@@ -1,6 +1,7 @@
 """Target preparation before the hot path: the per-image body of the reference's `overlay_masks`
-(`src/preparation.py:18-99`, called from `src/pipeline_manager.py:68-85`) on the device, for the shipped
-configuration `erode_selem_size = dilate_selem_size = 0` (`neptune.yaml:69-70`).
+(`src/preparation.py:18-99`, called from `src/pipeline_manager.py:68-85`) on the device, for
+`erode_selem_size = 0` -- the shipped and the reproduce configuration (`neptune.yaml:69`,
+`REPRODUCE_RESULTS.md:117`), in which `dilate_selem_size` plays no part (`src/preparation.py:57-60`).
 
 The reference builds one full-image Euclidean distance transform per building, stacks them with `np.dstack`
 and sorts the stack per pixel (O(buildings x H x W) host memory and time, `src/preparation.py:146-163`), then
@@ -59,9 +60,9 @@ def prepare_targets(masks, category_nr=None, border_width=0, erode=0, dilate=0, 
     reference writes to masks/, distances/ and sizes/.  return_details adds (second_nearest f64, kept i32[n])."""
     if erode < 0 or dilate < 0:
         raise ValueError('erode and dilate cannot be negative')                   # src/preparation.py:54-55
-    if erode or dilate:
-        raise NotImplementedError('HIP target preparation implements the shipped configuration erode = dilate = 0 '
-                                  '(neptune.yaml:69-70); the eroded / dilated variants (src/preparation.py:121-143) are not built')
+    if erode:          # erode == 0 takes the plain overlay whatever `dilate` is (src/preparation.py:57-60)
+        raise NotImplementedError('HIP target preparation implements erode_selem_size = 0 (neptune.yaml:69, REPRODUCE_RESULTS.md:117); '
+                                  'the eroded / eroded+dilated variants (src/preparation.py:61-77,121-143) are not built')
     lib = _lib.load()
     dev = _device()
     m = torch.as_tensor(masks)

@@ -50,5 +50,7 @@ def test_size_matrix_and_argument_errors():
         assert got.dtype == np.int64 and (got == prep_ref.get_size_matrix(m)).all()
     with pytest.raises(NotImplementedError):
         preparation.prepare_targets(np.zeros((1, 8, 8), np.uint8), erode=3)
+    ov, _, _ = preparation.prepare_targets(np.zeros((1, 8, 8), np.uint8), erode=0, dilate=2)       # plain path (:57-60)
+    assert not ov.any()
     with pytest.raises(ValueError):
         preparation.prepare_targets(np.zeros((1, 8, 8), np.uint8), erode=-1)
