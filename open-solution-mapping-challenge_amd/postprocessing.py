@@ -134,12 +134,22 @@ def _to_host(t):
     return h.numpy()
 
 
+def postprocess_device(probs, target_size=None, erode_selem_size=0, dilate_selem_size=0, category_layers=CATEGORY_LAYERS):
+    """postprocess_batch without the final copy of the label images: returns (labels cuda i32 [B,L,H,W], per-image
+    per-layer score lists) -- for consumers that stay on the device (utils.annotations_from_probabilities)."""
+    return _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, category_layers, to_host=False)
+
+
 def postprocess_batch(probs, target_size=None, erode_selem_size=0, dilate_selem_size=0, category_layers=CATEGORY_LAYERS):
     """The six Steps of `mask_postprocessing` (src/pipelines.py:248-304) for a whole batch on the device.
 
     probs: cuda f32 [B,2,h,w] softmax maps.  Returns the reference's `images_with_scores` list:
     [(labels i32 [L,H,W], [[score, ...] per layer]), ...] (numpy / python floats, one D2H at the end).
     """
+    return _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, category_layers, to_host=True)
+
+
+def _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, category_layers, to_host):
     if not probs.is_cuda:
         probs = probs.to(_device())
     probs = probs.contiguous().float()
@@ -163,15 +173,17 @@ def postprocess_batch(probs, target_size=None, erode_selem_size=0, dilate_selem_
         sl = lab4[:, :n_scored].contiguous().view(B * n_scored, H, W)
         sp = p[:, :n_scored].contiguous().view(B * n_scored, H, W)
         scores_h = score_batch(sl, sp, max_labels).cpu().numpy().reshape(B, n_scored, max_labels)
-    labels_h = _to_host(lab4)
-    out = []
+    scores = []
     for b in range(B):
         total = []
         for l in range(n_scored):
             n = int(counts_h[b, l])
             total.append([float(v) for v in scores_h[b, l, :n]] if n else [])
-        out.append((labels_h[b], total))
-    return out
+        scores.append(total)
+    if not to_host:
+        return lab4, scores
+    labels_h = _to_host(lab4)
+    return [(labels_h[b], scores[b]) for b in range(B)]
 
 
 # ------------------------------------------------------------------ reference-signature functions

@@ -139,6 +139,30 @@ def bounding_box_from_rle(rle):
     return [float(xs), float(ys), float(xe - xs + 1), float(ye - ys + 1)]
 
 
+def annotations_from_probabilities(image_ids, probs, category_ids, category_layers, target_size=None, erode_selem_size=0,
+                                   dilate_selem_size=0):
+    """The inference tail without a host round trip: softmax maps (cuda f32 [B,2,h,w]) -> mask_postprocessing
+    (src/pipelines.py:248-304) -> create_annotations (src/utils.py:76-115).  The label images stay on the device
+    (they are 46 MB per 64 images, the strings a few hundred KB); the result equals
+    create_annotations(meta, postprocessing.postprocess_batch(probs, ...), ...)."""
+    from . import postprocessing as post
+    lab4, scores = post.postprocess_device(probs, target_size, erode_selem_size, dilate_selem_size, category_layers)
+    B, L, H, W = lab4.shape
+    encoded = encode_labels(lab4.view(B * L, H, W))
+    inds = np.cumsum(category_layers)
+    size = [int(H), int(W)]
+    annotations = []
+    for b, image_id in enumerate(image_ids):
+        for category_ind, category_scores in enumerate(scores[b]):          # zip(prediction, image_scores), src/utils.py:96
+            category_nr = int(np.searchsorted(inds, category_ind, side='right'))
+            if category_ids[category_nr] is None:
+                continue
+            for (counts, bbox), score in zip(_instances(encoded[b * L + category_ind], size), category_scores):
+                annotations.append({'image_id': int(image_id), 'category_id': category_ids[category_nr], 'score': score,
+                                    'segmentation': {'size': size, 'counts': counts.decode('UTF-8')}, 'bbox': bbox})
+    return annotations
+
+
 def create_annotations(meta, predictions, logger, category_ids, category_layers, save=False, experiment_dir='./', chunk=64):
     """src/utils.py:76-115.  predictions: iterable of (labelled layers int[L,H,W], per-layer score lists) as produced by
     the `score_builder` Step; images are encoded `chunk` at a time on the device."""
