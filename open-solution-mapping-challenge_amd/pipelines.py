@@ -1,5 +1,5 @@
-"""Pipeline graphs for the hot path: `unet`, `unet_weighted` and `mask_postprocessing`
-(reference: src/pipelines.py:12-52, 248-304), built from the HIP transformers.
+"""Pipeline graphs for the hot path: `unet`, `unet_weighted`, `unet_tta`, `unet_padded` and `mask_postprocessing`
+(reference: src/pipelines.py:12-155, 248-304), built from the HIP transformers.
 
 `config` has the shape of the reference's SOLUTION_CONFIG (src/pipeline_config.py:33-166): attribute or
 key access to `env.cache_dirpath`, `execution.stream_mode`, `unet`, `postprocessor.mask_erosion /
@@ -149,6 +149,88 @@ def unet_weighted(config, train_mode, loader=None, fused_postprocessing=False):
     return unet(config, train_mode, loader=loader, fused_postprocessing=fused_postprocessing, weighted=True)
 
 
+class UNetTTA(BaseTransformer):
+    """The three Steps tta_generator -> unet -> tta_aggregator of the reference's `unet_tta` (src/pipelines.py:94-116,
+    src/loaders.py:401-517) as ONE transformer around a PyTorchUNet: every batch is expanded to its flip / rot90 variants,
+    predicted, un-transformed and aggregated on the device.  Registered under the Step name 'unet', so the weights a
+    `unet` training run persisted are the ones it loads."""
+
+    def __init__(self, unet_config, tta_generator, tta_aggregator):
+        self.unet = PyTorchUNet(**unet_config)
+        self.tta = dict(tta_generator)
+        self.method = dict(tta_aggregator).get('method', 'gmean')
+
+    def fit(self, *args, **kwargs):
+        raise NotImplementedError('unet_tta is an inference pipeline (src/pipelines.py:395-401)')
+
+    def transform(self, datagen, validation_datagen=None, *args, **kwargs):
+        return self.unet.transform_tta(datagen, self.tta, self.method)
+
+    def load(self, filepath):
+        self.unet.load(filepath)
+        return self
+
+    def save(self, filepath):
+        self.unet.save(filepath)
+
+
+def _prediction_crop(model, config):
+    """src/pipelines.py:68-83 / 118-133: centre crop of the predictions (loader_mode 'crop_and_pad') + rename"""
+    cache = _get(_get(config, 'env'), 'cache_dirpath')
+    crop = Step(name='prediction_crop',
+                transformer=make_apply_transformer(partial(post.crop_image_center_per_class,
+                                                           **dict(_get(_get(config, 'postprocessor'), 'prediction_crop'))),
+                                                   output_name='cropped_images'),
+                input_steps=[model], adapter={'images': ([(model.name, 'multichannel_map_prediction')])}, cache_dirpath=cache)
+    return Step(name='prediction_renamed', transformer=Dummy(), input_steps=[crop],
+                adapter={'multichannel_map_prediction': ([(crop.name, 'cropped_images')])}, cache_dirpath=cache)
+
+
+def _inference_tail(model, config, fused_postprocessing):
+    cache = _get(_get(config, 'env'), 'cache_dirpath')
+    mode = _get(_get(config, 'execution'), 'loader_mode') if _has(_get(config, 'execution'), 'loader_mode') else 'resize'
+    if mode == 'crop_and_pad':
+        model = _prediction_crop(model, config)
+    elif mode != 'resize':
+        raise NotImplementedError('only crop_and_pad and resize options available')      # src/pipelines.py:145
+    post_step = (mask_postprocessing_fused if fused_postprocessing else mask_postprocessing)(model, config)
+    return Step(name='output', transformer=Dummy(), input_steps=[post_step],
+                adapter={'y_pred': ([(post_step.name, 'images_with_scores')])}, cache_dirpath=cache)
+
+
+def _has(cfg, key):
+    return key in cfg if isinstance(cfg, dict) else hasattr(cfg, key)
+
+
+def unet_tta(config, loader=None, fused_postprocessing=False):
+    """src/pipelines.py:94-155"""
+    if bool(_get(_get(config, 'execution'), 'stream_mode')):
+        raise Exception('TTA not available in stream mode')                                # src/pipelines.py:95-96
+    cache = _get(_get(config, 'env'), 'cache_dirpath')
+    if loader is None:
+        loader = synthetic_loader(config, _get(_get(config, 'execution'), 'batch_size_inference')
+                                  if _has(_get(config, 'execution'), 'batch_size_inference') else 32)
+    step = Step(name='unet', transformer=UNetTTA(dict(_get(config, 'unet')), _get(config, 'tta_generator'), _get(config, 'tta_aggregator')),
+                input_data=['callback_input'], input_steps=[loader], cache_dirpath=cache, is_trainable=True)
+    return _inference_tail(step, config, fused_postprocessing)
+
+
+def unet_padded(config, loader=None, fused_postprocessing=False):
+    """src/pipelines.py:55-91: plain inference whose predictions are centre-cropped (loader_mode 'crop_and_pad')"""
+    cache = _get(_get(config, 'env'), 'cache_dirpath')
+    stream = bool(_get(_get(config, 'execution'), 'stream_mode'))
+    if loader is None:
+        loader = synthetic_loader(config, 32)
+    step = Step(name='unet', transformer=(PyTorchUNetStream if stream else PyTorchUNet)(**dict(_get(config, 'unet'))),
+                input_data=['callback_input'], input_steps=[loader], cache_dirpath=cache, is_trainable=True)
+    post_step = (mask_postprocessing_fused if fused_postprocessing else mask_postprocessing)(_prediction_crop(step, config), config)
+    return Step(name='output', transformer=Dummy(), input_steps=[post_step],
+                adapter={'y_pred': ([(post_step.name, 'images_with_scores')])}, cache_dirpath=cache)
+
+
+# the scoring-model pipelines (src/pipelines.py:307-392: LightGBM/random-forest second level) are outside the hot path
 PIPELINES = {'unet': {'train': partial(unet, train_mode=True), 'inference': partial(unet, train_mode=False)},
              'unet_weighted': {'train': partial(unet_weighted, train_mode=True),
-                               'inference': partial(unet_weighted, train_mode=False)}}
+                               'inference': partial(unet_weighted, train_mode=False)},
+             'unet_tta': {'inference': unet_tta},
+             'unet_padded': {'inference': unet_padded}}
