@@ -210,6 +210,8 @@ int msc_argmax_channels(const float* probs, int32_t* out, int B, int C, int H, i
  * window offsets -((k-1)/2) .. -((k-1)/2)+k-1 on both axes, clamped border; u8 or int32 images [B,H,W] */
 int msc_erode_u8(const uint8_t* in, uint8_t* out, int B, int H, int W, int k, void* stream);
 int msc_dilate_i32(const int32_t* in, int32_t* out, int B, int H, int W, int k, void* stream);
+/* min / max over the window offsets lo..hi (lo <= 0 <= hi) on both axes, reflected border; u8 images [B,H,W] */
+int msc_rect_filter_u8(const uint8_t* in, uint8_t* out, int B, int H, int W, int lo, int hi, int is_max, void* stream);
 /* label (src/utils.py:328-330 = scipy.ndimage.label, 4-connectivity, labels 1..n in raster order of each
  * component's first pixel): mask u8 [B,H,W] (nonzero = foreground) -> int32 labels; counts[b] = n.
  * workspace: msc_label_workspace_bytes(B,H,W) bytes. */
@@ -260,13 +262,24 @@ int msc_rle_encode(const void* seg_ws, int layers, int H, int W, int nseg, void*
  * instance masks of ONE image, masks u8 [n,H,W] in annotation order, category_nr i32 [n] (NULL: all 1):
  *   mask_overlayed u8 [H,W]; distances_f16 [H,W] = float16 bits of (nearest + second nearest instance distance);
  *   second_nearest f64 [H,W] (may be NULL); kept i32 [n] (may be NULL): 0 skipped by is_on_border(mask, 2),
- *   1 used, 2 overlayed but discarded by update_distances' `dist.sum() == 0` rule.  All pointers device memory.
+ *   1 used, 2 overlayed but discarded by update_distances' `dist.sum() == 0` rule.  border_masks (may be NULL = masks):
+ *   the tensors is_on_border() is applied to.  All pointers device memory.
  * msc_prep_border: the optional border class (:73-76), in place; synchronous (needs mask.max()).
  * msc_size_matrix: get_size_matrix (:181-187) from msc_label4 labels: sizes[p] = area of p's component, 1 on
  *   background; areas = scratch i32 [B][max_labels+1]. */
 int64_t msc_prep_workspace_bytes(int n, int H, int W);
-int msc_prep_targets(const uint8_t* masks, const int32_t* category_nr, int n, int H, int W, uint8_t* mask_overlayed,
-                     uint16_t* distances_f16, double* second_nearest, int32_t* kept, void* workspace, void* stream);
+int msc_prep_targets(const uint8_t* masks, const uint8_t* border_masks, const int32_t* category_nr, int n, int H, int W,
+                     uint8_t* mask_overlayed, uint16_t* distances_f16, double* second_nearest, int32_t* kept, void* workspace,
+                     void* stream);
+/* the eroded / eroded+dilated variants (src/preparation.py:61-77,121-143,166-178): chosen[i] = binary_erosion(mask_i,
+ * rectangle(erode, erode)) if mask_i has more than small_annotations_size^2 pixels, else mask_i (dilate == 0) or
+ * binary_dilation(mask_i, rectangle(dilate, dilate)).  msc_prep_targets then takes `chosen` as masks and the
+ * annotations themselves as border_masks (is_on_border looks at the annotation).  msc_prep_paint: overlay[p] = value
+ * where mask[p] (np.where(mask, category_nr, mask_overlayed), :79). */
+int64_t msc_prep_morph_workspace_bytes(int n, int H, int W);
+int msc_prep_morph(const uint8_t* masks, int n, int H, int W, int erode, int dilate, int small_annotations_size, uint8_t* chosen,
+                   void* workspace, void* stream);
+int msc_prep_paint(uint8_t* mask_overlayed, const uint8_t* mask, int value, int H, int W, void* stream);
 int msc_prep_border(uint8_t* mask_overlayed, const double* second_nearest, double border_width, int32_t* scratch, int H, int W,
                     void* stream);
 int msc_size_matrix(const int32_t* labels, int32_t* sizes, int32_t* areas, int B, int H, int W, int max_labels, void* stream);

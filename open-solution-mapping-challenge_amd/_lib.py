@@ -100,7 +100,11 @@ SIGNATURES = {
     'msc_rle_segments': (_i, [_vp, _i, _i, _i, _vp, _i64, C.POINTER(C.c_int32), _vp]),
     'msc_rle_encode_workspace': (_i64, [_i]),
     'msc_prep_workspace_bytes': (_i64, [_i, _i, _i]),
-    'msc_prep_targets': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'msc_prep_targets': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'msc_prep_morph_workspace_bytes': (_i64, [_i, _i, _i]),
+    'msc_prep_morph': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'msc_prep_paint': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'msc_rect_filter_u8': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'msc_prep_border': (_i, [_vp, _vp, C.c_double, _vp, _i, _i, _vp]),
     'msc_size_matrix': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'msc_rle_encode': (_i, [_vp, _i, _i, _i, _i, _vp, _i64, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(_vp), C.POINTER(_vp), _vp]),

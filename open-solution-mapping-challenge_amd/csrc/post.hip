@@ -482,6 +482,16 @@ extern "C" int msc_dilate_i32(const int32_t* in, int32_t* out, int B, int H, int
     return msc_check_launch("msc_dilate_i32");
 }
 
+extern "C" int msc_rect_filter_u8(const uint8_t* in, uint8_t* out, int B, int H, int W, int lo, int hi, int is_max, void* stream) {
+    POST_DIMS("msc_rect_filter_u8");
+    if (!in || !out || in == out || lo > 0 || hi < 0 || hi >= H || hi >= W || -lo >= H || -lo >= W)
+        return msc_fail(MSC_ERR_ARG, "msc_rect_filter_u8: bad argument");
+    const dim3 g(flat_grid((long)B * H * W));
+    if (is_max) hipLaunchKernelGGL((rect_filter_kernel<uint8_t, true>), g, dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, lo, hi);
+    else hipLaunchKernelGGL((rect_filter_kernel<uint8_t, false>), g, dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, lo, hi);
+    return msc_check_launch("msc_rect_filter_u8");
+}
+
 extern "C" int64_t msc_label_workspace_bytes(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     return (int64_t)B * H * W * 4;

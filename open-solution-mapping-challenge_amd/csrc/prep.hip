@@ -33,8 +33,8 @@ __global__ __launch_bounds__(256) void inst_stats_kernel(const uint8_t* __restri
     a = (int)wave_sum((float)a);      // exact: a block strides over < 2^24 pixels
     in = __any(in);
     if ((threadIdx.x & 63) == 0) {
-        if (a) atomicAdd(area + i, a);
-        if (in) atomicOr(interior + i, 1);
+        if (a && area) atomicAdd(area + i, a);
+        if (in && interior) atomicOr(interior + i, 1);
     }
 }
 
@@ -131,6 +131,21 @@ __global__ __launch_bounds__(256) void two_nearest_kernel(const unsigned short* 
     if (second) second[p] = d2;
 }
 
+// get_simple_eroded_mask / get_simple_eroded_dilated_mask (src/preparation.py:166-178): instances larger than
+// small^2 pixels take their eroded mask, the others stay as they are (other == NULL) or take the dilated one
+__global__ void select_kernel(const uint8_t* __restrict__ orig, const uint8_t* __restrict__ eroded, const uint8_t* __restrict__ other,
+                              const int* __restrict__ area, int thr, uint8_t* __restrict__ out, long hw, long total) {
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(p / hw);
+        out[p] = area[i] > thr ? eroded[p] : (other ? other[p] : (uint8_t)(orig[p] != 0));
+    }
+}
+
+__global__ void paint_kernel(uint8_t* __restrict__ overlay, const uint8_t* __restrict__ mask, int value, long hw) {
+    const long p = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (p < hw && mask[p]) overlay[p] = (uint8_t)value;
+}
+
 __global__ void border_kernel(uint8_t* __restrict__ overlay, const double* __restrict__ second, double width, int id, int hw) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= hw) return;
@@ -170,8 +185,9 @@ extern "C" int64_t msc_prep_workspace_bytes(int n, int H, int W) {
     return (int64_t)(up256(nn * (size_t)H * W * 2) + 5 * up256(nn * 4) + 256);
 }
 
-extern "C" int msc_prep_targets(const uint8_t* masks, const int32_t* category_nr, int n, int H, int W, uint8_t* mask_overlayed,
-                                uint16_t* distances_f16, double* second_nearest, int32_t* kept, void* workspace, void* stream) {
+extern "C" int msc_prep_targets(const uint8_t* masks, const uint8_t* border_masks, const int32_t* category_nr, int n, int H, int W,
+                                uint8_t* mask_overlayed, uint16_t* distances_f16, double* second_nearest, int32_t* kept, void* workspace,
+                                void* stream) {
     if ((n > 0 && !masks) || !mask_overlayed || !distances_f16 || !workspace || n < 0 || H <= 0 || W <= 0 || H >= 65535 || W >= 65535)
         return msc_fail(MSC_ERR_ARG, "msc_prep_targets: bad argument");
     hipStream_t st = (hipStream_t)stream;
@@ -187,7 +203,12 @@ extern "C" int msc_prep_targets(const uint8_t* masks, const int32_t* category_nr
     if (n > 0) {
         if (hipMemsetAsync(area, 0, 2 * up256(nn * 4), st) != hipSuccess) return msc_fail(MSC_ERR_HIP, "msc_prep_targets: memset");
         int bx = ceil_div(hw, 256 * 8);
-        hipLaunchKernelGGL(inst_stats_kernel, dim3(bx < 1 ? 1 : bx, n), dim3(256), 0, st, masks, H, W, 2, area, interior);
+        if (border_masks && border_masks != masks) {     // is_on_border() looks at the annotation, the rest at its eroded / dilated form
+            hipLaunchKernelGGL(inst_stats_kernel, dim3(bx < 1 ? 1 : bx, n), dim3(256), 0, st, border_masks, H, W, 2, (int*)nullptr, interior);
+            hipLaunchKernelGGL(inst_stats_kernel, dim3(bx < 1 ? 1 : bx, n), dim3(256), 0, st, masks, H, W, 2, area, (int*)nullptr);
+        } else {
+            hipLaunchKernelGGL(inst_stats_kernel, dim3(bx < 1 ? 1 : bx, n), dim3(256), 0, st, masks, H, W, 2, area, interior);
+        }
         hipLaunchKernelGGL(keep_kernel, dim3(1), dim3(1), 0, st, area, interior, keep, xlo, xhi, n, hw, W);
         hipLaunchKernelGGL(col_dist_kernel, dim3(ceil_div((long)n * W, 256)), dim3(256), 0, st, masks, keep, g, xlo, xhi, n, H, W);
     }
@@ -196,6 +217,44 @@ extern "C" int msc_prep_targets(const uint8_t* masks, const int32_t* category_nr
     if (kept && n > 0 && hipMemcpyAsync(kept, keep, (size_t)n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
         return msc_fail(MSC_ERR_HIP, "msc_prep_targets: copy");
     return msc_check_launch("msc_prep_targets");
+}
+
+extern "C" int64_t msc_prep_morph_workspace_bytes(int n, int H, int W) {
+    if (n <= 0 || H <= 0 || W <= 0) return -1;
+    return (int64_t)(2 * up256((size_t)n * H * W) + up256((size_t)n * 4));
+}
+
+extern "C" int msc_prep_morph(const uint8_t* masks, int n, int H, int W, int erode, int dilate, int small_annotations_size, uint8_t* chosen,
+                              void* workspace, void* stream) {
+    if (!masks || !chosen || !workspace || n <= 0 || H <= 0 || W <= 0 || erode <= 0 || dilate < 0 || chosen == masks)
+        return msc_fail(MSC_ERR_ARG, "msc_prep_morph: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const long hw = (long)H * W, total = (long)n * hw;
+    char* w = (char*)workspace;
+    uint8_t* eroded = (uint8_t*)w;       w += up256((size_t)total);
+    uint8_t* dilated = (uint8_t*)w;      w += up256((size_t)total);
+    int* area = (int*)w;
+    if (hipMemsetAsync(area, 0, (size_t)n * 4, st) != hipSuccess) return msc_fail(MSC_ERR_HIP, "msc_prep_morph: memset");
+    int bx = ceil_div(hw, 256 * 8);
+    hipLaunchKernelGGL(inst_stats_kernel, dim3(bx < 1 ? 1 : bx, n), dim3(256), 0, st, masks, H, W, 2, area, (int*)nullptr);
+    // skimage binary_erosion / binary_dilation with rectangle(k, k) = scipy's: windows -(k/2).. resp. -((k-1)/2)..
+    int rc = msc_rect_filter_u8(masks, eroded, n, H, W, -(erode / 2), -(erode / 2) + erode - 1, 0, stream);
+    if (rc) return rc;
+    if (dilate > 0) {
+        rc = msc_rect_filter_u8(masks, dilated, n, H, W, -((dilate - 1) / 2), -((dilate - 1) / 2) + dilate - 1, 1, stream);
+        if (rc) return rc;
+    }
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(select_kernel, dim3((int)blocks), dim3(256), 0, st, masks, eroded, dilate > 0 ? dilated : (const uint8_t*)nullptr, area,
+                       small_annotations_size * small_annotations_size, chosen, hw, total);
+    return msc_check_launch("msc_prep_morph");
+}
+
+extern "C" int msc_prep_paint(uint8_t* mask_overlayed, const uint8_t* mask, int value, int H, int W, void* stream) {
+    if (!mask_overlayed || !mask || H <= 0 || W <= 0 || value < 0 || value > 255) return msc_fail(MSC_ERR_ARG, "msc_prep_paint: bad argument");
+    hipLaunchKernelGGL(paint_kernel, dim3(ceil_div((long)H * W, 256)), dim3(256), 0, (hipStream_t)stream, mask_overlayed, mask, value, (long)H * W);
+    return msc_check_launch("msc_prep_paint");
 }
 
 extern "C" int msc_prep_border(uint8_t* mask_overlayed, const double* second_nearest, double border_width, int32_t* scratch, int H, int W,

@@ -1,7 +1,7 @@
 """Target preparation before the hot path: the per-image body of the reference's `overlay_masks`
-(`src/preparation.py:18-99`, called from `src/pipeline_manager.py:68-85`) on the device, for
-`erode_selem_size = 0` -- the shipped and the reproduce configuration (`neptune.yaml:69`,
-`REPRODUCE_RESULTS.md:117`), in which `dilate_selem_size` plays no part (`src/preparation.py:57-60`).
+(`src/preparation.py:18-99`, called from `src/pipeline_manager.py:68-85`) on the device: the plain overlay of the
+shipped configuration (`erode_selem_size = 0`, `neptune.yaml:69`, in which `dilate_selem_size` plays no part,
+`src/preparation.py:57-60`) and the eroded / eroded+dilated variants (`:61-77`).
 
 The reference builds one full-image Euclidean distance transform per building, stacks them with `np.dstack`
 and sorts the stack per pixel (O(buildings x H x W) host memory and time, `src/preparation.py:146-163`), then
@@ -51,7 +51,7 @@ def _size_matrix(mask_u8):
     return sizes
 
 
-def prepare_targets(masks, category_nr=None, border_width=0, erode=0, dilate=0, return_details=False):
+def prepare_targets(masks, category_nr=None, border_width=0, erode=0, dilate=0, small_annotations_size=14, return_details=False):
     """overlay_mask_one_image (src/preparation.py:44-84) for one image.
 
     masks: uint8 [n,H,W] decoded instance masks in annotation order (n may be 0: pass an array of shape [0,H,W]);
@@ -60,9 +60,6 @@ def prepare_targets(masks, category_nr=None, border_width=0, erode=0, dilate=0, 
     reference writes to masks/, distances/ and sizes/.  return_details adds (second_nearest f64, kept i32[n])."""
     if erode < 0 or dilate < 0:
         raise ValueError('erode and dilate cannot be negative')                   # src/preparation.py:54-55
-    if erode:          # erode == 0 takes the plain overlay whatever `dilate` is (src/preparation.py:57-60)
-        raise NotImplementedError('HIP target preparation implements erode_selem_size = 0 (neptune.yaml:69, REPRODUCE_RESULTS.md:117); '
-                                  'the eroded / eroded+dilated variants (src/preparation.py:61-77,121-143) are not built')
     lib = _lib.load()
     dev = _device()
     m = torch.as_tensor(masks)
@@ -71,18 +68,47 @@ def prepare_targets(masks, category_nr=None, border_width=0, erode=0, dilate=0, 
     m = (m.to(dev) != 0).to(torch.uint8).contiguous()
     n, H, W = m.shape
     stream = torch.cuda.current_stream(dev).cuda_stream
-    cat = None
-    if category_nr is not None:
-        cat = torch.as_tensor(np.asarray(category_nr, dtype=np.int32)).to(dev)
-        if cat.numel() != n:
-            raise ValueError('category_nr must have one entry per mask')
-    overlay = torch.empty((H, W), dtype=torch.uint8, device=dev)
-    dist = torch.empty((H, W), dtype=torch.int16, device=dev)       # float16 bit patterns
-    second = torch.empty((H, W), dtype=torch.float64, device=dev)
-    kept = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
-    ws = torch.empty(lib.msc_prep_workspace_bytes(n, H, W), dtype=torch.uint8, device=dev)
-    _lib.check(lib.msc_prep_targets(m.data_ptr() if n else None, cat.data_ptr() if cat is not None else None, n, H, W, overlay.data_ptr(),
-                                    dist.data_ptr(), second.data_ptr(), kept.data_ptr(), ws.data_ptr(), stream), 'msc_prep_targets')
+    cats_h = np.ones(n, np.int32) if category_nr is None else np.asarray(category_nr, dtype=np.int32)
+    if cats_h.size != n:
+        raise ValueError('category_nr must have one entry per mask')
+    order = np.argsort(cats_h, kind='stable')        # the reference walks the categories in turn (:49-52)
+    if n and (order != np.arange(n)).any():
+        m = m[torch.from_numpy(order).to(dev)].contiguous()
+    cats_s = cats_h[order]
+    cat = torch.from_numpy(np.ascontiguousarray(cats_s)).to(dev) if n else None
+
+    def targets(masks_used, border_masks, cat_t, k):
+        overlay = torch.empty((H, W), dtype=torch.uint8, device=dev)
+        dist = torch.empty((H, W), dtype=torch.int16, device=dev)       # float16 bit patterns
+        second = torch.empty((H, W), dtype=torch.float64, device=dev)
+        kept = torch.zeros(max(k, 1), dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.msc_prep_workspace_bytes(k, H, W), dtype=torch.uint8, device=dev)
+        _lib.check(lib.msc_prep_targets(masks_used.data_ptr() if k else None, border_masks.data_ptr() if (k and border_masks is not None) else None,
+                                        cat_t.data_ptr() if cat_t is not None else None, k, H, W, overlay.data_ptr(), dist.data_ptr(),
+                                        second.data_ptr(), kept.data_ptr(), ws.data_ptr(), stream), 'msc_prep_targets')
+        return overlay, dist, second, kept
+
+    if erode > 0 and n:
+        # :61-77 -- every instance is replaced by its eroded (big) / unchanged or dilated (small) form before it enters the
+        # overlay and the distance stack; is_on_border still looks at the annotation itself
+        chosen = torch.empty_like(m)
+        ws = torch.empty(lib.msc_prep_morph_workspace_bytes(n, H, W), dtype=torch.uint8, device=dev)
+        _lib.check(lib.msc_prep_morph(m.data_ptr(), n, H, W, int(erode), int(dilate), int(small_annotations_size), chosen.data_ptr(),
+                                      ws.data_ptr(), stream), 'msc_prep_morph')
+        overlay, dist, second, kept = targets(chosen, m, cat, n)
+        if dilate == 0:
+            # :62-71 -- per category: the eroded overlay plus every component of the plain overlay that erosion wiped out
+            from . import postprocessing as post
+            overlay = torch.zeros((H, W), dtype=torch.uint8, device=dev)
+            for c in sorted(set(cats_s.tolist())):
+                idx = torch.from_numpy(np.flatnonzero(cats_s == c)).to(dev)
+                k = int(idx.numel())
+                plain = targets(m[idx].contiguous(), None, None, k)[0]
+                eroded = targets(chosen[idx].contiguous(), m[idx].contiguous(), None, k)[0]
+                mask_c = post.add_dropped_batch(plain[None], eroded[None])[0]
+                _lib.check(lib.msc_prep_paint(overlay.data_ptr(), mask_c.data_ptr(), int(c), H, W, stream), 'msc_prep_paint')
+    else:
+        overlay, dist, second, kept = targets(m, None, cat, n)
     sizes = _size_matrix(overlay[None])[0]          # from the overlay BEFORE the border class is painted (:70 before :73)
     if border_width > 0:
         scratch = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -90,5 +116,7 @@ def prepare_targets(masks, category_nr=None, border_width=0, erode=0, dilate=0, 
                    'msc_prep_border')
     out = (overlay.cpu().numpy(), dist.cpu().numpy().view(np.float16), sizes.cpu().numpy().astype(np.int64))
     if return_details:
-        out += (second.cpu().numpy(), kept[:n].cpu().numpy())
+        kept_h = np.zeros(n, np.int32)
+        kept_h[order] = kept[:n].cpu().numpy()          # back to the caller's instance order
+        out += (second.cpu().numpy(), kept_h)
     return out

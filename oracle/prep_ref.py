@@ -41,9 +41,40 @@ def get_size_matrix(mask):
     return sizes
 
 
-def prepare_targets(masks, category_nr=None, border_width=0):
-    """overlay_mask_one_image (src/preparation.py:44-84) with erode = dilate = 0, for instance masks u8 [n,H,W] in
-    annotation order (category_nr[i] = index of the instance's category in CATEGORY_IDS, ascending).
+def binary_erosion(mask, k):
+    """skimage.morphology.binary_erosion(mask, rectangle(k, k)) (skimage 0.13: scipy's, border_value=True)"""
+    return ndi.binary_erosion(mask, structure=np.ones((k, k), np.uint8), border_value=True)
+
+
+def binary_dilation(mask, k):
+    return ndi.binary_dilation(mask, structure=np.ones((k, k), np.uint8))
+
+
+def get_simple_eroded_mask(mask, selem_size, small_annotations_size):
+    """src/preparation.py:166-172"""
+    return binary_erosion(mask, selem_size) if mask.sum() > small_annotations_size ** 2 else mask
+
+
+def get_simple_eroded_dilated_mask(mask, erode_selem_size, dilate_selem_size, small_annotations_size):
+    """src/preparation.py:175-182"""
+    if mask.sum() > small_annotations_size ** 2:
+        return binary_erosion(mask, erode_selem_size)
+    return binary_dilation(mask, dilate_selem_size)
+
+
+def add_dropped_objects(original, processed):
+    """src/utils.py:333-339"""
+    reconstructed = processed.copy()
+    labeled, n = ndi.label(original)
+    for i in range(1, n + 1):
+        if not np.any(np.where((labeled == i) & processed)):
+            reconstructed += (labeled == i)
+    return reconstructed.astype('uint8')
+
+
+def prepare_targets(masks, category_nr=None, border_width=0, erode=0, dilate=0, small_annotations_size=14):
+    """overlay_mask_one_image (src/preparation.py:44-84) for instance masks u8 [n,H,W] in annotation order
+    (category_nr[i] = index of the instance's category in CATEGORY_IDS, ascending).
     Returns (mask_overlayed u8, distances f16, sizes i64, second_nearest f64, kept i32[n])."""
     masks = np.asarray(masks)
     n = len(masks)
@@ -54,14 +85,22 @@ def prepare_targets(masks, category_nr=None, border_width=0):
     kept = np.zeros(n, np.int32)
     for c in sorted(set(cats.tolist())):
         mask = np.zeros(shape)
+        plain = np.zeros(shape)
         for i in np.flatnonzero(cats == c):
             mi = masks[i].reshape(shape)
             if is_on_border(mi, 2):
                 continue
+            plain += mi
+            if erode > 0:          # :61-77: distances and overlay from the eroded (or eroded / dilated) instance
+                mi = (get_simple_eroded_mask(mi, erode, small_annotations_size) if dilate == 0 else
+                      get_simple_eroded_dilated_mask(mi, erode, dilate, small_annotations_size)).astype(np.uint8)
             kept[i] = 2 if distances.sum() == 0 and mi.all() else 1
             distances = update_distances(distances, mi)
             mask += mi
-        mask_overlayed = np.where(mask > 0, c, mask_overlayed).astype(np.uint8)
+        mask = np.where(mask > 0, 1, 0).astype('uint8')
+        if erode > 0 and dilate == 0:      # :62-71
+            mask = add_dropped_objects(np.where(plain > 0, 1, 0).astype('uint8'), mask)
+        mask_overlayed = np.where(mask, c, mask_overlayed).astype(np.uint8)
     sizes = get_size_matrix(mask_overlayed)
     dist16, second = clean_distances(distances)
     if border_width > 0:

@@ -61,3 +61,27 @@ def test_restatement_equals_reference_functions():
         assert (d16.view(np.uint16) == ref_d16.view(np.uint16)).all() and (second == ref_second).all()
     m = rng.random((30, 30)) > 0.5
     assert (prep.get_size_matrix(m.astype(np.uint8)) == prep_ref.get_size_matrix(m.astype(np.uint8))).all()
+    # the eroded / eroded+dilated variants: the reference's per-instance functions and its accumulation loops
+    utils = ref_import.ref('utils')
+    for erode, dilate, small in ((3, 0, 3), (2, 0, 14), (4, 3, 4), (3, 2, 100)):
+        for mi in masks:
+            assert (prep.get_simple_eroded_mask(mi, erode, small) == prep_ref.get_simple_eroded_mask(mi, erode, small)).all()
+            if dilate:
+                assert (prep.get_simple_eroded_dilated_mask(mi, erode, dilate, small) ==
+                        prep_ref.get_simple_eroded_dilated_mask(mi, erode, dilate, small)).all()
+        dist, mask, plain = np.zeros((40, 52)), np.zeros((40, 52)), np.zeros((40, 52))
+        for mi in masks:                      # overlay_eroded_masks_from_annotations / ..._dilated_... without the COCO decoding
+            if prep.is_on_border(mi, 2):
+                continue
+            m_ = prep.get_simple_eroded_mask(mi, erode, small) if dilate == 0 else prep.get_simple_eroded_dilated_mask(mi, erode, dilate, small)
+            dist = prep.update_distances(dist, m_)
+            mask += m_
+            plain += mi
+        mask = np.where(mask > 0, 1, 0).astype('uint8')
+        if dilate == 0:
+            mask = utils.add_dropped_objects(np.where(plain > 0, 1, 0).astype('uint8'), mask)
+        overlay = np.where(mask, 1, np.zeros((40, 52)).astype('uint8'))
+        ref_d16, ref_second = prep.clean_distances(dist.copy())
+        ov, d16, sizes, second, kept = prep_ref.prepare_targets(masks, erode=erode, dilate=dilate, small_annotations_size=small)
+        assert (ov == overlay).all() and (sizes == prep.get_size_matrix(overlay)).all()
+        assert (d16.view(np.uint16) == ref_d16.view(np.uint16)).all() and (second == ref_second).all()
