@@ -120,6 +120,9 @@ __global__ __launch_bounds__(256) void two_nearest_kernel(const unsigned short* 
             const long d = dx * dx + (long)gg * gg;
             if (best < 0 || d < best) best = d;
         }
+        // an instance eroded to nothing: scipy's distance_transform_edt of an array without background measures to a
+        // virtual pixel at (y, x) = (-1, 0), and the reference stacks that layer like any other (src/preparation.py:150)
+        if (best < 0) best = (long)(y + 1) * (y + 1) + (long)x * x;
         ++layers;
         if (b1 < 0 || best < b1) { b2 = b1; b1 = best; }
         else if (b2 < 0 || best < b2) b2 = best;
