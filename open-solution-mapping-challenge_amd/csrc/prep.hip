@@ -1,5 +1,5 @@
-// Target preparation on gfx950: the body of overlay_mask_one_image (src/preparation.py:44-84) for the shipped
-// configuration erode = dilate = 0 (neptune.yaml:69-70), given the decoded instance masks of one image:
+// Target preparation on gfx950: the body of overlay_mask_one_image (src/preparation.py:44-84), given the decoded
+// instance masks of one image (plain overlay; msc_prep_morph adds the eroded / eroded+dilated variants, :61-77):
 //   * instances without a pixel in the interior [2:-2, 2:-2] are skipped             (is_on_border, :197-198, :111)
 //   * mask_overlayed = category number of the last category covering the pixel       (:65-68, :118)
 //   * per instance the exact Euclidean distance to its nearest pixel (scipy distance_transform_edt(1 - mask),
