@@ -932,7 +932,7 @@ bool use_v1_wgrad() { static int v = -1; if (v < 0) v = env_flag("MSC_WGRAD_V1")
 // heuristic (cfg 0) the caller may pick one explicitly -- UNetResNet times the valid ones per layer when it builds
 // a program (msc_conv_cfg_ok enumerates them).
 struct ConvCfg { int tp, tc, wp, wc, kb, nst; };
-constexpr int N_CONV_CFG = 23;
+constexpr int N_CONV_CFG = 26;
 static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {0, 0, 0, 0, 0, 0},
     {256, 128, 4, 2, 128, 3},   //  1: 144 KB, 8 waves, 1 block/CU
@@ -963,6 +963,10 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {64, 128, 2, 4, 256, 3},    // 21: 144 KB, 8 waves
     {128, 64, 4, 2, 256, 3},    // 22: 144 KB, 8 waves
     {128, 128, 4, 2, 256, 2},   // 23: 128 KB, 8 waves
+    // two resident 8-wave blocks per CU (4 waves per SIMD) to fill the time the waves of one block are parked
+    {64, 128, 2, 4, 128, 3},    // 24:  72 KB, 8 waves
+    {128, 64, 4, 2, 128, 3},    // 25:  72 KB, 8 waves
+    {64, 64, 2, 2, 256, 2},     // 26:  64 KB
 };
 
 template <typename T, int TP, int TC, int WP, int WC, int KB, int NST>
@@ -1038,7 +1042,10 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
         case 20: return launch_dma<T, 64, 64, 2, 2, 256, 4>(k, mode, st);
         case 21: return launch_dma<T, 64, 128, 2, 4, 256, 3>(k, mode, st);
         case 22: return launch_dma<T, 128, 64, 4, 2, 256, 3>(k, mode, st);
-        default: return launch_dma<T, 128, 128, 4, 2, 256, 2>(k, mode, st);
+        case 23: return launch_dma<T, 128, 128, 4, 2, 256, 2>(k, mode, st);
+        case 24: return launch_dma<T, 64, 128, 2, 4, 128, 3>(k, mode, st);
+        case 25: return launch_dma<T, 128, 64, 4, 2, 128, 3>(k, mode, st);
+        default: return launch_dma<T, 64, 64, 2, 2, 256, 2>(k, mode, st);
     }
 }
 
