@@ -226,7 +226,13 @@ class TrainStep:
             self._body()
             torch.cuda.synchronize()
             if self.dist:
-                self._capture_pieces()
+                try:
+                    self._capture_pieces()
+                except RuntimeError as e:          # capture next to a live communicator is the fragile part: keep training
+                    import warnings
+                    warnings.warn('hipGraph capture of the distributed step failed (%s); continuing with eager launches' % e)
+                    torch.cuda.synchronize()
+                    self.pieces, self.use_graph = None, False
             else:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
