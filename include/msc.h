@@ -102,8 +102,8 @@ void msc_wgrad_group_destroy(msc_wgrad_group* g);
 int msc_pack_cast(const float* src, void* dst, int dtype, int64_t n, void* stream);
 int msc_pack_transpose(const float* src, void* dst, int dtype, int A, int T, int B, void* stream);
 /* the same for MANY tensors in one launch: block b handles items[block_item[b]], piece block_local[b]
- * (kind 0: 2048-element piece of a cast; kind 1: one 32x32 tile of tap t of a transpose, local index
- * = (t*ceil(A/32) + a_tile)*ceil(B/32) + b_tile).  All three tables live in device memory. */
+ * (kind 0: 2048-element piece of a cast; kind 1: one 64x32 (A x B) tile of tap t of a transpose, local index
+ * = (t*ceil(A/64) + a_tile)*ceil(B/32) + b_tile).  All three tables live in device memory. */
 typedef struct msc_pack_item {
     const float* src;
     void* dst;

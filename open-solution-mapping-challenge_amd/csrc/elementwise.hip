@@ -415,37 +415,47 @@ extern "C" int msc_pack_transpose(const float* src, void* dst, int dtype, int A,
 }
 
 // All compute copies of the weights in ONE launch (the per-tensor launches cost ~230 x 4.7 us per step):
-// block b works on items[block_item[b]], piece block_local[b] (2048 elements of a cast, or one 32x32 tile of
-// one tap of a transpose).
+// block b works on items[block_item[b]], piece block_local[b] (2048 elements of a cast, or one 64x32 (a x b) tile of
+// one tap of a transpose: a 64 x 32 tile, see below).
 namespace {
 template <typename T>
 __global__ void pack_multi_kernel(const msc_pack_item* __restrict__ items, const int32_t* __restrict__ block_item,
                                   const int32_t* __restrict__ block_local) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[64][33];
     const msc_pack_item it = items[block_item[blockIdx.x]];
     const int lb = block_local[blockIdx.x];
     T* dst = reinterpret_cast<T*>(it.dst);
     if (it.kind == 0) {
-        const long base = (long)lb * 2048;
-        for (int j = 0; j < 8; ++j) {
-            const long i = base + j * 256 + threadIdx.x;
-            if (i < it.n) ElemIO<T>::store(dst + i, it.src[i]);
+        // 2048 elements per block, 8 consecutive ones per thread: two 16-byte loads, one 16-byte (bf16) or two (f32) stores
+        const long i = (long)lb * 2048 + threadIdx.x * 8;
+        if (i + 8 <= it.n && ((((uintptr_t)(it.src + i)) | ((uintptr_t)(dst + i))) & 15) == 0) {
+            float v[8];
+            const float4 lo = *reinterpret_cast<const float4*>(it.src + i), hi = *reinterpret_cast<const float4*>(it.src + i + 4);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            constexpr int CE = Vec16<T>::N;
+#pragma unroll
+            for (int j = 0; j < 8; j += CE) Vec16<T>::store(dst + i + j, v + j);
+        } else {
+            for (int j = 0; j < 8; ++j)
+                if (i + j < it.n) ElemIO<T>::store(dst + i + j, it.src[i + j]);
         }
         return;
     }
-    const int tiles_b = (it.B + 31) / 32, tiles_a = (it.A + 31) / 32;
+    // tile = 64 (a) x 32 (b): 128-byte row segments on the fp32 source side AND on the bf16 destination side
+    const int tiles_b = (it.B + 31) / 32, tiles_a = (it.A + 63) / 64;
     const int t = lb / (tiles_a * tiles_b);
     const int rem = lb - t * (tiles_a * tiles_b);
-    const int a0 = (rem / tiles_b) * 32, b0 = (rem % tiles_b) * 32;
+    const int a0 = (rem / tiles_b) * 64, b0 = (rem % tiles_b) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int r = ty; r < 32; r += 8) {
+    for (int r = ty; r < 64; r += 8) {
         const int a = a0 + r, b = b0 + tx;
         tile[r][tx] = (a < it.A && b < it.B) ? it.src[((long)a * it.T + t) * it.B + b] : 0.f;
     }
     __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const int b = b0 + r, a = a0 + tx;
-        if (a < it.A && b < it.B) ElemIO<T>::store(dst + ((long)b * it.T + t) * it.A + a, tile[tx][r]);
+    const int sx = threadIdx.x & 63, sy = threadIdx.x >> 6;
+    for (int r = sy; r < 32; r += 4) {
+        const int b = b0 + r, a = a0 + sx;
+        if (a < it.A && b < it.B) ElemIO<T>::store(dst + ((long)b * it.T + t) * it.A + a, tile[sx][r]);
     }
 }
 }  // namespace

@@ -381,7 +381,7 @@ class UNetResNet(nn.Module):
         def add(kind, src, dst, a, t, b, n):
             idx = len(items)
             items.append((src.data_ptr(), dst.data_ptr(), kind, a, t, b, n))
-            nb = (n + 2047) // 2048 if kind == 0 else t * ((a + 31) // 32) * ((b + 31) // 32)
+            nb = (n + 2047) // 2048 if kind == 0 else t * ((a + 63) // 64) * ((b + 31) // 32)     # as msc_pack_multi tiles
             blk_item.append(np.full(nb, idx, np.int32))
             blk_local.append(np.arange(nb, dtype=np.int32))
 
