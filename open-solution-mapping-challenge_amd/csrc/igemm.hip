@@ -53,6 +53,7 @@ struct ConvK {
     int M, Hq, Wq;
     unsigned in_bytes, wt_bytes;     // extents for the buffer descriptors of the DMA kernel
     int ntc;                         // channel tiles (DMA kernel: 1-D grid of ntm*ntc blocks, XCD-aware order)
+    int mode;                        // 0 gather, 1 transposed
     int xcd_order;                   // 1: XCD-aware tile order, 0: pixel tile fastest (for A/B measurements)
 };
 
@@ -528,6 +529,79 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
     conv_epilogue<T, FM, FN, WTP, WP, MODE>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px, mtile, nwg / p.ntc);
 }
 
+// ------------------------------------------------------------------------------------------------ halo tile
+// 3x3 / stride 1 / pad 1 convolutions of the 32-channel full-resolution layers (dec0 and its data gradient): as an
+// implicit GEMM every filter tap re-reads the pixel's 64-byte channel row from L2, and 64-byte row segments are the
+// slow LDS-DMA case -- the DMA kernel sits at ~12 TB/s of fill with the MFMA pipes idle.  Here a block owns a 16x16
+// pixel patch: the 18x18 halo of input rows goes to LDS once (20 KB), the nine taps read shifted windows of it, the
+// 18 KB of weights stay in registers (every block reads the same ones from L2).  bf16, Cin = Cout = 32.
+__global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
+    __shared__ uint4 halo[18 * 18 * 4];              // [18][18] pixels x 4 chunks of 8 channels
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, pl = lane & 15;
+    const int tiles_x = p.Wo / 16, tiles_y = p.Ho / 16;
+    const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, n = blockIdx.x / (tiles_x * tiles_y);
+    const int y0 = by * 16, x0 = bx * 16;
+    const bf16_t* in = reinterpret_cast<const bf16_t*>(p.in);
+    for (int c = tid; c < 18 * 18 * 4; c += 256) {
+        const int pix = c >> 2, ch = c & 3;
+        const int hy = pix / 18, hx = pix - hy * 18;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+            v = *reinterpret_cast<const uint4*>(in + ((long)(n * p.Hi + iy) * p.Wi + ix) * p.in_ld + ch * 8);
+        halo[c] = v;
+    }
+    // weights [Cout][3][3][Cin]: lane (g, pl) of fragment a holds input channels 8g..8g+7 of output channel a*16+pl
+    const bf16_t* wt = reinterpret_cast<const bf16_t*>(p.wt);
+    uint4 wf[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) wf[t][a] = *reinterpret_cast<const uint4*>(wt + ((long)(a * 16 + pl) * 9 + t) * 32 + g * 8);
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int kh = t / 3, kw = t - kh * 3;
+        const int dy = p.flip ? 1 - kh : kh - 1, dx = p.flip ? 1 - kw : kw - 1;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint4 bf = halo[((wid * 4 + b + 1 + dy) * 18 + (pl + 1 + dx)) * 4 + g];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) Mma<bf16_t>::run(wf[t][a], bf, acc[a][b]);
+        }
+    }
+    // D: column = pixel x0+pl, rows 4g..4g+3 of fragment a = output channels a*16+4g+r
+    bf16_t* out = reinterpret_cast<bf16_t*>(p.out);
+    const bf16_t* res = reinterpret_cast<const bf16_t*>(p.res);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const long opix = (long)(n * p.Ho + y0 + wid * 4 + b) * p.Wo + x0 + pl;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int c0 = a * 16 + 4 * g;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * (p.scale ? p.scale[c0 + r] : 1.f) + (p.shift ? p.shift[c0 + r] : 0.f);
+            if (res) {
+                const uint2 rv = *reinterpret_cast<const uint2*>(res + opix * p.res_ld + c0);
+                v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+                v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            *reinterpret_cast<uint2*>(out + opix * p.out_ld + c0) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight gradient:  dW[a][kh][kw][b] += sum_m P[m][a] * Q[pix(m)*stride - pad + (kh,kw)][b]
 //   conv  wgrad: P = dY (a = cout), Q = X  (b = cin)
@@ -932,7 +1006,8 @@ bool use_v1_wgrad() { static int v = -1; if (v < 0) v = env_flag("MSC_WGRAD_V1")
 // heuristic (cfg 0) the caller may pick one explicitly -- UNetResNet times the valid ones per layer when it builds
 // a program (msc_conv_cfg_ok enumerates them).
 struct ConvCfg { int tp, tc, wp, wc, kb, nst; };
-constexpr int N_CONV_CFG = 26;
+constexpr int N_CONV_CFG = 27;
+constexpr int CFG_HALO = 27;          // conv3x3_c32_halo_kernel (not a tile of the DMA kernel)
 static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {0, 0, 0, 0, 0, 0},
     {256, 128, 4, 2, 128, 3},   //  1: 144 KB, 8 waves, 1 block/CU
@@ -967,6 +1042,7 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {64, 128, 2, 4, 128, 3},    // 24:  72 KB, 8 waves
     {128, 64, 4, 2, 128, 3},    // 25:  72 KB, 8 waves
     {64, 64, 2, 2, 256, 2},     // 26:  64 KB
+    {16, 32, 1, 1, 64, 1},      // 27: halo-tile kernel for the 32-channel 3x3 layers
 };
 
 template <typename T, int TP, int TC, int WP, int WC, int KB, int NST>
@@ -991,6 +1067,9 @@ int launch_v1(const ConvK& k, int mode, hipStream_t st) {
 
 bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
     if (cfg < 1 || cfg > N_CONV_CFG) return false;
+    if (cfg == CFG_HALO)
+        return es == 2 && k.mode == 0 && k.KH == 3 && k.KW == 3 && k.stride == 1 && k.pad == 1 && k.Cin == 32 && k.Cout == 32 &&
+               k.Ho % 16 == 0 && k.Wo % 16 == 0 && k.Hi == k.Ho && k.Wi == k.Wo && !k.stats && k.res_ld % 4 == 0 && k.out_ld % 4 == 0;
     const ConvCfg& c = CONV_CFGS[cfg];
     if (k.Cout % c.tc) return false;
     if (c.tc == 32 && k.Cout % 64 == 0) return false;        // a 32-channel tile only for the 32-channel layers
@@ -1019,6 +1098,10 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
     }
     if (cfg == 0) cfg = pick_cfg(k);
     if (!conv_cfg_ok(k, (int)sizeof(T), cfg)) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: configuration %d is not valid for this layer", cfg);
+    if (cfg == CFG_HALO) {
+        hipLaunchKernelGGL(conv3x3_c32_halo_kernel, dim3(k.N * (k.Ho / 16) * (k.Wo / 16)), dim3(256), 0, st, k);
+        return msc_check_launch("conv3x3_c32_halo");
+    }
     switch (cfg) {
         case 1: return launch_dma<T, 256, 128, 4, 2, 128, 3>(k, mode, st);
         case 2: return launch_dma<T, 256, 128, 4, 2, 64, 4>(k, mode, st);
@@ -1075,6 +1158,7 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
     k->in_ld = d->in_ld; k->out_ld = d->out_ld; k->res_ld = d->res_ld;
     k->N = d->N; k->Hi = d->Hi; k->Wi = d->Wi; k->Cin = d->Cin; k->Ho = d->Ho; k->Wo = d->Wo; k->Cout = d->Cout;
     k->KH = d->KH; k->KW = d->KW; k->stride = d->stride; k->pad = d->pad; k->flip = d->flip; k->relu = d->relu;
+    k->mode = d->mode;
     if (d->mode == 1) {
         if (d->stride != 2 || (d->Ho & 1) || (d->Wo & 1)) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: transposed mode needs stride 2 and even output size");
         if (d->stats) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: stats not available in transposed mode");
