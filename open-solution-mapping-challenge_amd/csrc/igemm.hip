@@ -552,13 +552,16 @@ __global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
             v = *reinterpret_cast<const uint4*>(in + ((long)(n * p.Hi + iy) * p.Wi + ix) * p.in_ld + ch * 8);
         halo[c] = v;
     }
-    // weights [Cout][3][3][Cin]: lane (g, pl) of fragment a holds input channels 8g..8g+7 of output channel a*16+pl
+    // weights [Cout][3][3][Cin]: lane (g, pl) of fragment a holds input channels 8g..8g+7 of ONE output channel; row pl of
+    // fragment a is output channel 8*(pl>>2) + 4a + (pl&3), so that the D rows a lane ends up with (4g..4g+3 of both
+    // fragments) are the 8 consecutive channels 8g..8g+7 -> one 16-byte store per pixel
     const bf16_t* wt = reinterpret_cast<const bf16_t*>(p.wt);
     uint4 wf[9][2];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int a = 0; a < 2; ++a) wf[t][a] = *reinterpret_cast<const uint4*>(wt + ((long)(a * 16 + pl) * 9 + t) * 32 + g * 8);
+        for (int a = 0; a < 2; ++a)
+            wf[t][a] = *reinterpret_cast<const uint4*>(wt + ((long)(8 * (pl >> 2) + 4 * a + (pl & 3)) * 9 + t) * 32 + g * 8);
     f32x4 acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -576,29 +579,32 @@ __global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
             for (int a = 0; a < 2; ++a) Mma<bf16_t>::run(wf[t][a], bf, acc[a][b]);
         }
     }
-    // D: column = pixel x0+pl, rows 4g..4g+3 of fragment a = output channels a*16+4g+r
+    // D: column = pixel x0+pl; rows 4g..4g+3 of fragments 0 and 1 = output channels 8g..8g+3 and 8g+4..8g+7
     bf16_t* out = reinterpret_cast<bf16_t*>(p.out);
     const bf16_t* res = reinterpret_cast<const bf16_t*>(p.res);
+    const int c0 = 8 * g;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = p.scale ? p.scale[c0 + j] : 1.f; sh[j] = p.shift ? p.shift[c0 + j] : 0.f; }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const long opix = (long)(n * p.Ho + y0 + wid * 4 + b) * p.Wo + x0 + pl;
+        float v[8];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int c0 = a * 16 + 4 * g;
-            float v[4];
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * (p.scale ? p.scale[c0 + r] : 1.f) + (p.shift ? p.shift[c0 + r] : 0.f);
-            if (res) {
-                const uint2 rv = *reinterpret_cast<const uint2*>(res + opix * p.res_ld + c0);
-                v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-                v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
-            }
-            if (p.relu) {
+            for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][b][r] * sc[a * 4 + r] + sh[a * 4 + r];
+        if (res) {
+            float rv[8];
+            Vec16<bf16_t>::load(res + opix * p.res_ld + c0, rv);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            }
-            *reinterpret_cast<uint2*>(out + opix * p.out_ld + c0) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            for (int j = 0; j < 8; ++j) v[j] += rv[j];
         }
+        if (p.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        Vec16<bf16_t>::store(out + opix * p.out_ld + c0, v);
     }
 }
 
@@ -1069,7 +1075,7 @@ bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
     if (cfg < 1 || cfg > N_CONV_CFG) return false;
     if (cfg == CFG_HALO)
         return es == 2 && k.mode == 0 && k.KH == 3 && k.KW == 3 && k.stride == 1 && k.pad == 1 && k.Cin == 32 && k.Cout == 32 &&
-               k.Ho % 16 == 0 && k.Wo % 16 == 0 && k.Hi == k.Ho && k.Wi == k.Wo && !k.stats && k.res_ld % 4 == 0 && k.out_ld % 4 == 0;
+               k.Ho % 16 == 0 && k.Wo % 16 == 0 && k.Hi == k.Ho && k.Wi == k.Wo && !k.stats && k.res_ld % 8 == 0 && k.out_ld % 8 == 0;
     const ConvCfg& c = CONV_CFGS[cfg];
     if (k.Cout % c.tc) return false;
     if (c.tc == 32 && k.Cout % 64 == 0) return false;        // a 32-channel tile only for the 32-channel layers
