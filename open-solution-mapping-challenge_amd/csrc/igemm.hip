@@ -608,6 +608,99 @@ __global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
     }
 }
 
+// ConvTranspose2d(k4, s2, p1) 128 -> 32 channels (dec1's up-sampling to full resolution): per output-parity phase the DMA
+// kernel re-reads four taps of 256-byte input rows for a 32-channel output tile.  Here a block owns 8x16 input pixels
+// (16x32 outputs): their 10x18 halo goes to LDS once (46 KB), each phase's four taps of weights (32 KB) follow, both with
+// the 16-byte chunks of a row XOR-swizzled by the row index so that 16 lanes reading 16 different rows hit 16 bank groups.
+__global__ __launch_bounds__(256) void deconv4_c128_c32_halo_kernel(ConvK p) {
+    constexpr int HR = 10, HC = 18;                   // halo rows / columns
+    __shared__ uint4 halo[HR * HC * 16];              // [pixel][16 chunks of 8 channels], chunk ^= pixel & 15
+    __shared__ uint4 wl[4 * 32 * 16];                 // [tap][cout][16 chunks], chunk ^= key(cout), distinct over a fragment's rows
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, pl = lane & 15;
+    const int tiles_x = p.Wi / 16, tiles_y = p.Hi / 8;
+    const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, n = blockIdx.x / (tiles_x * tiles_y);
+    const int qy0 = by * 8, qx0 = bx * 16;
+    const bf16_t* in = reinterpret_cast<const bf16_t*>(p.in);
+    for (int c = tid; c < HR * HC * 16; c += 256) {
+        const int pix = c >> 4, ch = c & 15;
+        const int hy = pix / HC, hx = pix - hy * HC;
+        const int iy = qy0 - 1 + hy, ix = qx0 - 1 + hx;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+            v = *reinterpret_cast<const uint4*>(in + ((long)(n * p.Hi + iy) * p.Wi + ix) * p.in_ld + ch * 8);
+        halo[pix * 16 + (ch ^ (pix & 15))] = v;
+    }
+    const bf16_t* wt = reinterpret_cast<const bf16_t*>(p.wt);          // [Cout][4][4][Cin]
+    bf16_t* out = reinterpret_cast<bf16_t*>(p.out);
+    const bf16_t* res = reinterpret_cast<const bf16_t*>(p.res);
+    const int c0 = 8 * g;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = p.scale ? p.scale[c0 + j] : 1.f; sh[j] = p.shift ? p.shift[c0 + j] : 0.f; }
+    // row pl of weight fragment a is output channel 8*(pl>>2) + 4a + (pl&3): a lane ends with channels 8g..8g+7
+    int wrow[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) wrow[a] = 8 * (pl >> 2) + 4 * a + (pl & 3);
+    for (int ph = 0; ph < 4; ++ph) {
+        const int py = ph >> 1, px = ph & 1;
+        const int kh0 = (py + 1) & 1, kw0 = (px + 1) & 1;             // taps kh0, kh0+2 / kw0, kw0+2
+        __syncthreads();                                              // previous phase done with wl (and halo written)
+        for (int c = tid; c < 4 * 32 * 16; c += 256) {
+            const int t = c >> 9, co = (c >> 4) & 31, ch = c & 15;
+            const int kh = kh0 + 2 * (t >> 1), kw = kw0 + 2 * (t & 1);
+            wl[(t * 32 + co) * 16 + (ch ^ (((co >> 3) << 2) | (co & 3)))] = *reinterpret_cast<const uint4*>(wt + ((long)(co * 4 + kh) * 4 + kw) * 128 + ch * 8);
+        }
+        __syncthreads();
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kh = kh0 + 2 * (t >> 1), kw = kw0 + 2 * (t & 1);
+            const int dy = (py + 1 - kh) / 2, dx = (px + 1 - kw) / 2;  // input offset of this tap: -1, 0 or +1
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                uint4 af[2], bf[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) af[a] = wl[(t * 32 + wrow[a]) * 16 + ((kk * 4 + g) ^ pl)];     // key(wrow[a]) == pl
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int pix = (wid * 2 + b + 1 + dy) * HC + (pl + 1 + dx);
+                    bf[b] = halo[pix * 16 + ((kk * 4 + g) ^ (pix & 15))];
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) Mma<bf16_t>::run(af[a], bf[b], acc[a][b]);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int oy = 2 * (qy0 + wid * 2 + b) + py, ox = 2 * (qx0 + pl) + px;
+            const long opix = (long)(n * p.Ho + oy) * p.Wo + ox;
+            float v[8];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][b][r] * sc[a * 4 + r] + sh[a * 4 + r];
+            if (res) {
+                float rv[8];
+                Vec16<bf16_t>::load(res + opix * p.res_ld + c0, rv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += rv[j];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            Vec16<bf16_t>::store(out + opix * p.out_ld + c0, v);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight gradient:  dW[a][kh][kw][b] += sum_m P[m][a] * Q[pix(m)*stride - pad + (kh,kw)][b]
 //   conv  wgrad: P = dY (a = cout), Q = X  (b = cin)
@@ -1012,8 +1105,9 @@ bool use_v1_wgrad() { static int v = -1; if (v < 0) v = env_flag("MSC_WGRAD_V1")
 // heuristic (cfg 0) the caller may pick one explicitly -- UNetResNet times the valid ones per layer when it builds
 // a program (msc_conv_cfg_ok enumerates them).
 struct ConvCfg { int tp, tc, wp, wc, kb, nst; };
-constexpr int N_CONV_CFG = 27;
+constexpr int N_CONV_CFG = 28;
 constexpr int CFG_HALO = 27;          // conv3x3_c32_halo_kernel (not a tile of the DMA kernel)
+constexpr int CFG_HALO_T = 28;        // deconv4_c128_c32_halo_kernel
 static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {0, 0, 0, 0, 0, 0},
     {256, 128, 4, 2, 128, 3},   //  1: 144 KB, 8 waves, 1 block/CU
@@ -1049,6 +1143,7 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {128, 64, 4, 2, 128, 3},    // 25:  72 KB, 8 waves
     {64, 64, 2, 2, 256, 2},     // 26:  64 KB
     {16, 32, 1, 1, 64, 1},      // 27: halo-tile kernel for the 32-channel 3x3 layers
+    {16, 32, 1, 1, 256, 1},     // 28: halo-tile kernel for ConvTranspose2d(k4, s2, p1) 128 -> 32
 };
 
 template <typename T, int TP, int TC, int WP, int WC, int KB, int NST>
@@ -1076,6 +1171,9 @@ bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
     if (cfg == CFG_HALO)
         return es == 2 && k.mode == 0 && k.KH == 3 && k.KW == 3 && k.stride == 1 && k.pad == 1 && k.Cin == 32 && k.Cout == 32 &&
                k.Ho % 16 == 0 && k.Wo % 16 == 0 && k.Hi == k.Ho && k.Wi == k.Wo && !k.stats && k.res_ld % 8 == 0 && k.out_ld % 8 == 0;
+    if (cfg == CFG_HALO_T)
+        return es == 2 && k.mode == 1 && k.KH == 4 && k.KW == 4 && k.stride == 2 && k.pad == 1 && k.Cin == 128 && k.Cout == 32 &&
+               k.Hi % 8 == 0 && k.Wi % 16 == 0 && k.Ho == 2 * k.Hi && k.Wo == 2 * k.Wi && !k.stats && k.res_ld % 8 == 0 && k.out_ld % 8 == 0;
     const ConvCfg& c = CONV_CFGS[cfg];
     if (k.Cout % c.tc) return false;
     if (c.tc == 32 && k.Cout % 64 == 0) return false;        // a 32-channel tile only for the 32-channel layers
@@ -1107,6 +1205,10 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
     if (cfg == CFG_HALO) {
         hipLaunchKernelGGL(conv3x3_c32_halo_kernel, dim3(k.N * (k.Ho / 16) * (k.Wo / 16)), dim3(256), 0, st, k);
         return msc_check_launch("conv3x3_c32_halo");
+    }
+    if (cfg == CFG_HALO_T) {
+        hipLaunchKernelGGL(deconv4_c128_c32_halo_kernel, dim3(k.N * (k.Hi / 8) * (k.Wi / 16)), dim3(256), 0, st, k);
+        return msc_check_launch("deconv4_c128_c32_halo");
     }
     switch (cfg) {
         case 1: return launch_dma<T, 256, 128, 4, 2, 128, 3>(k, mode, st);
