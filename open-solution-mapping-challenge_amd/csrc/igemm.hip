@@ -642,16 +642,31 @@ __global__ __launch_bounds__(256) void deconv4_c128_c32_halo_kernel(ConvK p) {
     int wrow[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) wrow[a] = 8 * (pl >> 2) + 4 * a + (pl & 3);
+    // the four taps of a phase: 2048 16-byte chunks, 8 per thread; fetched into registers one phase ahead
+    uint4 wreg[8];
+    auto wfetch = [&](int ph) {
+        const int kh0 = ((ph >> 1) + 1) & 1, kw0 = ((ph & 1) + 1) & 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = tid + i * 256;
+            const int t = c >> 9, co = (c >> 4) & 31, ch = c & 15;
+            const int kh = kh0 + 2 * (t >> 1), kw = kw0 + 2 * (t & 1);
+            wreg[i] = *reinterpret_cast<const uint4*>(wt + ((long)(co * 4 + kh) * 4 + kw) * 128 + ch * 8);
+        }
+    };
+    wfetch(0);
     for (int ph = 0; ph < 4; ++ph) {
         const int py = ph >> 1, px = ph & 1;
         const int kh0 = (py + 1) & 1, kw0 = (px + 1) & 1;             // taps kh0, kh0+2 / kw0, kw0+2
         __syncthreads();                                              // previous phase done with wl (and halo written)
-        for (int c = tid; c < 4 * 32 * 16; c += 256) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = tid + i * 256;
             const int t = c >> 9, co = (c >> 4) & 31, ch = c & 15;
-            const int kh = kh0 + 2 * (t >> 1), kw = kw0 + 2 * (t & 1);
-            wl[(t * 32 + co) * 16 + (ch ^ (((co >> 3) << 2) | (co & 3)))] = *reinterpret_cast<const uint4*>(wt + ((long)(co * 4 + kh) * 4 + kw) * 128 + ch * 8);
+            wl[(t * 32 + co) * 16 + (ch ^ (((co >> 3) << 2) | (co & 3)))] = wreg[i];
         }
         __syncthreads();
+        if (ph < 3) wfetch(ph + 1);                                   // in flight while this phase computes
         f32x4 acc[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
