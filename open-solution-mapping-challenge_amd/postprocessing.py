@@ -13,7 +13,6 @@ Two levels:
 Integer outputs are bit-identical to the reference (via oracle/post_ref.py); float outputs
 (resize, scores, CRF) agree within the tolerances stated in tests/.  There is no CPU fallback.
 """
-import ctypes as C
 
 import numpy as np
 import torch

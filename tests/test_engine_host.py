@@ -1,7 +1,6 @@
 """CPU: host logic of the HIP engine (program construction, buffer wiring, concat slices, gradient
 accumulation flags, weight layouts) checked by executing its launch lists with tests/emu.py -- a numpy
 interpreter of the documented C-ABI semantics -- against the torch-CPU oracle."""
-import numpy as np
 import pytest
 import torch
 

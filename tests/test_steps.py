@@ -1,5 +1,4 @@
 """CPU: the Step / BaseTransformer operator-API mirror behaves like src/steps/base.py."""
-import numpy as np
 import pytest
 
 from mapping_challenge_amd.steps import BaseTransformer, Dummy, Step, make_apply_transformer
