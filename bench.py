@@ -92,7 +92,23 @@ def family_times(launches, stream, repeats=2):
             elif name == 'msc_wgrad_group_run':
                 f['flops'] += sum(wgrad_flops(d) for d in args[0].descs) / repeats
                 f['launches'] += (len(args[0].descs) - 1.0) / repeats      # counted as layers, not kernel launches
+            elif name in BN_TENSORS:
+                f['bytes'] = f.get('bytes', 0.0) + BN_TENSORS[name](args) / repeats
     return fam
+
+
+def _es(dtype):
+    from mapping_challenge_amd._lib import BF16
+    return 2 if dtype == BF16 else 4
+
+
+# algorithmic HBM bytes of the BatchNorm elementwise launches: tensors of pixels*C elements read or written
+# (argument positions: include/msc.h)
+BN_TENSORS = {
+    'msc_bn_apply': lambda a: a[10] * a[11] * _es(a[9]) * (2 + (1 if a[2] else 0)),
+    'msc_bn_bwd_reduce': lambda a: a[11] * a[12] * _es(a[10]) * (2 + (1 if a[6] == 1 else 0)),
+    'msc_bn_bwd_apply': lambda a: a[16] * a[17] * _es(a[15]) * (3 + (1 if a[6] == 1 else 0) + ((1 + (1 if a[14] else 0)) if a[12] else 0)),
+}
 
 
 def cpu_threads():
@@ -297,6 +313,11 @@ def main():
                 'algorithmic_gflop_per_step': conv['flops'] / 1e9,
                 'wgrad': {'achieved': (wg['flops'] / (wg['ms'] * 1e-3) / 1e12) if wg['ms'] else None, 'ms_per_step': wg['ms'],
                           'layers': round(wg['launches'])},
+                'hbm_family': (lambda bn: {'kernel': 'bn_apply / bn_bwd_reduce / bn_bwd_apply (BatchNorm elementwise passes)', 'bound': 'hbm',
+                                           'achieved': bn[0] / (bn[1] * 1e-3) / 1e9 if bn[1] else None, 'peak': PEAK_HBM / 1e9, 'unit': 'GB/s',
+                                           'frac': bn[0] / (bn[1] * 1e-3) / PEAK_HBM if bn[1] else None, 'ms_per_step': bn[1],
+                                           'algorithmic_gb_per_step': bn[0] / 1e9})(
+                    (sum(fam.get(k, {}).get('bytes', 0.0) for k in BN_TENSORS), sum(fam.get(k, {}).get('ms', 0.0) for k in BN_TENSORS))),
                 'dominant_family': dom[0], 'family_ms_per_step': {k: round(v['ms'], 3) for k, v in sorted(fam.items())},
                 'sum_kernel_ms_per_step': total_ms,
                 'whole_step_frac_of_mfma_peak': (conv['flops'] + wg['flops']) * (args.steps / dt) / peak}
