@@ -197,7 +197,6 @@ class TrainStep:
         from .unet_models import _Program
         net = self.net
         flat_g = net.flat_grads
-        stream = torch.cuda.current_stream(flat_g.device).cuda_stream
         if getattr(prog, '_ddp_plan', None) is None:
             prog._ddp_plan = ddp_plan(prog, flat_g)
         flat_g.zero_()

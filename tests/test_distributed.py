@@ -81,3 +81,79 @@ def test_two_rank_protocol_matches_full_batch():
     assert abs(res[0][1] - loss.item()) < 1e-5 and abs(res[1][1] - loss.item()) < 1e-5
     assert np.allclose(res[0][2], res[1][2])
     assert np.abs(res[0][2] - flat).max() <= 1e-4 * np.abs(flat).max()
+
+
+def _engine_worker(rank, world_size, port, q):
+    """the PRODUCT's distributed backward (TrainStep._backward_overlapped: backward in pieces, asynchronous all-reduce of the
+    gradient range each piece finishes) on the CPU interpreter of the launch lists, over gloo"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
+    import emu
+    import mapping_challenge_amd.unet_models as um
+    from mapping_challenge_amd.distributed import World
+    from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
+    from oracle import unet_ref, losses_ref
+    um._Program.run = staticmethod(emu.run)
+    world = World.from_env(backend='gloo')
+    n, hw = 4, 64
+    x = unet_ref.synthetic_batch(n, hw, hw)
+    tgt = losses_ref.synthetic_target(n, hw, hw)
+    lo, hi = world.shard(n)
+    net = um.UNetResNet(34, 2, num_filters=32, dropout_2d=0.0, is_deconv=True, compute_dtype='fp32')
+    net.load_state_dict(unet_ref.seeded_state_dict(unet_ref.UNetResNetRef(34)))
+    net._host_interpreter = True
+    net.flatten_parameters('cpu')
+    net.train()
+    prog = net.train_forward(x[lo:hi])
+    # dlogits of the GLOBAL-batch loss for the local logits (the two-phase loss kernels are HIP; here from the oracle's pieces)
+    out = prog.logits.clone().requires_grad_(True)
+    t = tgt[lo:hi]
+    p1 = torch.softmax(out, 1)[:, 1]
+    t1 = (t[:, 0].long() == 1).float()
+    w = losses_ref.loss_weights(t[:, 1:], 50., 10., (256, 256))
+    ce = torch.nn.functional.cross_entropy(out, t[:, 0].long(), reduction='none')
+    sums = torch.stack([(w * ce).sum(), (p1 * t1).sum(), p1.sum(), t1.sum()]).double()
+    glob = sums.detach().clone()
+    world.all_reduce(glob)
+    s = [sums[i] + (glob[i] - sums[i].detach()) for i in range(3)]
+    loss = 1.0 * s[0] / float(n * hw * hw) + 0.2 * (1 - (2 * s[1] + 1.0) / (s[2] + glob[3] + 1.0 + 1e-7))
+    loss.backward()
+    prog.dlogits.copy_(out.grad)
+    step = TrainStep(net, LossSpec.plain_ce(), HipAdam(net, lr=0.0), world=world)
+    step._backward_overlapped(prog)
+    plan = prog._ddp_plan
+    grads = {name: gv.numpy().copy() for (name, _), gv in zip(net._trainable(), net._grad_views())}
+    q.put((rank, float(loss.item()), grads, sum(1 for _, a, _ in plan if a is not None)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_product_backward_in_pieces_with_async_allreduce_matches_full_batch():
+    from oracle import unet_ref, losses_ref
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+    n, hw = 4, 64
+    x = unet_ref.synthetic_batch(n, hw, hw)
+    tgt = losses_ref.synthetic_target(n, hw, hw)
+    ref = unet_ref.UNetResNetRef(34)
+    ref.load_state_dict(unet_ref.seeded_state_dict(ref))
+    ref.train()
+    loss = losses_ref.mixed_dice_ce(torch.cat([ref(x[0:2]), ref(x[2:4])]), tgt)
+    loss.backward()
+    pr = dict(ref.named_parameters())
+    assert abs(res[0][1] - loss.item()) < 1e-5
+    assert res[0][3] >= 3                                      # several pieces really went out while backward continued
+    assert set(res[0][2]) == set(res[1][2]) and len(res[0][2]) > 100
+    for name, g in res[0][2].items():
+        assert np.array_equal(g, res[1][2][name]), name        # both ranks hold the same reduced gradient
+        gref = pr[name].grad.numpy()
+        err = np.abs(g - gref).max() / (np.abs(gref).max() + 1e-12)
+        assert err < 2e-3, (name, err)
