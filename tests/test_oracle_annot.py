@@ -91,3 +91,22 @@ def test_restatement_equals_reference_utils():
     meta = pd.DataFrame({'ImageId': list(range(100, 100 + len(preds)))})
     ref_ann = utils.create_annotations(meta, preds, logging.getLogger('t'), [None, 100], [1, 1])
     assert ref_ann == annot_ref.create_annotations(meta['ImageId'].values, preds, [None, 100], [1, 1])
+
+
+def test_string_coding_round_trips_for_arbitrary_counts():
+    """the 5-bit / continuation / sign-extension code of rleToString <-> rleFrString over the whole count range, incl. the
+    delta coding from the fourth count on (negative and multi-character deltas)"""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.lists(st.integers(min_value=0, max_value=2 ** 31 - 1), min_size=1, max_size=40))
+    def check(cnts):
+        s = annot_ref.rle_to_string(cnts)
+        assert all(48 <= ch < 112 for ch in s) and len(s) <= 7 * len(cnts)
+        assert annot_ref.rle_from_string(s) == cnts
+
+    check()
+    # boundaries of the character count: 15 / 16 need 1 / 2 chars (bit 4 is the sign bit of the last chunk)
+    assert len(annot_ref.rle_to_string([15])) == 1 and len(annot_ref.rle_to_string([16])) == 2
+    assert len(annot_ref.rle_to_string([511])) == 2 and len(annot_ref.rle_to_string([512])) == 3
+    assert annot_ref.rle_from_string(annot_ref.rle_to_string([0, 90000])) == [0, 90000]
