@@ -12,8 +12,9 @@
  *     global state; `stream` is a hipStream_t passed as void* (0 = default stream)
  *   - activations are NHWC: element (n,y,x,c) at ((n*H+y)*W+x)*ld + c, where `ld` (elements) >= C
  *     lets a tensor be a channel slice of a wider buffer (skip-concats are never materialised)
- *   - dtype: MSC_F32 (exact-fp32 parity mode, v_mfma_f32_16x16x4_f32) or MSC_BF16 (throughput mode,
- *     v_mfma_f32_16x16x32_bf16, fp32 accumulate); bf16 values are raw uint16 bit patterns
+ *   - dtype: MSC_DTYPE_F32 (exact-fp32 parity mode, v_mfma_f32_16x16x4_f32), MSC_DTYPE_BF16 (throughput mode,
+ *     v_mfma_f32_16x16x32_bf16) or MSC_DTYPE_F16 (v_mfma_f32_16x16x32_f16; BASELINE.json configs[4]); accumulation,
+ *     BatchNorm statistics, losses and master weights are fp32 in every mode; 16-bit values are raw uint16 bit patterns
  *   - re-entrant per stream; one host thread per GPU/process, no internal threads
  */
 #ifndef MSC_H
@@ -26,6 +27,7 @@ extern "C" {
 
 #define MSC_DTYPE_F32 0
 #define MSC_DTYPE_BF16 1
+#define MSC_DTYPE_F16 2
 
 const char* msc_last_error(void);
 int msc_abi_version(void);
@@ -113,6 +115,12 @@ typedef struct msc_pack_item {
 int msc_pack_multi(const msc_pack_item* items, const int32_t* block_item, const int32_t* block_local, int nblocks,
                    int dtype, void* stream);
 int msc_stem_pack(const float* w, void* dst, int dtype, int cout, void* stream);
+/* wire format of the data-parallel gradient exchange (replaces nn.DataParallel's reduce-add, src/models.py:65): the fp32
+ * gradient range is cast to `dtype` (msc_pack_cast), all-to-all'ed into recv[world][shard]; msc_grad_reduce sums the
+ * `world` shards in fp32 and rounds once: out[i] = dtype(sum_w recv[w][i]); msc_grad_unpack widens the all-gathered
+ * result back: g[i] = float(in[i]). */
+int msc_grad_reduce(const void* recv, void* out, int dtype, int world, int64_t shard, void* stream);
+int msc_grad_unpack(const void* in, float* g, int dtype, int64_t n, void* stream);
 int msc_stem_unpack_grad(const float* dpacked, float* dw, int cout, void* stream);
 
 /* network input: x f32 NCHW [N,3,H,W] (what the loaders hand to model(X), src/steps/pytorch/models.py:92)

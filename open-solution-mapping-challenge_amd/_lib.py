@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MSC_HIP_LIB', os.path.join(_HERE, 'lib', 'libmsc_hip.so'))
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 
 
 class MscError(RuntimeError):
@@ -62,6 +62,8 @@ SIGNATURES = {
     'msc_pack_transpose': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'msc_pack_multi': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'msc_stem_pack': (_i, [_vp, _vp, _i, _i, _vp]),
+    'msc_grad_reduce': (_i, [_vp, _vp, _i, _i, _i64, _vp]),
+    'msc_grad_unpack': (_i, [_vp, _vp, _i, _i64, _vp]),
     'msc_stem_unpack_grad': (_i, [_vp, _vp, _i, _vp]),
     'msc_stem_prepare': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'msc_maxpool2_fwd': (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),

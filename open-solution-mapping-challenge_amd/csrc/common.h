@@ -17,15 +17,22 @@
 // dtype enum of the C ABI (include/msc.h)
 #define MSC_F32 0
 #define MSC_BF16 1
+#define MSC_F16 2
+static inline bool msc_dtype_ok(int dtype) { return dtype == MSC_F32 || dtype == MSC_BF16 || dtype == MSC_F16; }
+static inline int msc_dtype_size(int dtype) { return dtype == MSC_F32 ? 4 : 2; }
+static inline int msc_dtype_vec(int dtype) { return 16 / msc_dtype_size(dtype); }      // elements per 16-byte vector
 
 extern thread_local char msc_err_buf[512];
 int msc_fail(int code, const char* fmt, ...);
 int msc_check_launch(const char* what);
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
+struct f16_t { uint16_t bits; };   // raw IEEE binary16 bits (a distinct type, so the kernel templates can tell the two apart)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
@@ -38,14 +45,31 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
+__device__ __forceinline__ float f16_to_f32(f16_t v) { return (float)__builtin_bit_cast(_Float16, v.bits); }
+__device__ __forceinline__ f16_t f32_to_f16(float f) {      // round to nearest even, overflow -> inf (v_cvt_f16_f32)
+    f16_t r;
+    r.bits = __builtin_bit_cast(uint16_t, (_Float16)f);
+    return r;
+}
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    return (uint32_t)f32_to_f16(lo).bits | ((uint32_t)f32_to_f16(hi).bits << 16);
+}
+
 template <typename T> struct ElemIO;
+template <> struct ElemIO<f16_t> {
+    static __device__ __forceinline__ float load(const f16_t* p) { return f16_to_f32(*p); }
+    static __device__ __forceinline__ void store(f16_t* p, float v) { *p = f32_to_f16(v); }
+    static __device__ __forceinline__ f16_t from(float v) { return f32_to_f16(v); }
+};
 template <> struct ElemIO<float> {
     static __device__ __forceinline__ float load(const float* p) { return *p; }
     static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+    static __device__ __forceinline__ float from(float v) { return v; }
 };
 template <> struct ElemIO<bf16_t> {
     static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
     static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+    static __device__ __forceinline__ bf16_t from(float v) { return f32_to_bf16(v); }
 };
 
 // 16-byte vector of T as floats: 4 x f32 or 8 x bf16
@@ -78,6 +102,26 @@ template <> struct Vec16<bf16_t> {
         uint4 t;
         t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]);
         t.z = pack_bf16x2(v[4], v[5]); t.w = pack_bf16x2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(p) = t;
+    }
+};
+
+template <> struct Vec16<f16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void unpack(uint4 t, float* v) {
+        uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f16x2 h = __builtin_bit_cast(f16x2, w[i]);
+            v[2 * i] = (float)h[0];
+            v[2 * i + 1] = (float)h[1];
+        }
+    }
+    static __device__ __forceinline__ void load(const f16_t* p, float* v) { unpack(*reinterpret_cast<const uint4*>(p), v); }
+    static __device__ __forceinline__ void store(f16_t* p, const float* v) {
+        uint4 t;
+        t.x = pack_f16x2(v[0], v[1]); t.y = pack_f16x2(v[2], v[3]);
+        t.z = pack_f16x2(v[4], v[5]); t.w = pack_f16x2(v[6], v[7]);
         *reinterpret_cast<uint4*>(p) = t;
     }
 };

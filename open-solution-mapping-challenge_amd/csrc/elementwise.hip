@@ -79,7 +79,7 @@ __global__ void stem_prepare_kernel(const float* __restrict__ x, T* __restrict__
         if (sizeof(T) == 4) {
             *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-            *reinterpret_cast<uint2*>(d) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            d[0] = ElemIO<T>::from(v[0]); d[1] = ElemIO<T>::from(v[1]); d[2] = ElemIO<T>::from(v[2]); d[3] = ElemIO<T>::from(v[3]);
         }
     }
 }
@@ -390,18 +390,71 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 }  // namespace
 
 #define DT_CHECK(name, dtype) \
-    if ((dtype) != MSC_BF16 && (dtype) != MSC_F32) return msc_fail(MSC_ERR_ARG, name ": dtype %d", (int)(dtype))
+    if (!msc_dtype_ok(dtype)) return msc_fail(MSC_ERR_ARG, name ": dtype %d", (int)(dtype))
 #define VEC_CHECK(name, dtype, C) \
-    if ((C) % ((dtype) == MSC_BF16 ? 8 : 4)) return msc_fail(MSC_ERR_UNSUPPORTED, name ": C=%d must be a multiple of the 16-byte vector", (int)(C))
+    if ((C) % msc_dtype_vec(dtype)) return msc_fail(MSC_ERR_UNSUPPORTED, name ": C=%d must be a multiple of the 16-byte vector", (int)(C))
 
 extern "C" int msc_pack_cast(const float* src, void* dst, int dtype, int64_t n, void* stream) {
     DT_CHECK("msc_pack_cast", dtype);
     if (!src || !dst || n < 0) return msc_fail(MSC_ERR_ARG, "msc_pack_cast: bad argument");
     if (n == 0) return MSC_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MSC_BF16) hipLaunchKernelGGL(pack_cast_kernel<bf16_t>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, st, src, (bf16_t*)dst, (long)n);
+    if (dtype == MSC_F16) hipLaunchKernelGGL(pack_cast_kernel<f16_t>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, st, src, (f16_t*)dst, (long)n);
+    else if (dtype == MSC_BF16) hipLaunchKernelGGL(pack_cast_kernel<bf16_t>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, st, src, (bf16_t*)dst, (long)n);
     else hipLaunchKernelGGL(pack_cast_kernel<float>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, st, src, (float*)dst, (long)n);
     return msc_check_launch("msc_pack_cast");
+}
+
+// ---- 16-bit wire format of the data-parallel gradient exchange (distributed.py): every rank casts its fp32 gradient
+// range to the compute dtype (msc_pack_cast), an all-to-all hands each rank the `world` partial shards of its own
+// slice, which are summed in fp32 here and rounded ONCE to the wire dtype; after the all-gather the result is widened
+// back into the fp32 gradient buffer.  Halves the bytes of the fp32 ring all-reduce on the per-link-bound xGMI ring.
+namespace {
+template <typename T>
+__global__ void grad_reduce_kernel(const T* __restrict__ recv, T* __restrict__ out, int world, long shard) {
+    constexpr int CE = Vec16<T>::N;
+    const long nv = shard / CE;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+        float acc[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) acc[e] = 0.f;
+        for (int w = 0; w < world; ++w) {
+            float v[CE];
+            Vec16<T>::load(recv + (long)w * shard + i * CE, v);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) acc[e] += v[e];
+        }
+        Vec16<T>::store(out + i * CE, acc);
+    }
+}
+template <typename T>
+__global__ void grad_unpack_kernel(const T* __restrict__ in, float* __restrict__ g, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) g[i] = ElemIO<T>::load(in + i);
+}
+}  // namespace
+
+extern "C" int msc_grad_reduce(const void* recv, void* out, int dtype, int world, int64_t shard, void* stream) {
+    DT_CHECK("msc_grad_reduce", dtype);
+    if (!recv || !out || world < 1 || shard < 0 || shard % msc_dtype_vec(dtype) || (((uintptr_t)recv | (uintptr_t)out) & 15))
+        return msc_fail(MSC_ERR_ARG, "msc_grad_reduce: bad argument (shard must be a multiple of the 16-byte vector)");
+    if (shard == 0) return MSC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ew_grid(shard / msc_dtype_vec(dtype));
+    if (dtype == MSC_F16) hipLaunchKernelGGL(grad_reduce_kernel<f16_t>, dim3(grid), dim3(EW_THREADS), 0, st, (const f16_t*)recv, (f16_t*)out, world, (long)shard);
+    else if (dtype == MSC_BF16) hipLaunchKernelGGL(grad_reduce_kernel<bf16_t>, dim3(grid), dim3(EW_THREADS), 0, st, (const bf16_t*)recv, (bf16_t*)out, world, (long)shard);
+    else hipLaunchKernelGGL(grad_reduce_kernel<float>, dim3(grid), dim3(EW_THREADS), 0, st, (const float*)recv, (float*)out, world, (long)shard);
+    return msc_check_launch("msc_grad_reduce");
+}
+
+extern "C" int msc_grad_unpack(const void* in, float* g, int dtype, int64_t n, void* stream) {
+    DT_CHECK("msc_grad_unpack", dtype);
+    if (!in || !g || n < 0) return msc_fail(MSC_ERR_ARG, "msc_grad_unpack: bad argument");
+    if (n == 0) return MSC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MSC_F16) hipLaunchKernelGGL(grad_unpack_kernel<f16_t>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, st, (const f16_t*)in, g, (long)n);
+    else if (dtype == MSC_BF16) hipLaunchKernelGGL(grad_unpack_kernel<bf16_t>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, st, (const bf16_t*)in, g, (long)n);
+    else hipLaunchKernelGGL(grad_unpack_kernel<float>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, st, (const float*)in, g, (long)n);
+    return msc_check_launch("msc_grad_unpack");
 }
 
 extern "C" int msc_pack_transpose(const float* src, void* dst, int dtype, int A, int T, int B, void* stream) {
@@ -409,7 +462,8 @@ extern "C" int msc_pack_transpose(const float* src, void* dst, int dtype, int A,
     if (!src || !dst || A <= 0 || T <= 0 || B <= 0 || T > 65535) return msc_fail(MSC_ERR_ARG, "msc_pack_transpose: bad argument");
     dim3 grid(ceil_div(B, 32), ceil_div(A, 32), T);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MSC_BF16) hipLaunchKernelGGL(pack_transpose_kernel<bf16_t>, grid, dim3(256), 0, st, src, (bf16_t*)dst, A, T, B);
+    if (dtype == MSC_F16) hipLaunchKernelGGL(pack_transpose_kernel<f16_t>, grid, dim3(256), 0, st, src, (f16_t*)dst, A, T, B);
+    else if (dtype == MSC_BF16) hipLaunchKernelGGL(pack_transpose_kernel<bf16_t>, grid, dim3(256), 0, st, src, (bf16_t*)dst, A, T, B);
     else hipLaunchKernelGGL(pack_transpose_kernel<float>, grid, dim3(256), 0, st, src, (float*)dst, A, T, B);
     return msc_check_launch("msc_pack_transpose");
 }
@@ -466,7 +520,8 @@ extern "C" int msc_pack_multi(const msc_pack_item* items, const int32_t* block_i
     if (!items || !block_item || !block_local || nblocks < 0) return msc_fail(MSC_ERR_ARG, "msc_pack_multi: bad argument");
     if (nblocks == 0) return MSC_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MSC_BF16) hipLaunchKernelGGL(pack_multi_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, st, items, block_item, block_local);
+    if (dtype == MSC_F16) hipLaunchKernelGGL(pack_multi_kernel<f16_t>, dim3(nblocks), dim3(256), 0, st, items, block_item, block_local);
+    else if (dtype == MSC_BF16) hipLaunchKernelGGL(pack_multi_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, st, items, block_item, block_local);
     else hipLaunchKernelGGL(pack_multi_kernel<float>, dim3(nblocks), dim3(256), 0, st, items, block_item, block_local);
     return msc_check_launch("msc_pack_multi");
 }
@@ -476,7 +531,8 @@ extern "C" int msc_stem_pack(const float* w, void* dst, int dtype, int cout, voi
     if (!w || !dst || cout <= 0) return msc_fail(MSC_ERR_ARG, "msc_stem_pack: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const int n = cout * 7 * 32;
-    if (dtype == MSC_BF16) hipLaunchKernelGGL(stem_pack_kernel<bf16_t>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, st, w, (bf16_t*)dst, cout);
+    if (dtype == MSC_F16) hipLaunchKernelGGL(stem_pack_kernel<f16_t>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, st, w, (f16_t*)dst, cout);
+    else if (dtype == MSC_BF16) hipLaunchKernelGGL(stem_pack_kernel<bf16_t>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, st, w, (bf16_t*)dst, cout);
     else hipLaunchKernelGGL(stem_pack_kernel<float>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, st, w, (float*)dst, cout);
     return msc_check_launch("msc_stem_pack");
 }
@@ -492,7 +548,8 @@ extern "C" int msc_stem_prepare(const float* x, void* xp, int dtype, int N, int 
     if (!x || !xp || N <= 0 || H <= 0 || W <= 0) return msc_fail(MSC_ERR_ARG, "msc_stem_prepare: bad argument");
     const long total = (long)N * (H + 6) * (W + 8);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MSC_BF16) hipLaunchKernelGGL(stem_prepare_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, x, (bf16_t*)xp, N, H, W);
+    if (dtype == MSC_F16) hipLaunchKernelGGL(stem_prepare_kernel<f16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, x, (f16_t*)xp, N, H, W);
+    else if (dtype == MSC_BF16) hipLaunchKernelGGL(stem_prepare_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, x, (bf16_t*)xp, N, H, W);
     else hipLaunchKernelGGL(stem_prepare_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, x, (float*)xp, N, H, W);
     return msc_check_launch("msc_stem_prepare");
 }
@@ -502,8 +559,9 @@ extern "C" int msc_maxpool2_fwd(const void* in, int64_t in_ld, void* out, int64_
     VEC_CHECK("msc_maxpool2_fwd", dtype, C);
     if (!in || !out) return msc_fail(MSC_ERR_ARG, "msc_maxpool2_fwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    const long total = (long)N * Ho * Wo * (C / (dtype == MSC_BF16 ? 8 : 4));
-    if (dtype == MSC_BF16) hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)in, (long)in_ld, (bf16_t*)out, (long)out_ld, N, Ho, Wo, C);
+    const long total = (long)N * Ho * Wo * (C / msc_dtype_vec(dtype));
+    if (dtype == MSC_F16) hipLaunchKernelGGL(maxpool2_fwd_kernel<f16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const f16_t*)in, (long)in_ld, (f16_t*)out, (long)out_ld, N, Ho, Wo, C);
+    else if (dtype == MSC_BF16) hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)in, (long)in_ld, (bf16_t*)out, (long)out_ld, N, Ho, Wo, C);
     else hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const float*)in, (long)in_ld, (float*)out, (long)out_ld, N, Ho, Wo, C);
     return msc_check_launch("msc_maxpool2_fwd");
 }
@@ -514,8 +572,9 @@ extern "C" int msc_maxpool2_bwd(const void* dout, int64_t dout_ld, const void* i
     VEC_CHECK("msc_maxpool2_bwd", dtype, C);
     if (!dout || !in || !din) return msc_fail(MSC_ERR_ARG, "msc_maxpool2_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    const long total = (long)N * Ho * Wo * (C / (dtype == MSC_BF16 ? 8 : 4));
-    if (dtype == MSC_BF16) hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)dout, (long)dout_ld, (const bf16_t*)in, (long)in_ld, (bf16_t*)din, (long)din_ld, N, Ho, Wo, C, accumulate);
+    const long total = (long)N * Ho * Wo * (C / msc_dtype_vec(dtype));
+    if (dtype == MSC_F16) hipLaunchKernelGGL(maxpool2_bwd_kernel<f16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const f16_t*)dout, (long)dout_ld, (const f16_t*)in, (long)in_ld, (f16_t*)din, (long)din_ld, N, Ho, Wo, C, accumulate);
+    else if (dtype == MSC_BF16) hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)dout, (long)dout_ld, (const bf16_t*)in, (long)in_ld, (bf16_t*)din, (long)din_ld, N, Ho, Wo, C, accumulate);
     else hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const float*)dout, (long)dout_ld, (const float*)in, (long)in_ld, (float*)din, (long)din_ld, N, Ho, Wo, C, accumulate);
     return msc_check_launch("msc_maxpool2_bwd");
 }
@@ -533,8 +592,9 @@ extern "C" int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_
     VEC_CHECK("msc_bn_apply", dtype, C);
     if (!y || !out || !scale || !shift) return msc_fail(MSC_ERR_ARG, "msc_bn_apply: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    const long total = pixels * (C / (dtype == MSC_BF16 ? 8 : 4));
-    if (dtype == MSC_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)y, (long)y_ld, (const bf16_t*)res, (long)res_ld, (bf16_t*)out, (long)out_ld, scale, shift, relu, (long)pixels, C);
+    const long total = pixels * (C / msc_dtype_vec(dtype));
+    if (dtype == MSC_F16) hipLaunchKernelGGL(bn_apply_kernel<f16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const f16_t*)y, (long)y_ld, (const f16_t*)res, (long)res_ld, (f16_t*)out, (long)out_ld, scale, shift, relu, (long)pixels, C);
+    else if (dtype == MSC_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)y, (long)y_ld, (const bf16_t*)res, (long)res_ld, (bf16_t*)out, (long)out_ld, scale, shift, relu, (long)pixels, C);
     else hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const float*)y, (long)y_ld, (const float*)res, (long)res_ld, (float*)out, (long)out_ld, scale, shift, relu, (long)pixels, C);
     return msc_check_launch("msc_bn_apply");
 }
@@ -547,8 +607,9 @@ extern "C" int msc_bn_bwd_apply(const void* dout, int64_t dout_ld, const void* o
     if (!dout || !y || !coef || !dy || relu < 0 || relu > 2 || (relu == 1 && !out) || (relu == 2 && (!scale || !shift)))
         return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_apply: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    const long total = pixels * (C / (dtype == MSC_BF16 ? 8 : 4));
-    if (dtype == MSC_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)dout, (long)dout_ld, (const bf16_t*)out, (long)out_ld, (const bf16_t*)y, (long)y_ld, relu, scale, shift, coef, (bf16_t*)dy, (long)dy_ld, (bf16_t*)dres, (long)dres_ld, dres_acc, (long)pixels, C);
+    const long total = pixels * (C / msc_dtype_vec(dtype));
+    if (dtype == MSC_F16) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const f16_t*)dout, (long)dout_ld, (const f16_t*)out, (long)out_ld, (const f16_t*)y, (long)y_ld, relu, scale, shift, coef, (f16_t*)dy, (long)dy_ld, (f16_t*)dres, (long)dres_ld, dres_acc, (long)pixels, C);
+    else if (dtype == MSC_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)dout, (long)dout_ld, (const bf16_t*)out, (long)out_ld, (const bf16_t*)y, (long)y_ld, relu, scale, shift, coef, (bf16_t*)dy, (long)dy_ld, (bf16_t*)dres, (long)dres_ld, dres_acc, (long)pixels, C);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const float*)dout, (long)dout_ld, (const float*)out, (long)out_ld, (const float*)y, (long)y_ld, relu, scale, shift, coef, (float*)dy, (long)dy_ld, (float*)dres, (long)dres_ld, dres_acc, (long)pixels, C);
     return msc_check_launch("msc_bn_bwd_apply");
 }
@@ -559,8 +620,9 @@ extern "C" int msc_relu_bwd(const void* dy, int64_t dy_ld, const void* y, int64_
     VEC_CHECK("msc_relu_bwd", dtype, C);
     if (!dy || !y || !dx) return msc_fail(MSC_ERR_ARG, "msc_relu_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    const long total = pixels * (C / (dtype == MSC_BF16 ? 8 : 4));
-    if (dtype == MSC_BF16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)dy, (long)dy_ld, (const bf16_t*)y, (long)y_ld, (bf16_t*)dx, (long)dx_ld, accumulate, (long)pixels, C);
+    const long total = pixels * (C / msc_dtype_vec(dtype));
+    if (dtype == MSC_F16) hipLaunchKernelGGL(relu_bwd_kernel<f16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const f16_t*)dy, (long)dy_ld, (const f16_t*)y, (long)y_ld, (f16_t*)dx, (long)dx_ld, accumulate, (long)pixels, C);
+    else if (dtype == MSC_BF16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)dy, (long)dy_ld, (const bf16_t*)y, (long)y_ld, (bf16_t*)dx, (long)dx_ld, accumulate, (long)pixels, C);
     else hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const float*)dy, (long)dy_ld, (const float*)y, (long)y_ld, (float*)dx, (long)dx_ld, accumulate, (long)pixels, C);
     return msc_check_launch("msc_relu_bwd");
 }
@@ -573,7 +635,8 @@ extern "C" int msc_final_fwd(const void* in, int64_t in_ld, const float* w, cons
     hipStream_t st = (hipStream_t)stream;
     const long hw = (long)H * W;
     const size_t shm = 2 * C * sizeof(float);
-    if (dtype == MSC_BF16) hipLaunchKernelGGL(final_fwd_kernel<bf16_t>, dim3(ew_grid((long)N * hw)), dim3(EW_THREADS), shm, st, (const bf16_t*)in, (long)in_ld, w, b, logits, probs, N, hw, C);
+    if (dtype == MSC_F16) hipLaunchKernelGGL(final_fwd_kernel<f16_t>, dim3(ew_grid((long)N * hw)), dim3(EW_THREADS), shm, st, (const f16_t*)in, (long)in_ld, w, b, logits, probs, N, hw, C);
+    else if (dtype == MSC_BF16) hipLaunchKernelGGL(final_fwd_kernel<bf16_t>, dim3(ew_grid((long)N * hw)), dim3(EW_THREADS), shm, st, (const bf16_t*)in, (long)in_ld, w, b, logits, probs, N, hw, C);
     else hipLaunchKernelGGL(final_fwd_kernel<float>, dim3(ew_grid((long)N * hw)), dim3(EW_THREADS), shm, st, (const float*)in, (long)in_ld, w, b, logits, probs, N, hw, C);
     return msc_check_launch("msc_final_fwd");
 }
@@ -588,7 +651,8 @@ extern "C" int msc_final_bwd(const float* dlogits, const void* in, int64_t in_ld
     const size_t shm = (4 * C + 2) * sizeof(float);
     long blocks = ((long)N * hw + EW_THREADS - 1) / EW_THREADS;
     if (blocks > 1024) blocks = 1024;
-    if (dtype == MSC_BF16) hipLaunchKernelGGL(final_bwd_kernel<bf16_t>, dim3((int)blocks), dim3(EW_THREADS), shm, st, dlogits, (const bf16_t*)in, (long)in_ld, w, (bf16_t*)din, (long)din_ld, dw, db, N, hw, C);
+    if (dtype == MSC_F16) hipLaunchKernelGGL(final_bwd_kernel<f16_t>, dim3((int)blocks), dim3(EW_THREADS), shm, st, dlogits, (const f16_t*)in, (long)in_ld, w, (f16_t*)din, (long)din_ld, dw, db, N, hw, C);
+    else if (dtype == MSC_BF16) hipLaunchKernelGGL(final_bwd_kernel<bf16_t>, dim3((int)blocks), dim3(EW_THREADS), shm, st, dlogits, (const bf16_t*)in, (long)in_ld, w, (bf16_t*)din, (long)din_ld, dw, db, N, hw, C);
     else hipLaunchKernelGGL(final_bwd_kernel<float>, dim3((int)blocks), dim3(EW_THREADS), shm, st, dlogits, (const float*)in, (long)in_ld, w, (float*)din, (long)din_ld, dw, db, N, hw, C);
     return msc_check_launch("msc_final_bwd");
 }

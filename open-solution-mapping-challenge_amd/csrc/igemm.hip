@@ -63,6 +63,11 @@ template <> struct Mma<bf16_t> {
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
+template <> struct Mma<f16_t> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
 template <> struct Mma<float> {
     static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
@@ -535,6 +540,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
 // slow LDS-DMA case -- the DMA kernel sits at ~12 TB/s of fill with the MFMA pipes idle.  Here a block owns a 16x16
 // pixel patch: the 18x18 halo of input rows goes to LDS once (20 KB), the nine taps read shifted windows of it, the
 // 18 KB of weights stay in registers (every block reads the same ones from L2).  bf16, Cin = Cout = 32.
+template <typename T>
 __global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
     __shared__ uint4 halo[18 * 18 * 4];              // [18][18] pixels x 4 chunks of 8 channels
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
     const int tiles_x = p.Wo / 16, tiles_y = p.Ho / 16;
     const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, n = blockIdx.x / (tiles_x * tiles_y);
     const int y0 = by * 16, x0 = bx * 16;
-    const bf16_t* in = reinterpret_cast<const bf16_t*>(p.in);
+    const T* in = reinterpret_cast<const T*>(p.in);
     for (int c = tid; c < 18 * 18 * 4; c += 256) {
         const int pix = c >> 2, ch = c & 3;
         const int hy = pix / 18, hx = pix - hy * 18;
@@ -555,7 +561,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
     // weights [Cout][3][3][Cin]: lane (g, pl) of fragment a holds input channels 8g..8g+7 of ONE output channel; row pl of
     // fragment a is output channel 8*(pl>>2) + 4a + (pl&3), so that the D rows a lane ends up with (4g..4g+3 of both
     // fragments) are the 8 consecutive channels 8g..8g+7 -> one 16-byte store per pixel
-    const bf16_t* wt = reinterpret_cast<const bf16_t*>(p.wt);
+    const T* wt = reinterpret_cast<const T*>(p.wt);
     uint4 wf[9][2];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -576,12 +582,12 @@ __global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
         for (int b = 0; b < 4; ++b) {
             const uint4 bf = halo[((wid * 4 + b + 1 + dy) * 18 + (pl + 1 + dx)) * 4 + g];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) Mma<bf16_t>::run(wf[t][a], bf, acc[a][b]);
+            for (int a = 0; a < 2; ++a) Mma<T>::run(wf[t][a], bf, acc[a][b]);
         }
     }
     // D: column = pixel x0+pl; rows 4g..4g+3 of fragments 0 and 1 = output channels 8g..8g+3 and 8g+4..8g+7
-    bf16_t* out = reinterpret_cast<bf16_t*>(p.out);
-    const bf16_t* res = reinterpret_cast<const bf16_t*>(p.res);
+    T* out = reinterpret_cast<T*>(p.out);
+    const T* res = reinterpret_cast<const T*>(p.res);
     const int c0 = 8 * g;
     float sc[8], sh[8];
 #pragma unroll
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
             for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][b][r] * sc[a * 4 + r] + sh[a * 4 + r];
         if (res) {
             float rv[8];
-            Vec16<bf16_t>::load(res + opix * p.res_ld + c0, rv);
+            Vec16<T>::load(res + opix * p.res_ld + c0, rv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += rv[j];
         }
@@ -604,7 +610,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
         }
-        Vec16<bf16_t>::store(out + opix * p.out_ld + c0, v);
+        Vec16<T>::store(out + opix * p.out_ld + c0, v);
     }
 }
 
@@ -612,6 +618,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
 // kernel re-reads four taps of 256-byte input rows for a 32-channel output tile.  Here a block owns 8x16 input pixels
 // (16x32 outputs): their 10x18 halo goes to LDS once (46 KB), each phase's four taps of weights (32 KB) follow, both with
 // the 16-byte chunks of a row XOR-swizzled by the row index so that 16 lanes reading 16 different rows hit 16 bank groups.
+template <typename T>
 __global__ __launch_bounds__(256) void deconv4_c128_c32_halo_kernel(ConvK p) {
     constexpr int HR = 10, HC = 18;                   // halo rows / columns
     __shared__ uint4 halo[HR * HC * 16];              // [pixel][16 chunks of 8 channels], chunk ^= pixel & 15
@@ -621,7 +628,7 @@ __global__ __launch_bounds__(256) void deconv4_c128_c32_halo_kernel(ConvK p) {
     const int tiles_x = p.Wi / 16, tiles_y = p.Hi / 8;
     const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, n = blockIdx.x / (tiles_x * tiles_y);
     const int qy0 = by * 8, qx0 = bx * 16;
-    const bf16_t* in = reinterpret_cast<const bf16_t*>(p.in);
+    const T* in = reinterpret_cast<const T*>(p.in);
     for (int c = tid; c < HR * HC * 16; c += 256) {
         const int pix = c >> 4, ch = c & 15;
         const int hy = pix / HC, hx = pix - hy * HC;
@@ -631,9 +638,9 @@ __global__ __launch_bounds__(256) void deconv4_c128_c32_halo_kernel(ConvK p) {
             v = *reinterpret_cast<const uint4*>(in + ((long)(n * p.Hi + iy) * p.Wi + ix) * p.in_ld + ch * 8);
         halo[pix * 16 + (ch ^ (pix & 15))] = v;
     }
-    const bf16_t* wt = reinterpret_cast<const bf16_t*>(p.wt);          // [Cout][4][4][Cin]
-    bf16_t* out = reinterpret_cast<bf16_t*>(p.out);
-    const bf16_t* res = reinterpret_cast<const bf16_t*>(p.res);
+    const T* wt = reinterpret_cast<const T*>(p.wt);          // [Cout][4][4][Cin]
+    T* out = reinterpret_cast<T*>(p.out);
+    const T* res = reinterpret_cast<const T*>(p.res);
     const int c0 = 8 * g;
     float sc[8], sh[8];
 #pragma unroll
@@ -689,7 +696,7 @@ __global__ __launch_bounds__(256) void deconv4_c128_c32_halo_kernel(ConvK p) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) Mma<bf16_t>::run(af[a], bf[b], acc[a][b]);
+                    for (int b = 0; b < 2; ++b) Mma<T>::run(af[a], bf[b], acc[a][b]);
             }
         }
 #pragma unroll
@@ -703,7 +710,7 @@ __global__ __launch_bounds__(256) void deconv4_c128_c32_halo_kernel(ConvK p) {
                 for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][b][r] * sc[a * 4 + r] + sh[a * 4 + r];
             if (res) {
                 float rv[8];
-                Vec16<bf16_t>::load(res + opix * p.res_ld + c0, rv);
+                Vec16<T>::load(res + opix * p.res_ld + c0, rv);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += rv[j];
             }
@@ -711,7 +718,7 @@ __global__ __launch_bounds__(256) void deconv4_c128_c32_halo_kernel(ConvK p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
             }
-            Vec16<bf16_t>::store(out + opix * p.out_ld + c0, v);
+            Vec16<T>::store(out + opix * p.out_ld + c0, v);
         }
     }
 }
@@ -902,12 +909,11 @@ __device__ __forceinline__ unsigned udiv_rcp(unsigned m, unsigned d, float rcp) 
     return q;
 }
 
-template <typename T> __device__ __forceinline__ int wg_swz(int unit, int row, int units_per_row);
-template <> __device__ __forceinline__ int wg_swz<bf16_t>(int unit, int row, int upr) {
-    const int key = ((row & 3) | (((row >> 3) & 1) << 2)) & (upr / 2 - 1);
-    return (((unit >> 1) ^ key) << 1) | (unit & 1);
-}
-template <> __device__ __forceinline__ int wg_swz<float>(int unit, int row, int upr) {
+template <typename T> __device__ __forceinline__ int wg_swz(int unit, int row, int upr) {
+    if (sizeof(T) == 2) {
+        const int key = ((row & 3) | (((row >> 3) & 1) << 2)) & (upr / 2 - 1);
+        return (((unit >> 1) ^ key) << 1) | (unit & 1);
+    }
     return unit ^ ((((row >> 2) & 1) << 2) & (upr - 1));
 }
 
@@ -1218,11 +1224,11 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
     if (cfg == 0) cfg = pick_cfg(k);
     if (!conv_cfg_ok(k, (int)sizeof(T), cfg)) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: configuration %d is not valid for this layer", cfg);
     if (cfg == CFG_HALO) {
-        hipLaunchKernelGGL(conv3x3_c32_halo_kernel, dim3(k.N * (k.Ho / 16) * (k.Wo / 16)), dim3(256), 0, st, k);
+        if constexpr (sizeof(T) == 2) hipLaunchKernelGGL(conv3x3_c32_halo_kernel<T>, dim3(k.N * (k.Ho / 16) * (k.Wo / 16)), dim3(256), 0, st, k);
         return msc_check_launch("conv3x3_c32_halo");
     }
     if (cfg == CFG_HALO_T) {
-        hipLaunchKernelGGL(deconv4_c128_c32_halo_kernel, dim3(k.N * (k.Hi / 8) * (k.Wi / 16)), dim3(256), 0, st, k);
+        if constexpr (sizeof(T) == 2) hipLaunchKernelGGL(deconv4_c128_c32_halo_kernel<T>, dim3(k.N * (k.Hi / 8) * (k.Wi / 16)), dim3(256), 0, st, k);
         return msc_check_launch("deconv4_c128_c32_halo");
     }
     switch (cfg) {
@@ -1260,8 +1266,8 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
 
 static int conv_fill(const msc_conv_desc* d, ConvK* k) {
     if (!d || !d->in || !d->wt || !d->out) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: null pointer");
-    const int es = d->dtype == MSC_BF16 ? 2 : 4;
-    if (d->dtype != MSC_BF16 && d->dtype != MSC_F32) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: dtype %d", d->dtype);
+    if (!msc_dtype_ok(d->dtype)) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: dtype %d", d->dtype);
+    const int es = msc_dtype_size(d->dtype);
     if ((d->Cin * es) % 64) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: Cin*%d must be a multiple of 64 bytes (Cin=%d)", es, d->Cin);
     if (d->Cout % 32) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: Cout must be a multiple of 32 (Cout=%d)", d->Cout);
     // 16-byte vector loads: every pixel start must be 16-byte aligned, or (stem form: KW == 1, pad == 0) every pixel
@@ -1313,7 +1319,7 @@ extern "C" int msc_conv_stats_slices(const msc_conv_desc* d) {
         return ceil_div(k.M, tp) * wp;
     }
     if (cfg == 0) cfg = pick_cfg(k);
-    if (!conv_cfg_ok(k, d->dtype == MSC_BF16 ? 2 : 4, cfg)) return -1;
+    if (!conv_cfg_ok(k, msc_dtype_size(d->dtype), cfg)) return -1;
     return ceil_div(k.M, CONV_CFGS[cfg].tp) * CONV_CFGS[cfg].wp;
 }
 
@@ -1322,7 +1328,7 @@ extern "C" int msc_conv_num_cfgs(void) { return N_CONV_CFG; }
 extern "C" int msc_conv_cfg_ok(const msc_conv_desc* d, int cfg) {
     ConvK k;
     if (conv_fill(d, &k) != MSC_OK) return 0;
-    return conv_cfg_ok(k, d->dtype == MSC_BF16 ? 2 : 4, cfg) ? 1 : 0;
+    return conv_cfg_ok(k, msc_dtype_size(d->dtype), cfg) ? 1 : 0;
 }
 
 extern "C" int msc_conv_igemm(const msc_conv_desc* d, void* stream) {
@@ -1330,6 +1336,7 @@ extern "C" int msc_conv_igemm(const msc_conv_desc* d, void* stream) {
     int rc = conv_fill(d, &k);
     if (rc != MSC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == MSC_F16) return conv_dispatch<f16_t>(k, d->mode, d->cfg, st);
     if (d->dtype == MSC_BF16) return conv_dispatch<bf16_t>(k, d->mode, d->cfg, st);
     return conv_dispatch<float>(k, d->mode, d->cfg, st);
 }
@@ -1344,8 +1351,8 @@ struct WgPlan { WgK k; int dtype, ta, tb; bool dma; };
 // fill the chip, so a block just runs that many k-steps) overrides the per-launch policy selected by d->cfg.
 int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPlan* out) {
     if (!d || !d->p || !d->q || !d->dw) return msc_fail(MSC_ERR_ARG, "msc_conv_wgrad: null pointer");
-    if (d->dtype != MSC_BF16 && d->dtype != MSC_F32) return msc_fail(MSC_ERR_ARG, "msc_conv_wgrad: dtype %d", d->dtype);
-    const int es = d->dtype == MSC_BF16 ? 2 : 4;
+    if (!msc_dtype_ok(d->dtype)) return msc_fail(MSC_ERR_ARG, "msc_conv_wgrad: dtype %d", d->dtype);
+    const int es = msc_dtype_size(d->dtype);
     if (d->A % 32 || d->B % 32) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_wgrad: channel counts must be multiples of 32 (A=%d B=%d)", d->A, d->B);
     const bool q_ok = (d->q_ld * es) % 16 == 0 ||
                       (d->KW == 1 && d->pad == 0 && (d->stride * d->q_ld * es) % 16 == 0 && ((int64_t)d->Wq * d->q_ld * es) % 16 == 0);
@@ -1418,7 +1425,7 @@ void wgrad_tile_dispatch(int dtype, int ta, int tb, F&& f) {
     else if (ta == 64) f.template operator()<T, 64, 32>(); \
     else if (tb == 64) f.template operator()<T, 32, 64>(); \
     else f.template operator()<T, 32, 32>();
-    if (dtype == MSC_BF16) { MSC_WG_CASE(bf16_t) } else { MSC_WG_CASE(float) }
+    if (dtype == MSC_F16) { MSC_WG_CASE(f16_t) } else if (dtype == MSC_BF16) { MSC_WG_CASE(bf16_t) } else { MSC_WG_CASE(float) }
 #undef MSC_WG_CASE
 }
 

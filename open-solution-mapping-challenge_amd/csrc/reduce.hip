@@ -192,7 +192,7 @@ int launch_colreduce(const void* dout, long dout_ld, const void* out, long out_l
 }  // namespace
 
 #define DT_CHECK(name, dtype) \
-    if ((dtype) != MSC_BF16 && (dtype) != MSC_F32) return msc_fail(MSC_ERR_ARG, name ": dtype %d", (int)(dtype))
+    if (!msc_dtype_ok(dtype)) return msc_fail(MSC_ERR_ARG, name ": dtype %d", (int)(dtype))
 
 extern "C" int msc_bn_finalize(const float* partials, int slices, int C, int64_t count, const float* gamma, const float* beta,
                                float eps, float momentum, float* running_mean, float* running_var,
@@ -205,7 +205,7 @@ extern "C" int msc_bn_finalize(const float* partials, int slices, int C, int64_t
 
 extern "C" int msc_bn_bwd_blocks(int64_t pixels, int C, int dtype) {
     RedGeom g;
-    if (pixels <= 0 || !red_geom(pixels, C, dtype == MSC_BF16 ? 8 : 4, &g)) return -1;
+    if (pixels <= 0 || !red_geom(pixels, C, msc_dtype_vec(dtype), &g)) return -1;
     return g.S;
 }
 
@@ -215,9 +215,10 @@ extern "C" int msc_bn_bwd_reduce(const void* dout, int64_t dout_ld, const void* 
     DT_CHECK("msc_bn_bwd_reduce", dtype);
     if (!dout || !y || !partials || relu < 0 || relu > 2 || (relu == 1 && !out) || (relu == 2 && (!scale || !shift)) || pixels <= 0)
         return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_reduce: bad argument");
-    if (C % (dtype == MSC_BF16 ? 32 : 16)) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bn_bwd_reduce: C=%d must be a multiple of %d", C, dtype == MSC_BF16 ? 32 : 16);
+    if (C % (4 * msc_dtype_vec(dtype))) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bn_bwd_reduce: C=%d must be a multiple of %d", C, 4 * msc_dtype_vec(dtype));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MSC_BF16) return launch_colreduce<bf16_t, 2>(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, partials, pixels, C, st);
+    if (dtype == MSC_F16) return launch_colreduce<f16_t, 2>(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, partials, pixels, C, st);
+    else if (dtype == MSC_BF16) return launch_colreduce<bf16_t, 2>(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, partials, pixels, C, st);
     return launch_colreduce<float, 2>(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, partials, pixels, C, st);
 }
 
@@ -231,20 +232,21 @@ extern "C" int msc_bn_bwd_finalize(const float* partials, int blocks, int C, int
 
 extern "C" int64_t msc_bias_grad_workspace_bytes(int64_t pixels, int C, int dtype) {
     RedGeom g;
-    if (pixels <= 0 || C <= 0 || !red_geom(pixels, C, dtype == MSC_BF16 ? 8 : 4, &g)) return 0;
+    if (pixels <= 0 || C <= 0 || !red_geom(pixels, C, msc_dtype_vec(dtype), &g)) return 0;
     return (int64_t)g.S * C * (int64_t)sizeof(float);
 }
 
 extern "C" int msc_bias_grad(const void* dy, int64_t dy_ld, float* db, void* workspace, int dtype, int64_t pixels, int C, void* stream) {
     DT_CHECK("msc_bias_grad", dtype);
     if (!dy || !db || !workspace || pixels <= 0) return msc_fail(MSC_ERR_ARG, "msc_bias_grad: bad argument");
-    if (C % (dtype == MSC_BF16 ? 32 : 16)) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bias_grad: C=%d must be a multiple of %d", C, dtype == MSC_BF16 ? 32 : 16);
+    if (C % (4 * msc_dtype_vec(dtype))) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bias_grad: C=%d must be a multiple of %d", C, 4 * msc_dtype_vec(dtype));
     hipStream_t st = (hipStream_t)stream;
-    int rc = dtype == MSC_BF16 ? launch_colreduce<bf16_t, 1>(dy, dy_ld, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, (float*)workspace, pixels, C, st)
+    int rc = dtype == MSC_F16  ? launch_colreduce<f16_t, 1>(dy, dy_ld, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, (float*)workspace, pixels, C, st)
+           : dtype == MSC_BF16 ? launch_colreduce<bf16_t, 1>(dy, dy_ld, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, (float*)workspace, pixels, C, st)
                                : launch_colreduce<float, 1>(dy, dy_ld, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, (float*)workspace, pixels, C, st);
     if (rc) return rc;
     RedGeom g;
-    red_geom(pixels, C, dtype == MSC_BF16 ? 8 : 4, &g);
+    red_geom(pixels, C, msc_dtype_vec(dtype), &g);
     hipLaunchKernelGGL(bias_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, g.S, C, db);
     return msc_check_launch("msc_bias_grad");
 }
@@ -253,13 +255,14 @@ extern "C" int msc_relu_bias_grad(const void* dy, int64_t dy_ld, const void* y, 
                                   void* workspace, int dtype, int64_t pixels, int C, void* stream) {
     DT_CHECK("msc_relu_bias_grad", dtype);
     if (!dy || !y || !dx || !db || !workspace || pixels <= 0) return msc_fail(MSC_ERR_ARG, "msc_relu_bias_grad: bad argument");
-    if (C % (dtype == MSC_BF16 ? 32 : 16)) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_relu_bias_grad: C=%d must be a multiple of %d", C, dtype == MSC_BF16 ? 32 : 16);
+    if (C % (4 * msc_dtype_vec(dtype))) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_relu_bias_grad: C=%d must be a multiple of %d", C, 4 * msc_dtype_vec(dtype));
     hipStream_t st = (hipStream_t)stream;
-    int rc = dtype == MSC_BF16 ? launch_colreduce<bf16_t, 1>(dy, dy_ld, y, y_ld, nullptr, 0, 1, nullptr, nullptr, (float*)workspace, pixels, C, st, dx, dx_ld)
+    int rc = dtype == MSC_F16  ? launch_colreduce<f16_t, 1>(dy, dy_ld, y, y_ld, nullptr, 0, 1, nullptr, nullptr, (float*)workspace, pixels, C, st, dx, dx_ld)
+           : dtype == MSC_BF16 ? launch_colreduce<bf16_t, 1>(dy, dy_ld, y, y_ld, nullptr, 0, 1, nullptr, nullptr, (float*)workspace, pixels, C, st, dx, dx_ld)
                                : launch_colreduce<float, 1>(dy, dy_ld, y, y_ld, nullptr, 0, 1, nullptr, nullptr, (float*)workspace, pixels, C, st, dx, dx_ld);
     if (rc) return rc;
     RedGeom g;
-    red_geom(pixels, C, dtype == MSC_BF16 ? 8 : 4, &g);
+    red_geom(pixels, C, msc_dtype_vec(dtype), &g);
     hipLaunchKernelGGL(bias_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, g.S, C, db);
     return msc_check_launch("msc_relu_bias_grad");
 }

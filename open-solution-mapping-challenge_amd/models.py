@@ -20,20 +20,58 @@ import numpy as np
 import torch
 
 from . import _lib
+from .callbacks import callbacks_unet
 from .distributed import World
 from .postprocessing import _to_host
 from .steps import BaseTransformer
-from .trainer import HipAdam, LossSpec, TrainStep
-from .unet_models import UNetResNet
+from .trainer import HipAdam, HipLoss, LossSpec, TrainStep
+from .unet_models import AlbuNet, UNetResNet
 
 logger = logging.getLogger('mapping-challenge')
 
-# src/models.py:22-47 (only the UNetResNet encoders are on the hot path)
+# src/models.py:22-47 (the ResNet-encoder U-Nets are the hot path; VGG11 / VGG16 / from_scratch are not)
 PRETRAINED_NETWORKS = {
+    'AlbuNet': {'model': AlbuNet, 'num_classes': 2, 'pretrained': True, 'is_deconv': True},
     'ResNet34': {'encoder_depth': 34, 'num_classes': 2, 'num_filters': 32, 'dropout_2d': 0.0, 'pretrained': True, 'is_deconv': True},
     'ResNet101': {'encoder_depth': 101, 'num_classes': 2, 'num_filters': 32, 'dropout_2d': 0.0, 'pretrained': True, 'is_deconv': True},
     'ResNet152': {'encoder_depth': 152, 'num_classes': 2, 'num_filters': 32, 'dropout_2d': 0.0, 'pretrained': True, 'is_deconv': True},
 }
+
+
+_HOST_INTERPRETER = False     # tests only: build programs on the CPU for tests/emu.py (there is still no CPU compute path)
+
+
+class _ModuleView(torch.nn.Module):
+    """What the callbacks get as `transformer.model`: the reference hands them the nn.DataParallel wrapper
+    (src/models.py:65), i.e. a callable whose state_dict keys carry the `module.` prefix and that save_model
+    (src/steps/pytorch/utils.py:67-75) moves to the CPU and back around torch.save.  Here the parameters live in ONE flat
+    device buffer that must not be re-homed, so cpu() / cuda() are no-ops and state_dict() returns host copies."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.module = net
+
+    def forward(self, x):
+        return self.module(x)
+
+    def cpu(self):
+        return self
+
+    def cuda(self, device=None):
+        return self
+
+    def state_dict(self, *args, **kwargs):
+        return {k: v.detach().cpu().contiguous() for k, v in super().state_dict(*args, **kwargs).items()}
+
+
+class _TransformerView:
+    """the attributes Callback.set_params reads from the transformer (src/steps/pytorch/callbacks.py:26-32)"""
+
+    def __init__(self, t):
+        self.model = _ModuleView(t.model)
+        self.optimizer, self.loss_function = t.optimizer, t.loss_function
+        self.output_names, self.validation_loss = t.output_names, t.validation_loss
+        self.callbacks = t.callbacks
 
 
 class BasePyTorchUNet(BaseTransformer):
@@ -51,8 +89,10 @@ class BasePyTorchUNet(BaseTransformer):
         wd = reg.get('weight_decay_conv2d', 0.0) if reg.get('regularize', False) else 0.0   # src/models.py:287-292
         self.optimizer = HipAdam(self.model, lr=opt.get('lr', 1e-3), weight_decay=wd)
         self.loss_spec = None
-        self.loss_function = None                    # [(name, spec, weight)] set by subclasses
-        self.world = World()
+        self.loss_function = None                    # [(name, callable(output, target) -> loss, weight)] set by subclasses
+        # gradients travel in the compute dtype when that is a 16-bit one (distributed.World.all_reduce_grad_range)
+        self.world = World(grad_wire=self.model.compute_dtype)
+        self.callbacks = callbacks_unet(self.callbacks_config)     # replaceable by the reference's own CallbackList
         self.epoch_losses = []
 
     # ---- reference API -------------------------------------------------------------------------
@@ -67,45 +107,65 @@ class BasePyTorchUNet(BaseTransformer):
             raise NotImplementedError('HIP path implements the UNetResNet encoders %s (got %r)'
                                       % (sorted(PRETRAINED_NETWORKS), encoder))
         dtype = params.get('compute_dtype', 'bf16')
-        self.model = UNetResNet(compute_dtype=dtype, **PRETRAINED_NETWORKS[encoder])
+        config = dict(PRETRAINED_NETWORKS[encoder])
+        self.model = config.pop('model', UNetResNet)(compute_dtype=dtype, **config)
+        if params.get('encoder_weights'):            # local torchvision checkpoint standing in for the model-zoo download
+            self.model.load_encoder_state_dict(params['encoder_weights'])
+        if _HOST_INTERPRETER:
+            self.model._host_interpreter = True
 
     def _device(self):
+        if _HOST_INTERPRETER:
+            return torch.device('cpu')
         if not torch.cuda.is_available():
             raise _lib.MscError('HIP transformers need a ROCm GPU: the product has no CPU path')
         return torch.device('cuda', torch.cuda.current_device())
 
     def fit(self, datagen, validation_datagen=None, meta_valid=None):
+        """src/models.py:62-86: the callback-driven epoch / batch loop around `_fit_loop`; nn.DataParallel is replaced by
+        one process per GPU (distributed.World), the callbacks see the model through a `module.`-prefixing view so the
+        checkpoints they write have the reference's format"""
         dev = self._device()
+        if self.model.pretrained_requested and not self.model.weights_loaded:
+            import warnings
+            warnings.warn("encoder '%s' asks for ImageNet-pretrained weights (src/models.py:22-47) but none were loaded: training "
+                          "starts from random encoder weights. Pass architecture_config['model_params']['encoder_weights'] (a local "
+                          'torchvision ResNet state_dict) or load() a checkpoint first.' % self.architecture_config['model_params']['encoder'])
         self.model.train()
         self.model.flatten_parameters(dev)
         self.world.sync_model(self.model)
-        step = TrainStep(self.model, self.loss_spec, self.optimizer, world=self.world,
-                         use_graph=bool(self.training_config.get('use_graph', False)))
+        self._step = TrainStep(self.model, self.loss_spec, self.optimizer, world=self.world,
+                               use_graph=bool(self.training_config.get('use_graph', False)),
+                               loss_scale=self.training_config.get('loss_scale'))
+        view = _TransformerView(self)
+        self.callbacks.set_params(view, validation_datagen=validation_datagen, meta_valid=meta_valid)
+        self.callbacks.on_train_begin()
         batch_gen, steps = datagen
-        gamma = self.callbacks_config.get('exp_lr_scheduler', {}).get('gamma', 1.0)
         for epoch_id in range(self.training_config['epochs']):
+            self.callbacks.on_epoch_begin()
             losses = []
             for batch_id, data in enumerate(batch_gen):
-                X, target = data[0], data[1]
-                loss = step(X.to(dev, non_blocking=True), target.to(dev, non_blocking=True).float())
-                losses.append(loss.clone())
+                self.callbacks.on_batch_begin()
+                metrics = self._fit_loop(data)
+                losses.append(metrics['sum'])
+                self.callbacks.on_batch_end(metrics=metrics)
                 if batch_id == steps:
                     break
             if losses:
-                mean = float(torch.stack(losses).mean().item())   # one D2H per epoch, not per batch
-                self.epoch_losses.append(mean)
-                logger.info('epoch {0} sum: {1:.5f}'.format(epoch_id, mean))
-            if gamma != 1.0:                                       # ExponentialLRScheduler, per epoch
-                self.optimizer.set_lr(self.optimizer.lr * gamma)
-            self._checkpoint()
+                self.epoch_losses.append(float(torch.stack(losses).mean().item()))     # one D2H per epoch
+            self.callbacks.on_epoch_end()
+            if self.callbacks.training_break():
+                break
+        self.callbacks.on_train_end()
         self.model.weights_changed()
         return self
 
-    def _checkpoint(self):
-        cfg = self.callbacks_config.get('model_checkpoint')
-        if cfg and cfg.get('filepath') and self.world.rank == 0:
-            os.makedirs(os.path.dirname(cfg['filepath']) or '.', exist_ok=True)
-            self._save_state(cfg['filepath'])
+    def _fit_loop(self, data):
+        """src/steps/pytorch/models.py:76-113 on the fused step (trainer.TrainStep); returns {'sum': loss[1]}"""
+        dev = self._device()
+        X, target = data[0], data[1]
+        loss = self._step(X.to(dev, non_blocking=True), target.to(dev, non_blocking=True).float())
+        return {'sum': loss.clone()}
 
     def _forward_probs(self, datagen):
         dev = self._device()
@@ -169,7 +229,7 @@ class PyTorchUNet(BasePyTorchUNet):
     def __init__(self, architecture_config, training_config, callbacks_config):
         super().__init__(architecture_config, training_config, callbacks_config)
         self.loss_spec = LossSpec.plain_ce()
-        self.loss_function = [(self.loss_name, self.loss_spec, 1.0)]
+        self.loss_function = [(self.loss_name, HipLoss(self.loss_spec, 'multiclass_segmentation_loss'), 1.0)]
 
 
 class PyTorchUNetWeighted(BasePyTorchUNet):
@@ -178,7 +238,7 @@ class PyTorchUNetWeighted(BasePyTorchUNet):
     def __init__(self, architecture_config, training_config, callbacks_config):
         super().__init__(architecture_config, training_config, callbacks_config)
         self.loss_spec = LossSpec.mixed(architecture_config)
-        self.loss_function = [(self.loss_name, self.loss_spec, 1.0)]
+        self.loss_function = [(self.loss_name, HipLoss(self.loss_spec, 'mixed_dice_cross_entropy_loss'), 1.0)]
 
 
 class _StreamMixin:

@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, WgradDesc, F32, BF16
+from ._lib import ConvDesc, WgradDesc, F32, BF16, F16
 
 
 def _dt(t):
@@ -18,7 +18,9 @@ def _dt(t):
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
-    raise TypeError('dtype must be float32 or bfloat16, got %s' % t.dtype)
+    if t.dtype == torch.float16:
+        return F16
+    raise TypeError('dtype must be float32, bfloat16 or float16, got %s' % t.dtype)
 
 
 def _stream(t):
@@ -114,7 +116,7 @@ def pack_transpose(src, dtype):
     """f32 [A, T, B] -> dtype [B, T, A]"""
     A, T, B = src.shape
     dst = torch.empty((B, T, A), dtype=dtype, device=src.device)
-    _lib.call('msc_pack_transpose', src.data_ptr(), dst.data_ptr(), F32 if dtype == torch.float32 else BF16, A, T, B, _stream(src))
+    _lib.call('msc_pack_transpose', src.data_ptr(), dst.data_ptr(), {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}[dtype], A, T, B, _stream(src))
     return dst
 
 

@@ -47,25 +47,28 @@ class LossSpec:
                    w0=wce['w0'], sigma=wce['sigma'], imsize=tuple(wce['imsize']))
 
 
+def _run(fn, args, device):
+    """one C-ABI launch on `device`'s current stream, through the same hook as the network's launch lists"""
+    from .unet_models import _Program, _stream_of
+    _Program.run([(fn, args)], _stream_of(device))
+
+
 def loss_sums(logits, target, spec, sums):
     """phase 1 of the fused loss: the four f64 sums of this rank's batch"""
     import ctypes as C
     N, Cc, H, W = logits.shape
     if Cc != 2:
         raise ValueError('loss kernels implement the 2-class head')
-    stream = torch.cuda.current_stream(logits.device).cuda_stream
-    _lib.check(_lib.load().msc_loss_sums(logits.data_ptr(), target.data_ptr(), target.shape[1], C.byref(spec.cfg), sums.data_ptr(),
-                                         N, H, W, stream), 'msc_loss_sums')
+    _run(_lib.load().msc_loss_sums, (logits.data_ptr(), target.data_ptr(), target.shape[1], C.byref(spec.cfg), sums.data_ptr(), N, H, W),
+         logits.device)
 
 
 def loss_grad(logits, target, spec, dlogits, loss_out, sums, total_pixels, grad_scale=1.0):
     """phase 2: loss value and dlogits from the (all-reduced) sums; total_pixels = pixels of the GLOBAL batch"""
     import ctypes as C
     N, _, H, W = logits.shape
-    stream = torch.cuda.current_stream(logits.device).cuda_stream
-    _lib.check(_lib.load().msc_loss_grad(logits.data_ptr(), target.data_ptr(), target.shape[1], C.byref(spec.cfg), sums.data_ptr(),
-                                         float(total_pixels), float(grad_scale), loss_out.data_ptr(), dlogits.data_ptr(), N, H, W, stream),
-               'msc_loss_grad')
+    _run(_lib.load().msc_loss_grad, (logits.data_ptr(), target.data_ptr(), target.shape[1], C.byref(spec.cfg), sums.data_ptr(),
+                                     float(total_pixels), float(grad_scale), loss_out.data_ptr(), dlogits.data_ptr(), N, H, W), logits.device)
 
 
 def loss_forward_backward(logits, target, spec, dlogits, loss_out, sums, world=None, grad_scale=1.0):
@@ -80,14 +83,56 @@ def loss_forward_backward(logits, target, spec, dlogits, loss_out, sums, world=N
     loss_grad(logits, target, spec, dlogits, loss_out, sums, total, grad_scale)
 
 
-class HipAdam:
-    """torch.optim.Adam(params, lr, weight_decay) semantics over the model's flat parameter buffer."""
+class _LossFunction(torch.autograd.Function):
+    """loss value with the fused kernels; backward hands out the dlogits the second kernel produced anyway"""
+
+    @staticmethod
+    def forward(ctx, output, target, spec):
+        out = output.detach().contiguous().float()
+        tgt = target.detach().contiguous().float()
+        dev = out.device
+        dl = torch.empty_like(out)
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        sums = torch.zeros(4, dtype=torch.float64, device=dev)
+        loss_forward_backward(out, tgt, spec, dl, loss, sums)
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad):
+        (dl,) = ctx.saved_tensors
+        return dl * grad.reshape(()), None, None
+
+
+class HipLoss:
+    """A reference-style loss callable `fn(output, target) -> loss` (what the transformers' `loss_function` lists hold and
+    the reference's callbacks / score_model call, src/steps/pytorch/validation.py:51-76, callbacks.py:58) on the fused HIP
+    loss kernels.  Returns a tensor of ONE element (so both `loss.item()` and the reference's `loss.data.cpu().numpy()[0]`
+    work); differentiable with respect to `output`, so the reference's own `_fit_loop` can call `.backward()` on it."""
+
+    def __init__(self, spec, name='loss'):
+        self.spec, self.__name__ = spec, name
+
+    def __call__(self, output, target):
+        if target.dim() == 3:
+            target = target.unsqueeze(1)
+        if target.shape[1] < self.spec.target_channels:
+            raise ValueError('%s needs a target with %d channels (class, distance, sqrt(size)), got %d'
+                             % (self.__name__, self.spec.target_channels, target.shape[1]))
+        return _LossFunction.apply(output, target, self.spec)
+
+
+class HipAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr, weight_decay) semantics over the model's flat parameter buffer.  It IS a
+    torch.optim.Optimizer (one param group holding the model's trainable parameters), so the reference's
+    `ExponentialLR(self.optimizer, gamma)` scheduler callback (src/steps/pytorch/callbacks.py:222) drives it unchanged:
+    the learning rate is read from `param_groups[0]['lr']` at every step."""
 
     def __init__(self, net, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__([p for _, p in net._trainable()], dict(lr=float(lr), betas=betas, eps=float(eps), weight_decay=float(weight_decay)))
         self.net, self.lr, self.betas, self.eps, self.weight_decay = net, float(lr), betas, float(eps), float(weight_decay)
-        self.m = self.v = self.state = None
+        self.m = self.v = self.dev_state = None
         self.steps = 0
-        self.param_groups = [{'lr': self.lr}]     # what the reference's LR scheduler callbacks poke at
 
     def _ensure(self):
         p = self.net.flat_params
@@ -95,35 +140,45 @@ class HipAdam:
             raise _lib.MscError('HipAdam: model parameters are not flattened yet (run a forward pass first)')
         if self.m is None or self.m.shape != p.shape or self.m.device != p.device:
             self.m, self.v = torch.zeros_like(p), torch.zeros_like(p)
-            self.state = torch.tensor([float(self.steps), self.lr], dtype=torch.float32, device=p.device)
+            self.dev_state = torch.tensor([float(self.steps), self.lr], dtype=torch.float32, device=p.device)
         return p
 
     def set_lr(self, lr):
         self.lr = float(lr)
         self.param_groups[0]['lr'] = self.lr
-        if self.state is not None:
-            self.state[1] = self.lr
+        if self.dev_state is not None:
+            self.dev_state[1] = self.lr
 
-    def zero_grad(self):
+    def sync_lr(self):
+        """pick up a learning rate a scheduler wrote into param_groups (also before a hipGraph replay: the captured
+        Adam launch reads step count and lr from device memory)"""
+        if self.param_groups[0]['lr'] != self.lr:
+            self.set_lr(self.param_groups[0]['lr'])
+
+    def zero_grad(self, set_to_none=False):
         if self.net.flat_grads is not None:
             self.net.flat_grads.zero_()
 
-    def step(self, grad_scale=1.0):
+    def launches(self, grad_scale=1.0):
+        """the two launches of one update (step counter tick + fused Adam) as (fn, args) pairs"""
         p = self._ensure()
-        if self.param_groups[0]['lr'] != self.lr:
-            self.set_lr(self.param_groups[0]['lr'])
-        g = self.net.flat_grads
-        stream = torch.cuda.current_stream(p.device).cuda_stream
         lib = _lib.load()
+        g = self.net.flat_grads
+        return [(lib.msc_adam_tick, (self.dev_state.data_ptr(),)),
+                (lib.msc_adam_step, (p.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), p.numel(), self.lr, self.betas[0],
+                                     self.betas[1], self.eps, self.weight_decay, 0, float(grad_scale), self.dev_state.data_ptr()))]
+
+    def step(self, closure=None, grad_scale=1.0):
+        p = self._ensure()
+        self.sync_lr()
+        from .unet_models import _Program, _stream_of
         self.steps += 1
-        _lib.check(lib.msc_adam_tick(self.state.data_ptr(), stream), 'msc_adam_tick')
-        _lib.check(lib.msc_adam_step(p.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), p.numel(), self.lr,
-                                     self.betas[0], self.betas[1], self.eps, self.weight_decay, 0, float(grad_scale),
-                                     self.state.data_ptr(), stream), 'msc_adam_step')
+        _Program.run(self.launches(grad_scale), _stream_of(p.device))
         self.net.weights_changed()
 
     def state_dict(self):
-        return {'m': self.m, 'v': self.v, 'steps': self.steps, 'lr': self.lr}
+        return {'m': self.m, 'v': self.v, 'steps': self.steps, 'lr': self.lr,
+                'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
 
 
 def ddp_plan(prog, flat_grads, nchunks=4):
@@ -157,43 +212,68 @@ def ddp_plan(prog, flat_grads, nchunks=4):
     return plan
 
 
-class TrainStep:
-    """forward -> loss -> backward -> (all-reduce) -> Adam for a fixed batch shape.  use_graph: the ~1.1k launches of
-    a step are captured so that they cost no host time on replay -- ONE hipGraph in a single process; with
-    collectives, a handful of graphs (forward + loss sums | loss gradient + backward piece 1 | piece 2.. | Adam) with the
-    RCCL calls issued eagerly between them, so the gradient all-reduce of a piece still overlaps the next pieces."""
+class _ShapeState:
+    """everything of a TrainStep that is bound to one batch shape: staging buffers, the program, captured graphs"""
+    __slots__ = ('x', 't', 'prog', 'graph', 'pieces')
 
-    def __init__(self, net, spec, optimizer, world=None, use_graph=False, force_collectives=False):
-        self.net, self.spec, self.opt, self.world = net, spec, optimizer, world
-        self.dist = world is not None and (world.size > 1 or force_collectives)     # force: exercise RCCL with one rank
-        self.use_graph = use_graph
-        self.graph = None
-        self.pieces = None
-        self.x = self.t = self.loss = self.sums = None
-        self.prog = None
-
-    def _setup(self, x, target):
-        dev = x.device
+    def __init__(self, x, target):
         self.x = torch.empty_like(x, dtype=torch.float32)
         self.t = torch.empty_like(target, dtype=torch.float32)
-        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.sums = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.prog = self.graph = self.pieces = None
+
+
+class TrainStep:
+    """forward -> loss -> backward -> (all-reduce) -> Adam.  use_graph: the ~1.1k launches of a step are captured so that
+    they cost no host time on replay -- ONE hipGraph in a single process; with collectives, a handful of graphs (forward +
+    loss sums | loss gradient + backward piece 1 | piece 2.. | Adam) with the RCCL calls issued eagerly between them, so
+    the gradient all-reduce of a piece still overlaps the next pieces.  Staging buffers, program and graphs are kept per
+    batch shape: the reference's DataLoader has no drop_last, so the last batch of an epoch is usually smaller, and a
+    graph (or graph piece) captured for one shape must never be replayed for another."""
+
+    def __init__(self, net, spec, optimizer, world=None, use_graph=False, force_collectives=False, loss_scale=None):
+        self.net, self.spec, self.opt, self.world = net, spec, optimizer, world
+        # fp16 activations cannot hold the gradients of a mean over millions of pixels (dlogits ~ 1e-7 per pixel, below
+        # the smallest fp16 subnormal): a static loss scale multiplies dlogits and is divided out again inside the
+        # Adam kernel, on the fp32 weight gradients.  bf16 / fp32 share fp32's exponent range and need none.
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (4096.0 if getattr(net, 'compute_dtype', '') == 'fp16' else 1.0)
+        self.dist = world is not None and (world.size > 1 or force_collectives)     # force: exercise RCCL with one rank
+        self.use_graph = use_graph
+        self.shapes = {}
+        self.cur = None
+        self.loss = self.sums = None
+
+    # the state of the batch shape in use (what the tests and bench.py look at)
+    x = property(lambda self: self.cur.x if self.cur else None)
+    t = property(lambda self: self.cur.t if self.cur else None)
+    prog = property(lambda self: self.cur.prog if self.cur else None)
+    graph = property(lambda self: self.cur.graph if self.cur else None)
+    pieces = property(lambda self: self.cur.pieces if self.cur else None)
+
+    def _setup(self, x, target):
+        key = (tuple(x.shape), tuple(target.shape), x.device)
+        st = self.shapes.get(key)
+        if st is None:
+            st = self.shapes[key] = _ShapeState(x, target)
+        self.cur = st
+        if self.loss is None or self.loss.device != x.device:
+            self.loss = torch.zeros(1, dtype=torch.float32, device=x.device)
+            self.sums = torch.zeros(4, dtype=torch.float64, device=x.device)
+        return st
 
     def _body(self):
-        net = self.net
-        prog = net.train_forward(self.x)
-        self.prog = prog
-        loss_forward_backward(prog.logits, self.t, self.spec, prog.dlogits, self.loss, self.sums, self.world)
+        net, st = self.net, self.cur
+        prog = net.train_forward(st.x)
+        st.prog = prog
+        loss_forward_backward(prog.logits, st.t, self.spec, prog.dlogits, self.loss, self.sums, self.world, self.loss_scale)
         if self.dist:
             self._backward_overlapped(prog)
         else:
             net.train_backward(prog)
-        self.opt.step()
+        self.opt.step(grad_scale=1.0 / self.loss_scale)
 
     def _backward_overlapped(self, prog):
         """backward in pieces; each piece's finished gradient range goes to RCCL (async, its own stream) while the
         next piece computes"""
-        import torch.distributed as dist
         from .unet_models import _Program
         net = self.net
         flat_g = net.flat_grads
@@ -206,22 +286,20 @@ class TrainStep:
             _Program.run_backward(prog.bwd[beg:end], flat_g.device)     # joins its side stream before returning
             beg = end
             if lo is not None:
-                works.append(dist.all_reduce(flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.world.group, async_op=True))
+                works.append(self.world.all_reduce_grad_range(flat_g, lo, hi))
         for w in works:
             w.wait()
 
     def __call__(self, x, target):
-        if self.x is None or self.x.shape != x.shape or self.t.shape != target.shape:
-            self._setup(x, target)
-            self.graph = None
-        self.x.copy_(x, non_blocking=True)
-        self.t.copy_(target, non_blocking=True)
+        st = self._setup(x, target)
+        st.x.copy_(x, non_blocking=True)
+        st.t.copy_(target, non_blocking=True)
         if not self.use_graph:
             self._body()
             return self.loss
-        if self.graph is None and self.pieces is None:
-            # the first step runs eagerly (builds the program, allocates, packs) and IS this call's step;
-            # capturing afterwards does not execute anything, replays start with the next call
+        if st.graph is None and st.pieces is None:
+            # the first step of a shape runs eagerly (builds the program, allocates, packs) and IS this call's step;
+            # capturing afterwards does not execute anything, replays start with the next call of this shape
             self._body()
             torch.cuda.synchronize()
             if self.dist:
@@ -231,24 +309,28 @@ class TrainStep:
                     import warnings
                     warnings.warn('hipGraph capture of the distributed step failed (%s); continuing with eager launches' % e)
                     torch.cuda.synchronize()
-                    self.pieces, self.use_graph = None, False
+                    st.pieces, self.use_graph = None, False
             else:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._body_captured()
-                self.graph = g
+                st.graph = g
             return self.loss
-        if self.pieces is not None:
+        self.opt.sync_lr()                # a scheduler callback may have changed it: the captured Adam reads it from the device
+        if st.pieces is not None:
             self._replay_pieces()
         else:
-            self.graph.replay()
+            st.graph.replay()
         self.opt.steps += 1
+        self.net._packed_version = -1     # the replay changed the master weights; packed copies are refreshed inside every replay
+        self.net._version += 1
         return self.loss
 
     # ---- piecewise capture: graphs around the collectives ----------------------------------------------
     def _capture_pieces(self):
         from .unet_models import _Program
-        net, prog, dev = self.net, self.prog, self.x.device
+        net, st = self.net, self.cur
+        prog, dev = st.prog, st.x.device
         N, _, H, W = prog.logits.shape
         total = float(N * H * W) * (self.world.size if self.world.size > 1 else 1)
         flat_g = net.flat_grads
@@ -264,36 +346,31 @@ class TrainStep:
 
         def forward(stream):
             _Program.run(net._pack['ops'], stream)
-            prog.x_in.copy_(self.x)
+            prog.x_in.copy_(st.x)
             _Program.run(prog.fwd, stream)
-            loss_sums(prog.logits, self.t, self.spec, self.sums)
+            loss_sums(prog.logits, st.t, self.spec, self.sums)
 
         def piece(beg, end, first):
             def fn(stream):
                 if first:
-                    loss_grad(prog.logits, self.t, self.spec, prog.dlogits, self.loss, self.sums, total)
+                    loss_grad(prog.logits, st.t, self.spec, prog.dlogits, self.loss, self.sums, total, self.loss_scale)
                     flat_g.zero_()
                     prog.stem_dw.zero_()
                 _Program.run_backward(prog.bwd[beg:end], dev)
             return fn
 
         def adam(stream):
-            o, lib = self.opt, _lib.load()
-            p = net.flat_params
-            _lib.check(lib.msc_adam_tick(o.state.data_ptr(), stream), 'msc_adam_tick')
-            _lib.check(lib.msc_adam_step(p.data_ptr(), flat_g.data_ptr(), o.m.data_ptr(), o.v.data_ptr(), p.numel(), o.lr, o.betas[0],
-                                         o.betas[1], o.eps, o.weight_decay, 0, 1.0, o.state.data_ptr(), stream), 'msc_adam_step')
+            _Program.run(self.opt.launches(1.0 / self.loss_scale), stream)
 
         pieces, beg = [], 0
         for end, lo, hi in prog._ddp_plan:
             pieces.append((capture(piece(beg, end, beg == 0)), lo, hi))
             beg = end
-        self.pieces = (capture(forward), pieces, capture(adam))
+        st.pieces = (capture(forward), pieces, capture(adam))
         net._packed_version = -1
 
     def _replay_pieces(self):
-        import torch.distributed as dist
-        fwd, pieces, adam = self.pieces
+        fwd, pieces, adam = self.cur.pieces
         flat_g = self.net.flat_grads
         fwd.replay()
         self.world.all_reduce(self.sums)
@@ -301,28 +378,23 @@ class TrainStep:
         for g, lo, hi in pieces:
             g.replay()
             if lo is not None:
-                works.append(dist.all_reduce(flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.world.group, async_op=True))
+                works.append(self.world.all_reduce_grad_range(flat_g, lo, hi))
         for w in works:
             w.wait()
         adam.replay()
 
     def _body_captured(self):
         # same as _body, but the weight repack after Adam is part of the graph so replays stay consistent
-        net = self.net
-        stream = torch.cuda.current_stream(self.x.device).cuda_stream
+        net, st = self.net, self.cur
+        stream = torch.cuda.current_stream(st.x.device).cuda_stream
         from .unet_models import _Program
         _Program.run(net._pack['ops'], stream)
-        prog = self.prog
-        prog.x_in.copy_(self.x)
+        prog = st.prog
+        prog.x_in.copy_(st.x)
         _Program.run(prog.fwd, stream)
-        loss_forward_backward(prog.logits, self.t, self.spec, prog.dlogits, self.loss, self.sums, None)
+        loss_forward_backward(prog.logits, st.t, self.spec, prog.dlogits, self.loss, self.sums, None, self.loss_scale)
         net._flat[1].zero_()
         prog.stem_dw.zero_()
-        _Program.run_backward(prog.bwd, self.x.device)
-        lib = _lib.load()
-        o = self.opt
-        p, gr = net.flat_params, net.flat_grads
-        _lib.check(lib.msc_adam_tick(o.state.data_ptr(), stream), 'msc_adam_tick')
-        _lib.check(lib.msc_adam_step(p.data_ptr(), gr.data_ptr(), o.m.data_ptr(), o.v.data_ptr(), p.numel(), o.lr, o.betas[0],
-                                     o.betas[1], o.eps, o.weight_decay, 0, 1.0, o.state.data_ptr(), stream), 'msc_adam_step')
+        _Program.run_backward(prog.bwd, st.x.device)
+        _Program.run(self.opt.launches(1.0 / self.loss_scale), stream)
         net._packed_version = -1      # host bookkeeping: packed copies refreshed at the head of every replay

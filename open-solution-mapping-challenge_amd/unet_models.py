@@ -21,7 +21,9 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._lib import ConvDesc, WgradDesc, F32, BF16
+from ._lib import ConvDesc, WgradDesc, F32, BF16, F16
+
+_DTYPES = {'bf16': (torch.bfloat16, BF16), 'fp16': (torch.float16, F16), 'fp32': (torch.float32, F32)}
 
 _ENC = {34: ('basic', [3, 4, 6, 3], 512), 101: ('bottle', [3, 4, 23, 3], 2048), 152: ('bottle', [3, 8, 36, 3], 2048)}
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
@@ -223,7 +225,8 @@ class UNetResNet(nn.Module):
     Args mirror src/unet_models.py:338-339.  `pretrained` cannot download ImageNet weights offline
     and is ignored (weights come from load_state_dict); `is_deconv` must be True and `dropout_2d`
     0.0, the only values any shipped configuration uses (src/models.py:32-46).
-    Extra keyword: compute_dtype 'bf16' (throughput mode, default) or 'fp32' (exact-f32 parity mode).
+    Extra keyword: compute_dtype 'bf16' (throughput mode, default), 'fp16' (BASELINE.json configs[4]; training in it needs
+    the static loss scale TrainStep applies, inference does not) or 'fp32' (exact-f32 parity mode).
     """
 
     def __init__(self, encoder_depth, num_classes, num_filters=32, dropout_2d=0.2, pretrained=False,
@@ -240,6 +243,9 @@ class UNetResNet(nn.Module):
         if num_filters % 32:
             raise NotImplementedError('num_filters must be a multiple of 32')
         self.num_classes, self.dropout_2d, self.encoder_depth = num_classes, dropout_2d, encoder_depth
+        # the reference downloads ImageNet weights for pretrained=True (torchvision model zoo); there is no network here:
+        # the request is remembered and the transformers warn if training starts from random encoder weights
+        self.pretrained_requested, self.weights_loaded = bool(pretrained), False
         kind, layers, bottom = _ENC[encoder_depth]
         self._kind, self._bottom, self._nf = kind, bottom, num_filters
         nf = num_filters
@@ -270,11 +276,10 @@ class UNetResNet(nn.Module):
 
     # ------------------------------------------------------------------ configuration
     def set_compute_dtype(self, compute_dtype):
-        if compute_dtype not in ('bf16', 'fp32'):
-            raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
+        if compute_dtype not in _DTYPES:
+            raise ValueError("compute_dtype must be 'bf16', 'fp16' or 'fp32'")
         self.compute_dtype = compute_dtype
-        self._tdtype = torch.bfloat16 if compute_dtype == 'bf16' else torch.float32
-        self._dt = BF16 if compute_dtype == 'bf16' else F32
+        self._tdtype, self._dt = _DTYPES[compute_dtype]
         self._programs = {}
         self._pack = None
         return self
@@ -289,6 +294,19 @@ class UNetResNet(nn.Module):
             state_dict = {k[len('module.'):]: v for k, v in state_dict.items()}
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         self._version += 1
+        self.weights_loaded = True
+        return out
+
+    def load_encoder_state_dict(self, state_dict):
+        """ImageNet weights for the encoder from a local torchvision ResNet checkpoint (a state_dict or a path to one):
+        what `pretrained=True` fetches from the model zoo in the reference (src/unet_models.py:344-352)"""
+        if isinstance(state_dict, str):
+            state_dict = torch.load(state_dict, map_location='cpu')
+        out = self.encoder.load_state_dict(state_dict, strict=False)
+        if out.unexpected_keys:
+            raise KeyError('not a torchvision ResNet%d state_dict: unexpected keys %s' % (self.encoder_depth, out.unexpected_keys[:4]))
+        self._version += 1
+        self.weights_loaded = True
         return out
 
     # ------------------------------------------------------------------ flat parameter storage
@@ -495,6 +513,15 @@ class UNetResNet(nn.Module):
         self._run_backward(prog, prog.dlogits if dlogits is None else dlogits)
 
 
+class AlbuNet(UNetResNet):
+    """src/unet_models.py:153-221: the ResNet34-encoder U-Net under its other name (`PRETRAINED_NETWORKS['AlbuNet']`,
+    src/models.py:29-31): the graph and state_dict of UNetResNet(34) without the dropout argument."""
+
+    def __init__(self, num_classes=1, num_filters=32, pretrained=False, is_deconv=False, compute_dtype='bf16', autotune=None):
+        super().__init__(34, num_classes, num_filters=num_filters, dropout_2d=0.0, pretrained=pretrained, is_deconv=is_deconv,
+                         compute_dtype=compute_dtype, autotune=autotune)
+
+
 class _UNetFunction(torch.autograd.Function):
     """The whole network as one autograd node: lets the reference's own training loop
     (`loss.backward(); optimizer.step()`, src/steps/pytorch/models.py:110-111) drive the HIP engine."""
@@ -572,7 +599,7 @@ class _Builder:
         _tune_load()
         self._tuned_new = False
         self.dt, self.tdtype = net._dt, net._tdtype
-        self.es = 2 if self.dt == BF16 else 4
+        self.es = 4 if self.dt == F32 else 2
         self.prog = _Program()
         self.prog.training = training
         self.prog.fold, self.prog.fold_version = [], -1

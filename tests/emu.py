@@ -26,6 +26,8 @@ def _rows(ptr, pixels, C_, ld):
 
 
 def _val(a):
+    if hasattr(a, '_obj') and not hasattr(a._obj, 'N'):      # byref(struct) of a plain configuration record (msc_loss_cfg)
+        return a._obj
     return a.value if hasattr(a, 'value') else a
 
 
@@ -110,8 +112,81 @@ def conv_wgrad(dref):
             dw[:, kh, kw, :] += (P[ok].T @ Q).astype(np.float32)
 
 
+def _wire(ptr, n, dtype):
+    """torch view of a raw buffer of n elements of the ABI dtype (0 f32, 1 bf16, 2 f16)"""
+    import torch
+    td = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[dtype]
+    nbytes = n * (4 if dtype == 0 else 2)
+    raw = np.ctypeslib.as_array((C.c_uint8 * int(nbytes)).from_address(int(ptr)))
+    return torch.from_numpy(raw).view(td)
+
+
 def pack_cast(src, dst, dtype, n):
-    _arr(dst, n)[...] = _arr(src, n)
+    import torch
+    _wire(dst, n, dtype).copy_(torch.from_numpy(_arr(src, n)))      # round to nearest even, like the kernel
+
+
+def grad_reduce(recv, out, dtype, world, shard):
+    r = _wire(recv, world * shard, dtype).view(world, shard).float()
+    acc = r[0].clone()
+    for w in range(1, world):            # fp32 accumulation in rank order, one rounding at the end
+        acc += r[w]
+    _wire(out, shard, dtype).copy_(acc)
+
+
+def grad_unpack(inp, g, dtype, n):
+    _arr(g, n)[...] = _wire(inp, n, dtype).float().numpy()
+
+
+def _loss_terms(logits, target, tc, cfg, N, H, W):
+    lg = _arr(logits, N * 2 * H * W).reshape(N, 2, H * W).astype(np.float64)
+    tg = _arr(target, N * tc * H * W).reshape(N, tc, H * W)
+    m = lg.max(1)
+    e = np.exp(lg - m[:, None])
+    s = e.sum(1)
+    p1, p0 = e[:, 1] / s, e[:, 0] / s
+    tcls = tg[:, 0].astype(np.int64)
+    ce = m + np.log(s) - np.where(tcls == 1, lg[:, 1], lg[:, 0])
+    t1 = (tcls == 1).astype(np.float64)
+    w = np.ones_like(ce)
+    if cfg.weighted:
+        d, sz = tg[:, 1].astype(np.float64), tg[:, 2].astype(np.float64)
+        dw = np.where(d == 0, 1.0, 1.0 + cfg.w0 * np.exp(-(d * d) / (cfg.sigma * cfg.sigma)))
+        s1 = np.where(sz == 0, 1.0, sz)
+        w = dw * np.where(s1 == 1, 1.0, cfg.size_c / s1)
+    return ce, w, p0, p1, t1
+
+
+def loss_sums(logits, target, tc, cfg, sums, N, H, W):
+    ce, w, p0, p1, t1 = _loss_terms(logits, target, tc, cfg, N, H, W)
+    _arr(sums, 4, np.float64)[...] = [(w * ce).sum(), (p1 * t1).sum(), p1.sum(), t1.sum()]
+
+
+def loss_grad(logits, target, tc, cfg, sums, total_pixels, grad_scale, loss, dlogits, N, H, W):
+    ce, w, p0, p1, t1 = _loss_terms(logits, target, tc, cfg, N, H, W)
+    s = _arr(sums, 4, np.float64)
+    A, B = 2.0 * s[1] + cfg.smooth, s[2] + s[3] + cfg.smooth + cfg.eps
+    if loss:
+        _arr(loss, 1)[0] = cfg.ce_weight * s[0] / total_pixels + cfg.dice_weight * (1.0 - A / B)
+    g1 = (cfg.ce_weight / total_pixels) * w * (p1 - t1) + (cfg.dice_weight * A / (B * B) - cfg.dice_weight * 2.0 / B * t1) * p1 * p0
+    dl = _arr(dlogits, N * 2 * H * W).reshape(N, 2, H * W)
+    dl[:, 0], dl[:, 1] = -g1 * grad_scale, g1 * grad_scale
+
+
+def adam_tick(state):
+    _arr(state, 2)[0] += 1.0
+
+
+def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, step, gscale, state):
+    if state:
+        st = _arr(state, 2)
+        step, lr = float(st[0]), float(st[1])
+    pp, gg, mm, vv = _arr(p, n), _arr(g, n), _arr(m, n), _arr(v, n)
+    gr = gg * np.float32(gscale) + np.float32(wd) * pp
+    mm[...] = b1 * mm + (1 - b1) * gr
+    vv[...] = b2 * vv + (1 - b2) * gr * gr
+    bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
+    pp[...] = pp - (lr / bc1) * (mm / (np.sqrt(vv) / np.sqrt(bc2) + eps))
 
 
 def pack_transpose(src, dst, dtype, A, T, B):
@@ -299,6 +374,8 @@ TABLE = {'msc_conv_igemm': conv_igemm, 'msc_conv_wgrad': conv_wgrad, 'msc_pack_c
          'msc_stem_prepare': stem_prepare, 'msc_maxpool2_fwd': maxpool2_fwd, 'msc_maxpool2_bwd': maxpool2_bwd,
          'msc_bn_finalize': bn_finalize, 'msc_bn_fold': bn_fold, 'msc_bn_apply': bn_apply,
          'msc_bn_bwd_reduce': bn_bwd_reduce, 'msc_bn_bwd_finalize': bn_bwd_finalize, 'msc_bn_bwd_apply': bn_bwd_apply,
+         'msc_loss_sums': loss_sums, 'msc_loss_grad': loss_grad, 'msc_adam_tick': adam_tick, 'msc_adam_step': adam_step,
+         'msc_grad_reduce': grad_reduce, 'msc_grad_unpack': grad_unpack,
          'msc_relu_bwd': relu_bwd, 'msc_bias_grad': bias_grad, 'msc_relu_bias_grad': relu_bias_grad, 'msc_final_fwd': final_fwd, 'msc_final_bwd': final_bwd}
 
 
