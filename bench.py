@@ -1,15 +1,20 @@
 """Benchmark of the U-Net hot path on MI355X (contract: see the task statement / DESIGN.md section 5).
 
-    python bench.py --gpus N --steps K --warmup W [--workload train|infer|post|annot] [--encoder 101] [--dtype bf16]
+    python bench.py --gpus N --steps K --warmup W [--workload train|infer|tta|post|annot] [--encoder 101] [--dtype bf16|fp16|fp32]
+                    [--size 256|320|512] [--batch B]
 
 One "step" = one pass of the hot path over one synthetic batch resident in HBM:
   train (default, BASELINE.json metric / configs[2]): ResNet101-U-Net forward + mixed weighted-CE/Dice loss + backward +
         Adam(+L2), batch 32 per GPU, 300x300 tiles resized to the 256x256 network input (the reference's default
         loader_mode, neptune.yaml:23,27-28), bf16 compute / fp32 accumulate & master weights
-  infer (configs[1]): ResNet34-U-Net eval forward + fused softmax, batch 32
+  infer (configs[1]): ResNet34-U-Net eval forward + fused softmax, batch 32 (--encoder 101: the north-star forward line)
+  tta   (configs[4]): ResNet152-U-Net fp16, batch 64, 512x512 tiles, test-time augmentation x4 (identity, two flips, both
+        -- the reference's elif chain, src/loaders.py:478-481), aggregated on the device
   post  (configs[3]): resize 256->300, threshold, 4-connected labelling, 2x2 label dilation, scoring, batch 64 masks
-N > 1: launched by torch.distributed.run, one rank per GPU, batch sharded (weak scaling), loss sums and gradients
-all-reduced over RCCL.  Rank 0 prints ONE JSON line.
+--size: network input edge; 256 = the reference's default loader (300x300 tiles resized, neptune.yaml:23,27-28), 320 = its
+crop_and_pad loader (tiles replicate-padded by 10 px, neptune.yaml:77-79).
+N > 1: one rank per GPU, batch sharded (weak scaling), loss sums and gradients all-reduced over RCCL.  Started without a
+torchrun environment, `--gpus N` re-executes itself under torch.distributed.run.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -148,13 +153,12 @@ def cpu_baseline_train(encoder, hw, budget_s=25.0):
                       % (encoder, n, hw, hw, k)}
 
 
-def cpu_baseline_infer(encoder, hw, budget_s=20.0):
+def cpu_baseline_infer(encoder, hw, budget_s=20.0, n=4):
     from oracle import unet_ref
     torch.set_num_threads(cpu_threads())
     net = unet_ref.UNetResNetRef(encoder)
     net.load_state_dict(unet_ref.seeded_state_dict(net))
     net.eval()
-    n = 4
     x = unet_ref.synthetic_batch(n, hw, hw)
     with torch.no_grad():
         net(x)
@@ -196,33 +200,57 @@ def cpu_baseline_annot(layers, budget_s=15.0):
             'sample': 'oracle/annot_ref.py (numpy restatement of src/utils.py:61-127 + maskApi.c) on %d images of 2 layers' % k}
 
 
+DEFAULT_STEPS = {'train': 200, 'infer': 200, 'tta': 20, 'post': 100, 'annot': 50}     # seconds of GPU work, not milliseconds
+
+
+def tile_text(hw):
+    return {256: '300x300 tiles as 256x256 network input (reference loader_mode resize)',
+            320: '300x300 tiles replicate-padded to 320x320 network input (reference loader_mode crop_and_pad)'}.get(hw, '%dx%d tiles' % (hw, hw))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='train', choices=['train', 'infer', 'post', 'annot'])
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='train', choices=['train', 'infer', 'tta', 'post', 'annot'])
     ap.add_argument('--encoder', type=int, default=None)
     ap.add_argument('--batch', type=int, default=None)
-    ap.add_argument('--size', type=int, default=256)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--size', type=int, default=None)
+    ap.add_argument('--dtype', default=None, choices=['bf16', 'fp16', 'fp32'])
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true')
     ap.add_argument('--dump-launches', default=None, help='write per-launch conv/wgrad timings to this JSON file')
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = DEFAULT_STEPS[args.workload]
+    if args.dtype is None:
+        args.dtype = 'fp16' if args.workload == 'tta' else 'bf16'
+    if args.size is None:
+        args.size = 512 if args.workload == 'tta' else 256
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` on its own: become N ranks (one per GPU) under torch.distributed.run
+        import socket
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+                                  '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:])
 
     from mapping_challenge_amd.distributed import World
     world = World.from_env()
     if args.gpus != world.size:
-        raise SystemExit('--gpus %d but WORLD_SIZE is %d (launch N>1 with torch.distributed.run)' % (args.gpus, world.size))
+        raise SystemExit('--gpus %d but WORLD_SIZE is %d' % (args.gpus, world.size))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     stream = torch.cuda.current_stream(dev).cuda_stream
     hw = args.size
     result = {'n_gpus': world.size, 'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True, 'scaling': 'weak',
-              'vs_baseline': None, 'data': 'synthetic', 'dtype': args.dtype}
+              'vs_baseline': None, 'data': 'synthetic', 'dtype': args.dtype,
+              'rccl_ranks': world.size if world.size > 1 else 0}
 
     def timed(step_fn):
         for _ in range(args.warmup):
@@ -240,16 +268,18 @@ def main():
             world.all_reduce(dt, op=dist.ReduceOp.MAX)
         return float(dt.item())
 
-    if args.workload in ('train', 'infer'):
+    if args.workload in ('train', 'infer', 'tta'):
         from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
         from mapping_challenge_amd.unet_models import UNetResNet
         from oracle import losses_ref, unet_ref     # synthetic data / seeded weights only (inputs, not the product path)
-        enc = args.encoder or (101 if args.workload == 'train' else 34)
-        batch = args.batch or 32
+        enc = args.encoder or {'train': 101, 'infer': 34, 'tta': 152}[args.workload]
+        batch = args.batch or (64 if args.workload == 'tta' else 32)
         net = UNetResNet(enc, 2, num_filters=32, dropout_2d=0.0, is_deconv=True, compute_dtype=args.dtype)
         net.load_state_dict(unet_ref.seeded_state_dict(net))
         net.flatten_parameters(dev)
         world.sync_model(net)
+        if args.dtype != 'fp32':
+            world.grad_wire = os.environ.get('MSC_GRAD_WIRE', args.dtype)      # 16-bit gradient exchange in the compute dtype
         x = unet_ref.synthetic_batch(batch, hw, hw, seed=1234 + world.rank).to(dev)
         fwd_gf = None
         if args.workload == 'train':
@@ -273,16 +303,30 @@ def main():
             loss = float(step.loss.item())
             result.update(metric='images/sec (train fwd+bwd) ResNet%d-U-Net' % enc, unit='img/s',
                           config={'workload': 'ResNet%d-U-Net train step (fwd + weighted-CE/Dice loss + bwd + Adam+L2), batch %d/GPU, '
-                                              '300x300 tiles as %dx%d network input (reference loader_mode resize), bf16 compute, '
-                                              'fp32 master weights; random-init seeded weights' % (enc, batch, hw, hw),
-                                  'global_batch': batch * world.size, 'parallelism': 'dp%d' % world.size, 'hipgraph': step.graph is not None,
-                                  'final_loss': loss})
+                                              '%s, %s compute, fp32 accumulate / master weights; random-init seeded weights'
+                                              % (enc, batch, tile_text(hw), args.dtype),
+                                  'global_batch': batch * world.size, 'parallelism': 'dp%d' % world.size,
+                                  'hipgraph': step.graph is not None or step.pieces is not None,
+                                  'grad_wire': world.grad_wire if world.size > 1 else None, 'final_loss': loss})
+        elif args.workload == 'tta':
+            from mapping_challenge_amd import tta
+            net.eval()
+            specs = tta.tta_specs(flip_ud=True, flip_lr=True)        # identity + 3: the reference generator with rotation off
+            dt = timed(lambda: tta.predict_tta(net, x, specs, 'gmean'))
+            prog = net._program(batch, hw, hw, False, dev)
+            result.update(metric='images/sec (inference forward, test-time augmentation x%d) ResNet%d-U-Net' % (len(specs), enc), unit='img/s',
+                          config={'workload': 'ResNet%d-U-Net eval forward + fused softmax over %d TTA variants (flips), geometric-mean '
+                                              'aggregation on the device, batch %d tiles/GPU, %s, %s compute'
+                                              % (enc, len(specs), batch, tile_text(hw), args.dtype),
+                                  'global_batch': batch * world.size, 'parallelism': 'dp%d' % world.size, 'tta_variants': len(specs),
+                                  'forward_passes_per_sec': batch * world.size * len(specs) * args.steps / dt})
         else:
             net.eval()
             dt = timed(lambda: net.predict_proba(x))
             prog = net._program(batch, hw, hw, False, dev)
             result.update(metric='images/sec (inference forward) ResNet%d-U-Net' % enc, unit='img/s',
-                          config={'workload': 'ResNet%d-U-Net eval forward + fused softmax, batch %d, %dx%d network input' % (enc, batch, hw, hw),
+                          config={'workload': 'ResNet%d-U-Net eval forward + fused softmax, batch %d/GPU, %s, %s compute'
+                                              % (enc, batch, tile_text(hw), args.dtype),
                                   'global_batch': batch * world.size, 'parallelism': 'dp%d' % world.size})
         value = batch * world.size * args.steps / dt
         result.update(value=value, ms_per_step=1e3 * dt / args.steps)
@@ -300,7 +344,7 @@ def main():
                     wg[key] += fam.get(name, {}).get(key, 0.0)
             total_ms = sum(f['ms'] for f in fam.values())
             dom = max(fam.items(), key=lambda kv: kv[1]['ms'])
-            peak = PEAK_BF16 if args.dtype == 'bf16' else PEAK_F32
+            peak = PEAK_F32 if args.dtype == 'fp32' else PEAK_BF16        # bf16 and fp16 MFMA share the dense peak
             ach = conv['flops'] / (conv['ms'] * 1e-3) if conv['ms'] else 0.0
             traffic = None
             pmc_file = os.path.join(ROOT, 'profiles', 'pmc_traffic_%s_r%d.json' % (args.workload, enc))
@@ -320,9 +364,9 @@ def main():
                     (sum(fam.get(k, {}).get('bytes', 0.0) for k in BN_TENSORS), sum(fam.get(k, {}).get('ms', 0.0) for k in BN_TENSORS))),
                 'dominant_family': dom[0], 'family_ms_per_step': {k: round(v['ms'], 3) for k, v in sorted(fam.items())},
                 'sum_kernel_ms_per_step': total_ms,
-                'whole_step_frac_of_mfma_peak': (conv['flops'] + wg['flops']) * (args.steps / dt) / peak}
+                'whole_step_frac_of_mfma_peak': (conv['flops'] + wg['flops']) * result['config'].get('tta_variants', 1) * (args.steps / dt) / peak}
         if world.rank == 0 and world.size == 1 and not args.no_cpu_baseline:      # reported at N=1 only
-            result['cpu_baseline'] = cpu_baseline_train(enc, hw) if args.workload == 'train' else cpu_baseline_infer(enc, hw)
+            result['cpu_baseline'] = cpu_baseline_train(enc, hw) if args.workload == 'train' else cpu_baseline_infer(enc, hw, n=4 if hw <= 320 else 1)
     elif args.workload == 'annot':
         # labelled 300x300 layers (2 per image, on the device) -> COCO RLE strings + boxes on the host
         from mapping_challenge_amd import postprocessing as post, utils

@@ -226,9 +226,11 @@ int msc_rect_filter_u8(const uint8_t* in, uint8_t* out, int B, int H, int W, int
 int64_t msc_label_workspace_bytes(int B, int H, int W);
 int msc_label4(const uint8_t* mask, int32_t* labels, int32_t* counts, void* workspace, int B, int H, int W, void* stream);
 /* add_dropped_objects (src/utils.py:333-339): out = processed + [component of `original` with no surviving pixel];
- * labels_orig = msc_label4(original); u8 result */
+ * labels_orig = msc_label4(original); u8 result.  As in the reference, which tests np.any(np.where(overlap)) -- the index
+ * arrays -- a component whose only surviving pixel is (0,0) counts as dropped.  bool_sum: `+=` on the bool masks the
+ * reference feeds it is a logical or (values stay 0/1); 0 = integer sum (the surviving (0,0) pixel becomes 2). */
 int msc_add_dropped(const uint8_t* processed, const int32_t* labels_orig, uint8_t* out, void* workspace,
-                    int B, int H, int W, void* stream);
+                    int B, int H, int W, int bool_sum, void* stream);
 /* build_score (src/postprocessing.py:228-236): per label, mean(prob over label) * sqrt(area).
  * labels int32 [B,H,W], probs f32 [B,H,W] (the matching channel); sums f64 [B][max_labels], areas i32 [B][max_labels]
  * are zeroed by the call; score[b][l-1] = sums/areas*sqrt(areas) (f64). */

@@ -156,7 +156,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct Ws1 {                       // segment extraction
     size_t cm, incl, S, E, key, val, tmp, tmp_bytes, total;
     Ws1(int layers, int H, int W) {
-        const size_t px = (size_t)layers * H * W, cap = (size_t)layers * ((size_t)H * W / 2 + 1);
+        const size_t px = (size_t)layers * H * W, cap = px;      // touching instances: every pixel can start a run
         size_t o = 0;
         cm = o;   o += align256(px * 4);
         incl = o; o += align256(px * 4);

@@ -210,16 +210,19 @@ __global__ void dropped_mark_kernel(const uint8_t* __restrict__ processed, const
     const long b = blockIdx.y;
     for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
         const int l = lab[b * HW + p];
-        if (l > 0 && processed[b * HW + p]) alive[b * HW + l - 1] = 1;
+        // the reference tests np.any(np.where(overlap)), i.e. the INDEX arrays: an overlap consisting of pixel (0,0) alone has
+        // only zero indices and counts as "no surviving pixel" (src/utils.py:337)
+        if (l > 0 && processed[b * HW + p] && p != 0) alive[b * HW + l - 1] = 1;
     }
 }
 __global__ void dropped_apply_kernel(const uint8_t* __restrict__ processed, const int32_t* __restrict__ lab,
-                                     const int32_t* __restrict__ alive, uint8_t* __restrict__ out, long HW) {
+                                     const int32_t* __restrict__ alive, uint8_t* __restrict__ out, long HW, int bool_sum) {
     const long b = blockIdx.y;
     for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
         const int l = lab[b * HW + p];
         const int add = (l > 0 && !alive[b * HW + l - 1]) ? 1 : 0;
-        out[b * HW + p] = (uint8_t)(processed[b * HW + p] + add);
+        const int v = processed[b * HW + p] + add;            // `reconstructed += (labeled == i)`: a sum for integer masks ...
+        out[b * HW + p] = (uint8_t)(bool_sum ? (v != 0) : v);   // ... a logical or for the bool masks of categorize_*
     }
 }
 
@@ -513,7 +516,7 @@ extern "C" int msc_label4(const uint8_t* mask, int32_t* labels, int32_t* counts,
 }
 
 extern "C" int msc_add_dropped(const uint8_t* processed, const int32_t* labels_orig, uint8_t* out, void* workspace,
-                               int B, int H, int W, void* stream) {
+                               int B, int H, int W, int bool_sum, void* stream) {
     POST_DIMS("msc_add_dropped");
     if (!processed || !labels_orig || !out || !workspace) return msc_fail(MSC_ERR_ARG, "msc_add_dropped: null pointer");
     hipStream_t st = (hipStream_t)stream;
@@ -521,7 +524,7 @@ extern "C" int msc_add_dropped(const uint8_t* processed, const int32_t* labels_o
     if (hipMemsetAsync(workspace, 0, (size_t)B * HW * 4, st) != hipSuccess) return msc_fail(MSC_ERR_HIP, "msc_add_dropped: memset failed");
     const dim3 g = plane_grid(HW, B);
     hipLaunchKernelGGL(dropped_mark_kernel, g, dim3(256), 0, st, processed, labels_orig, (int32_t*)workspace, HW);
-    hipLaunchKernelGGL(dropped_apply_kernel, g, dim3(256), 0, st, processed, labels_orig, (const int32_t*)workspace, out, HW);
+    hipLaunchKernelGGL(dropped_apply_kernel, g, dim3(256), 0, st, processed, labels_orig, (const int32_t*)workspace, out, HW, bool_sum);
     return msc_check_launch("msc_add_dropped");
 }
 

@@ -68,9 +68,21 @@ class MaskPostprocessingHIP(BaseTransformer):
             t = batch if isinstance(batch, torch.Tensor) else torch.as_tensor(batch)
             if t.dim() == 3:
                 t = t[None]
-            size = tuple(sizes[pos]) if sizes else None
-            pos += t.shape[0]
-            out += post.postprocess_batch(t, size, self.erode, self.dilate)
+            n = t.shape[0]
+            if not sizes:
+                out += post.postprocess_batch(t, None, self.erode, self.dilate)
+            else:
+                # the reference resizes image by image (mask_resize zips images with target_sizes, src/pipelines.py:249-260):
+                # one batched call per distinct target size, results put back in image order
+                mine = [tuple(sz) for sz in sizes[pos:pos + n]]
+                res = [None] * n
+                for size in dict.fromkeys(mine):
+                    idx = [i for i, sz in enumerate(mine) if sz == size]
+                    sel = t if len(idx) == n else t[torch.as_tensor(idx, device=t.device)]
+                    for i, r in zip(idx, post.postprocess_batch(sel, size, self.erode, self.dilate)):
+                        res[i] = r
+                out += res
+            pos += n
         return {'images_with_scores': out}
 
 

@@ -102,13 +102,14 @@ def dilate_batch(labels, k):
     return out
 
 
-def add_dropped_batch(original, processed):
-    """cuda u8 [B,H,W] x2 -> cuda u8 [B,H,W] (src/utils.py:333-339)"""
+def add_dropped_batch(original, processed, bool_sum=True):
+    """cuda u8 [B,H,W] x2 -> cuda u8 [B,H,W] (src/utils.py:333-339); bool_sum: the masks are bool in the reference (the
+    layers of categorize_*), where `reconstructed += component` is a logical or"""
     B, H, W = original.shape
     lab, _ = label_batch(original)
     out = torch.empty_like(processed)
     ws = torch.empty((B * H * W,), dtype=torch.int32, device=original.device)
-    _lib.call('msc_add_dropped', processed.data_ptr(), lab.data_ptr(), out.data_ptr(), ws.data_ptr(), B, H, W, _stream())
+    _lib.call('msc_add_dropped', processed.data_ptr(), lab.data_ptr(), out.data_ptr(), ws.data_ptr(), B, H, W, int(bool_sum), _stream())
     return out
 
 
@@ -247,7 +248,7 @@ def add_dropped_objects(original, processed):
     """src/utils.py:333-339."""
     o = _dev(np.asarray(original) != 0, np.uint8)[None]
     p = _dev(processed, np.uint8)[None]
-    return add_dropped_batch(o, p)[0].cpu().numpy()
+    return add_dropped_batch(o, p, np.asarray(processed).dtype == bool)[0].cpu().numpy()
 
 
 def erode_image(mask, erode_selem_size):
@@ -260,7 +261,7 @@ def erode_image(mask, erode_selem_size):
         raise ValueError('erode_image: only 2-D masks are defined behaviour in the reference (src/postprocessing.py:153-155)')
     d = _dev(mask, np.uint8)[None]
     er = erode_batch(d, erode_selem_size)
-    return add_dropped_batch(d, er)[0].cpu().numpy()
+    return add_dropped_batch(d, er, mask.dtype == bool)[0].cpu().numpy()
 
 
 def dilate_image(mask, dilate_selem_size):

@@ -600,6 +600,7 @@ class _Builder:
         self._tuned_new = False
         self.dt, self.tdtype = net._dt, net._tdtype
         self.es = 4 if self.dt == F32 else 2
+        self.tune_dt = BF16 if self.dt == F16 else self.dt      # fp16 runs the bf16 kernels' instruction stream: one set of per-layer choices
         self.prog = _Program()
         self.prog.training = training
         self.prog.fold, self.prog.fold_version = [], -1
@@ -766,7 +767,7 @@ class _Builder:
     def tune_conv(self, d, want_stats):
         if not self.net.autotune or self.dev.type != 'cuda':
             return
-        key = repr(('c', self.dt, d.mode, d.flip, d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad,
+        key = repr(('c', self.tune_dt, d.mode, d.flip, d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad,
                     bool(d.res), want_stats, d.in_ld, d.out_ld, bool(d.relu)))
         cache = _TUNE_CACHE
         lib = self.lib
@@ -792,7 +793,7 @@ class _Builder:
     def tune_wgrad(self, d):
         if not self.net.autotune or self.dev.type != 'cuda':
             return
-        key = repr(('w2', self.dt, d.N, d.Hp, d.Wp, d.A, d.Hq, d.Wq, d.B, d.KH, d.KW, d.stride, d.pad, d.p_ld, d.q_ld))
+        key = repr(('w2', self.tune_dt, d.N, d.Hp, d.Wp, d.A, d.Hq, d.Wq, d.B, d.KH, d.KW, d.stride, d.pad, d.p_ld, d.q_ld))
         cache = _TUNE_CACHE
         big_ok = d.A % 128 == 0 and d.B % 128 == 0
         ncfg = self.lib.msc_conv_wgrad_num_cfgs()

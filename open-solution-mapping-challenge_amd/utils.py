@@ -49,6 +49,9 @@ def encode_labels(labels):
     out = [dict() for _ in range(L)]
     if L == 0:
         return out
+    lo, hi = int(t.min().item()), int(t.max().item())
+    if lo < 0 or hi >= (1 << 24):          # the run sort key packs (layer << 24) | label
+        raise ValueError('encode_labels: instance ids must lie in [0, 2^24) (got %d..%d)' % (lo, hi))
     stream = torch.cuda.current_stream(dev).cuda_stream
     b1 = lib.msc_rle_segments_workspace(L, H, W)
     if b1 < 0:

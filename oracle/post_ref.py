@@ -144,7 +144,9 @@ def add_dropped_objects(original, processed):
     reconstructed = processed.copy()
     labeled = label(original)
     for i in range(1, labeled.max() + 1):
-        if not np.any((labeled == i) & (processed != 0)):
+        # literally the reference's test: np.any over the INDEX arrays np.where returns, so an overlap that consists of
+        # pixel (0,0) alone (all indices zero) counts as "no surviving pixel"
+        if not np.any(np.where((labeled == i) & (processed != 0))):
             reconstructed += (labeled == i).astype(reconstructed.dtype)
     return reconstructed.astype('uint8')
 

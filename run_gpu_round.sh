@@ -4,19 +4,42 @@ cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 export MSC_TUNE_CACHE="${GRAFT_REPO_ROOT:-.}/gpurun_out/tune_cache.json"
-STAGES="${1:-probe tests smoke bench}"
+R="$PWD"
+STAGES="${1:-tests smoke bench}"
+bench_line() {   # bench_line <tag> <timeout> <bench.py args...>: one JSON line -> gpurun_out/bench_<tag>.json
+  local tag=$1 to=$2; shift 2
+  timeout $to python bench.py "$@" > gpurun_out/bench_$tag.log 2>&1; echo "bench $tag rc=$?"
+  grep '^{' gpurun_out/bench_$tag.log | tail -1 > gpurun_out/bench_$tag.json; cut -c1-400 gpurun_out/bench_$tag.json
+}
+prof_stats() {   # prof_stats <tag> <bench.py args...>: rocprofv3 kernel-trace statistics of the same command -> gpurun_out/prof_<tag>/
+  local tag=$1; shift
+  ( cd /tmp; export TMPDIR=/tmp; rm -rf "$R/gpurun_out/prof_$tag"
+    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_$tag" -- python "$R/bench.py" "$@" --no-cpu-baseline > "$R/gpurun_out/prof_$tag.log" 2>&1; echo "prof $tag rc=$?" )
+  python tools/kernel_stats_summary.py gpurun_out/prof_$tag > gpurun_out/kernel_stats_$tag.txt 2>&1; head -12 gpurun_out/kernel_stats_$tag.txt | cut -c1-200
+}
 for s in $STAGES; do
 case $s in
 probe) timeout 60 ./probes/tr_probe > gpurun_out/tr_probe.txt 2>&1; echo "probe rc=$?";;
-tests) timeout 1500 python -m pytest tests -m gpu -q -rf --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -40 gpurun_out/pytest_gpu.log;;
+tests) timeout 1800 python -m pytest tests -m gpu -q -rf --tb=short -p no:cacheprovider --durations=8 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -40 gpurun_out/pytest_gpu.log;;
+ptests) timeout 1200 python -m pytest tests/test_gpu_parity_timed.py -m gpu -q -rf --tb=short -p no:cacheprovider > gpurun_out/pytest_parity.log 2>&1; echo "pytest rc=$?"; tail -30 gpurun_out/pytest_parity.log; cat gpurun_out/parity_timed.json;;
 smoke) timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -5 gpurun_out/smoke.log;;
-bench) timeout 900 python bench.py --workload infer --steps 10 --warmup 3 > gpurun_out/bench_infer.log 2>&1; echo "bench infer rc=$?"; tail -3 gpurun_out/bench_infer.log
-       timeout 900 python bench.py --workload post --steps 10 --warmup 3 > gpurun_out/bench_post.log 2>&1; echo "bench post rc=$?"; tail -3 gpurun_out/bench_post.log
-       timeout 1200 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_train.log 2>&1; echo "bench train rc=$?"; tail -3 gpurun_out/bench_train.log;;
+bench) # every line DESIGN.md quotes; the default command (BASELINE.json's metric) last
+       bench_line infer_r34 600 --workload infer
+       bench_line infer_r101 600 --workload infer --encoder 101
+       bench_line infer_r101_320 600 --workload infer --encoder 101 --size 320 --no-cpu-baseline
+       bench_line train_r101_320 900 --size 320 --steps 100 --no-cpu-baseline
+       bench_line train_r101_fp32 900 --dtype fp32 --steps 20 --no-cpu-baseline
+       bench_line infer_r101_fp32 600 --workload infer --encoder 101 --dtype fp32 --steps 20 --no-cpu-baseline
+       bench_line tta_r152_fp16 900 --workload tta
+       bench_line post 600 --workload post
+       bench_line annot 600 --workload annot
+       bench_line train 1200;;
+benchq) bench_line train 1200 --no-cpu-baseline;;
 prof)  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1   # fills the tune cache so the profile holds no tuning launches
-       cd /tmp; export TMPDIR=/tmp
-       timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_train" -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_train.log" 2>&1; echo "prof rc=$?"
-       cd "$GRAFT_REPO_ROOT";;
+       prof_stats train --steps 20 --warmup 2
+       python bench.py --workload infer --encoder 101 --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
+       prof_stats infer_r101 --workload infer --encoder 101 --steps 20 --warmup 2
+       prof_stats post --workload post --steps 20 --warmup 2;;
 pmc)   python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
        cd /tmp; export TMPDIR=/tmp
        for c in FETCH_SIZE WRITE_SIZE; do
@@ -37,7 +60,7 @@ ab)    # A/B of environment switches on the train step: AB="NAME=VAL,NAME2=VAL2 
        python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
        for cfg in $AB; do
          tag=$(echo "$cfg" | tr ',=' '__')
-         ( IFS=,; for kv in $cfg; do export "$kv"; done; unset IFS; timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline $ABFLAGS > "gpurun_out/ab_$tag.log" 2>&1 )
+         ( IFS=,; for kv in $cfg; do export "$kv"; done; unset IFS; timeout 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline $ABFLAGS > "gpurun_out/ab_$tag.log" 2>&1 )
          echo "$cfg: $(grep -o '"ms_per_step": [0-9.]*' "gpurun_out/ab_$tag.log" | head -1) $(grep -o '"wgrad": {[^}]*}' "gpurun_out/ab_$tag.log" | head -1)"
        done;;
 esac

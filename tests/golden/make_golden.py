@@ -52,6 +52,23 @@ def main():
                             g_center_conv_b=g['center.block.0.conv.bias'].grad.numpy(),
                             g_l2_conv1=g['encoder.layer2.0.conv1.weight'].grad.numpy()[:4, :8],
                             rm_bn1=net.encoder.bn1.running_mean.numpy(), rv_bn1=net.encoder.bn1.running_var.numpy())
+    # ---- the timed network (ResNet101) at 128x128, batch 4 (every BatchNorm population >= 64 samples): loss, logits and a
+    # digest of EVERY parameter gradient (L2 norm + its first 64 elements) from the reference's own backward
+    net = um.UNetResNet(101, 2, num_filters=32, dropout_2d=0.0, pretrained=True, is_deconv=True)
+    net.load_state_dict(unet_ref.seeded_state_dict(net))
+    x = unet_ref.synthetic_batch(4, 128, 128, seed=12)
+    tgt = losses_ref.synthetic_target(4, 128, 128, seed=12)
+    net.train()
+    out = net(x)
+    loss = ref_loss(rm, True)(out, tgt)
+    loss.backward()
+    rec = {'logits_train': out.detach().numpy(), 'loss': np.float32(loss.item())}
+    for name, p_ in net.named_parameters():
+        if p_.grad is not None and not name.startswith('encoder.fc') and not name.split('.')[0] in ('conv1', 'conv2', 'conv3', 'conv4', 'conv5'):
+            gflat = p_.grad.reshape(-1)
+            rec['n|' + name] = np.float64(gflat.double().norm().item())
+            rec['h|' + name] = gflat[:64].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'unet_r101_128.npz'), **rec)
     # ---- losses on seeded logits
     rng = np.random.default_rng(1234)
     logits = torch.from_numpy(rng.standard_normal((2, 2, 64, 64)).astype(np.float32) * 3).requires_grad_(True)

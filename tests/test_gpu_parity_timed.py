@@ -1,0 +1,195 @@
+"""GPU: parity of the configuration bench.py times (ResNet101-U-Net, 256x256 network input) against the torch-CPU fp32
+oracle -- forward logits, loss, dlogits and EVERY parameter gradient, in the exact-fp32 mode (north-star bound 1e-4 on the
+logits) and in the 16-bit throughput modes (bf16: the timed one; fp16: BASELINE.json configs[4]) -- plus the agreement of
+the post-processed instance masks between the 16-bit and the fp32 path.
+
+Tolerances of the 16-bit modes are derived, not tuned: every activation / gradient tensor is stored once in the 16-bit
+type (unit roundoff u = 2^-8 for bf16, 2^-11 for fp16; accumulation, BatchNorm statistics and the loss are fp32), the
+roundings of successive layers are independent, so the relative L2 error of a quantity d stored tensors downstream grows
+like u * sqrt(d).  ResNet101-U-Net: 113 convolution layers on the longest path, two stored tensors each in training (raw
+conv output, BN+ReLU output)  =>  d_fwd = 226 for the logits; a weight gradient sees the forward AND the backward chain
+=>  d = 2 * d_fwd.  Bound = K * u * sqrt(d) with K = 2 (two standard deviations of the random-walk model).
+The measured errors are written to gpurun_out/parity_timed.json so that the margins can be read off.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses_ref, post_ref, unet_ref
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARCH = {'weighted_cross_entropy': {'w0': 50, 'sigma': 10, 'imsize': (256, 256)},
+        'loss_weights': {'dice_mask': 0.2, 'bce_mask': 1.0}, 'dice': {'smooth': 1, 'dice_activation': 'softmax'}}
+UNIT = {'bf16': 2.0 ** -8, 'fp16': 2.0 ** -11}
+D_FWD, K = 226, 2.0
+
+
+def record(key, value):
+    path = os.path.join(ROOT, 'gpurun_out', 'parity_timed.json')
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data[key] = value
+    json.dump(data, open(path, 'w'), indent=1, sort_keys=True)
+
+
+def build(depth, dtype, sd=None):
+    from mapping_challenge_amd.unet_models import UNetResNet
+    ref = unet_ref.UNetResNetRef(depth)
+    sd = sd or unet_ref.seeded_state_dict(ref)
+    ref.load_state_dict(sd)
+    net = UNetResNet(depth, 2, num_filters=32, dropout_2d=0.0, pretrained=False, is_deconv=True, compute_dtype=dtype)
+    net.load_state_dict(sd)
+    net.flatten_parameters('cuda')
+    return ref, net
+
+
+def rel_l2(a, b):
+    return (a.double() - b.double()).norm().item() / (b.double().norm().item() + 1e-30)
+
+
+def oracle_step(ref, x, tgt):
+    """fp32 oracle: train-mode forward, mixed loss, backward -> logits, loss, dlogits, {name: grad}"""
+    ref.train()
+    ref.zero_grad()
+    out = ref(x)
+    out.retain_grad()
+    loss = losses_ref.mixed_dice_ce(out, tgt)
+    loss.backward()
+    grads = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+    return out.detach(), loss.item(), out.grad.clone(), grads
+
+
+def hip_step(net, x, tgt, loss_scale=1.0):
+    from mapping_challenge_amd.trainer import LossSpec, loss_forward_backward
+    net.train()
+    prog = net.train_forward(x.cuda())
+    loss = torch.zeros(1, device='cuda')
+    sums = torch.zeros(4, dtype=torch.float64, device='cuda')
+    loss_forward_backward(prog.logits, tgt.cuda(), LossSpec.mixed(ARCH), prog.dlogits, loss, sums, None, loss_scale)
+    dlogits = prog.dlogits.clone()
+    net.train_backward(prog)
+    grads = {n: g.cpu() / loss_scale for (n, _), g in zip(net._trainable(), net._grad_views())}
+    return prog.logits.cpu(), loss.item(), dlogits.cpu() / loss_scale, grads
+
+
+def test_fp32_mode_resnet101_256_logits_within_1e4_and_gradients_2e3():
+    """the exact-fp32 mode at the timed resolution: eval logits at 256x256 N=2 within the north star's 1e-4; train step at
+    128x128 N=4 (BatchNorm populations >= 64 everywhere): every gradient tensor within 2e-3 relative L2"""
+    ref, net = build(101, 'fp32')
+    x = unet_ref.synthetic_batch(2, 256, 256, seed=11)
+    ref.eval(); net.eval()
+    with torch.no_grad():
+        yr = ref(x)
+        yh = net(x.cuda()).cpu()
+    err = (yr - yh).abs().max().item()
+    record('fp32_r101_256_eval_logits_maxabs', err)
+    assert err < 1e-4
+    x = unet_ref.synthetic_batch(4, 128, 128, seed=12)
+    tgt = losses_ref.synthetic_target(4, 128, 128, seed=12)
+    lo, ll, ld, lg = oracle_step(ref, x, tgt)
+    ho, hl, hd, hg = hip_step(net, x, tgt)
+    assert (lo - ho).abs().max().item() < 2e-4 and abs(ll - hl) < 1e-4 * max(1.0, abs(ll))
+    assert rel_l2(hd, ld) < 1e-4
+    errs = {n: rel_l2(hg[n], lg[n]) for n in hg if n in lg}
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    record('fp32_r101_128_grad_rel_l2_worst', list(worst))
+    record('fp32_r101_128_grad_rel_l2_median', float(np.median(list(errs.values()))))
+    assert len(errs) > 300 and worst[1] < 2e-3, worst
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_16bit_train_step_resnet101_256_vs_fp32_oracle(dtype):
+    """the timed configuration (ResNet101, 256x256, train step) at batch 4 against the fp32 oracle"""
+    ref, net = build(101, dtype)
+    x = unet_ref.synthetic_batch(4, 256, 256, seed=21)
+    tgt = losses_ref.synthetic_target(4, 256, 256, seed=21)
+    scale = 4096.0 if dtype == 'fp16' else 1.0            # trainer.TrainStep's static loss scale for fp16
+    lo, ll, ld, lg = oracle_step(ref, x, tgt)
+    ho, hl, hd, hg = hip_step(net, x, tgt, scale)
+    u = UNIT[dtype]
+    tol_fwd, tol_grad = K * u * math.sqrt(D_FWD), K * u * math.sqrt(2 * D_FWD)
+    e_logits, e_dlogits = rel_l2(ho, lo), rel_l2(hd, ld)
+    errs = {n: rel_l2(hg[n], lg[n]) for n in hg if n in lg}
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    record('%s_r101_256_train' % dtype, {'logits_rel_l2': e_logits, 'dlogits_rel_l2': e_dlogits, 'loss': [hl, ll],
+                                          'grad_rel_l2_worst': list(worst), 'grad_rel_l2_median': float(np.median(list(errs.values()))),
+                                          'grad_rel_l2_p90': float(np.quantile(list(errs.values()), 0.9)),
+                                          'tol_fwd': tol_fwd, 'tol_grad': tol_grad})
+    assert torch.isfinite(ho).all() and all(torch.isfinite(g).all() for g in hg.values())
+    assert e_logits < tol_fwd, (e_logits, tol_fwd)
+    assert abs(hl - ll) < tol_fwd * max(1.0, abs(ll)), (hl, ll)
+    assert e_dlogits < tol_fwd, (e_dlogits, tol_fwd)
+    assert len(errs) > 300 and worst[1] < tol_grad, (worst, tol_grad)
+
+
+def _trained_state(depth=101, steps=40):
+    """a few dozen optimizer steps on inputs that carry the target (noise + mask), so that the eval masks are building-like
+    blobs instead of the near-0.5 noise of random weights; returns (state_dict on the host, inputs)"""
+    from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
+    _, net = build(depth, 'bf16')
+    tgt = losses_ref.synthetic_target(4, 256, 256, seed=31)
+    x = unet_ref.synthetic_batch(4, 256, 256, seed=31) * 0.5 + 2.0 * tgt[:, :1]
+    net.train()
+    step = TrainStep(net, LossSpec.mixed(ARCH), HipAdam(net, lr=5e-4, weight_decay=1e-4))
+    losses = [step(x.cuda(), tgt.cuda()).item() for _ in range(steps)]
+    assert losses[-1] < 0.5 * losses[0], losses[::8]
+    return {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, x, tgt
+
+
+def _instances_iou(la, lb, min_area=16):
+    """for every instance of label image la with >= min_area pixels: IoU with its best-overlapping instance of lb"""
+    out = []
+    for i in range(1, int(la.max()) + 1):
+        ma = la == i
+        if ma.sum() < min_area:
+            continue
+        cand = np.unique(lb[ma])
+        cand = cand[cand > 0]
+        best = 0.0
+        for j in cand:
+            mb = lb == j
+            best = max(best, (ma & mb).sum() / float((ma | mb).sum()))
+        out.append(best)
+    return out
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_16bit_masks_agree_with_fp32_path_after_postprocessing(dtype):
+    """eval forward + the shipped post-processing chain (resize 256->300, threshold, label, 2x2 dilation) in the 16-bit mode
+    and in the fp32 mode (itself held to 1e-4 of the oracle here) on trained weights: the INSTANCES must agree"""
+    from mapping_challenge_amd import postprocessing as post
+    sd, x, tgt = _trained_state()
+    ref, fp = build(101, 'fp32', sd)
+    _, lo = build(101, dtype, sd)
+    ref.eval()
+    with torch.no_grad():
+        yr = ref(x[:2])
+    pf = fp.predict_proba(x.cuda()).clone()
+    err = (torch.softmax(yr, 1) - pf[:2].cpu()).abs().max().item()
+    assert err < 1e-4, err                                   # the fp32 path is the oracle's, also on trained weights at 256x256
+    pl = lo.predict_proba(x.cuda()).clone()
+    dp = (pf - pl).abs()
+    lab_f = post.postprocess_batch(pf, (300, 300), 0, 2)
+    lab_l = post.postprocess_batch(pl, (300, 300), 0, 2)
+    agree, fg_iou, inst = [], [], []
+    for (a, _), (b, _) in zip(lab_f, lab_l):
+        ma, mb = a[1] > 0, b[1] > 0
+        agree.append((ma == mb).mean())
+        fg_iou.append((ma & mb).sum() / max(1.0, float((ma | mb).sum())))
+        inst += _instances_iou(a[1], b[1])
+    frac_fg = float(np.mean([(a[1] > 0).mean() for a, _ in lab_f]))
+    stats = {'prob_maxabs': dp.max().item(), 'prob_mean_abs': dp.mean().item(), 'pixel_agreement': float(np.mean(agree)),
+             'foreground_iou': float(np.mean(fg_iou)), 'instances': len(inst), 'instance_iou_mean': float(np.mean(inst)) if inst else None,
+             'instance_iou_min': float(np.min(inst)) if inst else None, 'foreground_fraction': frac_fg, 'fp32_vs_oracle_prob_maxabs': err}
+    record('%s_r101_256_masks' % dtype, stats)
+    assert 0.02 < frac_fg < 0.9 and len(inst) >= 4, stats      # the trained net draws blobs, not an empty / full mask
+    u = UNIT[dtype]
+    assert dp.mean().item() < K * u * math.sqrt(D_FWD) / 4, stats      # probabilities: softmax slope <= 1/4
+    assert np.mean(agree) > 0.99 and np.mean(fg_iou) > 0.95, stats
+    assert np.mean(inst) > 0.9 and np.mean(np.array(inst) > 0.5) > 0.95, stats

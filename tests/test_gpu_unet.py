@@ -86,11 +86,13 @@ def test_train_step_fp32_matches_reference_golden(golden_dir, depth):
     assert abs(loss.item() - float(g['loss'])) < 1e-4
     grads = {n_: gv.cpu() for (n_, _), gv in zip(net._trainable(), net._grad_views())}
 
-    # 64x64 tiles leave layer4's BatchNorm with 8 samples per channel at batch 2: the backward of the 100-layer
-    # encoder is poorly conditioned there, so ResNet101 gets a looser bound than ResNet34
-    base = 2e-3 if depth == 34 else 1e-2
+    assert np.allclose(net.encoder.bn1.running_mean.cpu().numpy(), g['rm_bn1'], atol=1e-5)
+    assert np.allclose(net.encoder.bn1.running_var.cpu().numpy(), g['rv_bn1'], atol=1e-5)
+    if depth != 34:
+        return       # 64x64 tiles leave ResNet101's layer4 BatchNorms 8 samples per channel: its gradients are checked at
+                     # 128x128 / batch 4 below, against the golden the reference produced there, to the same 2e-3
 
-    def close(a, b, rel=base):
+    def close(a, b, rel=2e-3):
         return (a - torch.from_numpy(b)).abs().max().item() <= rel * (np.abs(b).max() + 1e-12)
     assert close(grads['final.weight'], g['g_final_w']) and close(grads['final.bias'], g['g_final_b'])
     assert close(grads['encoder.conv1.weight'][:8], g['g_conv1'])
@@ -98,16 +100,43 @@ def test_train_step_fp32_matches_reference_golden(golden_dir, depth):
     assert close(grads['dec1.block.1.weight'][:4, :4], g['g_dec1_deconv'])
     assert close(grads['center.block.0.conv.bias'], g['g_center_conv_b'])
     assert close(grads['encoder.layer2.0.conv1.weight'][:4, :8], g['g_l2_conv1'])
-    assert np.allclose(net.encoder.bn1.running_mean.cpu().numpy(), g['rm_bn1'], atol=1e-5)
-    assert np.allclose(net.encoder.bn1.running_var.cpu().numpy(), g['rv_bn1'], atol=1e-5)
-    # every gradient against the oracle (tensor-wise relative L2 error; see the conditioning note above)
+    # every gradient against the oracle (tensor-wise relative L2 error)
     ref.train()
     lr = losses_ref.mixed_dice_ce(ref(x), tgt)
     lr.backward()
     for n_, p in ref.named_parameters():
         if n_ in grads and p.grad is not None:
             err = (grads[n_] - p.grad).norm().item() / (p.grad.norm().item() + 1e-12)
-            assert err < 2.5 * base, (n_, err)
+            assert err < 5e-3, (n_, err)
+
+
+def test_train_step_fp32_resnet101_128_matches_reference_golden_digest(golden_dir):
+    """ResNet101, 128x128, batch 4: loss, logits and EVERY parameter gradient (L2 norm and leading elements) against what
+    the reference's own UNetResNet + mixed loss + autograd produced (tests/golden/make_golden.py), 2e-3"""
+    from mapping_challenge_amd.trainer import LossSpec, loss_forward_backward
+    g = np.load(os.path.join(golden_dir, 'unet_r101_128.npz'))
+    ref, net = build(101, 'fp32')
+    x = unet_ref.synthetic_batch(4, 128, 128, seed=12)
+    tgt = losses_ref.synthetic_target(4, 128, 128, seed=12)
+    net.train()
+    prog = net.train_forward(x.cuda())
+    assert np.abs(prog.logits.cpu().numpy() - g['logits_train']).max() < 2e-4
+    arch = {'weighted_cross_entropy': {'w0': 50, 'sigma': 10, 'imsize': (256, 256)},
+            'loss_weights': {'dice_mask': 0.2, 'bce_mask': 1.0}, 'dice': {'smooth': 1, 'dice_activation': 'softmax'}}
+    loss = torch.zeros(1, device='cuda')
+    sums = torch.zeros(4, dtype=torch.float64, device='cuda')
+    loss_forward_backward(prog.logits, tgt.cuda(), LossSpec.mixed(arch), prog.dlogits, loss, sums)
+    net.train_backward(prog)
+    assert abs(loss.item() - float(g['loss'])) < 1e-4
+    checked = 0
+    for (name, _), gv in zip(net._trainable(), net._grad_views()):
+        flat = gv.contiguous().reshape(-1).cpu().double()
+        norm = float(g['n|' + name])
+        assert abs(flat.norm().item() - norm) <= 2e-3 * norm + 1e-12, (name, flat.norm().item(), norm)
+        head = torch.from_numpy(g['h|' + name]).double()
+        assert (flat[:head.numel()] - head).abs().max().item() <= 2e-3 * norm / np.sqrt(flat.numel()) * 8 + 1e-12, name
+        checked += 1
+    assert checked == len([k for k in g.files if k.startswith('n|')]) and checked > 300
 
 
 def test_autograd_node_drives_reference_style_loop():

@@ -68,6 +68,56 @@ def test_unet_oracle_matches_golden(golden_dir):
         assert np.allclose(net.encoder.conv1.weight.grad.numpy()[:8], g['g_conv1'], rtol=1e-3, atol=1e-6)
 
 
+def test_unet_oracle_matches_reference_digest_of_the_timed_network(golden_dir):
+    """ResNet101 at 128x128, batch 4 (what the GPU gradient-parity tests of the timed network compare with): the oracle's
+    loss, logits and every parameter gradient against the digest the reference's own backward produced"""
+    g = np.load(os.path.join(golden_dir, 'unet_r101_128.npz'))
+    net = unet_ref.UNetResNetRef(101)
+    net.load_state_dict(unet_ref.seeded_state_dict(net))
+    net.train()
+    out = net(unet_ref.synthetic_batch(4, 128, 128, seed=12))
+    loss = losses_ref.mixed_dice_ce(out, losses_ref.synthetic_target(4, 128, 128, seed=12))
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) < 1e-5 and np.allclose(out.detach().numpy(), g['logits_train'], atol=2e-5)
+    checked = 0
+    for name, p in net.named_parameters():
+        if 'n|' + name not in g.files:
+            continue
+        flat = p.grad.reshape(-1).double()
+        norm = float(g['n|' + name])
+        assert abs(flat.norm().item() - norm) <= 1e-4 * norm + 1e-12, name
+        head = torch.from_numpy(g['h|' + name]).double()
+        assert (flat[:head.numel()] - head).abs().max().item() <= 1e-4 * norm / np.sqrt(flat.numel()) * 8 + 1e-12, name
+        checked += 1
+    assert checked == len([k for k in g.files if k.startswith('n|')]) and checked > 300
+
+
+def _corner_cases():
+    """masks where erosion leaves (a) only pixel (0,0) of a component, (b) nothing of one, (c) an interior pixel"""
+    orig = np.zeros((9, 11), np.uint8)
+    orig[0:2, 0:2] = 1           # component touching the corner
+    orig[4:7, 4:7] = 1           # survives at its centre
+    orig[8, 9:11] = 1            # wiped out
+    proc = np.zeros_like(orig)
+    proc[0, 0] = 1
+    proc[5, 5] = 1
+    return orig, proc
+
+
+@needs_ref
+def test_add_dropped_objects_reproduces_the_reference_index_quirk():
+    """src/utils.py:337 evaluates np.any(np.where(overlap)): a component whose only surviving pixel is (0,0) is re-added"""
+    ref_utils = ref_import.ref('utils')
+    orig, proc = _corner_cases()
+    for o, p in ((orig, proc), (orig.astype(bool), proc.astype(bool)), (orig[::-1].copy(), proc[::-1].copy())):
+        exp = ref_utils.add_dropped_objects(o, p)
+        got = post_ref.add_dropped_objects(o, p)
+        assert exp.dtype == got.dtype == np.uint8 and (exp == got).all()
+    exp = ref_utils.add_dropped_objects(orig, proc)
+    assert exp[0, 0] == 2 and exp[1, 1] == 1 and exp[8, 10] == 1 and exp[4, 4] == 0      # integer masks: the corner pixel is summed
+    assert ref_utils.add_dropped_objects(orig.astype(bool), proc.astype(bool))[0, 0] == 1     # bool masks: logical or
+
+
 def test_loss_oracle_matches_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, 'loss.npz'))
     rng = np.random.default_rng(1234)

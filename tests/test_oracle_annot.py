@@ -35,6 +35,39 @@ def test_known_answers_of_the_published_algorithm():
     assert annot_ref.rle_from_string(b'151N') == [1, 5, 1, 3]
 
 
+
+# Hand-computed known answers of the published COCO mask coding (cocoapi common/maskApi.c: rleEncode, rleToString, rleToBbox),
+# derived on paper from the algorithm's definition -- NOT produced by oracle/annot_ref.py, so they pin it (and the HIP
+# encoder) independently.  rleToString per count x (from the 4th count on x -= count two places earlier):
+# repeat { c = x & 31; x >>= 5; more = (c & 16) ? x != -1 : x != 0; if (more) c |= 32; emit chr(c + 48) } while (more).
+HAND_KATS = [
+    # (mask rows, counts string, bbox [x, y, w, h])
+    ([[1]], b'01', [0, 0, 1, 1]),                                  # counts [0,1] -> '0','1'
+    ([[0]], b'1', [0, 0, 0, 0]),                                   # counts [1]
+    ([[1, 1, 1], [1, 1, 1], [1, 1, 1]], b'09', [0, 0, 3, 3]),      # counts [0,9]
+    # 2x2 block at (1,1) of a 4x4 mask; column-major stream 0000 0110 0110 0000 -> counts [5,2,2,2,5];
+    # 4th count 2-2=0 -> '0', 5th 5-2=3 -> '3'
+    ([[0, 0, 0, 0], [0, 1, 1, 0], [0, 1, 1, 0], [0, 0, 0, 0]], b'52203', [1, 1, 2, 2]),
+    # one column of 40 pixels, only the last set: counts [39,1]; 39 = 0b1_00111 -> (7|32)+48 = 'W', then 1 -> '1'; then '1'
+    ([[0]] * 39 + [[1]], b'W11', [0, 39, 1, 1]),
+    # column 0,1,1,1,1,1,0,1,1,1: counts [1,5,1,3]; 4th count 3-5 = -2 -> -2 & 31 = 30, x>>5 = -1, sign bit set -> stop: chr(78)='N'
+    ([[0], [1], [1], [1], [1], [1], [0], [1], [1], [1]], b'151N', [0, 1, 1, 9]),
+    # two columns of height 3: [[1,0],[0,0],[0,1]] -> stream 1,0,0, 0,0,1 -> counts [0,1,4,1]; 4th: 1-1 = 0 -> '0'
+    ([[1, 0], [0, 0], [0, 1]], b'0140', [0, 0, 2, 3]),             # a run crossing a column boundary: bbox spans the full height
+]
+
+
+def test_hand_computed_known_answers_pin_the_oracle():
+    for rows, counts, bbox in HAND_KATS:
+        m = np.array(rows, np.uint8)
+        c = annot_ref.rle_encode(m)
+        assert annot_ref.rle_to_string(c) == counts, (rows, annot_ref.rle_to_string(c))
+        assert annot_ref.rle_from_string(counts) == c
+        assert annot_ref.rle_to_bbox(c, *m.shape) == bbox, (rows, annot_ref.rle_to_bbox(c, *m.shape))
+        assert annot_ref.rle_from_binary(m) == {'size': list(m.shape), 'counts': counts.decode()} or \
+            annot_ref.rle_from_binary(m)['counts'] in (counts, counts.decode())
+
+
 def test_round_trips_and_bbox_on_random_masks():
     rng = np.random.default_rng(5)
     for h, w in ((1, 1), (1, 9), (9, 1), (7, 5), (40, 33)):
