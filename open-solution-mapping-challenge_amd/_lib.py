@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MSC_HIP_LIB', os.path.join(_HERE, 'lib', 'libmsc_hip.so'))
 
 F32, BF16, F16 = 0, 1, 2
+CFG_HALO, CFG_HALO_T = 27, 28     # msc_conv_igemm configurations that are halo-tile kernels, not tiles of the DMA kernel
 
 
 class MscError(RuntimeError):

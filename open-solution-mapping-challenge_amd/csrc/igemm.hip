@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
 // (16x32 outputs): their 10x18 halo goes to LDS once (46 KB), each phase's four taps of weights (32 KB) follow, both with
 // the 16-byte chunks of a row XOR-swizzled by the row index so that 16 lanes reading 16 different rows hit 16 bank groups.
 template <typename T>
-__global__ __launch_bounds__(256) void deconv4_c128_c32_halo_kernel(ConvK p) {
+__global__ __launch_bounds__(256, 2) void deconv4_c128_c32_halo_kernel(ConvK p) {      // 2 blocks per CU (LDS): up to 256 VGPRs, no spills
     constexpr int HR = 10, HC = 18;                   // halo rows / columns
     __shared__ uint4 halo[HR * HC * 16];              // [pixel][16 chunks of 8 channels], chunk ^= pixel & 15
     __shared__ uint4 wl[4 * 32 * 16];                 // [tap][cout][16 chunks], chunk ^= key(cout), distinct over a fragment's rows
@@ -1126,7 +1126,7 @@ bool use_v1_wgrad() { static int v = -1; if (v < 0) v = env_flag("MSC_WGRAD_V1")
 // heuristic (cfg 0) the caller may pick one explicitly -- UNetResNet times the valid ones per layer when it builds
 // a program (msc_conv_cfg_ok enumerates them).
 struct ConvCfg { int tp, tc, wp, wc, kb, nst; };
-constexpr int N_CONV_CFG = 28;
+constexpr int N_CONV_CFG = 36;
 constexpr int CFG_HALO = 27;          // conv3x3_c32_halo_kernel (not a tile of the DMA kernel)
 constexpr int CFG_HALO_T = 28;        // deconv4_c128_c32_halo_kernel
 static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
@@ -1165,6 +1165,16 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {64, 64, 2, 2, 256, 2},     // 26:  64 KB
     {16, 32, 1, 1, 64, 1},      // 27: halo-tile kernel for the 32-channel 3x3 layers
     {16, 32, 1, 1, 256, 1},     // 28: halo-tile kernel for ConvTranspose2d(k4, s2, p1) 128 -> 32
+    // wide wave tiles: LDS traffic per MFMA is (WTP + WTC) / (WTP * WTC) fragment reads -- a 32x32 wave tile reads one
+    // 16-byte fragment per MFMA and is LDS-bound (reads + DMA writes > MFMA cycles), 128x64 reads 0.375
+    {256, 128, 2, 2, 128, 3},   // 29: 144 KB, 4 waves of 128 px x 64 ch
+    {256, 128, 4, 1, 128, 3},   // 30: 144 KB, 4 waves of 64 px x 128 ch
+    {256, 256, 2, 4, 128, 2},   // 31: 128 KB, 8 waves of 128 px x 64 ch (the 256x256 tile of the large-K decoder layers)
+    {256, 256, 2, 4, 64, 4},    // 32: 128 KB, 8 waves of 128 px x 64 ch, 64-byte k-steps in a 4-deep ring
+    {128, 256, 2, 4, 128, 3},   // 33: 144 KB, 8 waves of 64 px x 64 ch
+    {128, 128, 1, 4, 128, 4},   // 34: 128 KB, 4 waves of 128 px x 32 ch
+    {128, 64, 2, 1, 128, 4},    // 35:  96 KB, 2 waves of 64 px x 64 ch
+    {64, 128, 1, 2, 256, 3},    // 36: 144 KB, 2 waves of 64 px x 64 ch, 256-byte k-steps
 };
 
 template <typename T, int TP, int TC, int WP, int WC, int KB, int NST>
@@ -1257,7 +1267,15 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
         case 23: return launch_dma<T, 128, 128, 4, 2, 256, 2>(k, mode, st);
         case 24: return launch_dma<T, 64, 128, 2, 4, 128, 3>(k, mode, st);
         case 25: return launch_dma<T, 128, 64, 4, 2, 128, 3>(k, mode, st);
-        default: return launch_dma<T, 64, 64, 2, 2, 256, 2>(k, mode, st);
+        case 26: return launch_dma<T, 64, 64, 2, 2, 256, 2>(k, mode, st);
+        case 29: return launch_dma<T, 256, 128, 2, 2, 128, 3>(k, mode, st);
+        case 30: return launch_dma<T, 256, 128, 4, 1, 128, 3>(k, mode, st);
+        case 31: return launch_dma<T, 256, 256, 2, 4, 128, 2>(k, mode, st);
+        case 32: return launch_dma<T, 256, 256, 2, 4, 64, 4>(k, mode, st);
+        case 33: return launch_dma<T, 128, 256, 2, 4, 128, 3>(k, mode, st);
+        case 34: return launch_dma<T, 128, 128, 1, 4, 128, 4>(k, mode, st);
+        case 35: return launch_dma<T, 128, 64, 2, 1, 128, 4>(k, mode, st);
+        default: return launch_dma<T, 64, 128, 1, 2, 256, 3>(k, mode, st);
     }
 }
 

@@ -325,7 +325,7 @@ def test_halo_tile_kernel_for_32_channel_3x3(hw, n, flip, with_res, relu, dtype)
     flipped-tap form used by the data gradient, against torch"""
     from mapping_challenge_amd import _lib, ops
     lib = _lib.load()
-    halo = lib.msc_conv_num_cfgs() - 1
+    halo = _lib.CFG_HALO
     x = rnd((n, 32, hw, hw), dtype, 1)
     w = rnd((32, 32, 3, 3), dtype, 2, 0.08)
     bias, scale = rnd((32,), torch.float32, 3), rnd((32,), torch.float32, 4) * 0.2 + 1.0
@@ -356,7 +356,7 @@ def test_halo_tile_kernel_for_32_channel_3x3(hw, n, flip, with_res, relu, dtype)
 def test_halo_tile_kernel_for_the_128_to_32_transposed_conv(hw, n, relu, with_res, dtype):
     """ConvTranspose2d(128, 32, k4, s2, p1) + bias (+ReLU) through the halo-tile configuration, against torch"""
     from mapping_challenge_amd import _lib, ops
-    cfg = _lib.load().msc_conv_num_cfgs()
+    cfg = _lib.CFG_HALO_T
     x = rnd((n, 128, hw, 2 * hw), dtype, 1)                     # non-square: 8 | H, 16 | W
     wt = rnd((128, 32, 4, 4), dtype, 2, 0.05)
     bias = rnd((32,), torch.float32, 3)
