@@ -37,6 +37,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -374,7 +375,10 @@ template <int KB> __device__ __forceinline__ int swz_frag(int pl) {      // key 
     return KB == 64 ? ((0x1320 >> (4 * ((pl >> 2) & 3))) & 3) : KB == 128 ? ((pl >> 1) & 7) : pl;
 }
 
-template <typename T, int TP, int TC, int WP, int WC, int MODE, int NST, int KB>
+// ABL (probes/conv_ablate.hip only; 0 in the product): bit 0 = no MFMA (fragments still read), bit 1 = no DMA after the
+// prologue (compute runs on whatever the ring holds), bit 2 = no fragment reads and no MFMA, bit 3 = no barrier,
+// bit 4 = scheduling barriers around every DMA piece (pins its place between the MFMAs)
+template <typename T, int TP, int TC, int WP, int WC, int MODE, int NST, int KB, int ABL = 0>
 __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
     constexpr int ES = sizeof(T);
     constexpr int NW = WP * WC;                  // waves per block
@@ -476,17 +480,28 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
 #pragma unroll
         for (int i = 0; i < WI; ++i) woff[i] = wrow[i] == OOB_OFF ? OOB_OFF : wrow[i] + toff;
     };
+    // One stage = LPW DMA wave-instructions per wave.  The prologue issues whole stages; in the main loop the LPW pieces
+    // of the stage being fetched are spread between the MFMAs of the k-step (piece i right before MFMA i*NM/LPW): an
+    // in-order wave that issues all its DMA instructions at once sits in the memory pipeline's queue until the CU's
+    // texture addresser (64 B/clk, shared by all waves that just passed the same barrier) has taken them, and only then
+    // starts its MFMAs -- measured with probes/conv_ablate.hip (profiles/r2_run4_conv_ablation_probe.txt):
+    // time(full) = time(DMA only) + time(MFMA only), no overlap.  Interleaved, the addresser works while the matrix pipes do.
+    auto piece = [&](int i, char* sx, char* sw, int soff) {
+        if (i < XI) dma16(rx, sx + (NIX >= NW ? i * NW + wid : wid % NIX) * 1024, xoff[i < XI ? i : 0], soff);
+        else dma16(rw, sw + (NIW >= NW ? (i - XI) * NW + wid : wid % NIW) * 1024, woff[i >= XI ? i - XI : 0], soff);
+    };
+    auto advance = [&]() {
+        if (++icch == cps) { icch = 0; ++itap; }
+        if (++istage == NST) istage = 0;
+    };
     auto issue = [&]() {
         if (icch == 0) set_tap(itap);
         const int soff = icch * KB;
         char* sx = smem + istage * STAGE;
         char* sw = sx + TP * KB;
 #pragma unroll
-        for (int i = 0; i < XI; ++i) dma16(rx, sx + (NIX >= NW ? i * NW + wid : wid % NIX) * 1024, xoff[i], soff);
-#pragma unroll
-        for (int i = 0; i < WI; ++i) dma16(rw, sw + (NIW >= NW ? i * NW + wid : wid % NIW) * 1024, woff[i], soff);
-        if (++icch == cps) { icch = 0; ++itap; }
-        if (++istage == NST) istage = 0;
+        for (int i = 0; i < LPW; ++i) piece(i, sx, sw, soff);
+        advance();
     };
 
     f32x4 acc[FM][FN];
@@ -503,18 +518,22 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
 #pragma unroll
     for (int b = 0; b < FN; ++b) boff[b] = (wp * WTP + b * 16 + pl) * KB;
 
-    if (nsteps > 0) {
-#pragma unroll
-        for (int st = 0; st < NST - 1; ++st)
-            if (st < nsteps) issue();
-        int cstage = 0;
-        for (int s = 0; s < nsteps; ++s) {
-            // stage s must have landed; stages s+1 .. s+NST-2 may stay in flight
-            if (s + NST - 2 <= nsteps - 1) wait_vmcnt<(NST - 2) * LPW>();
-            else wait_vmcnt<0>();
-            raw_barrier();                       // everyone's DMA of stage s is in LDS, everyone is done with stage s-1
-            if (s + NST - 1 < nsteps) issue();
-            const char* sb = smem + cstage * STAGE;
+    constexpr int NM = KSUB * FM * FN;           // MFMAs (fragment pairs) per k-step and wave
+    // one k-step on the landed stage `cstage`; ISSUE: also fetch the stage NST-1 steps ahead, piecewise
+    auto kstep = [&](auto issue_tag, int cstage) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        const bool live = (ABL & 2) ? p.N < 0 : true;       // ABL bit 1: never true, but not provably so (the code path stays)
+        int soff = 0;
+        char* sx = smem;
+        char* sw = smem;
+        if (ISSUE) {
+            if (icch == 0) set_tap(itap);
+            soff = icch * KB;
+            sx = smem + istage * STAGE;
+            sw = sx + TP * KB;
+        }
+        const char* sb = smem + cstage * STAGE;
+        if (!(ABL & 4)) {
 #pragma unroll
             for (int kk = 0; kk < KSUB; ++kk) {
                 const int so = ((kk * 4 + g) ^ key) * 16;
@@ -523,11 +542,55 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
                 for (int a = 0; a < FM; ++a) af[a] = *reinterpret_cast<const uint4*>(sb + aoff[a] + so);
 #pragma unroll
                 for (int b = 0; b < FN; ++b) bf[b] = *reinterpret_cast<const uint4*>(sb + boff[b] + so);
+                if (ABL & 1) {               // keep the reads alive without the matrix pipe
+#pragma unroll
+                    for (int a = 0; a < FM; ++a) asm volatile("" ::"v"(af[a].x), "v"(af[a].y), "v"(af[a].z), "v"(af[a].w));
+#pragma unroll
+                    for (int b = 0; b < FN; ++b) asm volatile("" ::"v"(bf[b].x), "v"(bf[b].y), "v"(bf[b].z), "v"(bf[b].w));
+                }
 #pragma unroll
                 for (int a = 0; a < FM; ++a)
 #pragma unroll
-                    for (int b = 0; b < FN; ++b) Mma<T>::run(af[a], bf[b], acc[a][b]);
+                    for (int b = 0; b < FN; ++b) {
+                        const int m = (kk * FM + a) * FN + b;
+                        if (ISSUE) {
+#pragma unroll
+                            for (int i = 0; i < LPW; ++i)
+                                if ((i * NM) / LPW == m && live) {
+                                    if (ABL & 16) __builtin_amdgcn_sched_barrier(0);       // probe: pin the placement
+                                    piece(i, sx, sw, soff);
+                                    if (ABL & 16) __builtin_amdgcn_sched_barrier(0);
+                                }
+                        }
+                        if (!(ABL & 1)) Mma<T>::run(af[a], bf[b], acc[a][b]);
+                    }
             }
+        } else if (ISSUE && live) {
+#pragma unroll
+            for (int i = 0; i < LPW; ++i) piece(i, sx, sw, soff);
+        }
+        if (ISSUE) advance();
+    };
+
+    if (nsteps > 0) {
+#pragma unroll
+        for (int st = 0; st < NST - 1; ++st)
+            if (st < nsteps) issue();
+        int cstage = 0;
+        const int nmain = nsteps - (NST - 1);    // k-steps that still have a stage to fetch
+        int s = 0;
+        for (; s < nmain; ++s) {
+            // stage s must have landed; stages s+1 .. s+NST-2 may stay in flight
+            wait_vmcnt<(NST - 2) * LPW>();
+            if (!(ABL & 8)) raw_barrier();       // everyone's DMA of stage s is in LDS, everyone is done with stage s-1
+            kstep(std::true_type{}, cstage);
+            if (++cstage == NST) cstage = 0;
+        }
+        for (; s < nsteps; ++s) {
+            if (s + NST - 2 <= nsteps - 1) wait_vmcnt<(NST - 2) * LPW>();
+            else wait_vmcnt<0>();
+            if (!(ABL & 8)) raw_barrier();
+            kstep(std::false_type{}, cstage);
             if (++cstage == NST) cstage = 0;
         }
     }
@@ -969,19 +1032,19 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
         qrow[i] = j * RPB + lane / UB;
         qcol[i] = (unsigned)b0 * ES + (unsigned)wg_swz<T>(lane % UB, qrow[i], UB) * 16u;
     }
-    auto issue = [&](int s, int stage) {
+    // one DMA wave-instruction of the stage holding k-step s (pieces 0..IA-1: P rows, IA..IA+IB-1: Q rows)
+    auto piece = [&](int i, int s, int stage) {
         const int mb = mbeg + s * KP;
         char* sp = smem + stage * STAGE;
         char* sq = sp + KP * RBA;
-#pragma unroll
-        for (int i = 0; i < IA; ++i) {
-            const int m = mb + prow[i];
-            const unsigned off = m < mend ? (unsigned)m * ppix + pcol[i] : OOB_OFF;
-            dma16(rp, sp + (NIA >= 4 ? i * 4 + wid : (wid & (NIA - 1))) * 1024, off, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < IB; ++i) {
-            const int m = mb + qrow[i];
+        if (i < IA) {
+            const int ii = i < IA ? i : 0;
+            const int m = mb + prow[ii];
+            const unsigned off = m < mend ? (unsigned)m * ppix + pcol[ii] : OOB_OFF;
+            dma16(rp, sp + (NIA >= 4 ? ii * 4 + wid : (wid & (NIA - 1))) * 1024, off, 0);
+        } else {
+            const int ii = i >= IA ? i - IA : 0;
+            const int m = mb + qrow[ii];
             unsigned off = OOB_OFF;
             if (m < mend) {
                 const unsigned n = udiv_rcp((unsigned)m, hw, p.rcp_hw);
@@ -990,10 +1053,14 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
                 const unsigned x = rem - y * (unsigned)p.Wp;
                 const int iy = (int)y * p.stride - p.pad + kh, ix = (int)x * p.stride - p.pad + kw;
                 if ((unsigned)iy < (unsigned)p.Hq && (unsigned)ix < (unsigned)p.Wq)
-                    off = (unsigned)(((int)n * p.Hq + iy) * p.Wq + ix) * qpix + qcol[i];
+                    off = (unsigned)(((int)n * p.Hq + iy) * p.Wq + ix) * qpix + qcol[ii];
             }
-            dma16(rq, sq + (NIB >= 4 ? i * 4 + wid : (wid & (NIB - 1))) * 1024, off, 0);
+            dma16(rq, sq + (NIB >= 4 ? ii * 4 + wid : (wid & (NIB - 1))) * 1024, off, 0);
         }
+    };
+    auto issue = [&](int s, int stage) {
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) piece(i, s, stage);
     };
 
     // fragment read offsets (bytes within a stage)
@@ -1058,11 +1125,10 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
 #pragma unroll
         for (int st = 0; st < NST - 1; ++st)
             if (st < nsteps) issue(st, st);
-        for (int s = 0; s < nsteps; ++s) {
-            if (s + NST - 2 <= nsteps - 1) wait_vmcnt<(NST - 2) * LPW>();
-            else wait_vmcnt<0>();
-            raw_barrier();
-            if (s + NST - 1 < nsteps) issue(s + NST - 1, (s + NST - 1) & (NST - 1));
+        constexpr int NM = FM * FN;
+        // the DMA pieces of the stage NST-1 steps ahead go out between the MFMAs (see conv_igemm_dma_kernel)
+        auto kstep = [&](auto issue_tag, int s) {
+            constexpr bool ISSUE = decltype(issue_tag)::value;
             const char* sb = smem + (s & (NST - 1)) * STAGE;
             uint4 af[FM], bf[FN];
 #pragma unroll
@@ -1072,7 +1138,27 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
 #pragma unroll
             for (int a = 0; a < FM; ++a)
 #pragma unroll
-                for (int b = 0; b < FN; ++b) Mma<T>::run(af[a], bf[b], acc[a][b]);
+                for (int b = 0; b < FN; ++b) {
+                    if (ISSUE) {
+#pragma unroll
+                        for (int i = 0; i < LPW; ++i)
+                            if ((i * NM) / LPW == a * FN + b) piece(i, s + NST - 1, (s + NST - 1) & (NST - 1));
+                    }
+                    Mma<T>::run(af[a], bf[b], acc[a][b]);
+                }
+        };
+        const int nmain = nsteps - (NST - 1);
+        int s = 0;
+        for (; s < nmain; ++s) {
+            wait_vmcnt<(NST - 2) * LPW>();
+            raw_barrier();
+            kstep(std::true_type{}, s);
+        }
+        for (; s < nsteps; ++s) {
+            if (s + NST - 2 <= nsteps - 1) wait_vmcnt<(NST - 2) * LPW>();
+            else wait_vmcnt<0>();
+            raw_barrier();
+            kstep(std::false_type{}, s);
         }
         const long taps = (long)p.KH * p.KW;
 #pragma unroll
@@ -1177,15 +1263,15 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {64, 128, 1, 2, 256, 3},    // 36: 144 KB, 2 waves of 64 px x 64 ch, 256-byte k-steps
 };
 
-template <typename T, int TP, int TC, int WP, int WC, int KB, int NST>
+template <typename T, int TP, int TC, int WP, int WC, int KB, int NST, int ABL = 0>
 int launch_dma(const ConvK& k0, int mode, hipStream_t st) {
     ConvK k = k0;
     k.ntc = ceil_div(k.Cout, TC);
     k.xcd_order = xcd_order_enabled() ? 1 : 0;
     dim3 grid(ceil_div(k.M, TP) * k.ntc, 1, mode ? 4 : 1);
     constexpr int NT = WP * WC * 64;
-    if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1, NST, KB>), grid, dim3(NT), 0, st, k);
-    else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, NST, KB>), grid, dim3(NT), 0, st, k);
+    if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1, NST, KB, ABL>), grid, dim3(NT), 0, st, k);
+    else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, NST, KB, ABL>), grid, dim3(NT), 0, st, k);
     return msc_check_launch("conv_igemm_dma");
 }
 
