@@ -1212,7 +1212,7 @@ bool use_v1_wgrad() { static int v = -1; if (v < 0) v = env_flag("MSC_WGRAD_V1")
 // heuristic (cfg 0) the caller may pick one explicitly -- UNetResNet times the valid ones per layer when it builds
 // a program (msc_conv_cfg_ok enumerates them).
 struct ConvCfg { int tp, tc, wp, wc, kb, nst; };
-constexpr int N_CONV_CFG = 36;
+constexpr int N_CONV_CFG = 41;
 constexpr int CFG_HALO = 27;          // conv3x3_c32_halo_kernel (not a tile of the DMA kernel)
 constexpr int CFG_HALO_T = 28;        // deconv4_c128_c32_halo_kernel
 static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
@@ -1261,6 +1261,14 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {128, 128, 1, 4, 128, 4},   // 34: 128 KB, 4 waves of 128 px x 32 ch
     {128, 64, 2, 1, 128, 4},    // 35:  96 KB, 2 waves of 64 px x 64 ch
     {64, 128, 1, 2, 256, 3},    // 36: 144 KB, 2 waves of 64 px x 64 ch, 256-byte k-steps
+    // two blocks per CU with full-line (128-byte) k-steps: a block's prologue (first fill from HBM) and epilogue (stores) are
+    // not overlapped with anything of its own -- 40 % of the time of the multi-tile layers (probes/conv_ablate.hip) -- so
+    // the second resident block computes meanwhile
+    {128, 128, 2, 2, 128, 2},   // 37:  64 KB, 4 waves
+    {128, 128, 4, 2, 128, 2},   // 38:  64 KB, 8 waves
+    {256, 64, 4, 1, 128, 2},    // 39:  80 KB, 4 waves of 64 px x 64 ch
+    {256, 64, 4, 2, 128, 2},    // 40:  80 KB, 8 waves
+    {128, 64, 2, 2, 128, 3},    // 41:  72 KB, 4 waves
 };
 
 template <typename T, int TP, int TC, int WP, int WC, int KB, int NST, int ABL = 0>
@@ -1361,7 +1369,12 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
         case 33: return launch_dma<T, 128, 256, 2, 4, 128, 3>(k, mode, st);
         case 34: return launch_dma<T, 128, 128, 1, 4, 128, 4>(k, mode, st);
         case 35: return launch_dma<T, 128, 64, 2, 1, 128, 4>(k, mode, st);
-        default: return launch_dma<T, 64, 128, 1, 2, 256, 3>(k, mode, st);
+        case 36: return launch_dma<T, 64, 128, 1, 2, 256, 3>(k, mode, st);
+        case 37: return launch_dma<T, 128, 128, 2, 2, 128, 2>(k, mode, st);
+        case 38: return launch_dma<T, 128, 128, 4, 2, 128, 2>(k, mode, st);
+        case 39: return launch_dma<T, 256, 64, 4, 1, 128, 2>(k, mode, st);
+        case 40: return launch_dma<T, 256, 64, 4, 2, 128, 2>(k, mode, st);
+        default: return launch_dma<T, 128, 64, 2, 2, 128, 3>(k, mode, st);
     }
 }
 
