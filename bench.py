@@ -398,11 +398,17 @@ def main():
         probs = torch.from_numpy(probs_h).to(dev)
         dt = timed(lambda: post.postprocess_batch(probs, (300, 300), 0, 2))
         value = batch * world.size * args.steps / dt
+        # the same chain with the label images left in HBM (what utils.annotations_from_probabilities consumes) and with the
+        # watershed extension in place of plain labelling (WATERSHED.md): secondary figures, not `value`
+        dt_dev = timed(lambda: post.postprocess_device(probs, (300, 300), 0, 2))
+        dt_ws = timed(lambda: post.postprocess_device(probs, (300, 300), 0, 2, watershed_selem_size=5))
         bytes_per_img = 3.4e6
         result.update(metric='post-processing images/sec (resize 256->300, threshold, label, dilate k=2, score)', unit='img/s',
                       value=value, ms_per_step=1e3 * dt / args.steps, dtype='u8/i32/f32',
                       config={'workload': 'mask post-processing of %d 256x256 2-class probability maps per step' % batch,
-                              'ms_per_img': 1e3 / value * world.size},
+                              'ms_per_img': 1e3 / value * world.size,
+                              'ms_per_img_labels_stay_on_device': 1e3 * dt_dev / (batch * args.steps),
+                              'ms_per_img_with_watershed_extension_on_device': 1e3 * dt_ws / (batch * args.steps)},
                       roofline={'bound': 'hbm', 'achieved': value * bytes_per_img / 1e9 / world.size, 'peak': PEAK_HBM / 1e9, 'unit': 'GB/s',
                                 'frac': value * bytes_per_img / world.size / PEAK_HBM, 'traffic': None,
                                 'note': 'whole chain incl. the final D2H of labels; latency/launch bound'})

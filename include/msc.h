@@ -231,6 +231,12 @@ int msc_label4(const uint8_t* mask, int32_t* labels, int32_t* counts, void* work
  * reference feeds it is a logical or (values stay 0/1); 0 = integer sum (the surviving (0,0) pixel becomes 2). */
 int msc_add_dropped(const uint8_t* processed, const int32_t* labels_orig, uint8_t* out, void* workspace,
                     int B, int H, int W, int bool_sum, void* stream);
+/* EXTENSION, no reference function (WATERSHED.md): marker-controlled watershed.  labels int32 [B,H,W] holds the markers
+ * (> 0) on entry and the flooded labels on return; mask u8 [B,H,W] bounds the flood; prob f32 [B,H,W] gives the relief
+ * h = clamp(floor((1-prob)*255), 0, 255); synchronous immersion, ties to the smaller label.  One workgroup per [H,W] plane.
+ * workspace: msc_watershed_workspace_bytes(B,H,W) bytes, 4-byte aligned. */
+int64_t msc_watershed_workspace_bytes(int B, int H, int W);
+int msc_watershed(const float* prob, const uint8_t* mask, int32_t* labels, void* workspace, int B, int H, int W, void* stream);
 /* build_score (src/postprocessing.py:228-236): per label, mean(prob over label) * sqrt(area).
  * labels int32 [B,H,W], probs f32 [B,H,W] (the matching channel); sums f64 [B][max_labels], areas i32 [B][max_labels]
  * are zeroed by the call; score[b][l-1] = sums/areas*sqrt(areas) (f64). */

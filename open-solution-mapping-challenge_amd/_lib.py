@@ -95,6 +95,8 @@ SIGNATURES = {
     'msc_label_workspace_bytes': (_i64, [_i, _i, _i]),
     'msc_label4': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'msc_add_dropped': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'msc_watershed_workspace_bytes': (_i64, [_i, _i, _i]),
+    'msc_watershed': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'msc_build_score': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'msc_crf_workspace_bytes': (_i64, [_i, _i, _i, _i]),
     'msc_tta_transform': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -226,6 +226,53 @@ __global__ void dropped_apply_kernel(const uint8_t* __restrict__ processed, cons
     }
 }
 
+// ------------------------------------------------------------------ watershed (EXTENSION: WATERSHED.md; no reference function)
+// Synchronous immersion flood of the 8-bit relief of 1 - P inside the mask, from labelled markers; one workgroup per
+// image-layer.  A round = candidates from the labels as they are (phase A), barrier, apply (phase B): simultaneous update,
+// ties to the smaller label, so the result does not depend on any traversal order.
+__global__ __launch_bounds__(1024) void watershed_flood_kernel(const float* __restrict__ prob, const uint8_t* __restrict__ mask,
+                                                               int32_t* labels, uint8_t* hq, int32_t* cand, int H, int W) {
+    const long HW = (long)H * W;
+    const long base = (long)blockIdx.x * HW;
+    const float* P = prob + base;
+    const uint8_t* M = mask + base;
+    int32_t* L = labels + base;
+    uint8_t* Hq = hq + base;
+    int32_t* C = cand + base;
+    int todo = 0;
+    for (long p = threadIdx.x; p < HW; p += blockDim.x) {
+        float v = floorf((1.0f - P[p]) * 255.0f);
+        v = fminf(fmaxf(v, 0.f), 255.f);
+        Hq[p] = (uint8_t)v;
+        C[p] = 0;
+        if (!M[p]) L[p] = 0;
+        else if (L[p] == 0) ++todo;
+    }
+    __syncthreads();
+    for (int level = 0; level < 256; ++level) {
+        if (!__syncthreads_or(todo > 0)) break;                       // every mask pixel is labelled
+        for (;;) {
+            int found = 0;
+            for (long p = threadIdx.x; p < HW; p += blockDim.x) {
+                if (!M[p] || L[p] != 0 || Hq[p] > level) continue;
+                const int y = (int)(p / W), x = (int)(p - (long)y * W);
+                int best = 0x7fffffff;
+                if (y > 0) { const int q = L[p - W]; if (q > 0 && q < best) best = q; }
+                if (y + 1 < H) { const int q = L[p + W]; if (q > 0 && q < best) best = q; }
+                if (x > 0) { const int q = L[p - 1]; if (q > 0 && q < best) best = q; }
+                if (x + 1 < W) { const int q = L[p + 1]; if (q > 0 && q < best) best = q; }
+                if (best != 0x7fffffff) { C[p] = best; found = 1; }
+            }
+            if (!__syncthreads_or(found)) break;                      // also orders phase A's reads before phase B's writes
+            for (long p = threadIdx.x; p < HW; p += blockDim.x) {
+                const int c = C[p];
+                if (c > 0) { L[p] = c; C[p] = 0; --todo; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ------------------------------------------------------------------ build_score
 __global__ void score_accum_kernel(const int32_t* __restrict__ labels, const float* __restrict__ probs, double* __restrict__ sums,
                                    int32_t* __restrict__ areas, long HW, int max_labels) {
@@ -513,6 +560,22 @@ extern "C" int msc_label4(const uint8_t* mask, int32_t* labels, int32_t* counts,
     hipLaunchKernelGGL(ccl_rank_kernel, dim3(B), dim3(1024), 0, st, labels, rank, counts, HW);
     hipLaunchKernelGGL(ccl_relabel_kernel, g, dim3(256), 0, st, labels, rank, HW);
     return msc_check_launch("msc_label4");
+}
+
+extern "C" int64_t msc_watershed_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return -1;
+    return (int64_t)B * H * W * 5;          // 8-bit relief + int32 candidates
+}
+
+extern "C" int msc_watershed(const float* prob, const uint8_t* mask, int32_t* labels, void* workspace, int B, int H, int W, void* stream) {
+    POST_DIMS("msc_watershed");
+    if (!prob || !mask || !labels || !workspace) return msc_fail(MSC_ERR_ARG, "msc_watershed: null pointer");
+    if (((uintptr_t)workspace) & 3) return msc_fail(MSC_ERR_ARG, "msc_watershed: workspace must be 4-byte aligned");
+    const long n = (long)B * H * W;
+    int32_t* cand = (int32_t*)workspace;
+    uint8_t* hq = (uint8_t*)workspace + n * 4;
+    hipLaunchKernelGGL(watershed_flood_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, prob, mask, labels, hq, cand, H, W);
+    return msc_check_launch("msc_watershed");
 }
 
 extern "C" int msc_add_dropped(const uint8_t* processed, const int32_t* labels_orig, uint8_t* out, void* workspace,

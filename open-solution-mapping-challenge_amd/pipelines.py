@@ -55,8 +55,9 @@ class MaskPostprocessingHIP(BaseTransformer):
     """All of mask_postprocessing as one transformer; `images` may be a numpy array [N,2,h,w], a list of
     per-image arrays, or an iterable of cuda batches (PyTorchUNet.transform_device)."""
 
-    def __init__(self, erode_selem_size=0, dilate_selem_size=0, batch_size=64):
+    def __init__(self, erode_selem_size=0, dilate_selem_size=0, batch_size=64, watershed_selem_size=0):
         self.erode, self.dilate, self.batch_size = erode_selem_size, dilate_selem_size, batch_size
+        self.watershed = watershed_selem_size         # extension (WATERSHED.md); 0 = the reference's plain labelling
 
     def transform(self, images, target_sizes):
         out = []
@@ -70,7 +71,7 @@ class MaskPostprocessingHIP(BaseTransformer):
                 t = t[None]
             n = t.shape[0]
             if not sizes:
-                out += post.postprocess_batch(t, None, self.erode, self.dilate)
+                out += post.postprocess_batch(t, None, self.erode, self.dilate, watershed_selem_size=self.watershed)
             else:
                 # the reference resizes image by image (mask_resize zips images with target_sizes, src/pipelines.py:249-260):
                 # one batched call per distinct target size, results put back in image order
@@ -79,7 +80,7 @@ class MaskPostprocessingHIP(BaseTransformer):
                 for size in dict.fromkeys(mine):
                     idx = [i for i, sz in enumerate(mine) if sz == size]
                     sel = t if len(idx) == n else t[torch.as_tensor(idx, device=t.device)]
-                    for i, r in zip(idx, post.postprocess_batch(sel, size, self.erode, self.dilate)):
+                    for i, r in zip(idx, post.postprocess_batch(sel, size, self.erode, self.dilate, watershed_selem_size=self.watershed)):
                         res[i] = r
                 out += res
             pos += n
@@ -134,7 +135,9 @@ def mask_postprocessing_fused(model, config, **kwargs):
     cache = _get(_get(config, 'env'), 'cache_dirpath')
     pp = _get(config, 'postprocessor')
     tr = MaskPostprocessingHIP(erode_selem_size=dict(_get(pp, 'mask_erosion')).get('erode_selem_size', 0),
-                               dilate_selem_size=dict(_get(pp, 'mask_dilation')).get('dilate_selem_size', 0))
+                               dilate_selem_size=dict(_get(pp, 'mask_dilation')).get('dilate_selem_size', 0),
+                               # extension, off unless configured (postprocessor.watershed.marker_erosion, WATERSHED.md)
+                               watershed_selem_size=dict(pp.get('watershed', {}) if hasattr(pp, 'get') else {}).get('marker_erosion', 0))
     return Step(name='score_builder', transformer=tr, input_data=['input'], input_steps=[model],
                 adapter={'images': ([(model.name, 'multichannel_map_prediction')]),
                          'target_sizes': ([('input', 'target_sizes')])},

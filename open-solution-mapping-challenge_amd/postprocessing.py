@@ -113,6 +113,21 @@ def add_dropped_batch(original, processed, bool_sum=True):
     return out
 
 
+def watershed_batch(layers, probs, marker_erosion):
+    """EXTENSION (WATERSHED.md; the reference has no watershed).  layers cuda u8 [B,H,W], probs cuda f32 [B,H,W] (the
+    channel each layer was thresholded from) -> (cuda i32 labels [B,H,W], cuda i32 counts [B]): markers = components of
+    erode_image(layer, k), flooded over the 8-bit relief of 1 - P inside the layer."""
+    if not marker_erosion > 0:
+        raise ValueError('watershed needs marker_erosion >= 1')
+    B, H, W = layers.shape
+    lib = _lib.load()
+    markers_mask = add_dropped_batch(layers, erode_batch(layers, marker_erosion))
+    labels, counts = label_batch(markers_mask)
+    ws = torch.empty((max(4, lib.msc_watershed_workspace_bytes(B, H, W)),), dtype=torch.uint8, device=layers.device)
+    _lib.call('msc_watershed', probs.contiguous().data_ptr(), layers.data_ptr(), labels.data_ptr(), ws.data_ptr(), B, H, W, _stream())
+    return labels, counts
+
+
 def score_batch(labels, probs, max_labels):
     """labels cuda i32 [B,H,W], probs cuda f32 [B,H,W] -> cuda f64 [B,max_labels] scores"""
     B, H, W = labels.shape
@@ -136,22 +151,29 @@ def _to_host(t):
     return h.numpy()
 
 
-def postprocess_device(probs, target_size=None, erode_selem_size=0, dilate_selem_size=0, category_layers=CATEGORY_LAYERS):
+def postprocess_device(probs, target_size=None, erode_selem_size=0, dilate_selem_size=0, category_layers=CATEGORY_LAYERS,
+                       watershed_selem_size=0):
     """postprocess_batch without the final copy of the label images: returns (labels cuda i32 [B,L,H,W], per-image
     per-layer score lists) -- for consumers that stay on the device (utils.annotations_from_probabilities)."""
-    return _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, category_layers, to_host=False)
+    return _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, category_layers, False, watershed_selem_size)
 
 
-def postprocess_batch(probs, target_size=None, erode_selem_size=0, dilate_selem_size=0, category_layers=CATEGORY_LAYERS):
+def postprocess_batch(probs, target_size=None, erode_selem_size=0, dilate_selem_size=0, category_layers=CATEGORY_LAYERS,
+                      watershed_selem_size=0):
     """The six Steps of `mask_postprocessing` (src/pipelines.py:248-304) for a whole batch on the device.
 
     probs: cuda f32 [B,2,h,w] softmax maps.  Returns the reference's `images_with_scores` list:
     [(labels i32 [L,H,W], [[score, ...] per layer]), ...] (numpy / python floats, one D2H at the end).
+    watershed_selem_size > 0 (extension, WATERSHED.md): the labelling step becomes a marker-controlled watershed.
     """
-    return _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, category_layers, to_host=True)
+    return _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, category_layers, True, watershed_selem_size)
 
 
-def _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, category_layers, to_host):
+def _layer_classes(category_layers):
+    return [c for c, n in enumerate(category_layers) for _ in range(n)]
+
+
+def _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, category_layers, to_host, watershed_selem_size=0):
     if not probs.is_cuda:
         probs = probs.to(_device())
     probs = probs.contiguous().float()
@@ -162,7 +184,11 @@ def _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, catego
     flat = layers.view(B * L, H, W)
     if erode_selem_size > 0:
         flat = add_dropped_batch(flat, erode_batch(flat, erode_selem_size))
-    labels, counts = label_batch(flat)
+    if watershed_selem_size > 0:      # extension (WATERSHED.md): instances split along the probability ridges instead of plain labelling
+        cls = torch.as_tensor(_layer_classes(category_layers), device=p.device)
+        labels, counts = watershed_batch(flat, p.index_select(1, cls).reshape(B * L, H, W), watershed_selem_size)
+    else:
+        labels, counts = label_batch(flat)
     if dilate_selem_size > 0:
         labels = dilate_batch(labels, dilate_selem_size)
     counts_h = counts.cpu().numpy().reshape(B, L)
@@ -242,6 +268,17 @@ def label_multiclass_image(mask):
     mask = np.asarray(mask)
     planes = np.stack([(mask == c) for c in range(0, int(mask.max()) + 1)])
     return label_multilayer_image(planes)
+
+
+def watershed_multilayer_image(image, probabilities, marker_erosion, category_layers=CATEGORY_LAYERS):
+    """EXTENSION (WATERSHED.md): layers bool [L,H,W] as categorize_multilayer_image orders them + the probability map
+    f [C,H,W] they were cut from -> int32 [L,H,W] instance labels split along the probability ridges."""
+    image = np.asarray(image)
+    pr = np.asarray(probabilities, np.float32)
+    cls = _layer_classes(category_layers)[:len(image)]
+    layers = _dev(image != 0, np.uint8)
+    labels, _ = watershed_batch(layers, _dev(np.stack([pr[c] for c in cls]), np.float32), marker_erosion)
+    return labels.cpu().numpy()
 
 
 def add_dropped_objects(original, processed):
