@@ -982,7 +982,9 @@ template <typename T> __device__ __forceinline__ int wg_swz(int unit, int row, i
 
 typedef short v4i16_t __attribute__((ext_vector_type(4)));
 
-template <typename T, int TA, int TB, int NST>
+// ABL (probes/wgrad_ablate.hip only; 0 in the product): bit 0 = no MFMA, bit 1 = no DMA after the prologue, bit 2 = no fragment
+// reads and no MFMA, bit 5 = no atomics (the epilogue keeps the accumulators alive only)
+template <typename T, int TA, int TB, int NST, int ABL = 0>
 __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, const int nwg) {
     constexpr int ES = sizeof(T);
     constexpr int KP = 64 / ES;                  // pixels per k-step (32 bf16 / 16 f32)
@@ -1032,7 +1034,23 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
         qrow[i] = j * RPB + lane / UB;
         qcol[i] = (unsigned)b0 * ES + (unsigned)wg_swz<T>(lane % UB, qrow[i], UB) * 16u;
     }
-    // one DMA wave-instruction of the stage holding k-step s (pieces 0..IA-1: P rows, IA..IA+IB-1: Q rows)
+    // (n, y, x) of the P-grid pixel each Q piece fetches next.  Stages are issued in k-step order, KP pixels apart, so the
+    // decode advances incrementally (one conditional wrap per axis) instead of two divisions per DMA instruction and
+    // k-step -- the address arithmetic was what bounded this kernel (probes/wgrad_ablate.hip: "DMA only" = 80 % of the full
+    // time at 20 B/clk/CU).  Images smaller than a k-step's pixel run keep the division path.
+    const bool incr = KP / p.Wp + 1 <= p.Hp;
+    const int dxs = KP % p.Wp, dys = KP / p.Wp;
+    int qn_[IB], qy_[IB], qx_[IB];
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+        const unsigned m = (unsigned)(mbeg + qrow[i]);
+        const unsigned n = udiv_rcp(m, hw, p.rcp_hw);
+        const unsigned rem = m - n * hw;
+        const unsigned y = udiv_rcp(rem, (unsigned)p.Wp, p.rcp_w);
+        qn_[i] = (int)n; qy_[i] = (int)y; qx_[i] = (int)(rem - y * (unsigned)p.Wp);
+    }
+    // one DMA wave-instruction of the stage holding k-step s (pieces 0..IA-1: P rows, IA..IA+IB-1: Q rows); every piece
+    // is issued exactly once per k-step, in k-step order
     auto piece = [&](int i, int s, int stage) {
         const int mb = mbeg + s * KP;
         char* sp = smem + stage * STAGE;
@@ -1045,17 +1063,24 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
         } else {
             const int ii = i >= IA ? i - IA : 0;
             const int m = mb + qrow[ii];
-            unsigned off = OOB_OFF;
-            if (m < mend) {
-                const unsigned n = udiv_rcp((unsigned)m, hw, p.rcp_hw);
-                const unsigned rem = (unsigned)m - n * hw;
-                const unsigned y = udiv_rcp(rem, (unsigned)p.Wp, p.rcp_w);
-                const unsigned x = rem - y * (unsigned)p.Wp;
-                const int iy = (int)y * p.stride - p.pad + kh, ix = (int)x * p.stride - p.pad + kw;
-                if ((unsigned)iy < (unsigned)p.Hq && (unsigned)ix < (unsigned)p.Wq)
-                    off = (unsigned)(((int)n * p.Hq + iy) * p.Wq + ix) * qpix + qcol[ii];
+            int n = qn_[ii], y = qy_[ii], x = qx_[ii];
+            if (!incr) {
+                const unsigned nn = udiv_rcp((unsigned)m, hw, p.rcp_hw);
+                const unsigned rem = (unsigned)m - nn * hw;
+                const unsigned yy = udiv_rcp(rem, (unsigned)p.Wp, p.rcp_w);
+                n = (int)nn; y = (int)yy; x = (int)(rem - yy * (unsigned)p.Wp);
             }
+            unsigned off = OOB_OFF;
+            const int iy = y * p.stride - p.pad + kh, ix = x * p.stride - p.pad + kw;
+            if (m < mend && (unsigned)iy < (unsigned)p.Hq && (unsigned)ix < (unsigned)p.Wq)
+                off = (unsigned)((n * p.Hq + iy) * p.Wq + ix) * qpix + qcol[ii];
             dma16(rq, sq + (NIB >= 4 ? ii * 4 + wid : (wid & (NIB - 1))) * 1024, off, 0);
+            // advance this piece's pixel by one k-step
+            x += dxs;
+            if (x >= p.Wp) { x -= p.Wp; ++y; }
+            y += dys;
+            if (y >= p.Hp) { y -= p.Hp; ++n; }
+            qn_[ii] = n; qy_[ii] = y; qx_[ii] = x;
         }
     };
     auto issue = [&](int s, int stage) {
@@ -1129,12 +1154,21 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
         // the DMA pieces of the stage NST-1 steps ahead go out between the MFMAs (see conv_igemm_dma_kernel)
         auto kstep = [&](auto issue_tag, int s) {
             constexpr bool ISSUE = decltype(issue_tag)::value;
+            const bool live = (ABL & 2) ? p.N < 0 : true;
             const char* sb = smem + (s & (NST - 1)) * STAGE;
             uint4 af[FM], bf[FN];
+            if (!(ABL & 4)) {
 #pragma unroll
-            for (int a = 0; a < FM; ++a) af[a] = frag(sb, aoff[a]);
+                for (int a = 0; a < FM; ++a) af[a] = frag(sb, aoff[a]);
 #pragma unroll
-            for (int b = 0; b < FN; ++b) bf[b] = frag(sb, boff[b]);
+                for (int b = 0; b < FN; ++b) bf[b] = frag(sb, boff[b]);
+                if (ABL & 1) {
+#pragma unroll
+                    for (int a = 0; a < FM; ++a) asm volatile("" ::"v"(af[a].x), "v"(af[a].y), "v"(af[a].z), "v"(af[a].w));
+#pragma unroll
+                    for (int b = 0; b < FN; ++b) asm volatile("" ::"v"(bf[b].x), "v"(bf[b].y), "v"(bf[b].z), "v"(bf[b].w));
+                }
+            }
 #pragma unroll
             for (int a = 0; a < FM; ++a)
 #pragma unroll
@@ -1142,9 +1176,9 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
                     if (ISSUE) {
 #pragma unroll
                         for (int i = 0; i < LPW; ++i)
-                            if ((i * NM) / LPW == a * FN + b) piece(i, s + NST - 1, (s + NST - 1) & (NST - 1));
+                            if ((i * NM) / LPW == a * FN + b && live) piece(i, s + NST - 1, (s + NST - 1) & (NST - 1));
                     }
-                    Mma<T>::run(af[a], bf[b], acc[a][b]);
+                    if (!(ABL & 5)) Mma<T>::run(af[a], bf[b], acc[a][b]);
                 }
         };
         const int nmain = nsteps - (NST - 1);
@@ -1169,15 +1203,16 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
 #pragma unroll
                 for (int b = 0; b < FN; ++b) {
                     const int ib = b0 + wb * WTB + b * 16 + pl;
-                    if (ia < p.A && ib < p.B) atomicAdd(p.dw + (ia * taps + tap) * p.B + ib, acc[a][b][r]);
+                    if (ABL & 32) asm volatile("" ::"v"(acc[a][b][r]));
+                    else if (ia < p.A && ib < p.B) atomicAdd(p.dw + (ia * taps + tap) * p.B + ib, acc[a][b][r]);
                 }
             }
     }
 }
 
-template <typename T, int TA, int TB, int NST>
+template <typename T, int TA, int TB, int NST, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgK p) {
-    wgrad_dma_body<T, TA, TB, NST>(p, blockIdx.x, gridDim.x);
+    wgrad_dma_body<T, TA, TB, NST, ABL>(p, blockIdx.x, gridDim.x);
 }
 
 // Several weight-gradient problems of one tile shape in a single launch (msc_wgrad_group_*): the layers of a

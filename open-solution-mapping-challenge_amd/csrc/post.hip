@@ -231,7 +231,9 @@ __global__ void dropped_apply_kernel(const uint8_t* __restrict__ processed, cons
 // image-layer.  A round = candidates from the labels as they are (phase A), barrier, apply (phase B): simultaneous update,
 // ties to the smaller label, so the result does not depend on any traversal order.
 __global__ __launch_bounds__(1024) void watershed_flood_kernel(const float* __restrict__ prob, const uint8_t* __restrict__ mask,
-                                                               int32_t* labels, uint8_t* hq, int32_t* cand, int H, int W) {
+                                                               int32_t* labels, uint8_t* hq, int32_t* cand, int32_t* list, int H, int W) {
+    __shared__ int n_list;
+    __shared__ int hist[256];
     const long HW = (long)H * W;
     const long base = (long)blockIdx.x * HW;
     const float* P = prob + base;
@@ -239,22 +241,33 @@ __global__ __launch_bounds__(1024) void watershed_flood_kernel(const float* __re
     int32_t* L = labels + base;
     uint8_t* Hq = hq + base;
     int32_t* C = cand + base;
-    int todo = 0;
+    int32_t* Q = list + base;                     // the unlabelled mask pixels: only they ever change (order irrelevant: rounds are synchronous)
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) n_list = 0;
+    __syncthreads();
     for (long p = threadIdx.x; p < HW; p += blockDim.x) {
         float v = floorf((1.0f - P[p]) * 255.0f);
         v = fminf(fmaxf(v, 0.f), 255.f);
         Hq[p] = (uint8_t)v;
         C[p] = 0;
         if (!M[p]) L[p] = 0;
-        else if (L[p] == 0) ++todo;
+        else if (L[p] == 0) {
+            Q[atomicAdd(&n_list, 1)] = (int32_t)p;
+            atomicAdd(&hist[(int)v], 1);
+        }
     }
     __syncthreads();
+    const int n = n_list;
+    int todo = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) ++todo;
     for (int level = 0; level < 256; ++level) {
-        if (!__syncthreads_or(todo > 0)) break;                       // every mask pixel is labelled
+        if (hist[level] == 0) continue;            // nothing new is eligible: the state is the fixed point the previous level ended in
+        if (!__syncthreads_or(todo > 0)) break;    // every mask pixel is labelled
         for (;;) {
             int found = 0;
-            for (long p = threadIdx.x; p < HW; p += blockDim.x) {
-                if (!M[p] || L[p] != 0 || Hq[p] > level) continue;
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const long p = Q[i];
+                if (L[p] != 0 || Hq[p] > level) continue;
                 const int y = (int)(p / W), x = (int)(p - (long)y * W);
                 int best = 0x7fffffff;
                 if (y > 0) { const int q = L[p - W]; if (q > 0 && q < best) best = q; }
@@ -263,8 +276,9 @@ __global__ __launch_bounds__(1024) void watershed_flood_kernel(const float* __re
                 if (x + 1 < W) { const int q = L[p + 1]; if (q > 0 && q < best) best = q; }
                 if (best != 0x7fffffff) { C[p] = best; found = 1; }
             }
-            if (!__syncthreads_or(found)) break;                      // also orders phase A's reads before phase B's writes
-            for (long p = threadIdx.x; p < HW; p += blockDim.x) {
+            if (!__syncthreads_or(found)) break;   // also orders phase A's reads before phase B's writes
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const long p = Q[i];
                 const int c = C[p];
                 if (c > 0) { L[p] = c; C[p] = 0; --todo; }
             }
@@ -564,7 +578,7 @@ extern "C" int msc_label4(const uint8_t* mask, int32_t* labels, int32_t* counts,
 
 extern "C" int64_t msc_watershed_workspace_bytes(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return -1;
-    return (int64_t)B * H * W * 5;          // 8-bit relief + int32 candidates
+    return (int64_t)B * H * W * 9;          // int32 candidates + int32 work list + 8-bit relief
 }
 
 extern "C" int msc_watershed(const float* prob, const uint8_t* mask, int32_t* labels, void* workspace, int B, int H, int W, void* stream) {
@@ -573,8 +587,9 @@ extern "C" int msc_watershed(const float* prob, const uint8_t* mask, int32_t* la
     if (((uintptr_t)workspace) & 3) return msc_fail(MSC_ERR_ARG, "msc_watershed: workspace must be 4-byte aligned");
     const long n = (long)B * H * W;
     int32_t* cand = (int32_t*)workspace;
-    uint8_t* hq = (uint8_t*)workspace + n * 4;
-    hipLaunchKernelGGL(watershed_flood_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, prob, mask, labels, hq, cand, H, W);
+    int32_t* list = cand + n;
+    uint8_t* hq = (uint8_t*)workspace + n * 8;
+    hipLaunchKernelGGL(watershed_flood_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, prob, mask, labels, hq, cand, list, H, W);
     return msc_check_launch("msc_watershed");
 }
 

@@ -616,7 +616,7 @@ class _Builder:
         env = _os_env.environ
         multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
         self.group_max = int(env.get('MSC_WGRAD_GROUP', '24' if multi else '1000')) if (training and device.type == 'cuda') else 0
-        self.group_steps = int(env.get('MSC_WGRAD_GROUP_STEPS', '64'))
+        self.group_steps = int(env.get('MSC_WGRAD_GROUP_STEPS', '128'))      # k-steps per block: fewer, longer blocks = fewer fp32-atomic passes over dW
         self.group_tile = int(env.get('MSC_WGRAD_GROUP_TILE', '128'))
         self.pending = []             # deferred (WgradDesc, gradient address or None)
         self.gcount = {}              # activation slice -> number of launches that write its gradient
