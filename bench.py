@@ -110,9 +110,9 @@ def _es(dtype):
 # algorithmic HBM bytes of the BatchNorm elementwise launches: tensors of pixels*C elements read or written
 # (argument positions: include/msc.h)
 BN_TENSORS = {
-    'msc_bn_apply': lambda a: a[10] * a[11] * _es(a[9]) * (2 + (1 if a[2] else 0)),
+    'msc_bn_apply': lambda a: a[20] * a[21] * _es(a[19]) * (2 + (1 if a[2] else 0)),
     'msc_bn_bwd_reduce': lambda a: a[11] * a[12] * _es(a[10]) * (2 + (1 if a[6] == 1 else 0)),
-    'msc_bn_bwd_apply': lambda a: a[16] * a[17] * _es(a[15]) * (3 + (1 if a[6] == 1 else 0) + ((1 + (1 if a[14] else 0)) if a[12] else 0)),
+    'msc_bn_bwd_apply': lambda a: a[22] * a[23] * _es(a[21]) * (3 + (1 if a[6] == 1 else 0) + ((1 + (1 if a[20] else 0)) if a[18] else 0)),
 }
 
 

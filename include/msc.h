@@ -39,12 +39,13 @@ int msc_abi_version(void);
  * mode 0 (gather):      out[q] = sum_t in[q*stride + off(t)] * W[.][t][.]   off = t-pad, or pad-t if flip
  * mode 1 (transposed):  out[q] = sum_{t:(q+pad-t) even} in[(q+pad-t)/2] * W[.][t][.]   (stride must be 2)
  * epilogue: v = acc*scale[c] + shift[c] (+ res) ; ReLU ; store.  scale/shift/res may be NULL.
- * stats (mode 0 only, may be NULL): per-channel partial sum / sum of squares of the raw accumulators,
- *   [Cout][msc_conv_stats_slices()][2] floats, reduced by msc_bn_finalize (BatchNorm2d training mode).
+ * stats (mode 0 only, may be NULL): per-channel sum / sum of squares of the raw accumulators, ADDED (fp32 atomics) into
+ *   [MSC_BN_SLOTS][Cout][2] doubles -- one slot per XCD, so that every address is only ever touched from one L2; the
+ *   caller zeroes the slots (msc_memset_zero), msc_bn_apply sums them in its prologue (BatchNorm2d training mode).
  *   stats_kind 1 (data-gradient convs): the launch also reduces what msc_bn_bwd_reduce would read back -- the output
  *   is the gradient w.r.t. a BatchNorm+ReLU layer's activation, stats_y that layer's pre-BN tensor (same shape as
  *   out), scale/shift its forward coefficients (used for the ReLU mask only, NULL = no ReLU; no affine is applied):
- *   stats[c][slice] = (sum dh, sum dh*y), dh = acc*[scale*y+shift > 0].  Same layout, feeds msc_bn_bwd_finalize.
+ *   stats[slot][c] += (sum dh, sum dh*y), dh = acc*[scale*y+shift > 0].  Same layout, consumed by msc_bn_bwd_apply.
  * weights: dtype [Cout][KH][KW][Cin].  Cin*sizeof(dtype) % 64 == 0, Cout % 32 == 0. */
 typedef struct msc_conv_desc {
     const void* in;
@@ -53,7 +54,7 @@ typedef struct msc_conv_desc {
     const void* res;
     const float* scale;
     const float* shift;
-    float* stats;
+    double* stats;
     int64_t in_ld, out_ld, res_ld;
     int32_t dtype, mode;
     int32_t N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, flip, relu;
@@ -132,29 +133,31 @@ int msc_maxpool2_fwd(const void* in, int64_t in_ld, void* out, int64_t out_ld, i
 int msc_maxpool2_bwd(const void* dout, int64_t dout_ld, const void* in, int64_t in_ld, void* din, int64_t din_ld,
                      int dtype, int N, int Ho, int Wo, int C, int accumulate, void* stream);
 
-/* BatchNorm2d, training mode (torchvision ResNet BNs; eps 1e-5, momentum 0.1).
- * finalize: partial sums -> batch mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale;
- *           running stats updated with the unbiased variance; mean / invstd saved for backward.
- * apply:    out = act(y*scale + shift (+ res)). */
-int msc_bn_finalize(const float* partials, int slices, int C, int64_t count, const float* gamma, const float* beta,
-                    float eps, float momentum, float* running_mean, float* running_var,
-                    float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+/* BatchNorm2d, training mode (torchvision ResNet BNs; eps 1e-5, momentum 0.1).  The statistics arrive as per-XCD partial
+ * sums, double slots[MSC_BN_SLOTS][C][2] (from msc_conv_igemm's `stats` or msc_bn_bwd_reduce), and are finalised in the prologue
+ * of the kernel that needs them -- there is no separate finalize launch.
+ * apply:  (sum y, sum y^2) -> batch mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale;
+ *         out = act(y*scale + shift (+ res)); also writes scale / shift / save_mean / save_invstd and updates the running
+ *         statistics (unbiased variance).  slots == NULL: scale / shift are inputs (no statistics involved). */
+#define MSC_BN_SLOTS 8
+int msc_memset_zero(void* ptr, int64_t bytes, void* stream);
+int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_t res_ld, void* out, int64_t out_ld,
+                 const double* slots, int64_t count, const float* gamma, const float* beta, float eps, float momentum,
+                 float* running_mean, float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
+                 int relu, int dtype, int64_t pixels, int C, void* stream);
 /* eval mode (model.eval(), src/steps/pytorch/models.py:116): scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
 int msc_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                 float eps, float* scale, float* shift, int C, void* stream);
-int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_t res_ld, void* out, int64_t out_ld,
-                 const float* scale, const float* shift, int relu, int dtype, int64_t pixels, int C, void* stream);
-/* backward of out = relu?(bn(y) (+res)):  dh = dout * [out>0] (if relu);
- * reduce: partial[C][msc_bn_bwd_blocks()][2] = (sum dh, sum dh*y) (deterministic, no atomics);  finalize: dgamma, dbeta (accumulated into fp32 grads) and
- * per-channel coefficients coef[3][C];  apply: dy = coef0*dh + coef1*y + coef2 ; dres (optional) = dh (or += if dres_acc). */
-int msc_bn_bwd_blocks(int64_t pixels, int C, int dtype);
+/* backward of out = relu?(bn(y) (+res)):  dh = dout * [out>0] (relu 1) or dout * [scale*y+shift > 0] (relu 2);
+ * reduce: slots[xcd][c] += (sum dh, sum dh*y)   (the data-gradient conv that writes dout can do this in its epilogue instead);
+ * apply:  prologue: dbeta += sum dh, dgamma += sum dh*xhat (into the fp32 gradients), dy = a*dh + b*y + k per channel;
+ *         dres (optional) = dh (or += if dres_acc). */
 int msc_bn_bwd_reduce(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
-                      int relu, const float* scale, const float* shift, float* partials, int dtype, int64_t pixels, int C,
+                      int relu, const float* scale, const float* shift, double* slots, int dtype, int64_t pixels, int C,
                       void* stream);
-int msc_bn_bwd_finalize(const float* partials, int blocks, int C, int64_t count, const float* gamma,
-                        const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef, void* stream);
 int msc_bn_bwd_apply(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
-                     int relu, const float* scale, const float* shift, const float* coef, void* dy, int64_t dy_ld,
+                     int relu, const float* scale, const float* shift, const double* slots, int64_t count, const float* gamma,
+                     const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* dy, int64_t dy_ld,
                      void* dres, int64_t dres_ld, int dres_acc, int dtype, int64_t pixels, int C, void* stream);
 
 /* ReLU backward for the decoder (ConvRelu / deconv+ReLU): dx = dy*[y>0], optionally dx += */

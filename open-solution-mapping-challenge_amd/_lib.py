@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MSC_HIP_LIB', os.path.join(_HERE, 'lib', 'libmsc_hip.so'))
 
 F32, BF16, F16 = 0, 1, 2
+BN_SLOTS = 8                      # MSC_BN_SLOTS: per-XCD accumulation slots of the BatchNorm sums
 CFG_HALO, CFG_HALO_T = 27, 28     # msc_conv_igemm configurations that are halo-tile kernels, not tiles of the DMA kernel
 
 
@@ -69,13 +70,11 @@ SIGNATURES = {
     'msc_stem_prepare': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'msc_maxpool2_fwd': (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     'msc_maxpool2_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
-    'msc_bn_finalize': (_i, [_vp, _i, _i, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'msc_bn_fold': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
-    'msc_bn_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i64, _i, _vp]),
-    'msc_bn_bwd_blocks': (_i, [_i64, _i, _i]),
+    'msc_memset_zero': (_i, [_vp, _i64, _vp]),
+    'msc_bn_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp]),
     'msc_bn_bwd_reduce': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i, _i64, _i, _vp]),
-    'msc_bn_bwd_finalize': (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'msc_bn_bwd_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i64, _i, _vp]),
+    'msc_bn_bwd_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i64, _i, _vp]),
     'msc_relu_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i64, _i, _vp]),
     'msc_bias_grad_workspace_bytes': (_i64, [_i64, _i, _i]),
     'msc_bias_grad': (_i, [_vp, _i64, _vp, _vp, _i, _i64, _i, _vp]),

@@ -22,6 +22,16 @@ static inline bool msc_dtype_ok(int dtype) { return dtype == MSC_F32 || dtype ==
 static inline int msc_dtype_size(int dtype) { return dtype == MSC_F32 ? 4 : 2; }
 static inline int msc_dtype_vec(int dtype) { return 16 / msc_dtype_size(dtype); }      // elements per 16-byte vector
 
+// Per-channel BatchNorm sums are accumulated with fp32 atomics into one slot per XCD ([MSC_BN_SLOTS][C][2] floats, zeroed by the
+// caller): every contribution to an address comes from ONE XCD, so the line stays in that XCD's L2 (a same-address atomic
+// from different XCDs migrates the line through the fabric: 5-7x slower, probes/xcd_atomic_probe.hip) and the consumer's
+// prologue reads 8 values per channel instead of launching a reduction.  The slot is the hardware XCC id: any workgroup ->
+// XCD placement gives the right total.
+#define MSC_BN_SLOTS 8
+#ifdef __HIPCC__
+__device__ __forceinline__ int msc_xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & (MSC_BN_SLOTS - 1); }   // HW_REG_XCC_ID[3:0]
+#endif
+
 extern thread_local char msc_err_buf[512];
 int msc_fail(int code, const char* fmt, ...);
 int msc_check_launch(const char* what);

@@ -164,24 +164,72 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
     }
 }
 
-template <typename T>
-__global__ void bn_apply_kernel(const T* __restrict__ y, long y_ld, const T* __restrict__ res, long res_ld,
-                                T* __restrict__ out, long out_ld, const float* __restrict__ scale,
-                                const float* __restrict__ shift, int relu, long pixels, int C) {
-    constexpr int CE = Vec16<T>::N;
-    const int cv = C / CE;
-    const long total = pixels * cv;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cv) * CE;
-        const long pix = i / cv;
-        float v[CE], r[CE];
+// BatchNorm2d training-mode apply / backward-apply with the statistics FINALISED IN THE PROLOGUE: the producer (conv epilogue
+// or column reduce) left one partial sum pair per XCD and channel ([MSC_BN_SLOTS][C][2], common.h); a block owns CT channels
+// x a pixel range, its first CT threads turn the 8 slots of their channel into the per-channel coefficients (double
+// arithmetic, as the former finalize kernels did) and park them in LDS -- 208 dependent 6-8 us finalize launches per
+// ResNet101 train step are gone.  The blocks of the first pixel range also publish what later kernels need (scale / shift /
+// mean / invstd, running statistics; dgamma / dbeta).
+struct BnFwdFin {
+    const double* slots; double count; const float* gamma; const float* beta; float eps, momentum;
+    float* running_mean; float* running_var; float* scale; float* shift; float* save_mean; float* save_invstd;
+};
+
+template <typename T, int CT>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, long y_ld, const T* __restrict__ res, long res_ld,
+                                                       T* __restrict__ out, long out_ld, BnFwdFin f, int relu, long pixels, int C, long ppb) {
+    constexpr int CE = Vec16<T>::N, VC = CT / CE, R = 256 / VC;
+    __shared__ float s_sc[CT], s_sh[CT];
+    const int tid = threadIdx.x, c0 = blockIdx.y * CT;
+    if (tid < CT) {
+        const int c = c0 + tid;
+        float sc, sh;
+        if (f.slots) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int x = 0; x < MSC_BN_SLOTS; ++x) {
+                const double2 v = *reinterpret_cast<const double2*>(f.slots + ((long)x * C + c) * 2);
+                s1 += v.x; s2 += v.y;
+            }
+            const double mean = s1 / f.count;
+            double var = s2 / f.count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+            const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+            sc = g * invstd;
+            sh = b - (float)mean * sc;
+            if (blockIdx.x == 0) {
+                f.scale[c] = sc;
+                f.shift[c] = sh;
+                if (f.save_mean) f.save_mean[c] = (float)mean;
+                if (f.save_invstd) f.save_invstd[c] = invstd;
+                if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
+                if (f.running_var) {
+                    const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+                    f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
+                }
+            }
+        } else {                        // coefficients given (no statistics to finalise)
+            sc = f.scale[c]; sh = f.shift[c];
+        }
+        s_sc[tid] = sc; s_sh[tid] = sh;
+    }
+    __syncthreads();
+    const int col = tid % VC, r = tid / VC;
+    const int c = c0 + col * CE;
+    float sc[CE], sh[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { sc[e] = s_sc[col * CE + e]; sh[e] = s_sh[col * CE + e]; }
+    const long p1 = min(pixels, ((long)blockIdx.x + 1) * ppb);
+    for (long pix = (long)blockIdx.x * ppb + r; pix < p1; pix += R) {
+        float v[CE], rr[CE];
         Vec16<T>::load(y + pix * y_ld + c, v);
 #pragma unroll
-        for (int e = 0; e < CE; ++e) v[e] = fmaf(v[e], scale[c + e], shift[c + e]);
+        for (int e = 0; e < CE; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
         if (res) {
-            Vec16<T>::load(res + pix * res_ld + c, r);
+            Vec16<T>::load(res + pix * res_ld + c, rr);
 #pragma unroll
-            for (int e = 0; e < CE; ++e) v[e] += r[e];
+            for (int e = 0; e < CE; ++e) v[e] += rr[e];
         }
         if (relu) {
 #pragma unroll
@@ -191,19 +239,54 @@ __global__ void bn_apply_kernel(const T* __restrict__ y, long y_ld, const T* __r
     }
 }
 
-template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, long dout_ld, const T* __restrict__ out, long out_ld,
-                                    const T* __restrict__ y, long y_ld, int relu, const float* __restrict__ scale,
-                                    const float* __restrict__ shift, const float* __restrict__ coef,
-                                    T* __restrict__ dy, long dy_ld, T* __restrict__ dres, long dres_ld, int dres_acc,
-                                    long pixels, int C) {
-    constexpr int CE = Vec16<T>::N;
-    const int cv = C / CE;
-    const long total = pixels * cv;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cv) * CE;
-        const long pix = i / cv;
-        float d[CE], o[CE], yy[CE], r[CE];
+struct BnBwdFin {
+    const double* slots; double count; const float* gamma; const float* save_mean; const float* save_invstd;
+    float* dgamma; float* dbeta;
+};
+
+template <typename T, int CT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, long dout_ld, const T* __restrict__ out, long out_ld,
+                                                           const T* __restrict__ y, long y_ld, int relu, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, BnBwdFin f, T* __restrict__ dy, long dy_ld,
+                                                           T* __restrict__ dres, long dres_ld, int dres_acc, long pixels, int C, long ppb) {
+    constexpr int CE = Vec16<T>::N, VC = CT / CE, R = 256 / VC;
+    __shared__ float s_a[CT], s_b[CT], s_k[CT], s_sc[CT], s_sh[CT];
+    const int tid = threadIdx.x, c0 = blockIdx.y * CT;
+    if (tid < CT) {
+        const int c = c0 + tid;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int x = 0; x < MSC_BN_SLOTS; ++x) {
+            const double2 v = *reinterpret_cast<const double2*>(f.slots + ((long)x * C + c) * 2);
+            s1 += v.x; s2 += v.y;
+        }
+        const double mu = f.save_mean[c], is = f.save_invstd[c], g = f.gamma ? f.gamma[c] : 1.0;
+        const double dbe = s1;                        // sum dh
+        const double dga = is * (s2 - mu * s1);       // sum dh * xhat
+        // dy = g*is*(dh - dbe/M - xhat*dga/M),  xhat = (y-mu)*is   ->   dy = a*dh + b*y + k0
+        const double a = g * is;
+        const double b = -g * is * is * dga / f.count;
+        const double k0 = -g * is * dbe / f.count - b * mu;
+        s_a[tid] = (float)a; s_b[tid] = (float)b; s_k[tid] = (float)k0;
+        s_sc[tid] = relu == 2 ? scale[c] : 0.f;
+        s_sh[tid] = relu == 2 ? shift[c] : 0.f;
+        if (blockIdx.x == 0) {
+            if (f.dgamma) f.dgamma[c] += (float)dga;
+            if (f.dbeta) f.dbeta[c] += (float)dbe;
+        }
+    }
+    __syncthreads();
+    const int col = tid % VC, r = tid / VC;
+    const int c = c0 + col * CE;
+    float ca[CE], cb[CE], ck[CE], sc[CE], sh[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+        ca[e] = s_a[col * CE + e]; cb[e] = s_b[col * CE + e]; ck[e] = s_k[col * CE + e];
+        sc[e] = s_sc[col * CE + e]; sh[e] = s_sh[col * CE + e];
+    }
+    const long p1 = min(pixels, ((long)blockIdx.x + 1) * ppb);
+    for (long pix = (long)blockIdx.x * ppb + r; pix < p1; pix += R) {
+        float d[CE], o[CE], yy[CE], rr[CE];
         Vec16<T>::load(dout + pix * dout_ld + c, d);
         Vec16<T>::load(y + pix * y_ld + c, yy);
         if (relu == 1) {
@@ -212,20 +295,20 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, long dout_ld, co
             for (int e = 0; e < CE; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
         } else if (relu == 2) {
 #pragma unroll
-            for (int e = 0; e < CE; ++e) d[e] = fmaf(yy[e], scale[c + e], shift[c + e]) > 0.f ? d[e] : 0.f;
+            for (int e = 0; e < CE; ++e) d[e] = fmaf(yy[e], sc[e], sh[e]) > 0.f ? d[e] : 0.f;
         }
         if (dres) {
             if (dres_acc) {
-                Vec16<T>::load(dres + pix * dres_ld + c, r);
+                Vec16<T>::load(dres + pix * dres_ld + c, rr);
 #pragma unroll
-                for (int e = 0; e < CE; ++e) r[e] += d[e];
-                Vec16<T>::store(dres + pix * dres_ld + c, r);
+                for (int e = 0; e < CE; ++e) rr[e] += d[e];
+                Vec16<T>::store(dres + pix * dres_ld + c, rr);
             } else {
                 Vec16<T>::store(dres + pix * dres_ld + c, d);
             }
         }
 #pragma unroll
-        for (int e = 0; e < CE; ++e) yy[e] = coef[c + e] * d[e] + coef[C + c + e] * yy[e] + coef[2 * C + c + e];
+        for (int e = 0; e < CE; ++e) yy[e] = ca[e] * d[e] + cb[e] * yy[e] + ck[e];
         Vec16<T>::store(dy + pix * dy_ld + c, yy);
     }
 }
@@ -586,32 +669,73 @@ extern "C" int msc_bn_fold(const float* gamma, const float* beta, const float* r
     return msc_check_launch("msc_bn_fold");
 }
 
+namespace {
+// grid of the channel-tiled BatchNorm kernels: CT channels x `ppb` pixels per block, about 2048 blocks in all
+template <int R>
+long bn_ppb(long pixels, int ctiles) {
+    long ppb = ceil_div(pixels * ctiles, 2048);
+    ppb = (ppb + R - 1) / R * R;
+    return ppb < R ? R : ppb;
+}
+template <typename T, int CT>
+void launch_bn_apply(const void* y, long y_ld, const void* res, long res_ld, void* out, long out_ld, const BnFwdFin& f, int relu, long pixels, int C,
+                     hipStream_t st) {
+    constexpr int R = 256 / (CT / Vec16<T>::N);
+    const long ppb = bn_ppb<R>(pixels, C / CT);
+    hipLaunchKernelGGL((bn_apply_kernel<T, CT>), dim3(ceil_div(pixels, ppb), C / CT), dim3(256), 0, st, (const T*)y, y_ld, (const T*)res, res_ld, (T*)out,
+                       out_ld, f, relu, pixels, C, ppb);
+}
+template <typename T, int CT>
+void launch_bn_bwd_apply(const void* dout, long dout_ld, const void* out, long out_ld, const void* y, long y_ld, int relu, const float* scale,
+                         const float* shift, const BnBwdFin& f, void* dy, long dy_ld, void* dres, long dres_ld, int dres_acc, long pixels, int C,
+                         hipStream_t st) {
+    constexpr int R = 256 / (CT / Vec16<T>::N);
+    const long ppb = bn_ppb<R>(pixels, C / CT);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, CT>), dim3(ceil_div(pixels, ppb), C / CT), dim3(256), 0, st, (const T*)dout, dout_ld, (const T*)out, out_ld,
+                       (const T*)y, y_ld, relu, scale, shift, f, (T*)dy, dy_ld, (T*)dres, dres_ld, dres_acc, pixels, C, ppb);
+}
+}  // namespace
+
+#define MSC_BN_DISPATCH(FN, ...) \
+    do { \
+        if (C % 64 == 0) { \
+            if (dtype == MSC_F16) FN<f16_t, 64>(__VA_ARGS__); else if (dtype == MSC_BF16) FN<bf16_t, 64>(__VA_ARGS__); else FN<float, 64>(__VA_ARGS__); \
+        } else { \
+            if (dtype == MSC_F16) FN<f16_t, 32>(__VA_ARGS__); else if (dtype == MSC_BF16) FN<bf16_t, 32>(__VA_ARGS__); else FN<float, 32>(__VA_ARGS__); \
+        } \
+    } while (0)
+
 extern "C" int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_t res_ld, void* out, int64_t out_ld,
-                            const float* scale, const float* shift, int relu, int dtype, int64_t pixels, int C, void* stream) {
+                            const double* slots, int64_t count, const float* gamma, const float* beta, float eps, float momentum,
+                            float* running_mean, float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
+                            int relu, int dtype, int64_t pixels, int C, void* stream) {
     DT_CHECK("msc_bn_apply", dtype);
-    VEC_CHECK("msc_bn_apply", dtype, C);
-    if (!y || !out || !scale || !shift) return msc_fail(MSC_ERR_ARG, "msc_bn_apply: null pointer");
-    hipStream_t st = (hipStream_t)stream;
-    const long total = pixels * (C / msc_dtype_vec(dtype));
-    if (dtype == MSC_F16) hipLaunchKernelGGL(bn_apply_kernel<f16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const f16_t*)y, (long)y_ld, (const f16_t*)res, (long)res_ld, (f16_t*)out, (long)out_ld, scale, shift, relu, (long)pixels, C);
-    else if (dtype == MSC_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)y, (long)y_ld, (const bf16_t*)res, (long)res_ld, (bf16_t*)out, (long)out_ld, scale, shift, relu, (long)pixels, C);
-    else hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const float*)y, (long)y_ld, (const float*)res, (long)res_ld, (float*)out, (long)out_ld, scale, shift, relu, (long)pixels, C);
+    if (C % 32) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bn_apply: C=%d must be a multiple of 32", C);
+    if (!y || !out || !scale || !shift || pixels <= 0 || (slots && count <= 0)) return msc_fail(MSC_ERR_ARG, "msc_bn_apply: bad argument");
+    const BnFwdFin f = {slots, (double)count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd};
+    MSC_BN_DISPATCH(launch_bn_apply, y, (long)y_ld, res, (long)res_ld, out, (long)out_ld, f, relu, (long)pixels, C, (hipStream_t)stream);
     return msc_check_launch("msc_bn_apply");
 }
 
 extern "C" int msc_bn_bwd_apply(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
-                                int relu, const float* scale, const float* shift, const float* coef, void* dy, int64_t dy_ld,
+                                int relu, const float* scale, const float* shift, const double* slots, int64_t count, const float* gamma,
+                                const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* dy, int64_t dy_ld,
                                 void* dres, int64_t dres_ld, int dres_acc, int dtype, int64_t pixels, int C, void* stream) {
     DT_CHECK("msc_bn_bwd_apply", dtype);
-    VEC_CHECK("msc_bn_bwd_apply", dtype, C);
-    if (!dout || !y || !coef || !dy || relu < 0 || relu > 2 || (relu == 1 && !out) || (relu == 2 && (!scale || !shift)))
+    if (C % 32) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bn_bwd_apply: C=%d must be a multiple of 32", C);
+    if (!dout || !y || !slots || !save_mean || !save_invstd || !dy || count <= 0 || pixels <= 0 || relu < 0 || relu > 2 || (relu == 1 && !out) ||
+        (relu == 2 && (!scale || !shift)))
         return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_apply: bad argument");
-    hipStream_t st = (hipStream_t)stream;
-    const long total = pixels * (C / msc_dtype_vec(dtype));
-    if (dtype == MSC_F16) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const f16_t*)dout, (long)dout_ld, (const f16_t*)out, (long)out_ld, (const f16_t*)y, (long)y_ld, relu, scale, shift, coef, (f16_t*)dy, (long)dy_ld, (f16_t*)dres, (long)dres_ld, dres_acc, (long)pixels, C);
-    else if (dtype == MSC_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const bf16_t*)dout, (long)dout_ld, (const bf16_t*)out, (long)out_ld, (const bf16_t*)y, (long)y_ld, relu, scale, shift, coef, (bf16_t*)dy, (long)dy_ld, (bf16_t*)dres, (long)dres_ld, dres_acc, (long)pixels, C);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, st, (const float*)dout, (long)dout_ld, (const float*)out, (long)out_ld, (const float*)y, (long)y_ld, relu, scale, shift, coef, (float*)dy, (long)dy_ld, (float*)dres, (long)dres_ld, dres_acc, (long)pixels, C);
+    const BnBwdFin f = {slots, (double)count, gamma, save_mean, save_invstd, dgamma, dbeta};
+    MSC_BN_DISPATCH(launch_bn_bwd_apply, dout, (long)dout_ld, out, (long)out_ld, y, (long)y_ld, relu, scale, shift, f, dy, (long)dy_ld, dres, (long)dres_ld,
+                    dres_acc, (long)pixels, C, (hipStream_t)stream);
     return msc_check_launch("msc_bn_bwd_apply");
+}
+
+extern "C" int msc_memset_zero(void* ptr, int64_t bytes, void* stream) {
+    if (!ptr || bytes < 0) return msc_fail(MSC_ERR_ARG, "msc_memset_zero: bad argument");
+    if (bytes && hipMemsetAsync(ptr, 0, (size_t)bytes, (hipStream_t)stream) != hipSuccess) return msc_fail(MSC_ERR_HIP, "msc_memset_zero: memset failed");
+    return MSC_OK;
 }
 
 extern "C" int msc_relu_bwd(const void* dy, int64_t dy_ld, const void* y, int64_t y_ld, void* dx, int64_t dx_ld,

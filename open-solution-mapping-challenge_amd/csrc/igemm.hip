@@ -47,7 +47,7 @@ namespace {
 
 struct ConvK {
     const char* in; const char* wt; char* out; const char* res;
-    const float* scale; const float* shift; float* stats;
+    const float* scale; const float* shift; double* stats;
     const char* sy; long sy_ld; int stats_kind;     // stats_kind 1: BatchNorm-backward sums against the tensor sy
     long in_ld, out_ld, res_ld;
     int N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, flip, relu;
@@ -82,6 +82,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr unsigned OOB_OFF = 0x80000000u;   // >= any buffer extent we accept: the load returns zeros
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ void raw_barrier() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -108,9 +109,9 @@ __device__ __forceinline__ void dma16(u32x4_t srd, char* lds_wave_base, unsigned
 }
 
 // shared epilogue: lane holds NV consecutive channels cb.. of pixel rows (b*16+pl), b < FN
-template <typename T, int FM, int FN, int WTP, int WP, int MODE>
+template <typename T, int FM, int FN, int WTP, int WP, int MODE, int WC = 1>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][FN], int m0, int wp, int cb, int pl, int py, int px,
-                                              int mtile, int ntm) {
+                                              int mtile, int ntm, float* red = nullptr, int wc = 0, int c0 = 0) {
     constexpr int NV = FM * 4;
     constexpr int CE = 16 / (int)sizeof(T);
     // stats_kind 1 (a data-gradient conv that also produces the BatchNorm-backward sums of the layer whose output
@@ -215,11 +216,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
                 s2[j] += __shfl_xor(s2[j], o, 64);
             }
         }
+        // One slot per XCD, layout [MSC_BN_SLOTS][Cout][2] (common.h); the consumer (msc_bn_apply / msc_bn_bwd_apply) sums the
+        // slots in its prologue.  The block's waves fold their sums through LDS and ONE coalesced atomic instruction per
+        // 64 consecutive floats goes out: an atomic costs the L2 per touched line, not per lane (4 scattered lanes per
+        // instruction cost 5 ms per train step), and ops on one line serialise, so the fewer per block the better.
+        constexpr int WTC = FM * 16, TC = WTC * WC;
+        raw_barrier();                               // every wave is done reading the operand ring
         if (pl == 0) {
-            // layout [Cout][slices][2]: msc_bn_finalize gives each channel one wavefront over its slices
-            const long nsl = (long)ntm * WP, sl = (long)mtile * WP + wp;
+            float* mine = red + ((wp * WC + wc) * WTC + (lane_id() >> 4) * NV) * 2;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) *reinterpret_cast<float2*>(p.stats + ((cb + j) * nsl + sl) * 2) = make_float2(s1[j], s2[j]);
+            for (int j = 0; j < NV; ++j) *reinterpret_cast<float2*>(mine + 2 * j) = make_float2(s1[j], s2[j]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        raw_barrier();
+        // double accumulation: the fp32 partial of a block is exact enough, a running fp32 total over all blocks is not -- the
+        // consumer forms sum(dh*y) - mean*sum(dh) and E[y^2] - mean^2, which cancel by orders of magnitude
+        double* slot = p.stats + ((long)msc_xcc_id() * p.Cout + c0) * 2;
+        for (int f = threadIdx.x; f < TC * 2; f += WP * WC * 64) {
+            const int ch = f >> 1, k = f & 1;
+            const int wcs = ch / WTC, chw = ch - wcs * WTC;
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < WP; ++w) a += red[((w * WC + wcs) * WTC + chw) * 2 + k];
+            atomicAdd(slot + f, (double)a);
         }
     }
 }
@@ -348,7 +367,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
             __syncthreads();
         }
     }
-    conv_epilogue<T, FM, FN, WTP, WP, MODE>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px, (int)blockIdx.x, (int)gridDim.x);
+    conv_epilogue<T, FM, FN, WTP, WP, MODE, WC>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px, (int)blockIdx.x, (int)gridDim.x,
+                                                reinterpret_cast<float*>(smem), wc, c0);
 }
 
 // ------------------------------------------------------------------------------------------------ v2 (DMA)
@@ -594,7 +614,8 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
             if (++cstage == NST) cstage = 0;
         }
     }
-    conv_epilogue<T, FM, FN, WTP, WP, MODE>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px, mtile, nwg / p.ntc);
+    conv_epilogue<T, FM, FN, WTP, WP, MODE, WC>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px, mtile, nwg / p.ntc,
+                                                reinterpret_cast<float*>(smem), wc, c0);
 }
 
 // ------------------------------------------------------------------------------------------------ halo tile
@@ -1463,16 +1484,8 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
 }
 
 extern "C" int msc_conv_stats_slices(const msc_conv_desc* d) {
-    ConvK k;
-    if (conv_fill(d, &k) != MSC_OK) return -1;
-    int cfg = d->cfg;
-    if (use_v1_conv() || k.in_bytes == 0) {
-        const int tp = k.Cout % 128 == 0 ? 128 : (k.Cout % 64 == 0 ? 64 : 256), wp = k.Cout % 64 == 0 ? 2 : 4;
-        return ceil_div(k.M, tp) * wp;
-    }
-    if (cfg == 0) cfg = pick_cfg(k);
-    if (!conv_cfg_ok(k, msc_dtype_size(d->dtype), cfg)) return -1;
-    return ceil_div(k.M, CONV_CFGS[cfg].tp) * CONV_CFGS[cfg].wp;
+    ConvK probe;
+    return conv_fill(d, &probe) == MSC_OK ? MSC_BN_SLOTS : -1;      // one accumulation slot per XCD, whatever the tile
 }
 
 extern "C" int msc_conv_num_cfgs(void) { return N_CONV_CFG; }

@@ -2,10 +2,10 @@
 // BatchNorm2d training statistics finalisation, BatchNorm2d backward sums, conv-bias gradients.
 //
 // Pattern: column reduce.  A block owns 128 pixels x up to 64 16-byte channel vectors; lanes run along
-// the channel dimension (coalesced 16-B loads), row lanes stride over pixels, LDS folds the row lanes,
-// one partial per (channel, pixel-chunk) is written to a [C][S][K] workspace.  A second kernel gives
-// every channel one wavefront that sums its S partials with coalesced loads (64-lane shuffle reduce)
-// and applies the per-channel formula.  No atomics: results are deterministic run to run.
+// the channel dimension (coalesced 16-B loads), row lanes stride over pixels, LDS folds the row lanes.
+// BatchNorm-backward sums (K = 2) are then added to the per-XCD slot of the layer ([MSC_BN_SLOTS][C][2], common.h), which
+// msc_bn_bwd_apply sums in its prologue; bias gradients (K = 1) write one partial per (channel, pixel chunk) to a [C][S]
+// workspace that a second kernel (one wavefront per channel) adds up.
 #include "common.h"
 #include "msc_internal.h"
 
@@ -18,10 +18,11 @@ constexpr int RED_PIX = 128;       // pixels per block: halved (down to the row-
 template <typename T, int K>
 __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ dout, long dout_ld, const T* __restrict__ out, long out_ld,
                                                         const T* __restrict__ y, long y_ld, int relu, const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, float* __restrict__ partials,
+                                                        const float* __restrict__ shift, void* __restrict__ partials_,
                                                         long pixels, int C, int cols, int S, int ppb, T* __restrict__ dx, long dx_ld) {
     constexpr int CE = Vec16<T>::N;
     __shared__ float red[256 * K * CE];
+    float* partials = reinterpret_cast<float*>(partials_);          // K = 1: [C][S] f32 workspace; K = 2: double slots, below
     const int tid = threadIdx.x;
     const int col = tid % cols, r = tid / cols, R = 256 / cols;
     const int vc = blockIdx.y * cols + col;
@@ -77,12 +78,22 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ do
                 if (K == 2) s2[e] += o[CE + e];
             }
         }
+        if (K == 2) {              // BatchNorm-backward sums: back to LDS as [channel][2] for a coalesced atomic pass below
 #pragma unroll
-        for (int e = 0; e < CE; ++e) {
-            float* dst = partials + ((long)(vc * CE + e) * S + blockIdx.x) * K;
-            dst[0] = s1[e];
-            if (K == 2) dst[1] = s2[e];
+            for (int e = 0; e < CE; ++e) *reinterpret_cast<float2*>(red + (col * CE + e) * 2) = make_float2(s1[e], s2[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) partials[(long)(vc * CE + e) * S + blockIdx.x] = s1[e];
         }
+    }
+    if (K == 2) {
+        // one slot per XCD ([MSC_BN_SLOTS][C][2], common.h); consecutive lanes -> consecutive floats: an atomic costs the L2 per
+        // touched line, so one instruction covers whole lines
+        __syncthreads();
+        const int cbase = blockIdx.y * cols * CE;
+        const int nval = min(cols * CE, C - cbase) * 2;
+        double* slot = reinterpret_cast<double*>(partials_) + ((long)msc_xcc_id() * C + cbase) * 2;      // double: see conv_epilogue (igemm.hip)
+        for (int f = tid; f < nval; f += 256) atomicAdd(slot + f, (double)red[f]);
     }
 }
 
@@ -101,56 +112,6 @@ __device__ __forceinline__ void channel_sums(const float* __restrict__ partials,
     }
     *a = wave_sum_d(s1);
     *b = K == 2 ? wave_sum_d(s2) : 0.0;
-}
-
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int S, int C, double count,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                          float momentum, float* running_mean, float* running_var, float* scale,
-                                                          float* shift, float* save_mean, float* save_invstd) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
-    double s1, s2;
-    channel_sums<2>(partials, S, c, lane, &s1, &s2);
-    if (lane == 0) {
-        const double mean = s1 / count;
-        double var = s2 / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-        const float sc = g * invstd;
-        scale[c] = sc;
-        shift[c] = b - (float)mean * sc;
-        if (save_mean) save_mean[c] = (float)mean;
-        if (save_invstd) save_invstd[c] = invstd;
-        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-        if (running_var) {
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int S, int C, double count,
-                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                              const float* __restrict__ invstd, float* dgamma, float* dbeta, float* coef) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
-    double s1, s2;
-    channel_sums<2>(partials, S, c, lane, &s1, &s2);
-    if (lane == 0) {
-        const double mu = mean[c], is = invstd[c], g = gamma ? gamma[c] : 1.0;
-        const double dbe = s1;                        // sum dh
-        const double dga = is * (s2 - mu * s1);       // sum dh * xhat
-        if (dgamma) dgamma[c] += (float)dga;
-        if (dbeta) dbeta[c] += (float)dbe;
-        // dy = g*is*(dh - dbe/M - xhat*dga/M),  xhat = (y-mu)*is   ->   dy = a*dh + b*y + k0
-        const double a = g * is;
-        const double b = -g * is * is * dga / count;
-        const double k0 = -g * is * dbe / count - b * mu;
-        coef[c] = (float)a; coef[C + c] = (float)b; coef[2 * C + c] = (float)k0;
-    }
 }
 
 __global__ __launch_bounds__(256) void bias_finalize_kernel(const float* __restrict__ partials, int S, int C, float* db) {
@@ -179,7 +140,7 @@ bool red_geom(long pixels, int C, int ce, RedGeom* g) {
 
 template <typename T, int K>
 int launch_colreduce(const void* dout, long dout_ld, const void* out, long out_ld, const void* y, long y_ld, int relu,
-                     const float* scale, const float* shift, float* partials, long pixels, int C, hipStream_t st,
+                     const float* scale, const float* shift, void* partials, long pixels, int C, hipStream_t st,
                      void* dx = nullptr, long dx_ld = 0) {
     RedGeom g;
     if (!red_geom(pixels, C, Vec16<T>::N, &g)) return msc_fail(MSC_ERR_UNSUPPORTED, "column reduce: C=%d not supported", C);
@@ -194,25 +155,11 @@ int launch_colreduce(const void* dout, long dout_ld, const void* out, long out_l
 #define DT_CHECK(name, dtype) \
     if (!msc_dtype_ok(dtype)) return msc_fail(MSC_ERR_ARG, name ": dtype %d", (int)(dtype))
 
-extern "C" int msc_bn_finalize(const float* partials, int slices, int C, int64_t count, const float* gamma, const float* beta,
-                               float eps, float momentum, float* running_mean, float* running_var,
-                               float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
-    if (!partials || !scale || !shift || slices <= 0 || C <= 0 || count <= 0) return msc_fail(MSC_ERR_ARG, "msc_bn_finalize: bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, slices, C, (double)count,
-                       gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
-    return msc_check_launch("msc_bn_finalize");
-}
-
-extern "C" int msc_bn_bwd_blocks(int64_t pixels, int C, int dtype) {
-    RedGeom g;
-    if (pixels <= 0 || !red_geom(pixels, C, msc_dtype_vec(dtype), &g)) return -1;
-    return g.S;
-}
-
 extern "C" int msc_bn_bwd_reduce(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
-                                 int relu, const float* scale, const float* shift, float* partials, int dtype, int64_t pixels, int C,
+                                 int relu, const float* scale, const float* shift, double* slots, int dtype, int64_t pixels, int C,
                                  void* stream) {
     DT_CHECK("msc_bn_bwd_reduce", dtype);
+    void* partials = slots;
     if (!dout || !y || !partials || relu < 0 || relu > 2 || (relu == 1 && !out) || (relu == 2 && (!scale || !shift)) || pixels <= 0)
         return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_reduce: bad argument");
     if (C % (4 * msc_dtype_vec(dtype))) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bn_bwd_reduce: C=%d must be a multiple of %d", C, 4 * msc_dtype_vec(dtype));
@@ -220,14 +167,6 @@ extern "C" int msc_bn_bwd_reduce(const void* dout, int64_t dout_ld, const void* 
     if (dtype == MSC_F16) return launch_colreduce<f16_t, 2>(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, partials, pixels, C, st);
     else if (dtype == MSC_BF16) return launch_colreduce<bf16_t, 2>(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, partials, pixels, C, st);
     return launch_colreduce<float, 2>(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, partials, pixels, C, st);
-}
-
-extern "C" int msc_bn_bwd_finalize(const float* partials, int blocks, int C, int64_t count, const float* gamma,
-                                   const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef, void* stream) {
-    if (!partials || !save_mean || !save_invstd || !coef || blocks <= 0 || C <= 0) return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_finalize: bad argument");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, blocks, C, (double)count,
-                       gamma, save_mean, save_invstd, dgamma, dbeta, coef);
-    return msc_check_launch("msc_bn_bwd_finalize");
 }
 
 extern "C" int64_t msc_bias_grad_workspace_bytes(int64_t pixels, int C, int dtype) {

@@ -639,6 +639,16 @@ class _Builder:
     def act(self, H, W, C):
         return Act(self.buf(H, W, C))
 
+    def slots(self, C_):
+        """device address of a fresh [BN_SLOTS][C][2] f64 block of the statistics arena (zeroed once per step by the first
+        forward launch)"""
+        n = _lib.BN_SLOTS * C_ * 2
+        if self.slot_used + n > self.slot_arena.numel():
+            raise RuntimeError('BatchNorm statistics arena too small')
+        ptr = self.slot_arena.data_ptr() + 8 * self.slot_used
+        self.slot_used += n
+        return ptr
+
     def g(self, param):
         """gradient address of `param`; records which backward launch (the next one emitted) writes it, so the
         data-parallel step knows when a suffix of the flat gradient buffer is final (trainer.ddp_plan)"""
@@ -780,7 +790,7 @@ class _Builder:
                 if want_stats:
                     need = lib.msc_conv_stats_slices(C.byref(d)) * d.Cout * 2
                     if getattr(self, '_tune_stats', None) is None or self._tune_stats.numel() < need:
-                        self._tune_stats = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=self.dev)
+                        self._tune_stats = torch.empty(max(need, 1 << 22), dtype=torch.float64, device=self.dev)
                     d.stats = self._tune_stats.data_ptr()
                 t = self._time(lib.msc_conv_igemm, C.byref(d))
                 if t is not None and t < best_t:
@@ -829,58 +839,47 @@ class _Builder:
             return
         y = self.act(out.H, out.W, cout)
         d = self.conv_desc(x, w, y, want_stats=True, **geo)
-        slices = lib.msc_conv_stats_slices(C.byref(d))
-        if slices <= 0:
-            _lib.check(-1, 'msc_conv_stats_slices')
-        part = self.vec(slices * cout * 2)
-        d.stats = part.data_ptr()
+        # batch statistics: the conv epilogue adds (sum, sum of squares) into one slot per XCD; bn_apply sums the slots in its
+        # prologue (no finalize launch).  The slots of every layer live in one arena zeroed once per step.
+        d.stats = self.slots(cout)
         self.emit(fwd, lib.msc_conv_igemm, C.byref(d))
         mean, invstd = self.vec(cout), self.vec(cout)
         count = self.N * out.H * out.W
-        self.emit(fwd, lib.msc_bn_finalize, part.data_ptr(), slices, cout, count, bn.weight.data_ptr(), bn.bias.data_ptr(),
-                  BN_EPS, BN_MOMENTUM, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-                  scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr())
         self.emit(fwd, lib.msc_bn_apply, y.ptr, y.ld, res.ptr if res is not None else None, res.ld if res is not None else 0,
-                  out.ptr, out.ld, scale.data_ptr(), shift.data_ptr(), int(relu), self.dt, count, cout)
+                  out.ptr, out.ld, d.stats, count, bn.weight.data_ptr(), bn.bias.data_ptr(), BN_EPS, BN_MOMENTUM,
+                  bn.running_mean.data_ptr(), bn.running_var.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                  invstd.data_ptr(), int(relu), self.dt, count, cout)
         self.ops.append(lambda: self._conv_bn_bwd(name, x, conv, bn, geo, relu, out, res, y, mean, invstd, count, stem, scale, shift))
 
     def _conv_bn_bwd(self, name, x, conv, bn, geo, relu, out, res, y, mean, invstd, count, stem, scale, shift):
         net, lib, P, bwd = self.net, self.lib, self.prog, self.prog.bwd
         cout = conv.out_channels
         dout = self.grad_of(out)
-        coef = self.vec(3 * cout)
         # ReLU mask: without a residual the pre-activation is scale*y + shift, recomputed from the y both kernels read
         # anyway (mode 2) instead of reading `out` (mode 1)
         mask = 0 if not relu else (1 if res is not None else 2)
         gkey = (id(out.buf), out.c0, out.C)      # grad_acc() keys gradient slices by their activation
         wd = self.gwriter.get(gkey) if (self.fuse_bn_bwd and mask != 1 and self.gcount.get(gkey, 0) == 1) else None
+        bslots = self.slots(cout)                # (sum dh, sum dh*y) per XCD slot, summed in bn_bwd_apply's prologue
         if wd is not None:
             # dout has exactly one writer, a data-gradient conv that ran earlier in this backward: its epilogue also
-            # reduces (sum dh, sum dh*y) per tile, so the column-reduce pass over dout and y is not launched
+            # accumulates (sum dh, sum dh*y), so the column-reduce pass over dout and y is not launched
             wd.stats_kind, wd.stats_y, wd.stats_y_ld = 1, y.ptr, y.ld
             wd.scale, wd.shift = (scale.data_ptr(), shift.data_ptr()) if mask == 2 else (None, None)
-            wd.stats = 1                     # any non-null value: the slice count depends on it being requested
-            blocks = lib.msc_conv_stats_slices(C.byref(wd))
-            if blocks <= 0:
-                _lib.check(-1, 'msc_conv_stats_slices')
-            part = self.vec(blocks * cout * 2)
-            wd.stats = part.data_ptr()
+            wd.stats = bslots
         else:
-            blocks = lib.msc_bn_bwd_blocks(count, cout, self.dt)
-            part = self.vec(blocks * cout * 2)
-        if wd is None:
             self.emit(bwd, lib.msc_bn_bwd_reduce, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, mask, scale.data_ptr(),
-                      shift.data_ptr(), part.data_ptr(), self.dt, count, cout)
-        self.emit(bwd, lib.msc_bn_bwd_finalize, part.data_ptr(), blocks, cout, count, bn.weight.data_ptr(),
-                  mean.data_ptr(), invstd.data_ptr(), self.g(bn.weight), self.g(bn.bias), coef.data_ptr())
+                      shift.data_ptr(), bslots, self.dt, count, cout)
         dres_ptr, dres_ld, dres_acc = None, 0, 0
         if res is not None:
             gres = self.grad_of(res)
             dres_acc = self.grad_acc(res)
             dres_ptr, dres_ld = gres.ptr, gres.ld
-        # dy overwrites y in place (each element is read, then written, by the same lane)
+        # dy overwrites y in place (each element is read, then written, by the same lane); the prologue also adds dgamma / dbeta
+        gw, gb = self.g(bn.weight), self.g(bn.bias)
         self.emit(bwd, lib.msc_bn_bwd_apply, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, mask, scale.data_ptr(),
-                  shift.data_ptr(), coef.data_ptr(), y.ptr, y.ld, dres_ptr, dres_ld, dres_acc, self.dt, count, cout)
+                  shift.data_ptr(), bslots, count, bn.weight.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gw, gb,
+                  y.ptr, y.ld, dres_ptr, dres_ld, dres_acc, self.dt, count, cout)
         dy = y
         if stem is not None:
             self.wgrad(bwd, dy, x, P.stem_dw.data_ptr(), 7, 1, 2, 0, q_hw=stem, q_ld=4, B=32)
@@ -963,6 +962,11 @@ class _Builder:
         P.probs = torch.empty((N, 2, H, W), dtype=torch.float32, device=self.dev)
         P.dlogits = torch.empty((N, 2, H, W), dtype=torch.float32, device=self.dev) if self.training else None
         P.stem_dw = torch.zeros(64 * 7 * 32, dtype=torch.float32, device=self.dev)
+        if self.training:
+            # forward + backward sums of every BatchNorm layer of the encoder: [BN_SLOTS][C][2] floats each
+            nbn = sum(m.num_features for m in enc.modules() if isinstance(m, nn.BatchNorm2d))
+            self.slot_arena, self.slot_used = self.vec(2 * nbn * _lib.BN_SLOTS * 2, dtype=torch.float64, zero=True), 0
+            self.emit(P.fwd, lib.msc_memset_zero, self.slot_arena.data_ptr(), self.slot_arena.numel() * 8)
 
         # concat buffers: [decoder part | encoder skip]; encoder stages write straight into their slice
         cat2 = self.buf(H // 4, W // 4, nf * 2 + 64 * exp)

@@ -25,6 +25,9 @@ def _rows(ptr, pixels, C_, ld):
     return np.lib.stride_tricks.as_strided(base, shape=(pixels, C_), strides=(ld * 4, 4))
 
 
+SLOTS = 8          # MSC_BN_SLOTS: per-XCD accumulation slots [SLOTS][C][2]; the interpreter uses slot 0
+
+
 def _val(a):
     if hasattr(a, '_obj') and not hasattr(a._obj, 'N'):      # byref(struct) of a plain configuration record (msc_loss_cfg)
         return a._obj
@@ -65,23 +68,16 @@ def conv_igemm(dref):
             x = src[off[:, None] + cidx[None, :]].astype(np.float64)
             acc[ok] += x @ w[:, kh, kw, :].astype(np.float64).T
     if d.stats and d.stats_kind == 1:
-        from mapping_challenge_amd import _lib
-        slices = _lib.load().msc_conv_stats_slices(dref)
-        st = _arr(d.stats, slices * Cout * 2).reshape(Cout, slices, 2)
+        st = _arr(d.stats, SLOTS * Cout * 2, np.float64).reshape(SLOTS, Cout, 2)          # accumulated (caller zeroes): all into slot 0
         yy = _rows(d.stats_y, N * Ho * Wo, Cout, d.stats_y_ld).astype(np.float64)
         dh = acc * (yy * _arr(d.scale, Cout) + _arr(d.shift, Cout) > 0) if d.scale else acc
-        st[...] = 0
-        st[:, 0, 0] = dh.sum(0)
-        st[:, 0, 1] = (dh * yy).sum(0)
+        st[0, :, 0] += dh.sum(0)
+        st[0, :, 1] += (dh * yy).sum(0)
         scale, shift = 1.0, 0.0          # the coefficients only define the mask
     elif d.stats:
-        # everything in slice 0, the other slices the real kernel would fill are zeroed
-        from mapping_challenge_amd import _lib
-        slices = _lib.load().msc_conv_stats_slices(dref)
-        st = _arr(d.stats, slices * Cout * 2).reshape(Cout, slices, 2)
-        st[...] = 0
-        st[:, 0, 0] = acc.sum(0)
-        st[:, 0, 1] = (acc * acc).sum(0)
+        st = _arr(d.stats, SLOTS * Cout * 2, np.float64).reshape(SLOTS, Cout, 2)
+        st[0, :, 0] += acc.sum(0)
+        st[0, :, 1] += (acc * acc).sum(0)
     v = acc * scale + shift
     if res is not None:
         v = v + res
@@ -243,8 +239,12 @@ def maxpool2_bwd(dout, dout_ld, inp, in_ld, din, din_ld, dtype, N, Ho, Wo, Cc, a
     dst[...] = dst + o if accumulate else o
 
 
-def bn_finalize(partials, slices, Cc, count, gamma, beta, eps, momentum, rm, rv, scale, shift, smean, sinv):
-    p = _arr(partials, slices * Cc * 2).reshape(Cc, slices, 2).astype(np.float64).sum(1)
+def memset_zero(ptr, nbytes):
+    np.ctypeslib.as_array((C.c_uint8 * int(nbytes)).from_address(int(ptr)))[...] = 0
+
+
+def _bn_finalize(slots, Cc, count, gamma, beta, eps, momentum, rm, rv, scale, shift, smean, sinv):
+    p = _arr(slots, SLOTS * Cc * 2, np.float64).reshape(SLOTS, Cc, 2).sum(0)
     mean = p[:, 0] / count
     var = np.maximum(p[:, 1] / count - mean * mean, 0)
     inv = 1.0 / np.sqrt(var + eps)
@@ -272,7 +272,9 @@ def bn_fold(gamma, beta, rm, rv, eps, scale, shift, Cc):
     _arr(shift, Cc)[...] = b - _arr(rm, Cc) * sc
 
 
-def bn_apply(y, y_ld, res, res_ld, out, out_ld, scale, shift, relu, dtype, pixels, Cc):
+def bn_apply(y, y_ld, res, res_ld, out, out_ld, slots, count, gamma, beta, eps, momentum, rm, rv, scale, shift, smean, sinv, relu, dtype, pixels, Cc):
+    if slots:
+        _bn_finalize(slots, Cc, count, gamma, beta, eps, momentum, rm, rv, scale, shift, smean, sinv)
     v = _rows(y, pixels, Cc, y_ld) * _arr(scale, Cc) + _arr(shift, Cc)
     if res:
         v = v + _rows(res, pixels, Cc, res_ld)
@@ -287,21 +289,19 @@ def _relu_mask(relu, out, out_ld, y, y_ld, scale, shift, pixels, Cc):
     return _rows(y, pixels, Cc, y_ld) * _arr(scale, Cc) + _arr(shift, Cc) > 0      # relu == 2: recomputed pre-activation
 
 
-def bn_bwd_reduce(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, partials, dtype, pixels, Cc):
+def bn_bwd_reduce(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, slots, dtype, pixels, Cc):
     d = _rows(dout, pixels, Cc, dout_ld).astype(np.float64)
     if relu:
         d = d * _relu_mask(relu, out, out_ld, y, y_ld, scale, shift, pixels, Cc)
     yy = _rows(y, pixels, Cc, y_ld).astype(np.float64)
-    from mapping_challenge_amd import _lib
-    nb = _lib.load().msc_bn_bwd_blocks(pixels, Cc, dtype)
-    p = _arr(partials, nb * Cc * 2).reshape(Cc, nb, 2)
-    p[...] = 0
-    p[:, 0, 0] = d.sum(0)
-    p[:, 0, 1] = (d * yy).sum(0)
+    p = _arr(slots, SLOTS * Cc * 2, np.float64).reshape(SLOTS, Cc, 2)
+    p[0, :, 0] += d.sum(0)
+    p[0, :, 1] += (d * yy).sum(0)
 
 
-def bn_bwd_finalize(partials, blocks, Cc, count, gamma, mean, invstd, dgamma, dbeta, coef):
-    p = _arr(partials, blocks * Cc * 2).reshape(Cc, blocks, 2).astype(np.float64).sum(1)
+def bn_bwd_apply(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, slots, count, gamma, mean, invstd, dgamma, dbeta, dy, dy_ld, dres, dres_ld,
+                 dres_acc, dtype, pixels, Cc):
+    p = _arr(slots, SLOTS * Cc * 2, np.float64).reshape(SLOTS, Cc, 2).sum(0)
     mu, inv = _arr(mean, Cc).astype(np.float64), _arr(invstd, Cc).astype(np.float64)
     g = _arr(gamma, Cc).astype(np.float64) if gamma else 1.0
     dbe = p[:, 0]
@@ -310,22 +310,17 @@ def bn_bwd_finalize(partials, blocks, Cc, count, gamma, mean, invstd, dgamma, db
         _arr(dgamma, Cc)[...] += dga
     if dbeta:
         _arr(dbeta, Cc)[...] += dbe
-    cf = _arr(coef, 3 * Cc).reshape(3, Cc)
-    a = g * inv
-    b = -g * inv * inv * dga / count
-    cf[0], cf[1], cf[2] = a, b, -g * inv * dbe / count - b * mu
-
-
-def bn_bwd_apply(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, coef, dy, dy_ld, dres, dres_ld, dres_acc, dtype, pixels, Cc):
+    ca = g * inv
+    cb = -g * inv * inv * dga / count
+    ck = -g * inv * dbe / count - cb * mu
     d = _rows(dout, pixels, Cc, dout_ld).copy()
     if relu:
         d = d * _relu_mask(relu, out, out_ld, y, y_ld, scale, shift, pixels, Cc)
-    cf = _arr(coef, 3 * Cc).reshape(3, Cc)
     yy = _rows(y, pixels, Cc, y_ld).copy()
     if dres:
         r = _rows(dres, pixels, Cc, dres_ld)
         r[...] = r + d if dres_acc else d
-    _rows(dy, pixels, Cc, dy_ld)[...] = cf[0] * d + cf[1] * yy + cf[2]
+    _rows(dy, pixels, Cc, dy_ld)[...] = ca * d + cb * yy + ck
 
 
 def relu_bwd(dy, dy_ld, y, y_ld, dx, dx_ld, accumulate, dtype, pixels, Cc):
@@ -372,8 +367,8 @@ def conv_stats_slices(dref):
 TABLE = {'msc_conv_igemm': conv_igemm, 'msc_conv_wgrad': conv_wgrad, 'msc_pack_cast': pack_cast,
          'msc_pack_transpose': pack_transpose, 'msc_pack_multi': pack_multi, 'msc_stem_pack': stem_pack, 'msc_stem_unpack_grad': stem_unpack_grad,
          'msc_stem_prepare': stem_prepare, 'msc_maxpool2_fwd': maxpool2_fwd, 'msc_maxpool2_bwd': maxpool2_bwd,
-         'msc_bn_finalize': bn_finalize, 'msc_bn_fold': bn_fold, 'msc_bn_apply': bn_apply,
-         'msc_bn_bwd_reduce': bn_bwd_reduce, 'msc_bn_bwd_finalize': bn_bwd_finalize, 'msc_bn_bwd_apply': bn_bwd_apply,
+         'msc_memset_zero': memset_zero, 'msc_bn_fold': bn_fold, 'msc_bn_apply': bn_apply,
+         'msc_bn_bwd_reduce': bn_bwd_reduce, 'msc_bn_bwd_apply': bn_bwd_apply,
          'msc_loss_sums': loss_sums, 'msc_loss_grad': loss_grad, 'msc_adam_tick': adam_tick, 'msc_adam_step': adam_step,
          'msc_grad_reduce': grad_reduce, 'msc_grad_unpack': grad_unpack,
          'msc_relu_bwd': relu_bwd, 'msc_bias_grad': bias_grad, 'msc_relu_bias_grad': relu_bias_grad, 'msc_final_fwd': final_fwd, 'msc_final_bwd': final_bwd}

@@ -63,12 +63,12 @@ def test_conv_channel_slices_and_stats(dtype):
     obuf = torch.full((n, hw, hw, 160), 7.0, dtype=dtype, device='cuda')
     xin, out = xbuf[..., 64:128], obuf[..., 32:96]
     slices = ops.conv_stats_slices(xin, w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda(), out, 1, 1)
-    stats = torch.zeros((cout, slices, 2), dtype=torch.float32, device='cuda')      # layout [Cout][slices][2]
+    stats = torch.zeros((slices, cout, 2), dtype=torch.float64, device='cuda')      # layout [XCD slot][Cout][2], accumulated
     ops.conv_igemm(xin, w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda(), out, stride=1, pad=1, stats=stats)
     ref = F.conv2d(x, w, padding=1)
     assert torch.allclose(to_nchw(out), ref, **tol(dtype))
     assert (obuf[..., :32] == 7).all() and (obuf[..., 96:] == 7).all()          # neighbours untouched
-    s = stats.sum(1).cpu()
+    s = stats.sum(0).float().cpu()
     assert torch.allclose(s[:, 0], ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
     assert torch.allclose(s[:, 1], (ref * ref).sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
 
@@ -228,10 +228,10 @@ def test_every_kernel_configuration_is_correct(dtype, cin, cout, k, stride, hw, 
     for c in cfgs:
         out.zero_()
         slices = ops.conv_stats_slices(xd, wk, out, stride, pad, cfg=c)
-        stats = torch.zeros((cout, slices, 2), dtype=torch.float32, device='cuda')
+        stats = torch.zeros((slices, cout, 2), dtype=torch.float64, device='cuda')
         ops.conv_igemm(xd, wk, out, stride=stride, pad=pad, stats=stats, cfg=c)
         assert torch.allclose(to_nchw(out), ref, **tol(dtype)), c
-        assert torch.allclose(stats.sum(1)[:, 0].cpu(), ref.sum((0, 2, 3)), rtol=2e-3, atol=5e-2), c
+        assert torch.allclose(stats.sum(0)[:, 0].float().cpu(), ref.sum((0, 2, 3)), rtol=2e-3, atol=5e-2), c
     if stride == 1 and k == 3:      # transposed mode with the same operands: ConvTranspose2d(k3,s2,p1,output_padding=1)
         wt = rnd((cin, cout, 4, 4), dtype, 3, 0.05)
         reft = F.conv_transpose2d(x, wt, stride=2, padding=1)
@@ -308,12 +308,12 @@ def test_conv_epilogue_batchnorm_backward_sums(dtype, cin, cout, k, hw, n, maske
             d.scale, d.shift = sc.data_ptr(), sh.data_ptr()
         d.stats = 1
         slices = lib.msc_conv_stats_slices(C.byref(d))
-        stats = torch.zeros((cout, slices, 2), dtype=torch.float32, device='cuda')
+        stats = torch.zeros((slices, cout, 2), dtype=torch.float64, device='cuda')
         d.stats = stats.data_ptr()
         out.zero_()
         _lib.check(lib.msc_conv_igemm(C.byref(d), torch.cuda.current_stream().cuda_stream), 'conv')
         assert torch.allclose(to_nchw(out), ref, **tol(dtype)), c          # the coefficients do not touch the output
-        s = stats.sum(1).cpu()
+        s = stats.sum(0).float().cpu()
         t = dict(rtol=2e-3, atol=5e-2) if dtype == torch.float32 else dict(rtol=2e-2, atol=0.5)
         assert torch.allclose(s[:, 0], e1, **t) and torch.allclose(s[:, 1], e2, **t), c
 
@@ -372,3 +372,69 @@ def test_halo_tile_kernel_for_the_128_to_32_transposed_conv(hw, n, relu, with_re
     assert cfg in ops.conv_valid_cfgs(xd, wk, out, 2, 1, mode=1)
     ops.conv_igemm(xd, wk, out, stride=2, pad=1, mode=1, relu=relu, shift=bias.cuda(), res=out if with_res else None, cfg=cfg)
     assert torch.allclose(to_nchw(out), ref, **tol(dtype))
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('c,hw,n,relu,with_res', [(64, 12, 3, True, False), (256, 8, 4, True, True), (128, 10, 2, False, False), (1024, 4, 8, True, True)])
+def test_batchnorm_training_forward_and_backward_with_prologue_finalize(dtype, c, hw, n, relu, with_res):
+    """BatchNorm2d (+residual)(+ReLU) in training mode and its backward against torch autograd: statistics accumulated per XCD
+    slot (here by msc_bn_bwd_reduce and, for the forward sums, scattered by hand over the slots) and finalised in the
+    prologues of msc_bn_apply / msc_bn_bwd_apply; running statistics, dgamma, dbeta, the residual gradient"""
+    from mapping_challenge_amd import _lib
+    lib = _lib.load()
+    dt = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}[dtype]
+    st = torch.cuda.current_stream().cuda_stream
+    y = rnd((n, c, hw, hw), dtype, 1, 1.5) + 0.3
+    y = y.to(dtype).float()
+    res = rnd((n, c, hw, hw), dtype, 2) if with_res else None
+    gamma, beta = torch.rand(c) + 0.5, torch.randn(c) * 0.2
+    bn = torch.nn.BatchNorm2d(c)
+    bn.weight.data, bn.bias.data = gamma.clone(), beta.clone()
+    bn.train()
+    yr = y.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if with_res else None
+    z = bn(yr) + (rr if with_res else 0)
+    o = torch.relu(z) if relu else z
+    dout = rnd(tuple(o.shape), dtype, 3)
+    o.backward(dout)
+    # device side
+    pixels = n * hw * hw
+    yd, outd = nhwc(y, dtype), torch.empty((n, hw, hw, c), dtype=dtype, device='cuda')
+    resd = nhwc(res, dtype) if with_res else None
+    flat = y.permute(0, 2, 3, 1).reshape(-1, c).double()
+    slots = torch.zeros((_lib.BN_SLOTS, c, 2), dtype=torch.float64, device='cuda')
+    # the forward sums as the conv epilogue leaves them: spread over the slots (here: pixel p into slot p % 8)
+    for x_ in range(_lib.BN_SLOTS):
+        part = flat[x_::_lib.BN_SLOTS]
+        slots[x_, :, 0] = part.sum(0).cuda()
+        slots[x_, :, 1] = (part * part).sum(0).cuda()
+    g_d, b_d = gamma.cuda(), beta.cuda()
+    rm, rv = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+    scale, shift, mean, invstd = (torch.empty(c, device='cuda') for _ in range(4))
+    _lib.check(lib.msc_bn_apply(yd.data_ptr(), c, resd.data_ptr() if with_res else None, c if with_res else 0, outd.data_ptr(), c, slots.data_ptr(),
+                                pixels, g_d.data_ptr(), b_d.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                mean.data_ptr(), invstd.data_ptr(), int(relu), dt, pixels, c, st), 'msc_bn_apply')
+    assert torch.allclose(to_nchw(outd), o.detach(), **tol(dtype))
+    assert torch.allclose(rm.cpu(), bn.running_mean, atol=1e-5) and torch.allclose(rv.cpu(), bn.running_var, rtol=1e-5, atol=1e-6)
+    # backward: reduce -> apply; mask from `out` (relu 1) with a residual, recomputed from y (relu 2) without
+    mask = 0 if not relu else (1 if with_res else 2)
+    doutd = nhwc(dout, dtype)
+    bslots = torch.zeros((_lib.BN_SLOTS, c, 2), dtype=torch.float64, device='cuda')
+    _lib.check(lib.msc_bn_bwd_reduce(doutd.data_ptr(), c, outd.data_ptr(), c, yd.data_ptr(), c, mask, scale.data_ptr(), shift.data_ptr(), bslots.data_ptr(),
+                                     dt, pixels, c, st), 'msc_bn_bwd_reduce')
+    dgamma, dbeta = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda')
+    dyd = torch.empty_like(yd)
+    dresd = torch.empty_like(yd) if with_res else None
+    _lib.check(lib.msc_bn_bwd_apply(doutd.data_ptr(), c, outd.data_ptr(), c, yd.data_ptr(), c, mask, scale.data_ptr(), shift.data_ptr(), bslots.data_ptr(),
+                                    pixels, g_d.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dyd.data_ptr(), c,
+                                    dresd.data_ptr() if with_res else None, c if with_res else 0, 0, dt, pixels, c, st), 'msc_bn_bwd_apply')
+    t = tol(dtype)
+    # the stored `out` is rounded to the dtype: a 16-bit out of exactly 0 vs a tiny positive reference value may flip a mask
+    # element; gradients are compared with that allowance (a handful of elements) in the 16-bit modes
+    bad = (~torch.isclose(to_nchw(dyd), yr.grad, **t)).float().mean().item()
+    assert bad <= (0.0 if dtype == torch.float32 else 2e-3), bad
+    scale_g = max(1.0, bn.weight.grad.abs().max().item())
+    assert (dgamma.cpu() - bn.weight.grad).abs().max().item() < (2e-4 if dtype == torch.float32 else 5e-2) * scale_g
+    assert (dbeta.cpu() - bn.bias.grad).abs().max().item() < (2e-4 if dtype == torch.float32 else 5e-2) * max(1.0, bn.bias.grad.abs().max().item())
+    if with_res:
+        assert (~torch.isclose(to_nchw(dresd), rr.grad, **t)).float().mean().item() <= (0.0 if dtype == torch.float32 else 2e-3)
