@@ -140,7 +140,10 @@ int msc_maxpool2_bwd(const void* dout, int64_t dout_ld, const void* in, int64_t 
  *         out = act(y*scale + shift (+ res)); also writes scale / shift / save_mean / save_invstd and updates the running
  *         statistics (unbiased variance).  slots == NULL: scale / shift are inputs (no statistics involved). */
 #define MSC_BN_SLOTS 8
+/* stream-ordered fill / device-to-device copy: with these the whole training step is a list of C-ABI launches (capturable
+ * as hipGraph nodes, interpretable on the host by the tests) */
 int msc_memset_zero(void* ptr, int64_t bytes, void* stream);
+int msc_copy(void* dst, const void* src, int64_t bytes, void* stream);
 int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_t res_ld, void* out, int64_t out_ld,
                  const double* slots, int64_t count, const float* gamma, const float* beta, float eps, float momentum,
                  float* running_mean, float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,

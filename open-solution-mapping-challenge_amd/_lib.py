@@ -72,6 +72,7 @@ SIGNATURES = {
     'msc_maxpool2_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
     'msc_bn_fold': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
     'msc_memset_zero': (_i, [_vp, _i64, _vp]),
+    'msc_copy': (_i, [_vp, _vp, _i64, _vp]),
     'msc_bn_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp]),
     'msc_bn_bwd_reduce': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i, _i64, _i, _vp]),
     'msc_bn_bwd_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i64, _i, _vp]),

@@ -732,6 +732,13 @@ extern "C" int msc_bn_bwd_apply(const void* dout, int64_t dout_ld, const void* o
     return msc_check_launch("msc_bn_bwd_apply");
 }
 
+extern "C" int msc_copy(void* dst, const void* src, int64_t bytes, void* stream) {
+    if (!dst || !src || bytes < 0) return msc_fail(MSC_ERR_ARG, "msc_copy: bad argument");
+    if (bytes && hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+        return msc_fail(MSC_ERR_HIP, "msc_copy: copy failed");
+    return MSC_OK;
+}
+
 extern "C" int msc_memset_zero(void* ptr, int64_t bytes, void* stream) {
     if (!ptr || bytes < 0) return msc_fail(MSC_ERR_ARG, "msc_memset_zero: bad argument");
     if (bytes && hipMemsetAsync(ptr, 0, (size_t)bytes, (hipStream_t)stream) != hipSuccess) return msc_fail(MSC_ERR_HIP, "msc_memset_zero: memset failed");

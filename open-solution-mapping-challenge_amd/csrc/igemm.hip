@@ -56,6 +56,7 @@ struct ConvK {
     int ntc;                         // channel tiles (DMA kernel: 1-D grid of ntm*ntc blocks, XCD-aware order)
     int mode;                        // 0 gather, 1 transposed
     int xcd_order;                   // 1: XCD-aware tile order, 0: pixel tile fastest (for A/B measurements)
+    float rcp_hw, rcp_w;             // 1/(Hq*Wq), 1/Wq for the pixel decode of the DMA kernel; 0 = pixel count >= 2^24: integer division
 };
 
 template <typename T> struct Mma;
@@ -77,6 +78,15 @@ template <> struct Mma<float> {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
     }
 };
+
+// floor(m / d) through the float reciprocal, exact for m < 2^24 (one correction step either way)
+__device__ __forceinline__ unsigned udiv_rcp(unsigned m, unsigned d, float rcp) {
+    unsigned q = (unsigned)((float)m * rcp);
+    int r = (int)(m - q * d);
+    if (r < 0) { --q; r += (int)d; }
+    if (r >= (int)d) ++q;
+    return q;
+}
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr unsigned OOB_OFF = 0x80000000u;   // >= any buffer extent we accept: the load returns zeros
@@ -462,9 +472,17 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
         const int m = m0 + row;
         xv[i] = m < p.M;
         const int mm = xv[i] ? m : 0;
-        const int n = mm / (p.Hq * p.Wq);
-        const int rem = mm - n * (p.Hq * p.Wq);
-        const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+        // two divisions per row and DMA instruction: a microsecond of integer-division VALU code at the head of a 10-20 us
+        // kernel unless they go through the float reciprocal
+        int n, qy;
+        if (p.rcp_hw != 0.f) {
+            n = (int)udiv_rcp((unsigned)mm, (unsigned)(p.Hq * p.Wq), p.rcp_hw);
+            qy = (int)udiv_rcp((unsigned)(mm - n * (p.Hq * p.Wq)), (unsigned)p.Wq, p.rcp_w);
+        } else {
+            n = mm / (p.Hq * p.Wq);
+            qy = (mm - n * (p.Hq * p.Wq)) / p.Wq;
+        }
+        const int qx = mm - n * (p.Hq * p.Wq) - qy * p.Wq;
         xn[i] = n * p.Hi;
         xby[i] = MODE ? qy : qy * p.stride;
         xbx[i] = MODE ? qx : qx * p.stride;
@@ -985,13 +1003,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgK p) {
 //   bf16: unit pair (32 B = the 16 channels one lane group reads) index ^= (r&3) | ((r>>3)&1)<<2
 //   f32 : 64-byte granule index ^= (r>>2)&1
 // applied on the DMA source side and on the read side alike.
-__device__ __forceinline__ unsigned udiv_rcp(unsigned m, unsigned d, float rcp) {
-    unsigned q = (unsigned)((float)m * rcp);
-    int r = (int)(m - q * d);
-    if (r < 0) { --q; r += (int)d; }
-    if (r >= (int)d) ++q;
-    return q;
-}
 
 template <typename T> __device__ __forceinline__ int wg_swz(int unit, int row, int upr) {
     if (sizeof(T) == 2) {
@@ -1474,6 +1485,8 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
     const long m = (long)d->N * k->Hq * k->Wq;
     if (m <= 0 || m > 0x7fffffffL) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: bad pixel count %ld", m);
     k->M = (int)m;
+    k->rcp_hw = m < (1L << 24) ? 1.0f / (float)(k->Hq * k->Wq) : 0.f;
+    k->rcp_w = 1.0f / (float)k->Wq;
     // extents for the DMA kernel's buffer descriptors; 0 = too large for 31-bit offsets -> v1 kernel
     const long in_b = (((long)d->N * d->Hi * d->Wi - 1) * d->in_ld + d->Cin) * es;
     const long wt_b = (long)d->Cout * d->KH * d->KW * d->Cin * es;

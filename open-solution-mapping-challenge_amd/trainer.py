@@ -53,6 +53,19 @@ def _run(fn, args, device):
     _Program.run([(fn, args)], _stream_of(device))
 
 
+def _zero(t, stream):
+    """stream-ordered zero fill of a tensor as a C-ABI launch (a memset node under capture)"""
+    from .unet_models import _Program
+    _Program.run([(_lib.load().msc_memset_zero, (t.data_ptr(), t.numel() * t.element_size()))], stream)
+
+
+def _copy(dst, src, stream):
+    """stream-ordered same-device copy of equally shaped contiguous tensors as a C-ABI launch"""
+    from .unet_models import _Program
+    assert dst.numel() == src.numel() and dst.dtype == src.dtype and dst.is_contiguous() and src.is_contiguous()
+    _Program.run([(_lib.load().msc_copy, (dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size()))], stream)
+
+
 def loss_sums(logits, target, spec, sums):
     """phase 1 of the fused loss: the four f64 sums of this rank's batch"""
     import ctypes as C
@@ -301,14 +314,16 @@ class TrainStep:
             # the first step of a shape runs eagerly (builds the program, allocates, packs) and IS this call's step;
             # capturing afterwards does not execute anything, replays start with the next call of this shape
             self._body()
-            torch.cuda.synchronize()
+            if st.x.is_cuda:
+                torch.cuda.synchronize()
             if self.dist:
                 try:
                     self._capture_pieces()
                 except RuntimeError as e:          # capture next to a live communicator is the fragile part: keep training
                     import warnings
                     warnings.warn('hipGraph capture of the distributed step failed (%s); continuing with eager launches' % e)
-                    torch.cuda.synchronize()
+                    if st.x.is_cuda:
+                        torch.cuda.synchronize()
                     st.pieces, self.use_graph = None, False
             else:
                 g = torch.cuda.CUDAGraph()
@@ -337,16 +352,19 @@ class TrainStep:
         if getattr(prog, '_ddp_plan', None) is None:
             prog._ddp_plan = ddp_plan(prog, flat_g)
 
+        from .unet_models import _stream_of
+
         def capture(fn):
-            # thread_local: the RCCL watchdog thread of torch.distributed may poll events while we capture
+            # thread_local: the RCCL watchdog thread of torch.distributed may poll events while we capture.  Everything a
+            # piece does is a C-ABI launch (kernels, memset and copy nodes): nothing runs at capture time
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                fn(torch.cuda.current_stream(dev).cuda_stream)
+                fn(_stream_of(dev))
             return g
 
         def forward(stream):
             _Program.run(net._pack['ops'], stream)
-            prog.x_in.copy_(st.x)
+            _copy(prog.x_in, st.x, stream)
             _Program.run(prog.fwd, stream)
             loss_sums(prog.logits, st.t, self.spec, self.sums)
 
@@ -354,8 +372,8 @@ class TrainStep:
             def fn(stream):
                 if first:
                     loss_grad(prog.logits, st.t, self.spec, prog.dlogits, self.loss, self.sums, total, self.loss_scale)
-                    flat_g.zero_()
-                    prog.stem_dw.zero_()
+                    _zero(flat_g, stream)
+                    _zero(prog.stem_dw, stream)
                 _Program.run_backward(prog.bwd[beg:end], dev)
             return fn
 
@@ -386,15 +404,15 @@ class TrainStep:
     def _body_captured(self):
         # same as _body, but the weight repack after Adam is part of the graph so replays stay consistent
         net, st = self.net, self.cur
-        stream = torch.cuda.current_stream(st.x.device).cuda_stream
-        from .unet_models import _Program
+        from .unet_models import _Program, _stream_of
+        stream = _stream_of(st.x.device)
         _Program.run(net._pack['ops'], stream)
         prog = st.prog
-        prog.x_in.copy_(st.x)
+        _copy(prog.x_in, st.x, stream)
         _Program.run(prog.fwd, stream)
         loss_forward_backward(prog.logits, st.t, self.spec, prog.dlogits, self.loss, self.sums, None, self.loss_scale)
-        net._flat[1].zero_()
-        prog.stem_dw.zero_()
+        _zero(net._flat[1], stream)
+        _zero(prog.stem_dw, stream)
         _Program.run_backward(prog.bwd, st.x.device)
         _Program.run(self.opt.launches(1.0 / self.loss_scale), stream)
         net._packed_version = -1      # host bookkeeping: packed copies refreshed at the head of every replay

@@ -243,6 +243,10 @@ def memset_zero(ptr, nbytes):
     np.ctypeslib.as_array((C.c_uint8 * int(nbytes)).from_address(int(ptr)))[...] = 0
 
 
+def copy(dst, src, nbytes):
+    C.memmove(int(dst), int(src), int(nbytes))
+
+
 def _bn_finalize(slots, Cc, count, gamma, beta, eps, momentum, rm, rv, scale, shift, smean, sinv):
     p = _arr(slots, SLOTS * Cc * 2, np.float64).reshape(SLOTS, Cc, 2).sum(0)
     mean = p[:, 0] / count
@@ -367,7 +371,7 @@ def conv_stats_slices(dref):
 TABLE = {'msc_conv_igemm': conv_igemm, 'msc_conv_wgrad': conv_wgrad, 'msc_pack_cast': pack_cast,
          'msc_pack_transpose': pack_transpose, 'msc_pack_multi': pack_multi, 'msc_stem_pack': stem_pack, 'msc_stem_unpack_grad': stem_unpack_grad,
          'msc_stem_prepare': stem_prepare, 'msc_maxpool2_fwd': maxpool2_fwd, 'msc_maxpool2_bwd': maxpool2_bwd,
-         'msc_memset_zero': memset_zero, 'msc_bn_fold': bn_fold, 'msc_bn_apply': bn_apply,
+         'msc_memset_zero': memset_zero, 'msc_copy': copy, 'msc_bn_fold': bn_fold, 'msc_bn_apply': bn_apply,
          'msc_bn_bwd_reduce': bn_bwd_reduce, 'msc_bn_bwd_apply': bn_bwd_apply,
          'msc_loss_sums': loss_sums, 'msc_loss_grad': loss_grad, 'msc_adam_tick': adam_tick, 'msc_adam_step': adam_step,
          'msc_grad_reduce': grad_reduce, 'msc_grad_unpack': grad_unpack,
