@@ -46,6 +46,10 @@ int msc_abi_version(void);
  *   is the gradient w.r.t. a BatchNorm+ReLU layer's activation, stats_y that layer's pre-BN tensor (same shape as
  *   out), scale/shift its forward coefficients (used for the ReLU mask only, NULL = no ReLU; no affine is applied):
  *   stats[slot][c] += (sum dh, sum dh*y), dh = acc*[scale*y+shift > 0].  Same layout, consumed by msc_bn_bwd_apply.
+ *   stats_kind 2 (data-gradient convs; no scale/shift/res/relu): the output is the gradient w.r.t. the activation of a
+ *   bias+ReLU layer (ConvRelu, ConvTranspose2d+ReLU: src/unet_models.py:25-34,138-140), stats_y that activation: the
+ *   launch STORES out = acc*[stats_y > 0] (the ReLU backward) and adds stats[slot][c][0] += sum_p out[p][c] (the layer's
+ *   bias gradient, folded into db by msc_bias_slots_finalize) -- what a separate msc_relu_bias_grad pass would do.
  * weights: dtype [Cout][KH][KW][Cin].  Cin*sizeof(dtype) % 64 == 0, Cout % 32 == 0. */
 typedef struct msc_conv_desc {
     const void* in;
@@ -174,15 +178,20 @@ int msc_bias_grad(const void* dy, int64_t dy_ld, float* db, void* workspace, int
 int msc_relu_bias_grad(const void* dy, int64_t dy_ld, const void* y, int64_t y_ld, void* dx, int64_t dx_ld, float* db,
                        void* workspace, int dtype, int64_t pixels, int C, void* stream);
 
+/* bias gradient out of the slots a stats_kind-2 conv filled ([MSC_BN_SLOTS][Cs][2] doubles): db[c] += sum_slots [.][c][0], c < C <= Cs */
+int msc_bias_slots_finalize(const double* slots, int Cs, float* db, int C, void* stream);
+
 /* final 1x1 conv 32 -> 2 with bias (src/unet_models.py:383,403; dropout p = 0) fused with the channel softmax
  * the reference applies on the host afterwards (src/models.py:88-92, src/utils.py:231-273).
  * in: NHWC dtype [pixels][C]; w f32 [2][C]; logits / probs: f32 NCHW [N,2,H,W] (either may be NULL). */
 int msc_final_fwd(const void* in, int64_t in_ld, const float* w, const float* b, float* logits, float* probs,
                   int dtype, int N, int H, int W, int C, void* stream);
 /* backward: dlogits f32 NCHW -> din[p][c] = sum_k dlogits[k][p]*w[k][c] (masked by in>0: the ReLU of dec0),
- * dw[k][c] += sum_p dlogits[k][p]*in[p][c], db[k] += sum_p dlogits[k][p] */
+ * dw[k][c] += sum_p dlogits[k][p]*in[p][c], db[k] += sum_p dlogits[k][p];
+ * dbias_in (f32[C], may be NULL): dbias_in[c] += sum_p din[p][c] -- the bias gradient of the layer that produced `in`
+ * (dec0's conv bias), so no separate msc_bias_grad pass reads din back.  C*sizeof(dtype) must be a multiple of 16, C <= 64. */
 int msc_final_bwd(const float* dlogits, const void* in, int64_t in_ld, const float* w, void* din, int64_t din_ld,
-                  float* dw, float* db, int dtype, int N, int H, int W, int C, void* stream);
+                  float* dw, float* db, float* dbias_in, int dtype, int N, int H, int W, int C, void* stream);
 
 /* ---------------------------------------------------------------- losses / optimizer ----------
  * mixed distance-weighted cross entropy + soft Dice (src/models.py:310-454, validation.py:8-16) or plain CE

@@ -81,7 +81,8 @@ SIGNATURES = {
     'msc_bias_grad': (_i, [_vp, _i64, _vp, _vp, _i, _i64, _i, _vp]),
     'msc_relu_bias_grad': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i64, _i, _vp]),
     'msc_final_fwd': (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    'msc_final_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'msc_bias_slots_finalize': (_i, [_vp, _i, _vp, _i, _vp]),
+    'msc_final_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'msc_loss_sums': (_i, [_vp, _vp, _i, C.POINTER(LossCfg), _vp, _i, _i, _i, _vp]),
     'msc_loss_grad': (_i, [_vp, _vp, _i, C.POINTER(LossCfg), _vp, _d, _f, _vp, _vp, _i, _i, _i, _vp]),
     'msc_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),

@@ -93,6 +93,9 @@ template <> struct Vec16<float> {
     static __device__ __forceinline__ void unpack(uint4 t, float* v) {      // a raw 16-byte load, converted later
         v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
     }
+    static __device__ __forceinline__ uint4 pack(const float* v) {
+        return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+    }
     static __device__ __forceinline__ void store(float* p, const float* v) {
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -108,12 +111,13 @@ template <> struct Vec16<bf16_t> {
         }
     }
     static __device__ __forceinline__ void load(const bf16_t* p, float* v) { unpack(*reinterpret_cast<const uint4*>(p), v); }
-    static __device__ __forceinline__ void store(bf16_t* p, const float* v) {
+    static __device__ __forceinline__ uint4 pack(const float* v) {
         uint4 t;
         t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]);
         t.z = pack_bf16x2(v[4], v[5]); t.w = pack_bf16x2(v[6], v[7]);
-        *reinterpret_cast<uint4*>(p) = t;
+        return t;
     }
+    static __device__ __forceinline__ void store(bf16_t* p, const float* v) { *reinterpret_cast<uint4*>(p) = pack(v); }
 };
 
 template <> struct Vec16<f16_t> {
@@ -128,12 +132,13 @@ template <> struct Vec16<f16_t> {
         }
     }
     static __device__ __forceinline__ void load(const f16_t* p, float* v) { unpack(*reinterpret_cast<const uint4*>(p), v); }
-    static __device__ __forceinline__ void store(f16_t* p, const float* v) {
+    static __device__ __forceinline__ uint4 pack(const float* v) {
         uint4 t;
         t.x = pack_f16x2(v[0], v[1]); t.y = pack_f16x2(v[2], v[3]);
         t.z = pack_f16x2(v[4], v[5]); t.w = pack_f16x2(v[6], v[7]);
-        *reinterpret_cast<uint4*>(p) = t;
+        return t;
     }
+    static __device__ __forceinline__ void store(f16_t* p, const float* v) { *reinterpret_cast<uint4*>(p) = pack(v); }
 };
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -48,7 +48,8 @@ namespace {
 struct ConvK {
     const char* in; const char* wt; char* out; const char* res;
     const float* scale; const float* shift; double* stats;
-    const char* sy; long sy_ld; int stats_kind;     // stats_kind 1: BatchNorm-backward sums against the tensor sy
+    const char* sy; long sy_ld; int stats_kind;     // stats_kind 1: BatchNorm-backward sums against the tensor sy;
+                                                    // 2: ReLU backward (mask [sy > 0] applied to the output) + bias-gradient sums
     long in_ld, out_ld, res_ld;
     int N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, flip, relu;
     int M, Hq, Wq;
@@ -126,7 +127,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
     constexpr int CE = 16 / (int)sizeof(T);
     // stats_kind 1 (a data-gradient conv that also produces the BatchNorm-backward sums of the layer whose output
     // gradient it writes): scale/shift are that layer's forward coefficients, used for the ReLU mask only
+    // stats_kind 2 (a data-gradient conv whose output is the gradient w.r.t. a bias+ReLU layer's activation sy): the stored
+    // value is dh = acc * [sy > 0] and the sums are (sum dh, -) = that layer's bias gradient -- the separate
+    // ReLU-backward / bias-gradient pass over the tensor (msc_relu_bias_grad) is not launched
     const bool bnb = p.stats && p.stats_kind == 1;
+    const bool rlb = p.stats && p.stats_kind == 2;
     float sc[NV], sh[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -141,8 +146,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
     // the tensor the epilogue reads (residual / BatchNorm-backward y) is fetched for all fragments before the first use --
     // nothing else is left to hide its latency behind -- where the wave tile is small enough to afford the registers
     constexpr bool PRE = FN * (NV / CE) <= 2;
-    const T* side = bnb ? reinterpret_cast<const T*>(p.sy) : res;
-    const long side_ld = bnb ? p.sy_ld : p.res_ld;
+    const T* side = (bnb || rlb) ? reinterpret_cast<const T*>(p.sy) : res;
+    const long side_ld = (bnb || rlb) ? p.sy_ld : p.res_ld;
     uint4 pre[PRE ? FN : 1][PRE ? NV / CE : 1];
     if (PRE && side) {
 #pragma unroll
@@ -169,9 +174,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
         for (int a = 0; a < FM; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][b][r];
-        if (p.stats && !bnb) {
+        if (p.stats && !bnb && !rlb) {
 #pragma unroll
             for (int j = 0; j < NV; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+        }
+        if (rlb && m < p.M) {          // dh = acc * [sy > 0], stored below; sum dh
+#pragma unroll
+            for (int j = 0; j < NV; j += CE) {
+                float yv[CE];
+                if (PRE) Vec16<T>::unpack(pre[PRE ? b : 0][PRE ? j / CE : 0], yv);
+                else Vec16<T>::load(side + (long)m * side_ld + cb + j, yv);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) {
+                    v[j + e] = yv[e] > 0.f ? v[j + e] : 0.f;
+                    s1[j + e] += v[j + e];
+                }
+            }
         }
         if (bnb && m < p.M) {          // (sum dh, sum dh*y), dh = dout * [scale*y + shift > 0] (no mask without scale)
 #pragma unroll
@@ -195,7 +213,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
                 const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
                 opix = ((long)n * p.Ho + 2 * qy + py) * p.Wo + 2 * qx + px;
             }
-            if (!bnb) {
+            if (!bnb && !rlb) {
 #pragma unroll
                 for (int j = 0; j < NV; ++j) v[j] = v[j] * sc[j] + sh[j];
             }
@@ -244,6 +262,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
         double* slot = p.stats + ((long)msc_xcc_id() * p.Cout + c0) * 2;
         for (int f = threadIdx.x; f < TC * 2; f += WP * WC * 64) {
             const int ch = f >> 1, k = f & 1;
+            if (rlb && k) continue;                  // only the first sum exists
             const int wcs = ch / WTC, chw = ch - wcs * WTC;
             float a = 0.f;
 #pragma unroll
@@ -691,9 +710,10 @@ __global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
     T* out = reinterpret_cast<T*>(p.out);
     const T* res = reinterpret_cast<const T*>(p.res);
     const int c0 = 8 * g;
-    float sc[8], sh[8];
+    const bool rlb = p.stats && p.stats_kind == 2;
+    float sc[8], sh[8], bs[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sc[j] = p.scale ? p.scale[c0 + j] : 1.f; sh[j] = p.shift ? p.shift[c0 + j] : 0.f; }
+    for (int j = 0; j < 8; ++j) { sc[j] = p.scale ? p.scale[c0 + j] : 1.f; sh[j] = p.shift ? p.shift[c0 + j] : 0.f; bs[j] = 0.f; }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const long opix = (long)(n * p.Ho + y0 + wid * 4 + b) * p.Wo + x0 + pl;
@@ -712,7 +732,36 @@ __global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
         }
+        if (rlb) {                  // stats_kind 2: ReLU backward of the layer whose activation is sy, and its bias-gradient sums
+            float yv[8];
+            Vec16<T>::load(reinterpret_cast<const T*>(p.sy) + opix * p.sy_ld + c0, yv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = yv[j] > 0.f ? v[j] : 0.f;
+                bs[j] += v[j];
+            }
+        }
         Vec16<T>::store(out + opix * p.out_ld + c0, v);
+    }
+    if (rlb) {
+        // fold the 16 pixel lanes of a channel group, then the four waves through LDS (the halo is no longer read), and add the
+        // block's 32 sums to this XCD's slot ([MSC_BN_SLOTS][32][2] doubles, first of each pair) with one coalesced atomic
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) bs[j] += __shfl_xor(bs[j], o, 64);
+        }
+        float* red = reinterpret_cast<float*>(halo);
+        __syncthreads();
+        if (pl == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[wid * 32 + c0 + j] = bs[j];
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const float a = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
+            atomicAdd(p.stats + ((long)msc_xcc_id() * 32 + tid) * 2, (double)a);
+        }
     }
 }
 
@@ -1362,7 +1411,7 @@ bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
     if (cfg < 1 || cfg > N_CONV_CFG) return false;
     if (cfg == CFG_HALO)
         return es == 2 && k.mode == 0 && k.KH == 3 && k.KW == 3 && k.stride == 1 && k.pad == 1 && k.Cin == 32 && k.Cout == 32 &&
-               k.Ho % 16 == 0 && k.Wo % 16 == 0 && k.Hi == k.Ho && k.Wi == k.Wo && !k.stats && k.res_ld % 8 == 0 && k.out_ld % 8 == 0;
+               k.Ho % 16 == 0 && k.Wo % 16 == 0 && k.Hi == k.Ho && k.Wi == k.Wo && (!k.stats || k.stats_kind == 2) && k.res_ld % 8 == 0 && k.out_ld % 8 == 0;
     if (cfg == CFG_HALO_T)
         return es == 2 && k.mode == 1 && k.KH == 4 && k.KW == 4 && k.stride == 2 && k.pad == 1 && k.Cin == 128 && k.Cout == 32 &&
                k.Hi % 8 == 0 && k.Wi % 16 == 0 && k.Ho == 2 * k.Hi && k.Wo == 2 * k.Wi && !k.stats && k.res_ld % 8 == 0 && k.out_ld % 8 == 0;
@@ -1465,7 +1514,9 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
     k->in = (const char*)d->in; k->wt = (const char*)d->wt; k->out = (char*)d->out; k->res = (const char*)d->res;
     k->scale = d->scale; k->shift = d->shift; k->stats = d->stats;
     k->sy = (const char*)d->stats_y; k->sy_ld = d->stats_y_ld; k->stats_kind = d->stats ? d->stats_kind : 0;
-    if (k->stats_kind < 0 || k->stats_kind > 1) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: stats_kind %d", d->stats_kind);
+    if (k->stats_kind < 0 || k->stats_kind > 2) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: stats_kind %d", d->stats_kind);
+    if (k->stats_kind == 2 && (!d->stats_y || d->res || d->relu || d->scale || d->shift || (d->stats_y_ld * es) % 16 || ((uintptr_t)d->stats_y & 15)))
+        return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: ReLU-backward statistics need stats_y (16-byte aligned), no residual, no ReLU, no scale/shift");
     if (k->stats_kind == 1 && (!d->stats_y || d->res || d->relu || (d->stats_y_ld * es) % 16 || ((uintptr_t)d->stats_y & 15) || !d->scale != !d->shift))
         return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: BatchNorm-backward statistics need stats_y (16-byte aligned), no residual, no ReLU");
     k->in_ld = d->in_ld; k->out_ld = d->out_ld; k->res_ld = d->res_ld;

@@ -123,6 +123,17 @@ __global__ __launch_bounds__(256) void bias_finalize_kernel(const float* __restr
     if (lane == 0) db[c] += (float)s1;
 }
 
+// bias gradient from the per-XCD slots a data-gradient conv with stats_kind 2 filled ([MSC_BN_SLOTS][Cs][2] doubles, first of
+// each pair): db[c] += sum over the slots, c < C <= Cs
+__global__ void bias_slots_finalize_kernel(const double* __restrict__ slots, int Cs, float* __restrict__ db, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+#pragma unroll
+    for (int x = 0; x < MSC_BN_SLOTS; ++x) s += slots[((long)x * Cs + c) * 2];
+    db[c] += (float)s;
+}
+
 // launch geometry shared by the reduce launches and the workspace-size queries
 struct RedGeom { int cols, chunks, ppb, S; };
 bool red_geom(long pixels, int C, int ce, RedGeom* g) {
@@ -188,6 +199,12 @@ extern "C" int msc_bias_grad(const void* dy, int64_t dy_ld, float* db, void* wor
     red_geom(pixels, C, msc_dtype_vec(dtype), &g);
     hipLaunchKernelGGL(bias_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, g.S, C, db);
     return msc_check_launch("msc_bias_grad");
+}
+
+extern "C" int msc_bias_slots_finalize(const double* slots, int Cs, float* db, int C, void* stream) {
+    if (!slots || !db || C <= 0 || Cs < C) return msc_fail(MSC_ERR_ARG, "msc_bias_slots_finalize: bad argument");
+    hipLaunchKernelGGL(bias_slots_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, slots, Cs, db, C);
+    return msc_check_launch("msc_bias_slots_finalize");
 }
 
 extern "C" int msc_relu_bias_grad(const void* dy, int64_t dy_ld, const void* y, int64_t y_ld, void* dx, int64_t dx_ld, float* db,

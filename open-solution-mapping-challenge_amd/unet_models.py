@@ -622,6 +622,10 @@ class _Builder:
         self.gcount = {}              # activation slice -> number of launches that write its gradient
         self.gwriter = {}             # activation slice -> ConvDesc of the (mode 0, no residual) dgrad conv that wrote it first
         self.fuse_bn_bwd = _os_env.environ.get('MSC_FUSE_BN_BWD', '1') != '0'
+        # decoder: the data-gradient conv that writes the gradient of a bias+ReLU layer's activation first also applies that
+        # layer's ReLU mask and sums its bias gradient (stats_kind 2) -- no msc_relu_bias_grad pass over the tensor
+        self.fuse_relu_bwd = _os_env.environ.get('MSC_FUSE_RELU_BWD', '1') != '0'
+        self.rwriter = {}             # id(activation buffer) -> (ConvDesc, c0, C) of that first writer
 
     # ---- memory
     def buf(self, H, W, C, dtype=None):
@@ -898,6 +902,32 @@ class _Builder:
         else:
             self.conv(bwd, dy, wt, gx, KH=k, KW=k, stride=2, pad=geo['pad'], mode=1, res=gx if acc else None)
 
+    def _relu_writer(self, x, d, acc):
+        """remember the data-gradient conv `d` as the first (non-accumulating) writer of grad(x)"""
+        if self.fuse_relu_bwd and not acc and self.dev.type != 'meta':
+            self.rwriter[id(x.buf)] = (d, x.c0, x.C)
+
+    def _fused_relu_bwd(self, out, bias):
+        """If the gradient of `out` (the activation of a bias+ReLU layer) was written by exactly one data-gradient conv, make
+        that launch mask it by [out > 0] and sum the bias gradient (stats_kind 2; include/msc.h) and emit the tiny finalize
+        that folds the slots into `bias`'s gradient.  The writer may cover a wider channel range than `out` (the whole
+        concat buffer): masking the skip half by ITS activation is idempotent with the mask its own backward applies
+        (every skip is the ReLU output of a residual block, mask mode 1 in _conv_bn_bwd).  Returns True when hooked."""
+        w = self.rwriter.get(id(out.buf))
+        if w is None:
+            return False
+        d, c0, C_ = w
+        key = (id(out.buf), c0, C_)
+        if d.stats or self.gcount.get(key, 0) != 1 or not (c0 <= out.c0 and out.c0 + out.C <= c0 + C_):
+            return False
+        full = Act(out.buf, c0, C_)
+        d.stats_kind, d.stats_y, d.stats_y_ld = 2, full.ptr, full.ld
+        d.stats = self.slots(C_)
+        if not self.lib.msc_conv_cfg_ok(C.byref(d), int(d.cfg)) and d.cfg:
+            d.cfg = 0                                    # the tuned configuration cannot carry statistics: heuristic one
+        self.emit(self.prog.bwd, self.lib.msc_bias_slots_finalize, d.stats + 16 * (out.c0 - c0), C_, self.g(bias), out.C)
+        return True
+
     def conv_relu(self, name, x, conv, out):
         """ConvRelu (src/unet_models.py:25-34): 3x3, pad 1, bias, ReLU."""
         net, lib, P = self.net, self.lib, self.prog
@@ -909,15 +939,21 @@ class _Builder:
         net, lib, P, bwd = self.net, self.lib, self.prog, self.prog.bwd
         dout = self.grad_of(out)
         count = out.pixels
-        if not masked:   # dmask = dout * [out > 0], in place (`out` has exactly one consumer), and the bias gradient in the same pass
-            self.emit(bwd, lib.msc_relu_bias_grad, dout.ptr, dout.ld, out.ptr, out.ld, dout.ptr, dout.ld, self.g(conv.bias),
-                      self.bias_ws(count, out.C), self.dt, count, out.C)
+        if masked == 'done':
+            pass             # mask and bias gradient came with the gradient itself (msc_final_bwd)
+        elif not masked:
+            # dmask = dout * [out > 0] and the bias gradient: by the conv that wrote dout, or in place in one pass over it
+            # (`out` has exactly one consumer)
+            if not self._fused_relu_bwd(out, conv.bias):
+                self.emit(bwd, lib.msc_relu_bias_grad, dout.ptr, dout.ld, out.ptr, out.ld, dout.ptr, dout.ld, self.g(conv.bias),
+                          self.bias_ws(count, out.C), self.dt, count, out.C)
         else:
             self.emit(bwd, lib.msc_bias_grad, dout.ptr, dout.ld, self.g(conv.bias), self.bias_ws(count, out.C), self.dt, count, out.C)
         self.wgrad(bwd, dout, x, self.g(conv.weight), 3, 3, 1, 1)
         gx = self.grad_of(x)
         acc = self.grad_acc(x)
-        self.conv(bwd, dout, net._pack['wt'][name], gx, KH=3, KW=3, stride=1, pad=1, flip=1, res=gx if acc else None)
+        d = self.conv(bwd, dout, net._pack['wt'][name], gx, KH=3, KW=3, stride=1, pad=1, flip=1, res=gx if acc else None)
+        self._relu_writer(x, d, acc)
 
     def deconv_relu(self, name, x, deconv, out):
         """ConvTranspose2d(k4,s2,p1)+bias+ReLU (src/unet_models.py:138-140) as 4 output-parity phases of 2x2 taps."""
@@ -930,14 +966,18 @@ class _Builder:
         net, lib, P, bwd = self.net, self.lib, self.prog, self.prog.bwd
         dout = self.grad_of(out)
         count = out.pixels
-        dm = self.act(out.H, out.W, out.C)           # compact masked gradient (dout may be a slice of a concat)
-        self.emit(bwd, lib.msc_relu_bias_grad, dout.ptr, dout.ld, out.ptr, out.ld, dm.ptr, dm.ld, self.g(deconv.bias),
-                  self.bias_ws(count, out.C), self.dt, count, out.C)
+        if self._fused_relu_bwd(out, deconv.bias):
+            dm = dout                                    # already masked by its writer; read in place (a slice of the concat)
+        else:
+            dm = self.act(out.H, out.W, out.C)           # compact masked gradient (dout may be a slice of a concat)
+            self.emit(bwd, lib.msc_relu_bias_grad, dout.ptr, dout.ld, out.ptr, out.ld, dm.ptr, dm.ld, self.g(deconv.bias),
+                      self.bias_ws(count, out.C), self.dt, count, out.C)
         # dW[ci][kh][kw][co] = sum_coarse x[c][ci] * dm[2c-1+k][co]
         self.wgrad(bwd, x, dm, self.g(deconv.weight), 4, 4, 2, 1)
         gx = self.grad_of(x)
         acc = self.grad_acc(x)
-        self.conv(bwd, dm, net._pack['wt'][name], gx, KH=4, KW=4, stride=2, pad=1, res=gx if acc else None)
+        d = self.conv(bwd, dm, net._pack['wt'][name], gx, KH=4, KW=4, stride=2, pad=1, res=gx if acc else None)
+        self._relu_writer(x, d, acc)
 
     def maxpool(self, x, out):
         lib, P = self.lib, self.prog
@@ -965,7 +1005,9 @@ class _Builder:
         if self.training:
             # forward + backward sums of every BatchNorm layer of the encoder: [BN_SLOTS][C][2] floats each
             nbn = sum(m.num_features for m in enc.modules() if isinstance(m, nn.BatchNorm2d))
-            self.slot_arena, self.slot_used = self.vec(2 * nbn * _lib.BN_SLOTS * 2, dtype=torch.float64, zero=True), 0
+            # ... plus the bias-gradient sums of the decoder's ReLU layers (stats_kind 2; at most every decoder channel once)
+            ndec = 2 * (nf * 8 * 4 + nf * 2 + 960 * exp) + 4096
+            self.slot_arena, self.slot_used = self.vec((2 * nbn + ndec) * _lib.BN_SLOTS * 2, dtype=torch.float64, zero=True), 0
             self.emit(P.fwd, lib.msc_memset_zero, self.slot_arena.data_ptr(), self.slot_arena.numel() * 8)
 
         # concat buffers: [decoder part | encoder skip]; encoder stages write straight into their slice
@@ -1040,9 +1082,10 @@ class _Builder:
             gd0 = self.grad_of(d0)
             self.grad_acc(d0)
             # final 1x1 backward also applies dec0's ReLU mask, so dec0's backward skips it
+            # ... and sums dec0's bias gradient while the masked gradient is in registers
             self.emit(P.bwd, lib.msc_final_bwd, P.dlogits.data_ptr(), d0.ptr, d0.ld, fin.weight.data_ptr(), gd0.ptr, gd0.ld,
-                      self.g(fin.weight), self.g(fin.bias), self.dt, N, H, W, nf)
-            self._conv_relu_bwd('dec0.conv', x, net.dec0.conv, d0, masked=True)
+                      self.g(fin.weight), self.g(fin.bias), self.g(net.dec0.conv.bias), self.dt, N, H, W, nf)
+            self._conv_relu_bwd('dec0.conv', x, net.dec0.conv, d0, masked='done')
             for op in reversed(self.ops):
                 op()
             self.flush_wgrads()

@@ -74,6 +74,12 @@ def conv_igemm(dref):
         st[0, :, 0] += dh.sum(0)
         st[0, :, 1] += (dh * yy).sum(0)
         scale, shift = 1.0, 0.0          # the coefficients only define the mask
+    elif d.stats and d.stats_kind == 2:
+        # ReLU backward of the layer whose activation is stats_y + its bias-gradient sums; the masked value is stored
+        assert not d.scale and not d.shift and res is None and not d.relu
+        st = _arr(d.stats, SLOTS * Cout * 2, np.float64).reshape(SLOTS, Cout, 2)
+        acc = acc * (_rows(d.stats_y, N * Ho * Wo, Cout, d.stats_y_ld) > 0)
+        st[0, :, 0] += acc.astype(np.float32).astype(np.float64).sum(0)
     elif d.stats:
         st = _arr(d.stats, SLOTS * Cout * 2, np.float64).reshape(SLOTS, Cout, 2)
         st[0, :, 0] += acc.sum(0)
@@ -354,7 +360,13 @@ def final_fwd(inp, in_ld, w, b, logits, probs, dtype, N, H, W, Cc):
         _arr(probs, N * 2 * H * W).reshape(N, 2, H * W)[...] = e / e.sum(1, keepdims=True)
 
 
-def final_bwd(dlogits, inp, in_ld, w, din, din_ld, dw, db, dtype, N, H, W, Cc):
+def bias_slots_finalize(slots, Cs, db, Cc):
+    p = _arr(slots, ((SLOTS - 1) * Cs + Cc) * 2, np.float64)
+    tot = sum(p[x * Cs * 2: (x * Cs + Cc) * 2: 2] for x in range(SLOTS))
+    _arr(db, Cc)[...] += tot
+
+
+def final_bwd(dlogits, inp, in_ld, w, din, din_ld, dw, db, dbin, dtype, N, H, W, Cc):
     g = _arr(dlogits, N * 2 * H * W).reshape(N, 2, H * W).transpose(0, 2, 1).reshape(-1, 2).astype(np.float64)
     x = _rows(inp, N * H * W, Cc, in_ld).astype(np.float64)
     ww = _arr(w, 2 * Cc).reshape(2, Cc).astype(np.float64)
@@ -362,6 +374,8 @@ def final_bwd(dlogits, inp, in_ld, w, din, din_ld, dw, db, dtype, N, H, W, Cc):
     _arr(dw, 2 * Cc).reshape(2, Cc)[...] += g.T @ x
     if db:
         _arr(db, 2)[...] += g.sum(0)
+    if dbin:
+        _arr(dbin, Cc)[...] += _rows(din, N * H * W, Cc, din_ld).astype(np.float64).sum(0)
 
 
 def conv_stats_slices(dref):
@@ -375,7 +389,8 @@ TABLE = {'msc_conv_igemm': conv_igemm, 'msc_conv_wgrad': conv_wgrad, 'msc_pack_c
          'msc_bn_bwd_reduce': bn_bwd_reduce, 'msc_bn_bwd_apply': bn_bwd_apply,
          'msc_loss_sums': loss_sums, 'msc_loss_grad': loss_grad, 'msc_adam_tick': adam_tick, 'msc_adam_step': adam_step,
          'msc_grad_reduce': grad_reduce, 'msc_grad_unpack': grad_unpack,
-         'msc_relu_bwd': relu_bwd, 'msc_bias_grad': bias_grad, 'msc_relu_bias_grad': relu_bias_grad, 'msc_final_fwd': final_fwd, 'msc_final_bwd': final_bwd}
+         'msc_relu_bwd': relu_bwd, 'msc_bias_grad': bias_grad, 'msc_relu_bias_grad': relu_bias_grad, 'msc_final_fwd': final_fwd, 'msc_final_bwd': final_bwd,
+         'msc_bias_slots_finalize': bias_slots_finalize}
 
 
 def run(launches, stream=None):

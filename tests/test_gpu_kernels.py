@@ -318,6 +318,97 @@ def test_conv_epilogue_batchnorm_backward_sums(dtype, cin, cout, k, hw, n, maske
         assert torch.allclose(s[:, 0], e1, **t) and torch.allclose(s[:, 1], e2, **t), c
 
 
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('cin,cout,k,stride,hw,n,flip', [(128, 64, 3, 1, 16, 2, 1), (32, 128, 4, 2, 32, 2, 0), (32, 32, 3, 1, 32, 3, 1),
+                                                         (128, 320, 3, 1, 12, 2, 1)])
+def test_conv_epilogue_relu_backward_and_bias_sums(dtype, cin, cout, k, stride, hw, n, flip):
+    """stats_kind 2: a data-gradient conv stores its result masked by [act > 0] (ReLU backward of the layer whose activation it
+    is given) and reduces the per-channel sums of what it stored (that layer's bias gradient, folded by
+    msc_bias_slots_finalize) -- the pass msc_relu_bias_grad would make over the tensors; every valid configuration, incl. the
+    halo-tile kernel of the 32-channel layers and the stride-2 gather form of the ConvTranspose2d data gradient"""
+    import ctypes as C
+    from mapping_challenge_amd import _lib, ops
+    lib = _lib.load()
+    pad = 1
+    ho = (hw + 2 * pad - k) // stride + 1
+    x = rnd((n, cin, hw, hw), dtype, 1)
+    w = rnd((cout, cin, k, k), dtype, 2, (2.0 / (cin * k * k)) ** 0.5)
+    act = torch.relu(rnd((n, cout, ho, ho), dtype, 3))
+    ref = F.conv2d(x, w.flip(2, 3) if flip else w, stride=stride, padding=pad) * (act > 0)
+    xd, ad = nhwc(x, dtype), nhwc(act, dtype)
+    wk = w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    out = torch.empty((n, ho, ho, cout), dtype=dtype, device='cuda')
+    tried = 0
+    for c in range(1, lib.msc_conv_num_cfgs() + 1):
+        d = ops.ConvDesc()
+        d.in_, d.wt, d.out = xd.data_ptr(), wk.data_ptr(), out.data_ptr()
+        d.in_ld, d.out_ld, d.dtype, d.mode, d.flip = cin, cout, ops._dt(xd), 0, flip
+        d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.cfg = n, hw, hw, cin, ho, ho, cout, k, k, stride, pad, c
+        d.stats_kind, d.stats_y, d.stats_y_ld = 2, ad.data_ptr(), cout
+        stats = torch.zeros((_lib.BN_SLOTS, cout, 2), dtype=torch.float64, device='cuda')
+        d.stats = stats.data_ptr()
+        if not lib.msc_conv_cfg_ok(C.byref(d), c):
+            continue
+        tried += 1
+        out.fill_(7.0)
+        _lib.check(lib.msc_conv_igemm(C.byref(d), torch.cuda.current_stream().cuda_stream), 'conv')
+        assert torch.allclose(to_nchw(out), ref, **tol(dtype)), c
+        # the sums are taken before the store rounds to the dtype; against a pass over the stored tensor that is rounding noise
+        stored = to_nchw(out).double().sum((0, 2, 3))
+        db = torch.zeros(cout + 3, device='cuda')
+        _lib.check(lib.msc_bias_slots_finalize(stats.data_ptr(), cout, db.data_ptr(), cout, torch.cuda.current_stream().cuda_stream), 'fin')
+        assert (stats[:, :, 1] == 0).all(), c
+        assert torch.allclose(db[:cout].cpu().double(), stored, rtol=2e-3, atol=(5e-2 if dtype == torch.float32 else 0.5)), c
+        assert (db[cout:] == 0).all()
+        # a channel sub-range of wider slots (the decoder half of a concat buffer)
+        if cout >= 64:
+            db2 = torch.ones(32, device='cuda')
+            _lib.check(lib.msc_bias_slots_finalize(stats.data_ptr() + 16 * 32, cout, db2.data_ptr(), 32, torch.cuda.current_stream().cuda_stream), 'fin')
+            assert torch.allclose(db2.cpu().double() - 1, stored[32:64], rtol=2e-3, atol=(5e-2 if dtype == torch.float32 else 0.5)), c
+    assert tried >= 2
+    if cin == 32 and cout == 32 and dtype != torch.float32:
+        d.cfg = _lib.CFG_HALO
+        assert lib.msc_conv_cfg_ok(C.byref(d), _lib.CFG_HALO)          # the halo-tile kernel carries the mask and the sums too
+    # no residual / scale / ReLU with this kind
+    d.cfg, d.relu = 0, 1
+    assert lib.msc_conv_igemm(C.byref(d), torch.cuda.current_stream().cuda_stream) != 0
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('n,hw,c,with_bias_in', [(2, 24, 32, True), (3, 17, 32, False), (1, 64, 64, True), (2, 9, 16, True)])
+def test_final_1x1_backward(dtype, n, hw, c, with_bias_in):
+    """msc_final_bwd against torch autograd of ReLU -> Conv2d(C, 2, 1): the input gradient masked by the producer's ReLU, the
+    1x1 weight / bias gradients, and the producer's bias gradient summed from the stored (rounded) input gradient"""
+    from mapping_challenge_amd import _lib, ops
+    lib = _lib.load()
+    if c * (4 if dtype == torch.float32 else 2) % 16:
+        pytest.skip('C must keep 16-byte channel vectors')
+    a = torch.relu(rnd((n, c, hw, hw), dtype, 1))
+    w = rnd((2, c), torch.float32, 2, 0.3)
+    g = rnd((n, 2, hw, hw), torch.float32, 3)
+    pre = a.clone().requires_grad_(True)
+    wt = w.clone().requires_grad_(True)
+    b = torch.zeros(2, requires_grad=True)
+    y = F.conv2d(pre, wt.view(2, c, 1, 1), b)
+    y.backward(g)
+    din_ref = pre.grad * (a > 0)
+    ad = nhwc(a, dtype)
+    din = torch.full((n, hw, hw, c), 5.0, dtype=dtype, device='cuda')
+    dw = torch.ones(2, c, device='cuda')
+    db = torch.ones(2, device='cuda')
+    dbin = torch.ones(c, device='cuda') if with_bias_in else None
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.msc_final_bwd(g.cuda().data_ptr(), ad.data_ptr(), c, w.cuda().data_ptr(), din.data_ptr(), c, dw.data_ptr(), db.data_ptr(),
+                                 dbin.data_ptr() if with_bias_in else None, ops._dt(ad), n, hw, hw, c, st), 'final_bwd')
+    torch.cuda.synchronize()
+    assert torch.allclose(to_nchw(din), din_ref, **tol(dtype))
+    t = dict(rtol=1e-4, atol=1e-3)
+    assert torch.allclose(dw.cpu() - 1, wt.grad, **t)
+    assert torch.allclose(db.cpu() - 1, b.grad, **t)
+    if with_bias_in:
+        assert torch.allclose(dbin.cpu() - 1, to_nchw(din).sum((0, 2, 3)), rtol=1e-4, atol=2e-2)
+
+
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('hw,n,flip,with_res,relu', [(32, 3, False, False, True), (48, 2, True, True, False), (16, 1, True, False, False)])
 def test_halo_tile_kernel_for_32_channel_3x3(hw, n, flip, with_res, relu, dtype):
