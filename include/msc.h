@@ -180,6 +180,14 @@ int msc_relu_bias_grad(const void* dy, int64_t dy_ld, const void* y, int64_t y_l
 
 /* bias gradient out of the slots a stats_kind-2 conv filled ([MSC_BN_SLOTS][Cs][2] doubles): db[c] += sum_slots [.][c][0], c < C <= Cs */
 int msc_bias_slots_finalize(const double* slots, int Cs, float* db, int C, void* stream);
+/* several layers in one launch; `items` is a HOST array of n <= MSC_BIAS_SLOTS_MAX entries, copied into the launch */
+#define MSC_BIAS_SLOTS_MAX 16
+typedef struct msc_bias_slots_item {
+    const double* slots;
+    float* db;
+    int32_t Cs, C;
+} msc_bias_slots_item;
+int msc_bias_slots_finalize_multi(const msc_bias_slots_item* items, int n, void* stream);
 
 /* final 1x1 conv 32 -> 2 with bias (src/unet_models.py:383,403; dropout p = 0) fused with the channel softmax
  * the reference applies on the host afterwards (src/models.py:88-92, src/utils.py:231-273).

@@ -38,6 +38,13 @@ class WgradDesc(C.Structure):
                 ('stride', C.c_int32), ('pad', C.c_int32), ('cfg', C.c_int32)]
 
 
+class BiasSlotsItem(C.Structure):         # == msc_bias_slots_item
+    _fields_ = [('slots', C.c_void_p), ('db', C.c_void_p), ('Cs', C.c_int32), ('C', C.c_int32)]
+
+
+BIAS_SLOTS_MAX = 16
+
+
 class LossCfg(C.Structure):
     _fields_ = [('w0', C.c_float), ('sigma', C.c_float), ('size_c', C.c_float),
                 ('dice_weight', C.c_float), ('ce_weight', C.c_float), ('smooth', C.c_float), ('eps', C.c_float),
@@ -82,6 +89,7 @@ SIGNATURES = {
     'msc_relu_bias_grad': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i64, _i, _vp]),
     'msc_final_fwd': (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'msc_bias_slots_finalize': (_i, [_vp, _i, _vp, _i, _vp]),
+    'msc_bias_slots_finalize_multi': (_i, [C.POINTER(BiasSlotsItem), _i, _vp]),
     'msc_final_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'msc_loss_sums': (_i, [_vp, _vp, _i, C.POINTER(LossCfg), _vp, _i, _i, _i, _vp]),
     'msc_loss_grad': (_i, [_vp, _vp, _i, C.POINTER(LossCfg), _vp, _d, _f, _vp, _vp, _i, _i, _i, _vp]),

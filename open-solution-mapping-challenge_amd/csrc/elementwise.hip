@@ -3,6 +3,8 @@
 // gradient, the final 1x1 conv fused with softmax, and Adam.  All activations NHWC with a channel
 // stride; every global access is a 16-byte vector per lane (4 f32 / 8 bf16), lanes run along the
 // channel (contiguous) dimension first.
+#include <stdlib.h>
+
 #include "common.h"
 #include "msc_internal.h"
 
@@ -702,7 +704,9 @@ namespace {
 // grid of the channel-tiled BatchNorm kernels: CT channels x `ppb` pixels per block, about 2048 blocks in all
 template <int R>
 long bn_ppb(long pixels, int ctiles) {
-    long ppb = ceil_div(pixels * ctiles, 2048);
+    static int target = -1;      // MSC_BN_BLOCKS: blocks per launch aimed at (A/B measurements)
+    if (target < 0) { const char* e = getenv("MSC_BN_BLOCKS"); target = e ? atoi(e) : 2048; if (target < 64) target = 64; }
+    long ppb = ceil_div(pixels * ctiles, target);
     ppb = (ppb + R - 1) / R * R;
     return ppb < R ? R : ppb;
 }

@@ -134,6 +134,18 @@ __global__ void bias_slots_finalize_kernel(const double* __restrict__ slots, int
     db[c] += (float)s;
 }
 
+// the same for several layers in one launch (one block per layer): the decoder's ReLU layers all at once
+struct BiasSlotsBatch { msc_bias_slots_item it[MSC_BIAS_SLOTS_MAX]; };
+__global__ __launch_bounds__(256) void bias_slots_finalize_multi_kernel(BiasSlotsBatch b) {
+    const msc_bias_slots_item it = b.it[blockIdx.x];
+    for (int c = threadIdx.x; c < it.C; c += 256) {
+        double s = 0.0;
+#pragma unroll
+        for (int x = 0; x < MSC_BN_SLOTS; ++x) s += it.slots[((long)x * it.Cs + c) * 2];
+        it.db[c] += (float)s;
+    }
+}
+
 // launch geometry shared by the reduce launches and the workspace-size queries
 struct RedGeom { int cols, chunks, ppb, S; };
 bool red_geom(long pixels, int C, int ce, RedGeom* g) {
@@ -205,6 +217,18 @@ extern "C" int msc_bias_slots_finalize(const double* slots, int Cs, float* db, i
     if (!slots || !db || C <= 0 || Cs < C) return msc_fail(MSC_ERR_ARG, "msc_bias_slots_finalize: bad argument");
     hipLaunchKernelGGL(bias_slots_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, slots, Cs, db, C);
     return msc_check_launch("msc_bias_slots_finalize");
+}
+
+extern "C" int msc_bias_slots_finalize_multi(const msc_bias_slots_item* items, int n, void* stream) {
+    if (!items || n < 1 || n > MSC_BIAS_SLOTS_MAX) return msc_fail(MSC_ERR_ARG, "msc_bias_slots_finalize_multi: 1..%d items", MSC_BIAS_SLOTS_MAX);
+    BiasSlotsBatch b;
+    for (int i = 0; i < n; ++i) {
+        if (!items[i].slots || !items[i].db || items[i].C <= 0 || items[i].Cs < items[i].C)
+            return msc_fail(MSC_ERR_ARG, "msc_bias_slots_finalize_multi: bad item %d", i);
+        b.it[i] = items[i];
+    }
+    hipLaunchKernelGGL(bias_slots_finalize_multi_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, b);
+    return msc_check_launch("msc_bias_slots_finalize_multi");
 }
 
 extern "C" int msc_relu_bias_grad(const void* dy, int64_t dy_ld, const void* y, int64_t y_ld, void* dx, int64_t dx_ld, float* db,

@@ -626,6 +626,7 @@ class _Builder:
         # layer's ReLU mask and sums its bias gradient (stats_kind 2) -- no msc_relu_bias_grad pass over the tensor
         self.fuse_relu_bwd = _os_env.environ.get('MSC_FUSE_RELU_BWD', '1') != '0'
         self.rwriter = {}             # id(activation buffer) -> (ConvDesc, c0, C) of that first writer
+        self.bias_items = []          # (slots address, slot channel count, bias parameter, channels) awaiting flush_bias_slots
 
     # ---- memory
     def buf(self, H, W, C, dtype=None):
@@ -925,8 +926,20 @@ class _Builder:
         d.stats = self.slots(C_)
         if not self.lib.msc_conv_cfg_ok(C.byref(d), int(d.cfg)) and d.cfg:
             d.cfg = 0                                    # the tuned configuration cannot carry statistics: heuristic one
-        self.emit(self.prog.bwd, self.lib.msc_bias_slots_finalize, d.stats + 16 * (out.c0 - c0), C_, self.g(bias), out.C)
+        self.bias_items.append((d.stats + 16 * (out.c0 - c0), C_, bias, out.C))
         return True
+
+    def flush_bias_slots(self):
+        """ONE launch folds the bias-gradient slots of all decoder layers hooked so far into their gradients (emitted after the
+        last decoder layer's backward: the decoder's gradients sit at the tail of the flat buffer and complete first)"""
+        items, self.bias_items = self.bias_items, []
+        for i in range(0, len(items), _lib.BIAS_SLOTS_MAX):
+            part = items[i:i + _lib.BIAS_SLOTS_MAX]
+            arr = (_lib.BiasSlotsItem * len(part))()
+            for a, (slots, cs, bias, c_) in zip(arr, part):
+                a.slots, a.Cs, a.db, a.C = slots, cs, self.g(bias), c_
+            self.prog.keep.append(arr)
+            self.emit(self.prog.bwd, self.lib.msc_bias_slots_finalize_multi, arr, len(part))
 
     def conv_relu(self, name, x, conv, out):
         """ConvRelu (src/unet_models.py:25-34): 3x3, pad 1, bias, ReLU."""
@@ -1056,6 +1069,7 @@ class _Builder:
         c5 = cur
 
         # decoder (:392-401)
+        self.ops.append(self.flush_bias_slots)      # backward runs the ops in reverse: this one right after the decoder's
         pooled = self.act(H // 64, W // 64, c5.C)
         self.maxpool(c5, pooled)
         specs = [('center', pooled, self.slice(cat5, 0, nf * 8)), ('dec5', Act(cat5), self.slice(cat4, 0, nf * 8)),

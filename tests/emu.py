@@ -366,6 +366,11 @@ def bias_slots_finalize(slots, Cs, db, Cc):
     _arr(db, Cc)[...] += tot
 
 
+def bias_slots_finalize_multi(items, n):
+    for i in range(n):
+        bias_slots_finalize(items[i].slots, items[i].Cs, items[i].db, items[i].C)
+
+
 def final_bwd(dlogits, inp, in_ld, w, din, din_ld, dw, db, dbin, dtype, N, H, W, Cc):
     g = _arr(dlogits, N * 2 * H * W).reshape(N, 2, H * W).transpose(0, 2, 1).reshape(-1, 2).astype(np.float64)
     x = _rows(inp, N * H * W, Cc, in_ld).astype(np.float64)
@@ -390,7 +395,7 @@ TABLE = {'msc_conv_igemm': conv_igemm, 'msc_conv_wgrad': conv_wgrad, 'msc_pack_c
          'msc_loss_sums': loss_sums, 'msc_loss_grad': loss_grad, 'msc_adam_tick': adam_tick, 'msc_adam_step': adam_step,
          'msc_grad_reduce': grad_reduce, 'msc_grad_unpack': grad_unpack,
          'msc_relu_bwd': relu_bwd, 'msc_bias_grad': bias_grad, 'msc_relu_bias_grad': relu_bias_grad, 'msc_final_fwd': final_fwd, 'msc_final_bwd': final_bwd,
-         'msc_bias_slots_finalize': bias_slots_finalize}
+         'msc_bias_slots_finalize': bias_slots_finalize, 'msc_bias_slots_finalize_multi': bias_slots_finalize_multi}
 
 
 def run(launches, stream=None):

@@ -398,7 +398,8 @@ def test_final_1x1_backward(dtype, n, hw, c, with_bias_in):
     db = torch.ones(2, device='cuda')
     dbin = torch.ones(c, device='cuda') if with_bias_in else None
     st = torch.cuda.current_stream().cuda_stream
-    _lib.check(lib.msc_final_bwd(g.cuda().data_ptr(), ad.data_ptr(), c, w.cuda().data_ptr(), din.data_ptr(), c, dw.data_ptr(), db.data_ptr(),
+    gd, wd = g.cuda(), w.cuda()          # kept alive: a temporary's memory is recycled by the next allocation
+    _lib.check(lib.msc_final_bwd(gd.data_ptr(), ad.data_ptr(), c, wd.data_ptr(), din.data_ptr(), c, dw.data_ptr(), db.data_ptr(),
                                  dbin.data_ptr() if with_bias_in else None, ops._dt(ad), n, hw, hw, c, st), 'final_bwd')
     torch.cuda.synchronize()
     assert torch.allclose(to_nchw(din), din_ref, **tol(dtype))
