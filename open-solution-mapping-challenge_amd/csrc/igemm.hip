@@ -120,7 +120,9 @@ __device__ __forceinline__ void dma16(u32x4_t srd, char* lds_wave_base, unsigned
 }
 
 // shared epilogue: lane holds NV consecutive channels cb.. of pixel rows (b*16+pl), b < FN
-template <typename T, int FM, int FN, int WTP, int WP, int MODE, int WC = 1>
+// PATCH (halo-tile kernels): fragment b of pixel wave wp is row wp*FN + b of a 16-pixel-wide image patch whose first pixel
+// is m0, i.e. pixel m0 + (wp*FN + b)*Wo + pl -- otherwise the tile is M-linear
+template <typename T, int FM, int FN, int WTP, int WP, int MODE, int WC = 1, bool PATCH = false>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][FN], int m0, int wp, int cb, int pl, int py, int px,
                                               int mtile, int ntm, float* red = nullptr, int wc = 0, int c0 = 0) {
     constexpr int NV = FM * 4;
@@ -152,7 +154,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
     if (PRE && side) {
 #pragma unroll
         for (int b = 0; b < FN; ++b) {
-            const int m = m0 + wp * WTP + b * 16 + pl;
+            const int m = PATCH ? m0 + (wp * FN + b) * p.Wo + pl : m0 + wp * WTP + b * 16 + pl;
             if (m < p.M) {
                 long opix = m;
                 if (MODE) {
@@ -168,7 +170,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
     }
 #pragma unroll
     for (int b = 0; b < FN; ++b) {
-        const int m = m0 + wp * WTP + b * 16 + pl;
+        const int m = PATCH ? m0 + (wp * FN + b) * p.Wo + pl : m0 + wp * WTP + b * 16 + pl;
         float v[NV];
 #pragma unroll
         for (int a = 0; a < FM; ++a)
@@ -653,6 +655,173 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
     }
     conv_epilogue<T, FM, FN, WTP, WP, MODE, WC>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px, mtile, nwg / p.ntc,
                                                 reinterpret_cast<float*>(smem), wc, c0);
+}
+
+// ------------------------------------------------------------------------------------------------ halo tile, any width
+// 3x3 / stride 1 / pad 1 convolutions (forward and, with flip, data gradient) of any channel count that is a multiple of
+// 64: the implicit GEMM above re-fetches every pixel row nine times (once per tap) into LDS, and the L2 -> LDS fill -- not
+// the matrix pipes -- is what bounds it (64x128 tile: 42 FLOP per filled byte against 300+ for the MFMA peak at the
+// measured 14-34 TB/s of fill).  Here a block owns a PH x 16 pixel patch of one image and TC output channels.  The
+// reduction runs chunk-major: for each 64-channel chunk (128-byte rows) the (PH+2) x 18 halo of input rows is fetched ONCE
+// and the nine taps read shifted windows of it, while the nine [TC][128 B] weight slices stream through a ring.  Per
+// chunk and block that is 9 x TC x 128 B of weights + ~1.3 x the patch instead of 9 x (patch + TC rows): 2.3x fewer
+// bytes for a 128-pixel x 64-channel tile, 2.1x for 256 x 128.
+//   LDS: two halo buffers (chunk c+1 arrives during the nine k-steps of chunk c, one DMA piece per wave and k-step) +
+//   NWS weight stages.  Every wave issues the same number of DMA instructions per k-step -- pieces past the end of the
+//   reduction or of the halo go out with an out-of-range offset (no memory traffic) -- so the counted vmcnt of a k-step is
+//   a compile-time constant per tap.
+template <typename T, int PH, int TC, int WP, int WC, int NWS>
+__global__ __launch_bounds__(WP * WC * 64) void conv3x3_halo_dma_kernel(ConvK p) {
+    static_assert(sizeof(T) == 2, "16-bit types");
+    constexpr int ES = 2, KB = 128;
+    constexpr int NW = WP * WC;
+    constexpr int HCOLS = 18, HPIX = (PH + 2) * HCOLS;
+    constexpr int NHI = (HPIX + 7) / 8;                       // DMA wave-instructions per halo chunk (8 pixels x 128 B)
+    constexpr int XH = (NHI + NW - 1) / NW;                   // ... per wave
+    constexpr int HBUF = XH * NW * 1024;                      // a halo buffer (padded to whole instructions of every wave)
+    constexpr int NIW = TC / 8;                               // DMA wave-instructions per weight stage
+    constexpr int WI = (NIW + NW - 1) / NW;
+    constexpr int WSTAGE = TC * KB;
+    constexpr int FN = PH / WP, WTC = TC / WC, FM = WTC / 16, NV = FM * 4;
+    static_assert(PH % WP == 0 && TC % (WC * 16) == 0, "wave tiling");
+    static_assert(XH <= 9 - (NWS - 2), "halo pieces of a chunk must be out before the waits that cover them");
+    static_assert(NIW % NW == 0 || NIW < NW, "weight tile / wave count");
+    static_assert(2 * HBUF + NWS * WSTAGE <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) char smem[2 * HBUF + NWS * WSTAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wid / WC, wc = wid % WC;
+    const int g = lane >> 4, pl = lane & 15;
+    // XCD-aware order (see conv_igemm_dma_kernel): consecutive tiles on one XCD, channel tile fastest
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, wq = nwg >> 3, wr = nwg & 7;
+    const int wgid = p.xcd_order ? (xcd < wr ? xcd * (wq + 1) : wr * (wq + 1) + (xcd - wr) * wq) + (orig >> 3) : orig;
+    const int patch = wgid / p.ntc, ctile = wgid - patch * p.ntc;
+    const int tiles_x = p.Wo / 16, tiles_y = p.Ho / PH;
+    const int bx = patch % tiles_x, by = (patch / tiles_x) % tiles_y, n = patch / (tiles_x * tiles_y);
+    const int y0 = by * PH, x0 = bx * 16;
+    const int c0 = ctile * TC;
+    const int nchunks = (p.Cin * ES) / KB;
+
+    const u32x4_t rx = make_srd(p.in, p.in_bytes);
+    const u32x4_t rw = make_srd(p.wt, p.wt_bytes);
+    const int lr = lane >> 3, slot = lane & 7;
+    const unsigned pix_bytes = (unsigned)p.in_ld * ES;
+    const unsigned tap_bytes = (unsigned)p.Cin * ES;
+
+    // ---- per-lane source offsets, chunk/tap independent (the chunk and tap advance through the scalar offset)
+    unsigned hoff[XH];
+#pragma unroll
+    for (int i = 0; i < XH; ++i) {
+        const int hp = (i * NW + wid) * 8 + lr;
+        const int hy = hp / HCOLS, hx = hp - hy * HCOLS;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = hp < HPIX && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        hoff[i] = ok ? (unsigned)((n * p.Hi + iy) * p.Wi + ix) * pix_bytes + (unsigned)(slot ^ ((hp >> 1) & 7)) * 16u : OOB_OFF;
+    }
+    unsigned woff[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int j = NIW >= NW ? i * NW + wid : wid % NIW;
+        const int row = j * 8 + lr;
+        const int co = c0 + row;
+        woff[i] = co < p.Cout ? (unsigned)co * 9u * tap_bytes + (unsigned)(slot ^ swz_w<KB, NV>(row)) * 16u : OOB_OFF;
+    }
+    // ---- fragment read offsets: weights as in the implicit-GEMM kernel; pixels = halo position of (patch row, pl) shifted by the tap
+    const int key = swz_frag<KB>(pl);
+    int aoff[FM];
+#pragma unroll
+    for (int a = 0; a < FM; ++a) aoff[a] = (wc * WTC + (pl >> 2) * NV + a * 4 + (pl & 3)) * KB + ((g ^ key) * 16);
+    int boff[9][FN];                      // byte offset within a halo buffer of sub-step 0 (sub-step 1: ^ 64)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int kh = t / 3, kw = t - kh * 3;
+        const int dy = p.flip ? 1 - kh : kh - 1, dx = p.flip ? 1 - kw : kw - 1;
+#pragma unroll
+        for (int b = 0; b < FN; ++b) {
+            const int hp = (wp * FN + b + 1 + dy) * HCOLS + pl + 1 + dx;
+            boff[t][b] = hp * KB + ((g ^ ((hp >> 1) & 7)) * 16);
+        }
+    }
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    char* const hbase = smem;
+    char* const wbase = smem + 2 * HBUF;
+    // ---- issue state: the next weight stage to fetch is (chunk iwc, tap iwt) into ring slot iws
+    int iwc = 0, iwt = 0, iws = 0;
+    auto w_piece = [&](int i) {
+        const bool live = iwc < nchunks;
+        const int soff = iwt * (int)tap_bytes + iwc * KB;
+        dma16(rw, wbase + iws * WSTAGE + (NIW >= NW ? i * NW + wid : wid % NIW) * 1024, live ? woff[i] : OOB_OFF, live ? soff : 0);
+    };
+    auto w_advance = [&]() {
+        if (++iwt == 9) { iwt = 0; ++iwc; }
+        if (++iws == NWS) iws = 0;
+    };
+    auto h_piece = [&](int i, int chunk) {            // piece i of the halo of `chunk` into buffer chunk & 1
+        const bool live = chunk < nchunks;
+        dma16(rx, hbase + (chunk & 1) * HBUF + (i * NW + wid) * 1024, live ? hoff[i] : OOB_OFF, live ? chunk * KB : 0);
+    };
+
+    // ---- prologue: halo of chunk 0, then NWS-1 weight stages
+#pragma unroll
+    for (int i = 0; i < XH; ++i) h_piece(i, 0);
+#pragma unroll
+    for (int st = 0; st < NWS - 1; ++st) {
+#pragma unroll
+        for (int i = 0; i < WI; ++i) w_piece(i);
+        w_advance();
+    }
+
+    int cst = 0;                                      // ring slot of the weight stage being consumed
+    constexpr int NM = 2 * FM * FN;                   // MFMAs per k-step and wave
+    for (int c = 0; c < nchunks; ++c) {
+        const char* hb = hbase + (c & 1) * HBUF;
+        auto tap = [&](auto tt) {
+            constexpr int t = decltype(tt)::value;
+            // operations issued after the last piece of this k-step's weight stage: the NWS-2 later stages and the halo
+            // pieces of the NWS-2 k-steps before this one (taps < XH carry one)
+            constexpr int NH = [] { int h = 0; for (int d = 1; d <= NWS - 2; ++d) h += ((t - d + 9) % 9) < XH ? 1 : 0; return h; }();
+            wait_vmcnt<(NWS - 2) * WI + NH>();
+            raw_barrier();
+            const char* wb = wbase + cst * WSTAGE;
+            if (t < XH) h_piece(t < XH ? t : 0, c + 1);          // before this k-step's weight pieces (the count above relies on it)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                uint4 af[FM], bf[FN];
+#pragma unroll
+                for (int a = 0; a < FM; ++a) af[a] = *reinterpret_cast<const uint4*>(wb + (aoff[a] ^ (kk * 64)));
+#pragma unroll
+                for (int b = 0; b < FN; ++b) bf[b] = *reinterpret_cast<const uint4*>(hb + (boff[t][b] ^ (kk * 64)));
+#pragma unroll
+                for (int a = 0; a < FM; ++a)
+#pragma unroll
+                    for (int b = 0; b < FN; ++b) {
+                        const int m = (kk * FM + a) * FN + b;
+#pragma unroll
+                        for (int i = 0; i < WI; ++i)
+                            if ((i * NM) / WI == m) w_piece(i);
+                        Mma<T>::run(af[a], bf[b], acc[a][b]);
+                    }
+            }
+            w_advance();
+            if (++cst == NWS) cst = 0;
+        };
+        tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
+        tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
+        tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+    }
+    wait_vmcnt<0>();                                  // the trailing out-of-range pieces still write zeros into the ring
+    const int m0 = (n * p.Ho + y0) * p.Wo + x0;
+    conv_epilogue<T, FM, FN, FN * 16, WP, 0, WC, true>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, 0, 0, patch, nwg / p.ntc,
+                                                        reinterpret_cast<float*>(smem), wc, c0);
 }
 
 // ------------------------------------------------------------------------------------------------ halo tile
@@ -1328,7 +1497,8 @@ bool use_v1_wgrad() { static int v = -1; if (v < 0) v = env_flag("MSC_WGRAD_V1")
 // heuristic (cfg 0) the caller may pick one explicitly -- UNetResNet times the valid ones per layer when it builds
 // a program (msc_conv_cfg_ok enumerates them).
 struct ConvCfg { int tp, tc, wp, wc, kb, nst; };
-constexpr int N_CONV_CFG = 41;
+constexpr int N_CONV_CFG = 46;
+constexpr int CFG_HALO3_FIRST = 42;      // 42..46: conv3x3_halo_dma_kernel
 constexpr int CFG_HALO = 27;          // conv3x3_c32_halo_kernel (not a tile of the DMA kernel)
 constexpr int CFG_HALO_T = 28;        // deconv4_c128_c32_halo_kernel
 static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
@@ -1385,6 +1555,13 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {256, 64, 4, 1, 128, 2},    // 39:  80 KB, 4 waves of 64 px x 64 ch
     {256, 64, 4, 2, 128, 2},    // 40:  80 KB, 8 waves
     {128, 64, 2, 2, 128, 3},    // 41:  72 KB, 4 waves
+    // halo-tile kernel for 3x3 / stride 1 convs of any width (conv3x3_halo_dma_kernel): tp = patch rows x 16 pixels, kb = 128,
+    // nst = weight ring depth; LDS = 2 halo buffers + nst weight stages
+    {256, 128, 4, 2, 128, 3},   // 42: 16x16 patch x 128 ch, 8 waves of 64 px x 64 ch, 144 KB
+    {128, 128, 2, 4, 128, 4},   // 43:  8x16 patch x 128 ch, 8 waves of 64 px x 32 ch, 112 KB
+    {128, 64, 2, 2, 128, 4},    // 44:  8x16 patch x  64 ch, 4 waves of 64 px x 32 ch,  80 KB, 2 blocks/CU
+    {256, 64, 4, 2, 128, 4},    // 45: 16x16 patch x  64 ch, 8 waves of 64 px x 32 ch, 128 KB
+    {128, 64, 4, 2, 128, 4},    // 46:  8x16 patch x  64 ch, 8 waves of 32 px x 32 ch,  80 KB, 2 blocks/CU
 };
 
 template <typename T, int TP, int TC, int WP, int WC, int KB, int NST, int ABL = 0>
@@ -1397,6 +1574,18 @@ int launch_dma(const ConvK& k0, int mode, hipStream_t st) {
     if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1, NST, KB, ABL>), grid, dim3(NT), 0, st, k);
     else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, NST, KB, ABL>), grid, dim3(NT), 0, st, k);
     return msc_check_launch("conv_igemm_dma");
+}
+
+template <typename T, int PH, int TC, int WP, int WC, int NWS>
+int launch_halo3(const ConvK& k0, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        ConvK k = k0;
+        k.ntc = k.Cout / TC;
+        k.xcd_order = xcd_order_enabled() ? 1 : 0;
+        const int blocks = k.N * (k.Ho / PH) * (k.Wo / 16) * k.ntc;
+        hipLaunchKernelGGL((conv3x3_halo_dma_kernel<T, PH, TC, WP, WC, NWS>), dim3(blocks), dim3(WP * WC * 64), 0, st, k);
+    }
+    return msc_check_launch("conv3x3_halo_dma");
 }
 
 template <typename T, int TP, int TC, int WP, int WC>
@@ -1416,6 +1605,9 @@ bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
         return es == 2 && k.mode == 1 && k.KH == 4 && k.KW == 4 && k.stride == 2 && k.pad == 1 && k.Cin == 128 && k.Cout == 32 &&
                k.Hi % 8 == 0 && k.Wi % 16 == 0 && k.Ho == 2 * k.Hi && k.Wo == 2 * k.Wi && !k.stats && k.res_ld % 8 == 0 && k.out_ld % 8 == 0;
     const ConvCfg& c = CONV_CFGS[cfg];
+    if (cfg >= CFG_HALO3_FIRST)
+        return es == 2 && k.mode == 0 && k.KH == 3 && k.KW == 3 && k.stride == 1 && k.pad == 1 && k.Hi == k.Ho && k.Wi == k.Wo &&
+               k.Wo % 16 == 0 && k.Ho % (c.tp / 16) == 0 && (k.Cin * es) % 128 == 0 && k.Cout % c.tc == 0 && k.in_bytes != 0;
     if (k.Cout % c.tc) return false;
     if (c.tc == 32 && k.Cout % 64 == 0) return false;        // a 32-channel tile only for the 32-channel layers
     if (((long)k.Cin * es) % c.kb) return false;
@@ -1490,6 +1682,11 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
         case 38: return launch_dma<T, 128, 128, 4, 2, 128, 2>(k, mode, st);
         case 39: return launch_dma<T, 256, 64, 4, 1, 128, 2>(k, mode, st);
         case 40: return launch_dma<T, 256, 64, 4, 2, 128, 2>(k, mode, st);
+        case 42: return launch_halo3<T, 16, 128, 4, 2, 3>(k, st);
+        case 43: return launch_halo3<T, 8, 128, 2, 4, 4>(k, st);
+        case 44: return launch_halo3<T, 8, 64, 2, 2, 4>(k, st);
+        case 45: return launch_halo3<T, 16, 64, 4, 2, 4>(k, st);
+        case 46: return launch_halo3<T, 8, 64, 4, 2, 4>(k, st);
         default: return launch_dma<T, 128, 64, 2, 2, 128, 3>(k, mode, st);
     }
 }

@@ -411,6 +411,89 @@ def test_final_1x1_backward(dtype, n, hw, c, with_bias_in):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('cin,cout,hw,n', [(64, 64, 16, 2), (128, 128, 32, 2), (320, 128, 16, 3), (256, 256, 16, 2), (128, 320, 32, 1),
+                                           (64, 128, 48, 1)])
+def test_halo_tile_kernel_for_3x3_convs_of_any_width(dtype, cin, cout, hw, n):
+    """configurations 42..46 (conv3x3_halo_dma_kernel: the halo of a 64-channel chunk is fetched once for the nine taps): plain,
+    flipped taps + accumulate (data gradient), folded BN + ReLU, channel slices of wider buffers, and the three kinds of
+    epilogue statistics, against torch"""
+    import ctypes as C
+    from mapping_challenge_amd import _lib, ops
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    x = rnd((n, cin, hw, hw), dtype, 1)
+    w = rnd((cout, cin, 3, 3), dtype, 2, (2.0 / (cin * 9)) ** 0.5)
+    prev = rnd((n, cout, hw, hw), dtype, 3)
+    act = torch.relu(rnd((n, cout, hw, hw), dtype, 4))
+    scale, shift = torch.rand(cout) + 0.5, torch.randn(cout) * 0.1
+    ref = F.conv2d(x, w, padding=1)
+    ref_flip = F.conv2d(x, w.flip(2, 3), padding=1)
+    # operands as channel slices: input channels [8, 8+cin) of a wider buffer, output channels [16, 16+cout)
+    xin = torch.zeros((n, hw, hw, cin + 24), dtype=dtype, device='cuda')
+    xin[..., 8:8 + cin] = nhwc(x, dtype)
+    xs = xin[..., 8:8 + cin]
+    wk = w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    obuf = torch.zeros((n, hw, hw, cout + 32), dtype=dtype, device='cuda')
+    resd, actd = nhwc(prev, dtype), nhwc(act, dtype)
+    sc, sh = scale.cuda(), shift.cuda()
+
+    def desc(cfg):
+        d = ops.ConvDesc()
+        d.in_, d.wt, d.out = xs.data_ptr(), wk.data_ptr(), obuf.data_ptr() + 16 * obuf.element_size()
+        d.in_ld, d.out_ld, d.dtype, d.mode = cin + 24, cout + 32, ops._dt(xin), 0
+        d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.cfg = n, hw, hw, cin, hw, hw, cout, 3, 3, 1, 1, cfg
+        return d
+
+    def result():
+        assert (obuf[..., :16] == 0).all() and (obuf[..., 16 + cout:] == 0).all()      # nothing outside the slice
+        return to_nchw(obuf[..., 16:16 + cout])
+
+    tried = 0
+    for cfg in range(42, lib.msc_conv_num_cfgs() + 1):
+        d = desc(cfg)
+        if not lib.msc_conv_cfg_ok(C.byref(d), cfg):
+            continue
+        tried += 1
+        obuf.zero_()
+        _lib.check(lib.msc_conv_igemm(C.byref(d), st), 'plain')
+        assert torch.allclose(result(), ref, **tol(dtype)), cfg
+        # data-gradient form: flipped taps, accumulated onto what the output already holds
+        d = desc(cfg)
+        obuf[..., 16:16 + cout] = resd
+        d.flip, d.res, d.res_ld = 1, d.out, cout + 32
+        _lib.check(lib.msc_conv_igemm(C.byref(d), st), 'flip+res')
+        assert torch.allclose(result(), ref_flip + prev, **tol(dtype)), cfg
+        # folded BatchNorm + ReLU, with the BN partial statistics of the raw accumulators
+        d = desc(cfg)
+        obuf.zero_()
+        stats = torch.zeros((_lib.BN_SLOTS, cout, 2), dtype=torch.float64, device='cuda')
+        d.scale, d.shift, d.relu, d.stats = sc.data_ptr(), sh.data_ptr(), 1, stats.data_ptr()
+        _lib.check(lib.msc_conv_igemm(C.byref(d), st), 'bn')
+        assert torch.allclose(result(), torch.relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)), **tol(dtype)), cfg
+        ssum = stats.sum(0).float().cpu()
+        assert torch.allclose(ssum[:, 0], ref.sum((0, 2, 3)), rtol=2e-2, atol=0.5), cfg
+        assert torch.allclose(ssum[:, 1], (ref * ref).sum((0, 2, 3)), rtol=2e-2, atol=0.5), cfg
+        # stats_kind 1 (BatchNorm-backward sums against y = act, masked by scale*y+shift > 0) and 2 (ReLU backward + bias sums)
+        d = desc(cfg)
+        obuf.zero_(); stats.zero_()
+        d.flip, d.stats, d.stats_kind, d.stats_y, d.stats_y_ld = 1, stats.data_ptr(), 1, actd.data_ptr(), cout
+        d.scale, d.shift = sc.data_ptr(), sh.data_ptr()
+        _lib.check(lib.msc_conv_igemm(C.byref(d), st), 'kind1')
+        assert torch.allclose(result(), ref_flip, **tol(dtype)), cfg
+        m1 = ((act * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) > 0).float()
+        ssum = stats.sum(0).float().cpu()
+        assert torch.allclose(ssum[:, 0], (ref_flip * m1).sum((0, 2, 3)), rtol=2e-2, atol=0.5), cfg
+        assert torch.allclose(ssum[:, 1], (ref_flip * m1 * act).sum((0, 2, 3)), rtol=2e-2, atol=0.5), cfg
+        d = desc(cfg)
+        obuf.zero_(); stats.zero_()
+        d.flip, d.stats, d.stats_kind, d.stats_y, d.stats_y_ld = 1, stats.data_ptr(), 2, actd.data_ptr(), cout
+        _lib.check(lib.msc_conv_igemm(C.byref(d), st), 'kind2')
+        assert torch.allclose(result(), ref_flip * (act > 0), **tol(dtype)), cfg
+        assert torch.allclose(stats.sum(0)[:, 0].float().cpu(), (ref_flip * (act > 0)).sum((0, 2, 3)), rtol=2e-2, atol=0.5), cfg
+    assert tried >= 2, tried
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('hw,n,flip,with_res,relu', [(32, 3, False, False, True), (48, 2, True, True, False), (16, 1, True, False, False)])
 def test_halo_tile_kernel_for_32_channel_3x3(hw, n, flip, with_res, relu, dtype):
     """the halo-tile configuration (last one) of the 32-channel 3x3 layers: bias / scale, ReLU, residual accumulate and the
