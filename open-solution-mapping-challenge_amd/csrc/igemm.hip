@@ -1060,6 +1060,7 @@ struct WgK {
     int nblocks;                     // ntiles*ntaps*splits
     unsigned p_bytes, q_bytes;
     float rcp_hw, rcp_w;
+    int kw3, sw;                     // kw3: a block covers the three taps of a kernel row (wgrad3_dma_body; ntaps = KH); sw = min(Wp, 32)
 };
 
 // Blocks that share a pixel range (one split) share P/Q: give each XCD (block b runs on XCD b % 8) a contiguous
@@ -1460,6 +1461,212 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
     }
 }
 
+// Three taps per block (3x3, stride 1, pad 1, 16-bit): the P rows (the output gradient) of a k-step do not depend on the tap,
+// and the Q rows of the taps (kh, 0..2) are the same image-row segment shifted by one pixel -- so the segment is staged ONCE
+// with a one-pixel halo on both sides (row q = k + kw + 2*(k / sw), sw = pixels per image-row segment of a k-step) and the
+// three taps read it at row offsets 0, 1, 2: per k-step 32 P rows + 34..40 Q rows feed three tile products instead of
+// 3 x (32 + 32) rows feeding them one by one (2.9x fewer bytes through the L2 -> LDS fill that bounds the single-tap kernel,
+// and the P fragments are read from LDS once for the three).  A block accumulates 3 tiles; the kernel rows (kh) stay separate
+// blocks.  Geometry: Wp a multiple of 32, or 16, or 8 (a k-step is 32 consecutive pixels = one segment, 2 or 4 image rows).
+template <typename T, int TA, int TB, int NST>
+__device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, const int nwg) {
+    static_assert(sizeof(T) == 2, "16-bit types");
+    constexpr int ES = 2, KP = 32;
+    constexpr int RBA = TA * ES, RBB = TB * ES;
+    constexpr int UA = RBA / 16, UB = RBB / 16;
+    constexpr int RPA = 1024 / RBA, RPB = 1024 / RBB;            // pixel rows per DMA wave-instruction
+    constexpr int NIA = KP * RBA / 1024;
+    constexpr int IA = (NIA + 3) / 4;
+    constexpr int QRMAX = KP + 8;                                  // sw = 8: four segments with two halo rows each
+    constexpr int IB = ((QRMAX + RPB - 1) / RPB + 3) / 4;          // Q wave-instructions per wave (uniform; rows past the image: out of range)
+    constexpr int QROWS = IB * 4 * RPB;                            // rows the Q part of a stage holds
+    constexpr int STAGE = KP * RBA + QROWS * RBB;
+    constexpr int LPW = IA + IB;
+    constexpr int WTA = TA / 2, WTB = TB / 2;
+    constexpr int FM = WTA / 16, FN = WTB / 16;
+    static_assert(NIA >= 2, "tile too small");
+    static_assert(NST * STAGE <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wid >> 1, wb = wid & 1;
+    const int g = lane >> 4, pl = lane & 15;
+    int tile, kh, split;
+    wgrad_block(p, orig, nwg, tile, kh, split);
+    const int ta = tile / p.tiles_b, tb = tile - ta * p.tiles_b;
+    const int a0 = ta * TA, b0 = tb * TB;
+    const int mbeg = split * p.mchunk;
+    const int mend = min(p.M, mbeg + p.mchunk);
+    const int nsteps = mend > mbeg ? (mend - mbeg + KP - 1) / KP : 0;
+    const int sw = p.sw, seg_rows = sw + 2;
+    const int qr_used = KP + 2 * (KP / sw);
+
+    const u32x4_t rp = make_srd(p.p, p.p_bytes);
+    const u32x4_t rq = make_srd(p.q, p.q_bytes);
+    const unsigned ppix = (unsigned)p.p_ld * ES, qpix = (unsigned)p.q_ld * ES;
+    const unsigned hw = (unsigned)(p.Hp * p.Wp);
+
+    int prow[IA];
+    unsigned pcol[IA];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+        const int j = NIA >= 4 ? i * 4 + wid : (wid & (NIA - 1));
+        prow[i] = j * RPA + lane / UA;
+        pcol[i] = (unsigned)a0 * ES + (unsigned)wg_swz<T>(lane % UA, prow[i], UA) * 16u;
+    }
+    // Q rows: LDS row q of the stage = segment q / (sw+2), position q % (sw+2) - 1 in [-1, sw] relative to the segment's first
+    // pixel; (n, y, x) of that first pixel advance by one k-step (32 pixels) per stage
+    unsigned qcol[IB];
+    int qxi[IB], qn_[IB], qy_[IB], qx_[IB];
+    bool qlive[IB];
+    const int dxs = KP % p.Wp, dys = KP / p.Wp;
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+        const int q = (i * 4 + wid) * RPB + lane / UB;
+        const int sg = q / seg_rows;
+        qlive[i] = q < qr_used;
+        qxi[i] = q - sg * seg_rows - 1;
+        qcol[i] = (unsigned)b0 * ES + (unsigned)wg_swz<T>(lane % UB, q, UB) * 16u;
+        const unsigned m = (unsigned)(mbeg + (qlive[i] ? sg * sw : 0));
+        const unsigned n = udiv_rcp(m, hw, p.rcp_hw);
+        const unsigned rem = m - n * hw;
+        const unsigned y = udiv_rcp(rem, (unsigned)p.Wp, p.rcp_w);
+        qn_[i] = (int)n; qy_[i] = (int)y; qx_[i] = (int)(rem - y * (unsigned)p.Wp);
+    }
+    auto piece = [&](int i, int s, int stage) {
+        const int mb = mbeg + s * KP;
+        char* sp = smem + stage * STAGE;
+        char* sq = sp + KP * RBA;
+        if (i < IA) {
+            const int ii = i < IA ? i : 0;
+            const int m = mb + prow[ii];
+            const unsigned off = m < mend ? (unsigned)m * ppix + pcol[ii] : OOB_OFF;
+            dma16(rp, sp + (NIA >= 4 ? ii * 4 + wid : (wid & (NIA - 1))) * 1024, off, 0);
+        } else {
+            const int ii = i >= IA ? i - IA : 0;
+            int n = qn_[ii], y = qy_[ii], x = qx_[ii];
+            unsigned off = OOB_OFF;
+            const int iy = y - 1 + kh, ix = x + qxi[ii];
+            if (qlive[ii] && mb < mend && (unsigned)iy < (unsigned)p.Hq && (unsigned)ix < (unsigned)p.Wq)
+                off = (unsigned)((n * p.Hq + iy) * p.Wq + ix) * qpix + qcol[ii];
+            dma16(rq, sq + (ii * 4 + wid) * 1024, off, 0);
+            x += dxs;
+            if (x >= p.Wp) { x -= p.Wp; ++y; }
+            y += dys;
+            if (y >= p.Hp) { y -= p.Hp; ++n; }
+            qn_[ii] = n; qy_[ii] = y; qx_[ii] = x;
+        }
+    };
+    auto issue = [&](int s, int stage) {
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) piece(i, s, stage);
+    };
+
+    // fragment read offsets (bytes within a stage): lane t=pl of a 16-lane group addresses pixel row 8g + (pl>>2) (+4 for the
+    // second half), channels 4*(pl&3)..+3; Q rows additionally shifted by the tap and the halo rows of the segments before
+    int aoff[FM][2], boff[3][FN][2];
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+        const int c = wa * WTA + a * 16 + 4 * (pl & 3);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = 8 * g + (pl >> 2) + 4 * h;
+            aoff[a][h] = r * RBA + wg_swz<T>(c >> 3, r, UA) * 16 + (c & 7) * 2;
+        }
+    }
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int b = 0; b < FN; ++b) {
+            const int c = wb * WTB + b * 16 + 4 * (pl & 3);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = 8 * g + (pl >> 2) + 4 * h;
+                const int q = r + kw + 2 * (r / sw);
+                boff[kw][b][h] = KP * RBA + q * RBB + wg_swz<T>(c >> 3, q, UB) * 16 + (c & 7) * 2;
+            }
+        }
+    auto frag = [&](const char* sb, const int* off) -> uint4 {
+        typedef __attribute__((address_space(3))) v4i16_t* lp_t;
+        const v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(sb + off[0]));
+        const v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(sb + off[1]));
+        const uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+        return make_uint4(l.x, l.y, h.x, h.y);
+    };
+
+    f32x4 acc[3][FM][FN];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+            for (int b = 0; b < FN; ++b) acc[kw][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nsteps > 0) {
+#pragma unroll
+        for (int st = 0; st < NST - 1; ++st)
+            if (st < nsteps) issue(st, st);
+        constexpr int NM = 3 * FM * FN;
+        auto kstep = [&](auto issue_tag, int s) {
+            constexpr bool ISSUE = decltype(issue_tag)::value;
+            const char* sb = smem + (s & (NST - 1)) * STAGE;
+            uint4 af[FM];
+#pragma unroll
+            for (int a = 0; a < FM; ++a) af[a] = frag(sb, aoff[a]);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                uint4 bf[FN];
+#pragma unroll
+                for (int b = 0; b < FN; ++b) bf[b] = frag(sb, boff[kw][b]);
+#pragma unroll
+                for (int a = 0; a < FM; ++a)
+#pragma unroll
+                    for (int b = 0; b < FN; ++b) {
+                        if (ISSUE) {
+#pragma unroll
+                            for (int i = 0; i < LPW; ++i)
+                                if ((i * NM) / LPW == (kw * FM + a) * FN + b) piece(i, s + NST - 1, (s + NST - 1) & (NST - 1));
+                        }
+                        Mma<T>::run(af[a], bf[b], acc[kw][a][b]);
+                    }
+            }
+        };
+        const int nmain = nsteps - (NST - 1);
+        int s = 0;
+        for (; s < nmain; ++s) {
+            wait_vmcnt<(NST - 2) * LPW>();
+            raw_barrier();
+            kstep(std::true_type{}, s);
+        }
+        for (; s < nsteps; ++s) {
+            if (s + NST - 2 <= nsteps - 1) wait_vmcnt<(NST - 2) * LPW>();
+            else wait_vmcnt<0>();
+            raw_barrier();
+            kstep(std::false_type{}, s);
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int a = 0; a < FM; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ia = a0 + wa * WTA + a * 16 + 4 * g + r;
+#pragma unroll
+                    for (int b = 0; b < FN; ++b) {
+                        const int ib = b0 + wb * WTB + b * 16 + pl;
+                        if (ia < p.A && ib < p.B) atomicAdd(p.dw + (ia * 9L + kh * 3 + kw) * p.B + ib, acc[kw][a][b][r]);
+                    }
+                }
+    }
+}
+
+template <typename T, int TA, int TB, int NST>
+__global__ __launch_bounds__(256) void conv_wgrad3_dma_kernel(WgK p) {
+    if constexpr (sizeof(T) == 2) wgrad3_dma_body<T, TA, TB, NST>(p, blockIdx.x, gridDim.x);
+}
+
 template <typename T, int TA, int TB, int NST, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgK p) {
     wgrad_dma_body<T, TA, TB, NST, ABL>(p, blockIdx.x, gridDim.x);
@@ -1481,6 +1688,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_group_kernel(const WgK* __rest
     const int orig = b - __builtin_amdgcn_readfirstlane(starts[i]);
     if (orig >= p.nblocks) return;
     wgrad_dma_body<T, TA, TB, NST>(p, orig, p.nblocks);
+}
+
+template <typename T, int TA, int TB, int NST>
+__global__ __launch_bounds__(256) void conv_wgrad3_group_kernel(const WgK* __restrict__ tab, const int* __restrict__ starts, int n) {
+    if constexpr (sizeof(T) == 2) {
+        const int b = blockIdx.x;
+        int i = 0;
+        while (i + 1 < n && starts[i + 1] <= b) ++i;
+        WgK p;
+        const int* src = reinterpret_cast<const int*>(tab + i);
+        int* dst = reinterpret_cast<int*>(&p);
+#pragma unroll
+        for (unsigned j = 0; j < sizeof(WgK) / 4; ++j) dst[j] = __builtin_amdgcn_readfirstlane(src[j]);
+        const int orig = b - __builtin_amdgcn_readfirstlane(starts[i]);
+        if (orig >= p.nblocks) return;
+        wgrad3_dma_body<T, TA, TB, NST>(p, orig, p.nblocks);
+    }
 }
 
 bool env_flag(const char* name) {
@@ -1771,7 +1995,7 @@ extern "C" int msc_conv_wgrad_num_cfgs(void) { return WGRAD_NCFG; }
 
 namespace {
 
-struct WgPlan { WgK k; int dtype, ta, tb; bool dma; };
+struct WgPlan { WgK k; int dtype, ta, tb; bool dma, kw3; };
 
 // Validates a descriptor and fixes tile shape and split-K.  steps_per_block > 0 (grouped launches: other problems
 // fill the chip, so a block just runs that many k-steps) overrides the per-launch policy selected by d->cfg.
@@ -1801,6 +2025,14 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
     k.rcp_w = 1.0f / (float)d->Wp;
     const int kp = 64 / es;
     const int ksteps = ceil_div(k.M, kp);
+    // three taps of a kernel row per block (wgrad3_dma_body): 3x3 / stride 1 / pad 1 in a 16-bit type, image rows that a
+    // 32-pixel k-step covers in whole segments
+    static const bool kw3_on = [] { const char* e = getenv("MSC_WGRAD_KW3"); return !(e && e[0] == '0'); }();
+    const bool kw3 = kw3_on && !use_v1_wgrad() && fits && es == 2 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Hq == d->Hp &&
+                     d->Wq == d->Wp && (d->Wp % 32 == 0 || d->Wp == 16 || d->Wp == 8) && d->Hp >= 8 && k.M % 32 == 0;
+    const int ntaps = kw3 ? d->KH : d->KH * d->KW;
+    k.kw3 = kw3 ? 1 : 0;
+    k.sw = d->Wp < 32 ? d->Wp : 32;
     bool big = (d->A % 128 == 0) && (d->B % 128 == 0);
     int tsel = 0, splits;
     if (steps_per_block > 0) {
@@ -1820,13 +2052,13 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
         if (d->cfg) {
             if (tsel) big = false;
         } else if (big) {
-            const int tiles128 = (d->A / 128) * (d->B / 128) * d->KH * d->KW;
+            const int tiles128 = (d->A / 128) * (d->B / 128) * ntaps;
             int sp = ceil_div(768, tiles128);
             if (sp > max_splits) sp = max_splits;
             if ((long)tiles128 * sp < 384) big = false;     // not enough parallelism: 64x64 tiles instead
         }
         const int ta0 = big ? 128 : (d->A % 64 == 0 && tsel != 2 ? 64 : 32), tb0 = big ? 128 : (d->B % 64 == 0 ? 64 : 32);
-        splits = ceil_div(target, (d->A / ta0) * (d->B / tb0) * d->KH * d->KW);
+        splits = ceil_div(target, (d->A / ta0) * (d->B / tb0) * ntaps);
         if (splits > max_splits) splits = max_splits;
     }
     const int ta = big ? 128 : (d->A % 64 == 0 && tsel != 2 ? 64 : 32), tbs = big ? 128 : (d->B % 64 == 0 ? 64 : 32);
@@ -1835,10 +2067,20 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
     mchunk = ceil_div(mchunk, kp) * kp;
     splits = ceil_div(k.M, mchunk);
     k.mchunk = mchunk; k.tiles_b = d->B / tbs;
-    k.ntiles = (d->A / ta) * (d->B / tbs); k.ntaps = d->KH * d->KW; k.xcd_order = xcd_order_enabled() ? 1 : 0;
+    k.ntiles = (d->A / ta) * (d->B / tbs); k.ntaps = ntaps; k.xcd_order = xcd_order_enabled() ? 1 : 0;
     k.nblocks = k.ntiles * k.ntaps * splits;
     out->dtype = d->dtype; out->ta = ta; out->tb = tbs;
     out->dma = !use_v1_wgrad() && k.p_bytes != 0;
+    out->kw3 = kw3;
+    // 128x128 tiles: three accumulator sets leave one wave per SIMD and one block per CU -- measured 15 % slower than the
+    // single-tap blocks at two blocks per CU (profiles: 859 vs 745 us for the 3x3 layers of the ResNet101 step); MSC_WGRAD_KW3=2 forces it
+    static const bool kw3_big = [] { const char* e = getenv("MSC_WGRAD_KW3"); return e && e[0] == '2'; }();
+    if (kw3 && ta == 128 && !kw3_big) {
+        out->kw3 = false;
+        k.kw3 = 0;
+        k.ntaps = d->KH * d->KW;
+        k.nblocks = k.ntiles * k.ntaps * splits;
+    }
     return MSC_OK;
 }
 
@@ -1858,15 +2100,17 @@ void wgrad_tile_dispatch(int dtype, int ta, int tb, F&& f) {
 struct WgLaunchOne {
     const WgK& k; bool dma; hipStream_t st;
     template <typename T, int TA, int TB> void operator()() const {
-        if (dma) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, TA, TB, 4>), dim3(k.nblocks), dim3(256), 0, st, k);
+        if (dma && k.kw3) hipLaunchKernelGGL((conv_wgrad3_dma_kernel<T, TA, TB, 4>), dim3(k.nblocks), dim3(256), 0, st, k);
+        else if (dma) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, TA, TB, 4>), dim3(k.nblocks), dim3(256), 0, st, k);
         else hipLaunchKernelGGL((conv_wgrad_kernel<T, TA, TB>), dim3(k.nblocks), dim3(256), 0, st, k);
     }
 };
 
 struct WgLaunchGroup {
-    const WgK* tab; const int* starts; int n, blocks; hipStream_t st;
+    const WgK* tab; const int* starts; int n, blocks; hipStream_t st; bool kw3;
     template <typename T, int TA, int TB> void operator()() const {
-        hipLaunchKernelGGL((conv_wgrad_group_kernel<T, TA, TB, 4>), dim3(blocks), dim3(256), 0, st, tab, starts, n);
+        if (kw3) hipLaunchKernelGGL((conv_wgrad3_group_kernel<T, TA, TB, 4>), dim3(blocks), dim3(256), 0, st, tab, starts, n);
+        else hipLaunchKernelGGL((conv_wgrad_group_kernel<T, TA, TB, 4>), dim3(blocks), dim3(256), 0, st, tab, starts, n);
     }
 };
 
@@ -1882,7 +2126,7 @@ extern "C" int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream) {
 
 // ---- grouped weight gradients ---------------------------------------------------------------------
 struct msc_wgrad_group {
-    struct Bucket { int dtype, ta, tb, n, blocks; WgK* tab; int* starts; };
+    struct Bucket { int dtype, ta, tb, n, blocks; WgK* tab; int* starts; bool kw3; };
     std::vector<Bucket> buckets;      // DMA-kernel problems by (dtype, tile): one launch each
     std::vector<WgPlan> singles;      // problems the DMA kernel cannot take (>= 2 GiB operands): launched one by one
     void* dev = nullptr;              // one allocation behind every table
@@ -1904,8 +2148,8 @@ extern "C" int msc_wgrad_group_create(const msc_wgrad_desc* descs, int n, int st
         if (!p.dma) { g->singles.push_back(p); continue; }
         size_t b = 0;
         for (; b < g->buckets.size(); ++b)
-            if (g->buckets[b].dtype == p.dtype && g->buckets[b].ta == p.ta && g->buckets[b].tb == p.tb) break;
-        if (b == g->buckets.size()) { g->buckets.push_back({p.dtype, p.ta, p.tb, 0, 0, nullptr, nullptr}); members.emplace_back(); }
+            if (g->buckets[b].dtype == p.dtype && g->buckets[b].ta == p.ta && g->buckets[b].tb == p.tb && g->buckets[b].kw3 == p.kw3) break;
+        if (b == g->buckets.size()) { g->buckets.push_back({p.dtype, p.ta, p.tb, 0, 0, nullptr, nullptr, p.kw3}); members.emplace_back(); }
         members[b].push_back(i);
     }
     size_t bytes = 0;
@@ -1944,7 +2188,7 @@ extern "C" int msc_wgrad_group_run(const msc_wgrad_group* g, void* stream) {
     if (!g) return msc_fail(MSC_ERR_ARG, "msc_wgrad_group_run: null group");
     hipStream_t st = (hipStream_t)stream;
     for (const auto& bk : g->buckets)
-        wgrad_tile_dispatch(bk.dtype, bk.ta, bk.tb, WgLaunchGroup{bk.tab, bk.starts, bk.n, bk.blocks, st});
+        wgrad_tile_dispatch(bk.dtype, bk.ta, bk.tb, WgLaunchGroup{bk.tab, bk.starts, bk.n, bk.blocks, st, bk.kw3});
     for (const auto& p : g->singles) wgrad_tile_dispatch(p.dtype, p.ta, p.tb, WgLaunchOne{p.k, p.dma, st});
     return msc_check_launch("wgrad_group");
 }

@@ -160,6 +160,40 @@ def test_weight_gradient(dtype, cin, cout, k, stride, hw, n):
     assert (dw.cpu() - ref).abs().max().item() / scale < (2e-5 if dtype == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('cin,cout,hw,n', [(128, 128, 32, 2), (128, 256, 16, 3), (64, 64, 64, 1), (64, 64, 8, 4), (64, 32, 16, 2), (32, 64, 32, 1),
+                                           (32, 32, 16, 2), (320, 128, 8, 2), (128, 128, 96, 1)])
+def test_weight_gradient_three_taps_per_block(dtype, cin, cout, hw, n):
+    """3x3 / stride 1 / pad 1 in a 16-bit type on image rows of 8, 16 or a multiple of 32 pixels: a block covers the three taps of
+    a kernel row from ONE staged segment with a one-pixel halo (wgrad3_dma_body) -- every tile shape, every split-K policy, alone
+    and grouped, channel slices of wider buffers, against torch; MSC_WGRAD_KW3=0 (single-tap blocks) must agree bit for bit in
+    the structure of the result (same tolerance)"""
+    from mapping_challenge_amd import _lib, ops
+    x = rnd((n, cin, hw, hw), dtype, 1)
+    w = rnd((cout, cin, 3, 3), dtype, 2, 0.05).requires_grad_(True)
+    y = F.conv2d(x, w, padding=1)
+    dy = rnd(tuple(y.shape), dtype, 3)
+    y.backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1)
+    scale = ref.abs().max().item()
+    # operands as channel slices of wider buffers (the concat halves the decoder reads in place)
+    xb = torch.zeros((n, hw, hw, cin + 32), dtype=dtype, device='cuda'); xb[..., 16:16 + cin] = nhwc(x, dtype)
+    db = torch.zeros((n, hw, hw, cout + 64), dtype=dtype, device='cuda'); db[..., 32:32 + cout] = nhwc(dy, dtype)
+    xs, ds = xb[..., 16:16 + cin], db[..., 32:32 + cout]
+    ncfg = _lib.load().msc_conv_wgrad_num_cfgs()
+    for c in [0] + list(range(1 if (cin % 128 == 0 and cout % 128 == 0) else 6, ncfg + 1)):
+        dw = torch.zeros((cout, 3, 3, cin), dtype=torch.float32, device='cuda')
+        ops.conv_wgrad(ds, xs, dw, 3, 3, stride=1, pad=1, cfg=c)
+        assert (dw.cpu() - ref).abs().max().item() / scale < 1e-2, c
+    for steps, cap in [(64, 128), (4, 64), (1, 32)]:
+        dw = torch.zeros((cout, 3, 3, cin), dtype=torch.float32, device='cuda')
+        dw1 = torch.zeros((cin, 1, 1, cin), dtype=torch.float32, device='cuda')      # a 1x1 problem in the same group (other bucket)
+        ops.conv_wgrad_group([(ds, xs, dw, 3, 3, 1, 1), (xs, xs, dw1, 1, 1, 1, 0)], steps, cap)
+        assert (dw.cpu() - ref).abs().max().item() / scale < 1e-2, (steps, cap)
+        g1 = torch.einsum('nhwa,nhwb->ab', xs.float(), xs.float()).cpu()
+        assert (dw1.cpu().view(cin, cin) - g1).abs().max().item() / g1.abs().max().item() < 1e-2
+
+
 @pytest.mark.parametrize('dtype', DT)
 def test_maxpool_forward_backward(dtype):
     from mapping_challenge_amd import ops
