@@ -147,7 +147,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
     const T* res = reinterpret_cast<const T*>(p.res);
     // the tensor the epilogue reads (residual / BatchNorm-backward y) is fetched for all fragments before the first use --
     // nothing else is left to hide its latency behind -- where the wave tile is small enough to afford the registers
-    constexpr bool PRE = FN * (NV / CE) <= 2;
+    constexpr bool PRE = FN * (NV / CE) <= 8;
     const T* side = (bnb || rlb) ? reinterpret_cast<const T*>(p.sy) : res;
     const long side_ld = (bnb || rlb) ? p.sy_ld : p.res_ld;
     uint4 pre[PRE ? FN : 1][PRE ? NV / CE : 1];
@@ -1721,8 +1721,8 @@ bool use_v1_wgrad() { static int v = -1; if (v < 0) v = env_flag("MSC_WGRAD_V1")
 // heuristic (cfg 0) the caller may pick one explicitly -- UNetResNet times the valid ones per layer when it builds
 // a program (msc_conv_cfg_ok enumerates them).
 struct ConvCfg { int tp, tc, wp, wc, kb, nst; };
-constexpr int N_CONV_CFG = 46;
-constexpr int CFG_HALO3_FIRST = 42;      // 42..46: conv3x3_halo_dma_kernel
+constexpr int N_CONV_CFG = 50;
+constexpr int CFG_HALO3_FIRST = 42, CFG_HALO3_LAST = 46;      // conv3x3_halo_dma_kernel
 constexpr int CFG_HALO = 27;          // conv3x3_c32_halo_kernel (not a tile of the DMA kernel)
 constexpr int CFG_HALO_T = 28;        // deconv4_c128_c32_halo_kernel
 static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
@@ -1786,6 +1786,12 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {128, 64, 2, 2, 128, 4},    // 44:  8x16 patch x  64 ch, 4 waves of 64 px x 32 ch,  80 KB, 2 blocks/CU
     {256, 64, 4, 2, 128, 4},    // 45: 16x16 patch x  64 ch, 8 waves of 64 px x 32 ch, 128 KB
     {128, 64, 4, 2, 128, 4},    // 46:  8x16 patch x  64 ch, 8 waves of 32 px x 32 ch,  80 KB, 2 blocks/CU
+    // many resident blocks for the HBM-bound 1x1 layers with one or two k-steps (64 / 128 input channels, >= 32 k pixels): the
+    // ring hides nothing there, the bytes in flight per CU are what counts
+    {64, 64, 2, 2, 128, 2},     // 47:  32 KB, 5 blocks/CU
+    {128, 64, 2, 2, 128, 2},    // 48:  48 KB, 3 blocks/CU
+    {64, 128, 2, 2, 128, 2},    // 49:  48 KB, 3 blocks/CU
+    {128, 128, 2, 2, 64, 2},    // 50:  32 KB, 5 blocks/CU (64-byte k-steps)
 };
 
 template <typename T, int TP, int TC, int WP, int WC, int KB, int NST, int ABL = 0>
@@ -1829,7 +1835,7 @@ bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
         return es == 2 && k.mode == 1 && k.KH == 4 && k.KW == 4 && k.stride == 2 && k.pad == 1 && k.Cin == 128 && k.Cout == 32 &&
                k.Hi % 8 == 0 && k.Wi % 16 == 0 && k.Ho == 2 * k.Hi && k.Wo == 2 * k.Wi && !k.stats && k.res_ld % 8 == 0 && k.out_ld % 8 == 0;
     const ConvCfg& c = CONV_CFGS[cfg];
-    if (cfg >= CFG_HALO3_FIRST)
+    if (cfg >= CFG_HALO3_FIRST && cfg <= CFG_HALO3_LAST)
         return es == 2 && k.mode == 0 && k.KH == 3 && k.KW == 3 && k.stride == 1 && k.pad == 1 && k.Hi == k.Ho && k.Wi == k.Wo &&
                k.Wo % 16 == 0 && k.Ho % (c.tp / 16) == 0 && (k.Cin * es) % 128 == 0 && k.Cout % c.tc == 0 && k.in_bytes != 0;
     if (k.Cout % c.tc) return false;
@@ -1911,6 +1917,10 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
         case 44: return launch_halo3<T, 8, 64, 2, 2, 4>(k, st);
         case 45: return launch_halo3<T, 16, 64, 4, 2, 4>(k, st);
         case 46: return launch_halo3<T, 8, 64, 4, 2, 4>(k, st);
+        case 47: return launch_dma<T, 64, 64, 2, 2, 128, 2>(k, mode, st);
+        case 48: return launch_dma<T, 128, 64, 2, 2, 128, 2>(k, mode, st);
+        case 49: return launch_dma<T, 64, 128, 2, 2, 128, 2>(k, mode, st);
+        case 50: return launch_dma<T, 128, 128, 2, 2, 64, 2>(k, mode, st);
         default: return launch_dma<T, 128, 64, 2, 2, 128, 3>(k, mode, st);
     }
 }
