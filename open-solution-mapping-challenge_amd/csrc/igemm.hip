@@ -670,22 +670,32 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
 //   NWS weight stages.  Every wave issues the same number of DMA instructions per k-step -- pieces past the end of the
 //   reduction or of the halo go out with an out-of-range offset (no memory traffic) -- so the counted vmcnt of a k-step is
 //   a compile-time constant per tap.
-template <typename T, int PH, int TC, int WP, int WC, int NWS>
-__global__ __launch_bounds__(WP * WC * 64) void conv3x3_halo_dma_kernel(ConvK p) {
+//   TPS taps per k-step (1 or 3): on the 16x16 maps a k-step of one tap is 257 MFMA cycles per SIMD between two barriers;
+//   a kernel row per k-step (weight stage = 3 slices) has 12 barriers per chunk-loop pass instead of 36.
+//   MINB = blocks per CU the register allocation has to allow (HIP's second launch bound counts waves per SIMD).
+template <typename T, int PH, int TC, int WP, int WC, int NWS, int TPS = 1, int MINB = 1>
+__global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo_dma_kernel(ConvK p) {
     static_assert(sizeof(T) == 2, "16-bit types");
+    static_assert(TPS == 1 || TPS == 3, "taps per k-step");
     constexpr int ES = 2, KB = 128;
     constexpr int NW = WP * WC;
+    constexpr int SPC = 9 / TPS;                              // k-steps per chunk
     constexpr int HCOLS = 18, HPIX = (PH + 2) * HCOLS;
     constexpr int NHI = (HPIX + 7) / 8;                       // DMA wave-instructions per halo chunk (8 pixels x 128 B)
     constexpr int XH = (NHI + NW - 1) / NW;                   // ... per wave
     constexpr int HBUF = XH * NW * 1024;                      // a halo buffer (padded to whole instructions of every wave)
-    constexpr int NIW = TC / 8;                               // DMA wave-instructions per weight stage
-    constexpr int WI = (NIW + NW - 1) / NW;
-    constexpr int WSTAGE = TC * KB;
+    constexpr int NIW = TC / 8;                               // DMA wave-instructions per weight slice (one tap)
+    constexpr int WI1 = (NIW + NW - 1) / NW;                  // ... per wave
+    constexpr int WI = WI1 * TPS;                             // weight pieces per wave and k-step
+    constexpr int WSLICE = TC * KB, WSTAGE = TPS * WSLICE;
+    // halo pieces of the next chunk: HPS per k-step, all of them out by k-step SPC - (NWS - 1) (the k-step that issues the
+    // first weight stage of the next chunk -- the wait that covers that stage then covers them too)
+    constexpr int HSTEPS = SPC - (NWS - 1) + 1 > 0 ? SPC - (NWS - 1) + 1 : 1;
+    constexpr int HPS = (XH + HSTEPS - 1) / HSTEPS;
     constexpr int FN = PH / WP, WTC = TC / WC, FM = WTC / 16, NV = FM * 4;
     static_assert(PH % WP == 0 && TC % (WC * 16) == 0, "wave tiling");
-    static_assert(XH <= 9 - (NWS - 2), "halo pieces of a chunk must be out before the waits that cover them");
-    static_assert(NIW % NW == 0 || NIW < NW, "weight tile / wave count");
+    static_assert(NWS - 1 <= SPC, "ring deeper than a chunk");
+    static_assert(NIW % NW == 0 || (NIW < NW && TPS == 1), "weight tile / wave count");
     static_assert(2 * HBUF + NWS * WSTAGE <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) char smem[2 * HBUF + NWS * WSTAGE];
 
@@ -721,9 +731,9 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_halo_dma_kernel(ConvK p)
         const bool ok = hp < HPIX && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
         hoff[i] = ok ? (unsigned)((n * p.Hi + iy) * p.Wi + ix) * pix_bytes + (unsigned)(slot ^ ((hp >> 1) & 7)) * 16u : OOB_OFF;
     }
-    unsigned woff[WI];
+    unsigned woff[WI1];
 #pragma unroll
-    for (int i = 0; i < WI; ++i) {
+    for (int i = 0; i < WI1; ++i) {
         const int j = NIW >= NW ? i * NW + wid : wid % NIW;
         const int row = j * 8 + lr;
         const int co = c0 + row;
@@ -754,15 +764,17 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_halo_dma_kernel(ConvK p)
 
     char* const hbase = smem;
     char* const wbase = smem + 2 * HBUF;
-    // ---- issue state: the next weight stage to fetch is (chunk iwc, tap iwt) into ring slot iws
+    // ---- issue state: the next weight stage to fetch is (chunk iwc, first tap iwt) into ring slot iws
     int iwc = 0, iwt = 0, iws = 0;
-    auto w_piece = [&](int i) {
+    auto w_piece = [&](int i) {                      // piece i of the stage: slice i / WI1 (a tap), rows of piece i % WI1
+        const int ts = i / WI1, ii = i % WI1;
         const bool live = iwc < nchunks;
-        const int soff = iwt * (int)tap_bytes + iwc * KB;
-        dma16(rw, wbase + iws * WSTAGE + (NIW >= NW ? i * NW + wid : wid % NIW) * 1024, live ? woff[i] : OOB_OFF, live ? soff : 0);
+        const int soff = (iwt + ts) * (int)tap_bytes + iwc * KB;
+        dma16(rw, wbase + iws * WSTAGE + ts * WSLICE + (NIW >= NW ? ii * NW + wid : wid % NIW) * 1024, live ? woff[ii] : OOB_OFF, live ? soff : 0);
     };
     auto w_advance = [&]() {
-        if (++iwt == 9) { iwt = 0; ++iwc; }
+        iwt += TPS;
+        if (iwt == 9) { iwt = 0; ++iwc; }
         if (++iws == NWS) iws = 0;
     };
     auto h_piece = [&](int i, int chunk) {            // piece i of the halo of `chunk` into buffer chunk & 1
@@ -781,42 +793,60 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_halo_dma_kernel(ConvK p)
     }
 
     int cst = 0;                                      // ring slot of the weight stage being consumed
-    constexpr int NM = 2 * FM * FN;                   // MFMAs per k-step and wave
+    constexpr int NM = 2 * FM * FN * TPS;             // MFMAs per k-step and wave
     for (int c = 0; c < nchunks; ++c) {
         const char* hb = hbase + (c & 1) * HBUF;
-        auto tap = [&](auto tt) {
-            constexpr int t = decltype(tt)::value;
-            // operations issued after the last piece of this k-step's weight stage: the NWS-2 later stages and the halo
-            // pieces of the NWS-2 k-steps before this one (taps < XH carry one)
-            constexpr int NH = [] { int h = 0; for (int d = 1; d <= NWS - 2; ++d) h += ((t - d + 9) % 9) < XH ? 1 : 0; return h; }();
+        auto step = [&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            // halo pieces this k-step issues, and those the NWS-2 k-steps before it issued: the operations younger than the
+            // last piece of this k-step's weight stage are the NWS-2 later stages and those halo pieces
+            constexpr int H0 = j * HPS < XH ? j * HPS : XH, H1 = (j + 1) * HPS < XH ? (j + 1) * HPS : XH;
+            constexpr int NH = [] {
+                int h = 0;
+                for (int d = 1; d <= NWS - 2; ++d) {
+                    const int jp = (j - d + SPC) % SPC;
+                    const int a0 = jp * HPS < XH ? jp * HPS : XH, a1 = (jp + 1) * HPS < XH ? (jp + 1) * HPS : XH;
+                    h += a1 - a0;
+                }
+                return h;
+            }();
             wait_vmcnt<(NWS - 2) * WI + NH>();
             raw_barrier();
             const char* wb = wbase + cst * WSTAGE;
-            if (t < XH) h_piece(t < XH ? t : 0, c + 1);          // before this k-step's weight pieces (the count above relies on it)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                uint4 af[FM], bf[FN];
+            for (int i = H0; i < H1; ++i) h_piece(i, c + 1);          // before this k-step's weight pieces (the count above relies on it)
 #pragma unroll
-                for (int a = 0; a < FM; ++a) af[a] = *reinterpret_cast<const uint4*>(wb + (aoff[a] ^ (kk * 64)));
+            for (int ts = 0; ts < TPS; ++ts) {
+                constexpr int dummy = 0; (void)dummy;
 #pragma unroll
-                for (int b = 0; b < FN; ++b) bf[b] = *reinterpret_cast<const uint4*>(hb + (boff[t][b] ^ (kk * 64)));
+                for (int kk = 0; kk < 2; ++kk) {
+                    uint4 af[FM], bf[FN];
 #pragma unroll
-                for (int a = 0; a < FM; ++a)
+                    for (int a = 0; a < FM; ++a) af[a] = *reinterpret_cast<const uint4*>(wb + ts * WSLICE + (aoff[a] ^ (kk * 64)));
 #pragma unroll
-                    for (int b = 0; b < FN; ++b) {
-                        const int m = (kk * FM + a) * FN + b;
+                    for (int b = 0; b < FN; ++b) bf[b] = *reinterpret_cast<const uint4*>(hb + (boff[j * TPS + ts][b] ^ (kk * 64)));
 #pragma unroll
-                        for (int i = 0; i < WI; ++i)
-                            if ((i * NM) / WI == m) w_piece(i);
-                        Mma<T>::run(af[a], bf[b], acc[a][b]);
-                    }
+                    for (int a = 0; a < FM; ++a)
+#pragma unroll
+                        for (int b = 0; b < FN; ++b) {
+                            const int m = ((ts * 2 + kk) * FM + a) * FN + b;
+#pragma unroll
+                            for (int i = 0; i < WI; ++i)
+                                if ((i * NM) / WI == m) w_piece(i);
+                            Mma<T>::run(af[a], bf[b], acc[a][b]);
+                        }
+                }
             }
             w_advance();
             if (++cst == NWS) cst = 0;
         };
-        tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
-        tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
-        tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+        if constexpr (TPS == 1) {
+            step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+        } else {
+            step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+        }
     }
     wait_vmcnt<0>();                                  // the trailing out-of-range pieces still write zeros into the ring
     const int m0 = (n * p.Ho + y0) * p.Wo + x0;
@@ -1721,8 +1751,8 @@ bool use_v1_wgrad() { static int v = -1; if (v < 0) v = env_flag("MSC_WGRAD_V1")
 // heuristic (cfg 0) the caller may pick one explicitly -- UNetResNet times the valid ones per layer when it builds
 // a program (msc_conv_cfg_ok enumerates them).
 struct ConvCfg { int tp, tc, wp, wc, kb, nst; };
-constexpr int N_CONV_CFG = 50;
-constexpr int CFG_HALO3_FIRST = 42, CFG_HALO3_LAST = 46;      // conv3x3_halo_dma_kernel
+constexpr int N_CONV_CFG = 56;
+static inline bool cfg_is_halo3(int cfg) { return (cfg >= 42 && cfg <= 46) || (cfg >= 51 && cfg <= 56); }      // conv3x3_halo_dma_kernel
 constexpr int CFG_HALO = 27;          // conv3x3_c32_halo_kernel (not a tile of the DMA kernel)
 constexpr int CFG_HALO_T = 28;        // deconv4_c128_c32_halo_kernel
 static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
@@ -1792,6 +1822,13 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {128, 64, 2, 2, 128, 2},    // 48:  48 KB, 3 blocks/CU
     {64, 128, 2, 2, 128, 2},    // 49:  48 KB, 3 blocks/CU
     {128, 128, 2, 2, 64, 2},    // 50:  32 KB, 5 blocks/CU (64-byte k-steps)
+    // more halo-tile variants: a kernel row (three taps) per k-step = a third of the barriers; two blocks per CU
+    {128, 64, 4, 2, 128, 3},    // 51:  8x16 patch x  64 ch, 8 waves, 3 taps per k-step, 120 KB
+    {128, 64, 2, 2, 128, 3},    // 52:  8x16 patch x  64 ch, 4 waves, 3 taps per k-step, 120 KB
+    {256, 64, 4, 2, 128, 2},    // 53: 16x16 patch x  64 ch, 8 waves, 3 taps per k-step, 144 KB
+    {128, 128, 2, 4, 128, 2},   // 54:  8x16 patch x 128 ch, 8 waves, 3 taps per k-step, 144 KB
+    {128, 128, 2, 4, 128, 2},   // 55:  8x16 patch x 128 ch, 8 waves, 80 KB, 2 blocks/CU
+    {256, 128, 4, 2, 128, 2},   // 56: 16x16 patch x 128 ch, 8 waves, 128 KB
 };
 
 template <typename T, int TP, int TC, int WP, int WC, int KB, int NST, int ABL = 0>
@@ -1806,14 +1843,14 @@ int launch_dma(const ConvK& k0, int mode, hipStream_t st) {
     return msc_check_launch("conv_igemm_dma");
 }
 
-template <typename T, int PH, int TC, int WP, int WC, int NWS>
+template <typename T, int PH, int TC, int WP, int WC, int NWS, int TPS = 1, int MINB = 1>
 int launch_halo3(const ConvK& k0, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         ConvK k = k0;
         k.ntc = k.Cout / TC;
         k.xcd_order = xcd_order_enabled() ? 1 : 0;
         const int blocks = k.N * (k.Ho / PH) * (k.Wo / 16) * k.ntc;
-        hipLaunchKernelGGL((conv3x3_halo_dma_kernel<T, PH, TC, WP, WC, NWS>), dim3(blocks), dim3(WP * WC * 64), 0, st, k);
+        hipLaunchKernelGGL((conv3x3_halo_dma_kernel<T, PH, TC, WP, WC, NWS, TPS, MINB>), dim3(blocks), dim3(WP * WC * 64), 0, st, k);
     }
     return msc_check_launch("conv3x3_halo_dma");
 }
@@ -1835,7 +1872,7 @@ bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
         return es == 2 && k.mode == 1 && k.KH == 4 && k.KW == 4 && k.stride == 2 && k.pad == 1 && k.Cin == 128 && k.Cout == 32 &&
                k.Hi % 8 == 0 && k.Wi % 16 == 0 && k.Ho == 2 * k.Hi && k.Wo == 2 * k.Wi && !k.stats && k.res_ld % 8 == 0 && k.out_ld % 8 == 0;
     const ConvCfg& c = CONV_CFGS[cfg];
-    if (cfg >= CFG_HALO3_FIRST && cfg <= CFG_HALO3_LAST)
+    if (cfg_is_halo3(cfg))
         return es == 2 && k.mode == 0 && k.KH == 3 && k.KW == 3 && k.stride == 1 && k.pad == 1 && k.Hi == k.Ho && k.Wi == k.Wo &&
                k.Wo % 16 == 0 && k.Ho % (c.tp / 16) == 0 && (k.Cin * es) % 128 == 0 && k.Cout % c.tc == 0 && k.in_bytes != 0;
     if (k.Cout % c.tc) return false;
@@ -1921,6 +1958,12 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
         case 48: return launch_dma<T, 128, 64, 2, 2, 128, 2>(k, mode, st);
         case 49: return launch_dma<T, 64, 128, 2, 2, 128, 2>(k, mode, st);
         case 50: return launch_dma<T, 128, 128, 2, 2, 64, 2>(k, mode, st);
+        case 51: return launch_halo3<T, 8, 64, 4, 2, 3, 3>(k, st);
+        case 52: return launch_halo3<T, 8, 64, 2, 2, 3, 3>(k, st);
+        case 53: return launch_halo3<T, 16, 64, 4, 2, 2, 3>(k, st);
+        case 54: return launch_halo3<T, 8, 128, 2, 4, 2, 3>(k, st);
+        case 55: return launch_halo3<T, 8, 128, 2, 4, 2, 1, 2>(k, st);
+        case 56: return launch_halo3<T, 16, 128, 4, 2, 2, 1>(k, st);
         default: return launch_dma<T, 128, 64, 2, 2, 128, 3>(k, mode, st);
     }
 }

@@ -765,7 +765,7 @@ class _Builder:
 
     # ---- per-layer kernel configuration (like cuDNN's benchmark mode): time the valid configurations once per
     # distinct layer shape on the real buffers and keep the fastest; results are cached process-wide
-    def _time(self, fn, dref, reps=3):
+    def _time(self, fn, dref, reps=5):
         stream = _stream_of(self.dev)
         if fn(dref, stream) != 0:
             return None
