@@ -140,8 +140,18 @@ def test_product_backward_in_pieces_with_async_allreduce_matches_full_batch(wire
     q = ctx.Queue()
     port = 31500 + os.getpid() % 2000 + (7 if wire == 'bf16' else 0)
     procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, q, wire)) for r in range(2)]
-    for p in procs:
-        p.start()
+    threads = str(max(1, (os.cpu_count() or 2) // 2))          # two ranks share the host's cores: no BLAS oversubscription
+    saved = {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS')}
+    os.environ.update({k: threads for k in saved})
+    try:
+        for p in procs:
+            p.start()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(60)
