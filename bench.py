@@ -351,7 +351,9 @@ def main():
             if os.path.exists(pmc_file):      # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_summary.py)
                 traffic = json.load(open(pmc_file)).get('hbm_bytes_per_launch')
             result['roofline'] = {
-                'kernel': 'conv_igemm_dma_kernel (implicit-GEMM conv / dgrad / deconv, %d launches per step, per-layer autotuned tile)' % round(conv['launches']),
+                'kernel': ('msc_conv_igemm family: conv3x3_halo_dma_kernel (3x3 stride-1 layers) + conv_igemm_dma_kernel (1x1, strided, transposed) '
+                           '+ the two 32-channel halo kernels; conv / dgrad / deconv, %d launches per step, per-layer autotuned configuration'
+                           % round(conv['launches'])),
                 'bound': 'mfma', 'achieved': ach / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
                 'avg_launch_us': 1e3 * conv['ms'] / max(conv['launches'], 1),
                 'algorithmic_gflop_per_step': conv['flops'] / 1e9,

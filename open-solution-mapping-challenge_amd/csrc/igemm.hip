@@ -1498,7 +1498,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
 // 3 x (32 + 32) rows feeding them one by one (2.9x fewer bytes through the L2 -> LDS fill that bounds the single-tap kernel,
 // and the P fragments are read from LDS once for the three).  A block accumulates 3 tiles; the kernel rows (kh) stay separate
 // blocks.  Geometry: Wp a multiple of 32, or 16, or 8 (a k-step is 32 consecutive pixels = one segment, 2 or 4 image rows).
-template <typename T, int TA, int TB, int NST>
+template <typename T, int TA, int TB, int NST, int NWV = 4>
 __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, const int nwg) {
     static_assert(sizeof(T) == 2, "16-bit types");
     constexpr int ES = 2, KP = 32;
@@ -1506,15 +1506,16 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
     constexpr int UA = RBA / 16, UB = RBB / 16;
     constexpr int RPA = 1024 / RBA, RPB = 1024 / RBB;            // pixel rows per DMA wave-instruction
     constexpr int NIA = KP * RBA / 1024;
-    constexpr int IA = (NIA + 3) / 4;
+    constexpr int NWA = NWV / 2;                                    // waves along the A (output-gradient channel) dimension x 2 along B
+    constexpr int IA = (NIA + NWV - 1) / NWV;
     constexpr int QRMAX = KP + 8;                                  // sw = 8: four segments with two halo rows each
-    constexpr int IB = ((QRMAX + RPB - 1) / RPB + 3) / 4;          // Q wave-instructions per wave (uniform; rows past the image: out of range)
-    constexpr int QROWS = IB * 4 * RPB;                            // rows the Q part of a stage holds
+    constexpr int IB = ((QRMAX + RPB - 1) / RPB + NWV - 1) / NWV;  // Q wave-instructions per wave (uniform; rows past the image: out of range)
+    constexpr int QROWS = IB * NWV * RPB;                          // rows the Q part of a stage holds
     constexpr int STAGE = KP * RBA + QROWS * RBB;
     constexpr int LPW = IA + IB;
-    constexpr int WTA = TA / 2, WTB = TB / 2;
+    constexpr int WTA = TA / NWA, WTB = TB / 2;
     constexpr int FM = WTA / 16, FN = WTB / 16;
-    static_assert(NIA >= 2, "tile too small");
+    static_assert(NIA >= 2 && (NIA >= NWV || NWV == 4), "tile too small");
     static_assert(NST * STAGE <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
 
@@ -1542,7 +1543,7 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
     unsigned pcol[IA];
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-        const int j = NIA >= 4 ? i * 4 + wid : (wid & (NIA - 1));
+        const int j = NIA >= NWV ? i * NWV + wid : (wid & (NIA - 1));
         prow[i] = j * RPA + lane / UA;
         pcol[i] = (unsigned)a0 * ES + (unsigned)wg_swz<T>(lane % UA, prow[i], UA) * 16u;
     }
@@ -1554,7 +1555,7 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
     const int dxs = KP % p.Wp, dys = KP / p.Wp;
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-        const int q = (i * 4 + wid) * RPB + lane / UB;
+        const int q = (i * NWV + wid) * RPB + lane / UB;
         const int sg = q / seg_rows;
         qlive[i] = q < qr_used;
         qxi[i] = q - sg * seg_rows - 1;
@@ -1573,7 +1574,7 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
             const int ii = i < IA ? i : 0;
             const int m = mb + prow[ii];
             const unsigned off = m < mend ? (unsigned)m * ppix + pcol[ii] : OOB_OFF;
-            dma16(rp, sp + (NIA >= 4 ? ii * 4 + wid : (wid & (NIA - 1))) * 1024, off, 0);
+            dma16(rp, sp + (NIA >= NWV ? ii * NWV + wid : (wid & (NIA - 1))) * 1024, off, 0);
         } else {
             const int ii = i >= IA ? i - IA : 0;
             int n = qn_[ii], y = qy_[ii], x = qx_[ii];
@@ -1581,7 +1582,7 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
             const int iy = y - 1 + kh, ix = x + qxi[ii];
             if (qlive[ii] && mb < mend && (unsigned)iy < (unsigned)p.Hq && (unsigned)ix < (unsigned)p.Wq)
                 off = (unsigned)((n * p.Hq + iy) * p.Wq + ix) * qpix + qcol[ii];
-            dma16(rq, sq + (ii * 4 + wid) * 1024, off, 0);
+            dma16(rq, sq + (ii * NWV + wid) * 1024, off, 0);
             x += dxs;
             if (x >= p.Wp) { x -= p.Wp; ++y; }
             y += dys;
@@ -1692,9 +1693,9 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
     }
 }
 
-template <typename T, int TA, int TB, int NST>
-__global__ __launch_bounds__(256) void conv_wgrad3_dma_kernel(WgK p) {
-    if constexpr (sizeof(T) == 2) wgrad3_dma_body<T, TA, TB, NST>(p, blockIdx.x, gridDim.x);
+template <typename T, int TA, int TB, int NST, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void conv_wgrad3_dma_kernel(WgK p) {
+    if constexpr (sizeof(T) == 2) wgrad3_dma_body<T, TA, TB, NST, NWV>(p, blockIdx.x, gridDim.x);
 }
 
 template <typename T, int TA, int TB, int NST, int ABL = 0>
@@ -1720,8 +1721,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_group_kernel(const WgK* __rest
     wgrad_dma_body<T, TA, TB, NST>(p, orig, p.nblocks);
 }
 
-template <typename T, int TA, int TB, int NST>
-__global__ __launch_bounds__(256) void conv_wgrad3_group_kernel(const WgK* __restrict__ tab, const int* __restrict__ starts, int n) {
+template <typename T, int TA, int TB, int NST, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void conv_wgrad3_group_kernel(const WgK* __restrict__ tab, const int* __restrict__ starts, int n) {
     if constexpr (sizeof(T) == 2) {
         const int b = blockIdx.x;
         int i = 0;
@@ -1733,7 +1734,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_group_kernel(const WgK* __res
         for (unsigned j = 0; j < sizeof(WgK) / 4; ++j) dst[j] = __builtin_amdgcn_readfirstlane(src[j]);
         const int orig = b - __builtin_amdgcn_readfirstlane(starts[i]);
         if (orig >= p.nblocks) return;
-        wgrad3_dma_body<T, TA, TB, NST>(p, orig, p.nblocks);
+        wgrad3_dma_body<T, TA, TB, NST, NWV>(p, orig, p.nblocks);
     }
 }
 
@@ -2125,8 +2126,9 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
     out->dtype = d->dtype; out->ta = ta; out->tb = tbs;
     out->dma = !use_v1_wgrad() && k.p_bytes != 0;
     out->kw3 = kw3;
-    // 128x128 tiles: three accumulator sets leave one wave per SIMD and one block per CU -- measured 15 % slower than the
-    // single-tap blocks at two blocks per CU (profiles: 859 vs 745 us for the 3x3 layers of the ResNet101 step); MSC_WGRAD_KW3=2 forces it
+    // 128x128 tiles: with 4 waves three accumulator sets leave one wave per SIMD and one block per CU -- measured 15 % slower
+    // than the single-tap blocks at two blocks per CU (859 vs 745 us for the 3x3 layers of the ResNet101 step); the 8-wave form
+    // (two waves per SIMD, 96 accumulator registers) is what MSC_WGRAD_KW3=2 selects
     static const bool kw3_big = [] { const char* e = getenv("MSC_WGRAD_KW3"); return e && e[0] == '2'; }();
     if (kw3 && ta == 128 && !kw3_big) {
         out->kw3 = false;
@@ -2153,7 +2155,10 @@ void wgrad_tile_dispatch(int dtype, int ta, int tb, F&& f) {
 struct WgLaunchOne {
     const WgK& k; bool dma; hipStream_t st;
     template <typename T, int TA, int TB> void operator()() const {
-        if (dma && k.kw3) hipLaunchKernelGGL((conv_wgrad3_dma_kernel<T, TA, TB, 4>), dim3(k.nblocks), dim3(256), 0, st, k);
+        if (dma && k.kw3) {
+            if constexpr (TA == 128) hipLaunchKernelGGL((conv_wgrad3_dma_kernel<T, TA, TB, 4, 8>), dim3(k.nblocks), dim3(512), 0, st, k);
+            else hipLaunchKernelGGL((conv_wgrad3_dma_kernel<T, TA, TB, 4>), dim3(k.nblocks), dim3(256), 0, st, k);
+        }
         else if (dma) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, TA, TB, 4>), dim3(k.nblocks), dim3(256), 0, st, k);
         else hipLaunchKernelGGL((conv_wgrad_kernel<T, TA, TB>), dim3(k.nblocks), dim3(256), 0, st, k);
     }
@@ -2162,7 +2167,10 @@ struct WgLaunchOne {
 struct WgLaunchGroup {
     const WgK* tab; const int* starts; int n, blocks; hipStream_t st; bool kw3;
     template <typename T, int TA, int TB> void operator()() const {
-        if (kw3) hipLaunchKernelGGL((conv_wgrad3_group_kernel<T, TA, TB, 4>), dim3(blocks), dim3(256), 0, st, tab, starts, n);
+        if (kw3) {
+            if constexpr (TA == 128) hipLaunchKernelGGL((conv_wgrad3_group_kernel<T, TA, TB, 4, 8>), dim3(blocks), dim3(512), 0, st, tab, starts, n);
+            else hipLaunchKernelGGL((conv_wgrad3_group_kernel<T, TA, TB, 4>), dim3(blocks), dim3(256), 0, st, tab, starts, n);
+        }
         else hipLaunchKernelGGL((conv_wgrad_group_kernel<T, TA, TB, 4>), dim3(blocks), dim3(256), 0, st, tab, starts, n);
     }
 };
