@@ -172,30 +172,40 @@ __global__ void ccl_compress_kernel(int32_t* __restrict__ L, long HW) {
         }
     }
 }
-// one block per image: rank[p] = number of roots before p (raster order), for roots only
+// one block per image: rank[p] = number of roots before p (raster order), for roots only.  The image is walked in chunks of
+// 1024 consecutive pixels (coalesced: lane = pixel), the roots of a chunk are ranked by wave ballots + a scan of the 16 wave
+// totals; one thread per contiguous 88-pixel segment (64 cache lines per wave-instruction) took 99 us per 128 images.
 __global__ __launch_bounds__(1024) void ccl_rank_kernel(const int32_t* __restrict__ L, int32_t* __restrict__ rank,
                                                         int32_t* __restrict__ counts, long HW) {
-    __shared__ int part[1024];
+    __shared__ int wtot[16];
+    __shared__ int base_s;
     const long b = blockIdx.x;
     const int* l = L + b * HW;
     int* r = rank + b * HW;
-    const long seg = (HW + 1023) / 1024;
-    const long beg = threadIdx.x * seg, end = min(HW, beg + seg);
-    int c = 0;
-    for (long p = beg; p < end; ++p) c += (l[p] == (int)p);
-    part[threadIdx.x] = c;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
     __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 per-thread counts
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    for (long p0 = 0; p0 < HW; p0 += 1024) {
+        const long p = p0 + threadIdx.x;
+        const bool root = p < HW && l[p] == (int)p;
+        const unsigned long long m = __ballot(root);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wtot[wid] = __popcll(m);
         __syncthreads();
-        part[threadIdx.x] += v;
+        int off = base_s;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) off += w < wid ? wtot[w] : 0;
+        if (root) r[p] = off + before;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) t += wtot[w];
+            base_s += t;
+        }
         __syncthreads();
     }
-    int base = part[threadIdx.x] - c;
-    for (long p = beg; p < end; ++p)
-        if (l[p] == (int)p) r[p] = base++;
-    if (threadIdx.x == 1023 && counts) counts[b] = part[1023];
+    if (threadIdx.x == 0 && counts) counts[b] = base_s;
 }
 __global__ void ccl_relabel_kernel(int32_t* __restrict__ L, const int32_t* __restrict__ rank, long HW) {
     const long b = blockIdx.y;

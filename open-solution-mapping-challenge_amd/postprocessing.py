@@ -151,6 +151,22 @@ def _to_host(t):
     return h.numpy()
 
 
+def _to_host_many(tensors):
+    """several D2H copies through pinned buffers behind one stream synchronisation"""
+    if not tensors[0].is_cuda:
+        return [t.detach().numpy().copy() for t in tensors]
+    hs = []
+    for t in tensors:
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t, non_blocking=True)
+        hs.append(h)
+    torch.cuda.current_stream(tensors[0].device).synchronize()
+    return [h.numpy() for h in hs]
+
+
+LABEL_CAPACITY = 512          # instances per image layer the score table is sized for before the counts are known (more: one re-score)
+
+
 def postprocess_device(probs, target_size=None, erode_selem_size=0, dilate_selem_size=0, category_layers=CATEGORY_LAYERS,
                        watershed_selem_size=0):
     """postprocess_batch without the final copy of the label images: returns (labels cuda i32 [B,L,H,W], per-image
@@ -191,26 +207,32 @@ def _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, catego
         labels, counts = label_batch(flat)
     if dilate_selem_size > 0:
         labels = dilate_batch(labels, dilate_selem_size)
-    counts_h = counts.cpu().numpy().reshape(B, L)
     # build_score zips layer l with probability channel l (src/postprocessing.py:230)
     n_scored = min(L, Cc)
-    max_labels = int(counts_h.max()) if counts_h.size else 0
     lab4 = labels.view(B, L, H, W)
-    scores_h = None
-    if max_labels > 0:
-        sl = lab4[:, :n_scored].contiguous().view(B * n_scored, H, W)
-        sp = p[:, :n_scored].contiguous().view(B * n_scored, H, W)
+    sl = lab4[:, :n_scored].contiguous().view(B * n_scored, H, W)
+    sp = p[:, :n_scored].contiguous().view(B * n_scored, H, W)
+    # The score table needs the largest label count, which lives on the device: score with a capacity guess straight away and
+    # fetch counts, scores (and labels) with ONE synchronisation; only a layer with more components than the guess costs a
+    # second scoring pass (the chain used to stop twice for the host: counts, then scores).
+    cap = LABEL_CAPACITY
+    scores_d = score_batch(sl, sp, cap)
+    got = _to_host_many([counts, scores_d] + ([lab4] if to_host else []))
+    counts_h = got[0].reshape(B, L)
+    max_labels = int(counts_h.max()) if counts_h.size else 0
+    scores_h = got[1].reshape(B, n_scored, cap)
+    if max_labels > cap:
         scores_h = score_batch(sl, sp, max_labels).cpu().numpy().reshape(B, n_scored, max_labels)
     scores = []
     for b in range(B):
         total = []
         for l in range(n_scored):
             n = int(counts_h[b, l])
-            total.append([float(v) for v in scores_h[b, l, :n]] if n else [])
+            total.append(scores_h[b, l, :n].tolist() if n else [])
         scores.append(total)
     if not to_host:
         return lab4, scores
-    labels_h = _to_host(lab4)
+    labels_h = got[2]
     return [(labels_h[b], scores[b]) for b in range(B)]
 
 
