@@ -893,6 +893,14 @@ __global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // stats_kind 2: the activation rows the epilogue masks by are requested before the tap loop (nothing after it could hide them)
+    const bool rlb0 = p.stats && p.stats_kind == 2;
+    uint4 ypre[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        ypre[b] = make_uint4(0u, 0u, 0u, 0u);
+        if (rlb0) ypre[b] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.sy) + ((long)(n * p.Ho + y0 + wid * 4 + b) * p.Wo + x0 + pl) * p.sy_ld + 8 * g);
+    }
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -933,7 +941,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
         }
         if (rlb) {                  // stats_kind 2: ReLU backward of the layer whose activation is sy, and its bias-gradient sums
             float yv[8];
-            Vec16<T>::load(reinterpret_cast<const T*>(p.sy) + opix * p.sy_ld + c0, yv);
+            Vec16<T>::unpack(ypre[b], yv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 v[j] = yv[j] > 0.f ? v[j] : 0.f;
