@@ -31,9 +31,10 @@ def main():
         rows.append({'kernel': name, 'launches': max(n_f, n_w), 'fetch_bytes_per_launch': fetch, 'write_bytes_per_launch': write,
                      'hbm_bytes_per_launch': fetch + write})
     rows.sort(key=lambda r: -r['hbm_bytes_per_launch'] * r['launches'])
-    fam = [r for r in rows if r['kernel'].startswith('conv_igemm_dma_kernel')]
+    FAMILY = ('conv_igemm_dma_kernel', 'conv3x3_halo_dma_kernel', 'conv3x3_c32_halo_kernel', 'deconv4_c128_c32_halo_kernel')      # = msc_conv_igemm
+    fam = [r for r in rows if r['kernel'].startswith(FAMILY)]
     tot_l = sum(r['launches'] for r in fam)
-    summary = {'family': 'conv_igemm_dma_kernel', 'launches': tot_l,
+    summary = {'family': 'msc_conv_igemm (conv_igemm_dma_kernel + halo-tile kernels)', 'launches': tot_l,
                'hbm_bytes_per_launch': sum(r['hbm_bytes_per_launch'] * r['launches'] for r in fam) / max(tot_l, 1),
                'note': 'FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes, averaged over all launches of the family',
                'kernels': rows[:40]}
