@@ -28,7 +28,14 @@ def main():
     for key, cs in rows[:60]:
         n = max(len(v) for v in cs.values())
         g, wg = grid[key]
-        print('%-72s %6d %8d ' % (key[0], n, g // max(wg, 1)) + ' '.join('%16.0f' % (sum(cs[c]) / len(cs[c])) if c in cs else '%16s' % '-' for c in counters))
+        avg = {c: sum(v) / len(v) for c, v in cs.items()}
+        line = '%-72s %6d %8d ' % (key[0], n, g // max(wg, 1)) + ' '.join('%16.0f' % avg[c] if c in cs else '%16s' % '-' for c in counters)
+        wc = avg.get('SQ_WAVE_CYCLES', 0)
+        if wc:      # shares of the wave cycles: parked (s_waitcnt / barrier), issue-stalled, issuing; MFMA-busy cycles per wave cycle (x waves per SIMD = pipe utilisation)
+            line += '   parked %4.1f%%  stalled %4.1f%%  issuing %4.1f%%  mfma/wave-cycle %5.3f' % (
+                100 * avg.get('SQ_WAIT_ANY', 0) / wc, 100 * avg.get('SQ_WAIT_INST_ANY', 0) / wc, 100 * avg.get('SQ_ACTIVE_INST_ANY', 0) / wc,
+                avg.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (4 * wc))
+        print(line)
 
 
 if __name__ == '__main__':
