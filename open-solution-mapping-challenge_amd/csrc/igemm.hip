@@ -53,6 +53,8 @@ struct ConvK {
     long in_ld, out_ld, res_ld;
     int N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, flip, relu;
     int M, Hq, Wq;
+    int span_bytes;                  // > 0: a K row of Cin*ES bytes spans several consecutive input pixels of span_bytes each (the KW taps of
+                                     // a compact narrow tensor merged into one tap, conv_fill); the lanes of the later pixels are bounds-checked on their own
     unsigned in_bytes, wt_bytes;     // extents for the buffer descriptors of the DMA kernel
     int ntc;                         // channel tiles (DMA kernel: 1-D grid of ntm*ntc blocks, XCD-aware order)
     int mode;                        // 0 gather, 1 transposed
@@ -508,6 +510,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
         xby[i] = MODE ? qy : qy * p.stride;
         xbx[i] = MODE ? qx : qx * p.stride;
         xkc[i] = (unsigned)(slot ^ swz_x<KB>(row)) * 16u;
+        if (p.span_bytes) xbx[i] += (int)(xkc[i] / (unsigned)p.span_bytes);      // merged taps (one k-step per tap row): this lane's own pixel
     }
     unsigned wrow[WI];
 #pragma unroll
@@ -533,7 +536,9 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
         for (int i = 0; i < XI; ++i) {
             const int iy = xby[i] + dy, ix = xbx[i] + dx;
             const bool ok = xv[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            xoff[i] = ok ? (unsigned)((xn[i] + iy) * p.Wi + ix) * pix_bytes + xkc[i] : OOB_OFF;
+            // merged taps: the row starts at the first pixel; xkc already is the lane's byte offset within the whole row
+            const int ix0 = p.span_bytes ? ix - (int)(xkc[i] / (unsigned)p.span_bytes) : ix;
+            xoff[i] = ok ? (unsigned)((xn[i] + iy) * p.Wi + ix0) * pix_bytes + xkc[i] : OOB_OFF;
         }
         const unsigned toff = (unsigned)(kh * p.KW + kw) * tap_bytes;
 #pragma unroll
@@ -1099,6 +1104,7 @@ struct WgK {
     unsigned p_bytes, q_bytes;
     float rcp_hw, rcp_w;
     int kw3, sw;                     // kw3: a block covers the three taps of a kernel row (wgrad3_dma_body; ntaps = KH); sw = min(Wp, 32)
+    int span_bytes;                  // > 0: a Q row of B*ES bytes spans several consecutive pixels of span_bytes each (KW taps merged, wgrad_plan)
 };
 
 // Blocks that share a pixel range (one split) share P/Q: give each XCD (block b runs on XCD b % 8) a contiguous
@@ -1360,9 +1366,12 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
                 n = (int)nn; y = (int)yy; x = (int)(rem - yy * (unsigned)p.Wp);
             }
             unsigned off = OOB_OFF;
-            const int iy = y * p.stride - p.pad + kh, ix = x * p.stride - p.pad + kw;
+            // merged taps (span_bytes): the Q row covers several pixels, this lane's 16 bytes belong to pixel ix0 + qsp and are
+            // bounds-checked as such; qcol already is the byte offset within the whole row
+            const int qsp = p.span_bytes ? (int)(qcol[ii] / (unsigned)p.span_bytes) : 0;
+            const int iy = y * p.stride - p.pad + kh, ix = x * p.stride - p.pad + kw + qsp;
             if (m < mend && (unsigned)iy < (unsigned)p.Hq && (unsigned)ix < (unsigned)p.Wq)
-                off = (unsigned)((n * p.Hq + iy) * p.Wq + ix) * qpix + qcol[ii];
+                off = (unsigned)((n * p.Hq + iy) * p.Wq + ix - qsp) * qpix + qcol[ii];
             dma16(rq, sq + (NIB >= 4 ? ii * 4 + wid : (wid & (NIB - 1))) * 1024, off, 0);
             // advance this piece's pixel by one k-step
             x += dxs;
@@ -1885,6 +1894,7 @@ bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
         return es == 2 && k.mode == 0 && k.KH == 3 && k.KW == 3 && k.stride == 1 && k.pad == 1 && k.Hi == k.Ho && k.Wi == k.Wo &&
                k.Wo % 16 == 0 && k.Ho % (c.tp / 16) == 0 && (k.Cin * es) % 128 == 0 && k.Cout % c.tc == 0 && k.in_bytes != 0;
     if (k.Cout % c.tc) return false;
+    if (k.span_bytes && (long)k.Cin * es != c.kb) return false;      // merged taps: the row is one k-step
     if (c.tc == 32 && k.Cout % 64 == 0) return false;        // a 32-channel tile only for the 32-channel layers
     if (((long)k.Cin * es) % c.kb) return false;
     return k.in_bytes != 0;
@@ -1893,6 +1903,7 @@ bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
 // heuristic: largest tile that still gives every CU a block; 64-byte K steps (best on average over the network)
 int pick_cfg(const ConvK& k) {
     const int M = k.M, Cout = k.Cout;
+    if (k.span_bytes) return Cout % 128 == 0 ? 23 : 20;      // merged taps: 256-byte k-steps only
     if (Cout % 128 == 0) {
         if ((long)ceil_div(M, 256) * (Cout / 128) >= 512) return 2;
         if ((long)ceil_div(M, 128) * (Cout / 128) >= 512) return 4;
@@ -2006,6 +2017,7 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
     k->N = d->N; k->Hi = d->Hi; k->Wi = d->Wi; k->Cin = d->Cin; k->Ho = d->Ho; k->Wo = d->Wo; k->Cout = d->Cout;
     k->KH = d->KH; k->KW = d->KW; k->stride = d->stride; k->pad = d->pad; k->flip = d->flip; k->relu = d->relu;
     k->mode = d->mode;
+    k->span_bytes = 0;
     if (d->mode == 1) {
         if (d->stride != 2 || (d->Ho & 1) || (d->Wo & 1)) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: transposed mode needs stride 2 and even output size");
         if (d->stats) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: stats not available in transposed mode");
@@ -2027,6 +2039,21 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
     const bool fits = in_b < 0x7fffffffL && wt_b < 0x7fffffffL;
     k->in_bytes = fits ? (unsigned)in_b : 0;
     k->wt_bytes = fits ? (unsigned)wt_b : 0;
+    // Narrow compact inputs (32 channels = 64-byte rows, the slow LDS-DMA case): the KW taps of a kernel row read KW consecutive
+    // pixels = KW*Cin contiguous elements, and the weights of those taps are contiguous too ([Cout][KH][KW][Cin]) -- run the layer
+    // as KW' = 1 with Cin' = KW*Cin (one 256-byte k-step per kernel row instead of four 64-byte ones); the DMA kernel bounds-checks
+    // every lane against the pixel its 16 bytes belong to (span_bytes).  Gather mode without flip only (the 4x4 / stride-2 data
+    // gradient of dec1's ConvTranspose2d: 32 -> 128 channels at full resolution).
+    // Measured on the one layer it applies to (32 -> 128, 524288 output pixels): 250 us merged vs 174 us with four 64-byte k-steps per
+    // kernel row -- the merged rows start 64 bytes off the 128-byte lines (pixel 2x-1) and straddle three of them; OFF by default
+    // (MSC_CONV_MERGE_KW=2 enables it).  The same merge in the weight gradient (wgrad_plan) is a gain and on by default.
+    static const bool merge_on = [] { const char* e = getenv("MSC_CONV_MERGE_KW"); return e && e[0] == '2'; }();
+    if (merge_on && fits && !use_v1_conv() && d->mode == 0 && !d->flip && d->KW > 1 && d->in_ld == d->Cin && (long)d->KW * d->Cin * es == 256 &&
+        (d->Cin * es) % 16 == 0 && d->Cout % 64 == 0) {
+        k->span_bytes = d->Cin * es;
+        k->Cin = d->KW * d->Cin;
+        k->KW = 1;
+    }
     return MSC_OK;
 }
 
@@ -2070,7 +2097,23 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
                       (d->KW == 1 && d->pad == 0 && (d->stride * d->q_ld * es) % 16 == 0 && ((int64_t)d->Wq * d->q_ld * es) % 16 == 0);
     if ((d->p_ld * es) % 16 || !q_ok || (((uintptr_t)d->p | (uintptr_t)d->q) & 15))
         return msc_fail(MSC_ERR_ARG, "msc_conv_wgrad: operands must keep 16-byte alignment");
+    // Narrow compact Q operand (32 channels = 64-byte rows): the KW taps of a kernel row read KW consecutive pixels = KW*B contiguous
+    // elements and write KW*B contiguous gradient columns ([A][KH][KW][B]) -- run it as KW' = 1, B' = KW*B (256-byte Q rows, the
+    // 128x128 tile instead of 64x32); the kernel bounds-checks every lane against the pixel its 16 bytes belong to.
+    msc_wgrad_desc merged = *d;
+    int span_bytes = 0;
+    static const bool merge_on = [] { const char* e = getenv("MSC_CONV_MERGE_KW"); return !(e && e[0] == '0'); }();
+    const long m_all = (long)d->N * d->Hp * d->Wp;
+    const bool dma_ok = m_all > 0 && m_all < (1L << 24) && ((m_all - 1) * d->p_ld + d->A) * es < 0x7fffffffL &&
+                        (((long)d->N * d->Hq * d->Wq - 1) * d->q_ld + (long)d->KW * d->B) * es < 0x7fffffffL;      // the DMA kernel will take it (see `fits` below)
+    if (merge_on && dma_ok && !use_v1_wgrad() && d->KW > 1 && d->q_ld == d->B && (long)d->KW * d->B * es == 256 && (d->B * es) % 16 == 0) {
+        span_bytes = d->B * es;
+        merged.B = d->KW * d->B;
+        merged.KW = 1;
+        d = &merged;
+    }
     WgK& k = out->k;
+    k.span_bytes = span_bytes;
     k.p = (const char*)d->p; k.q = (const char*)d->q; k.dw = d->dw; k.p_ld = d->p_ld; k.q_ld = d->q_ld;
     k.N = d->N; k.Hp = d->Hp; k.Wp = d->Wp; k.A = d->A; k.Hq = d->Hq; k.Wq = d->Wq; k.B = d->B;
     k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad;
