@@ -394,6 +394,14 @@ def test_conv_epilogue_relu_backward_and_bias_sums(dtype, cin, cout, k, stride, 
         assert (stats[:, :, 1] == 0).all(), c
         assert torch.allclose(db[:cout].cpu().double(), stored, rtol=2e-3, atol=(5e-2 if dtype == torch.float32 else 0.5)), c
         assert (db[cout:] == 0).all()
+        # several layers in one launch (what the program emits after the decoder's backward)
+        items = (_lib.BiasSlotsItem * 2)()
+        dbm = torch.zeros(2, cout, device='cuda')
+        for it, row, cc in ((items[0], dbm[0], cout), (items[1], dbm[1], 32)):
+            it.slots, it.db, it.Cs, it.C = stats.data_ptr(), row.data_ptr(), cout, cc
+        _lib.check(lib.msc_bias_slots_finalize_multi(items, 2, torch.cuda.current_stream().cuda_stream), 'fin multi')
+        assert torch.equal(dbm[0], db[:cout]) and torch.equal(dbm[1, :32], db[:32]) and (dbm[1, 32:] == 0).all(), c
+        assert lib.msc_bias_slots_finalize_multi(items, _lib.BIAS_SLOTS_MAX + 1, torch.cuda.current_stream().cuda_stream) != 0
         # a channel sub-range of wider slots (the decoder half of a concat buffer)
         if cout >= 64:
             db2 = torch.ones(32, device='cuda')
