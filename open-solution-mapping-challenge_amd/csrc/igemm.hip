@@ -822,7 +822,6 @@ __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo
             for (int i = H0; i < H1; ++i) h_piece(i, c + 1);          // before this k-step's weight pieces (the count above relies on it)
 #pragma unroll
             for (int ts = 0; ts < TPS; ++ts) {
-                constexpr int dummy = 0; (void)dummy;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     uint4 af[FM], bf[FN];
