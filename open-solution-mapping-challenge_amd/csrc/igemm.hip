@@ -1104,6 +1104,7 @@ struct WgK {
     float rcp_hw, rcp_w;
     int kw3, sw;                     // kw3: a block covers the three taps of a kernel row (wgrad3_dma_body; ntaps = KH); sw = min(Wp, 32)
     int span_bytes;                  // > 0: a Q row of B*ES bytes spans several consecutive pixels of span_bytes each (KW taps merged, wgrad_plan)
+    int no_direct;                   // 1: keep the general pixel decode also for 1x1 / stride 1 (A/B measurements, MSC_WGRAD_DIRECT=0)
 };
 
 // Blocks that share a pixel range (one split) share P/Q: give each XCD (block b runs on XCD b % 8) a contiguous
@@ -1333,6 +1334,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
     // k-step -- the address arithmetic was what bounded this kernel (probes/wgrad_ablate.hip: "DMA only" = 80 % of the full
     // time at 20 B/clk/CU).  Images smaller than a k-step's pixel run keep the division path.
     const bool incr = KP / p.Wp + 1 <= p.Hp;
+    const bool direct = !p.no_direct && p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Hq == p.Hp && p.Wq == p.Wp && !p.span_bytes;
     const int dxs = KP % p.Wp, dys = KP / p.Wp;
     int qn_[IB], qy_[IB], qx_[IB];
 #pragma unroll
@@ -1354,6 +1356,11 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
             const int m = mb + prow[ii];
             const unsigned off = m < mend ? (unsigned)m * ppix + pcol[ii] : OOB_OFF;
             dma16(rp, sp + (NIA >= 4 ? ii * 4 + wid : (wid & (NIA - 1))) * 1024, off, 0);
+        } else if (direct) {          // 1x1 / stride 1: the Q pixel IS the P pixel -- no decode, no bounds beyond the pixel range
+            const int ii = i >= IA ? i - IA : 0;
+            const int m = mb + qrow[ii];
+            const unsigned off = m < mend ? (unsigned)m * qpix + qcol[ii] : OOB_OFF;
+            dma16(rq, sq + (NIB >= 4 ? ii * 4 + wid : (wid & (NIB - 1))) * 1024, off, 0);
         } else {
             const int ii = i >= IA ? i - IA : 0;
             const int m = mb + qrow[ii];
@@ -2113,6 +2120,8 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
     }
     WgK& k = out->k;
     k.span_bytes = span_bytes;
+    static const bool direct_off = [] { const char* e = getenv("MSC_WGRAD_DIRECT"); return e && e[0] == '0'; }();
+    k.no_direct = direct_off ? 1 : 0;
     k.p = (const char*)d->p; k.q = (const char*)d->q; k.dw = d->dw; k.p_ld = d->p_ld; k.q_ld = d->q_ld;
     k.N = d->N; k.Hp = d->Hp; k.Wp = d->Wp; k.A = d->A; k.Hq = d->Hq; k.Wq = d->Wq; k.B = d->B;
     k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad;
