@@ -984,7 +984,6 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void deconv4_c128_c32_halo_kernel(ConvK p) {      // 2 blocks per CU (LDS): up to 256 VGPRs, no spills
     constexpr int HR = 10, HC = 18;                   // halo rows / columns
     __shared__ uint4 halo[HR * HC * 16];              // [pixel][16 chunks of 8 channels], chunk ^= pixel & 15
-    __shared__ uint4 wl[4 * 32 * 16];                 // [tap][cout][16 chunks], chunk ^= key(cout), distinct over a fragment's rows
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, pl = lane & 15;
     const int tiles_x = p.Wi / 16, tiles_y = p.Hi / 8;
@@ -1007,81 +1006,59 @@ __global__ __launch_bounds__(256, 2) void deconv4_c128_c32_halo_kernel(ConvK p) 
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = p.scale ? p.scale[c0 + j] : 1.f; sh[j] = p.shift ? p.shift[c0 + j] : 0.f; }
+    // One wave = one output-parity phase, for the whole 8 x 16 patch.  The 4 taps x 128 input channels x 32 output channels of
+    // its phase are 32 weight fragments = 128 VGPRs, fetched ONCE straight from L2 and held; only the pixel fragments come from
+    // LDS (one read per two MFMAs).  With the weights in LDS too (the first version: one phase at a time for all waves) every
+    // MFMA cost one fragment read and the LDS port, not the matrix pipe, set the pace.
     // row pl of weight fragment a is output channel 8*(pl>>2) + 4a + (pl&3): a lane ends with channels 8g..8g+7
-    int wrow[2];
+    const int ph = wid, py = ph >> 1, px = ph & 1;
+    const int kh0 = (py + 1) & 1, kw0 = (px + 1) & 1;                 // taps kh0, kh0+2 / kw0, kw0+2
+    uint4 aw[4][4][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) wrow[a] = 8 * (pl >> 2) + 4 * a + (pl & 3);
-    // the four taps of a phase: 2048 16-byte chunks, 8 per thread; fetched into registers one phase ahead
-    uint4 wreg[8];
-    auto wfetch = [&](int ph) {
-        const int kh0 = ((ph >> 1) + 1) & 1, kw0 = ((ph & 1) + 1) & 1;
+    for (int t = 0; t < 4; ++t) {
+        const int kh = kh0 + 2 * (t >> 1), kw = kw0 + 2 * (t & 1);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = tid + i * 256;
-            const int t = c >> 9, co = (c >> 4) & 31, ch = c & 15;
-            const int kh = kh0 + 2 * (t >> 1), kw = kw0 + 2 * (t & 1);
-            wreg[i] = *reinterpret_cast<const uint4*>(wt + ((long)(co * 4 + kh) * 4 + kw) * 128 + ch * 8);
-        }
-    };
-    wfetch(0);
-    for (int ph = 0; ph < 4; ++ph) {
-        const int py = ph >> 1, px = ph & 1;
-        const int kh0 = (py + 1) & 1, kw0 = (px + 1) & 1;             // taps kh0, kh0+2 / kw0, kw0+2
-        __syncthreads();                                              // previous phase done with wl (and halo written)
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = tid + i * 256;
-            const int t = c >> 9, co = (c >> 4) & 31, ch = c & 15;
-            wl[(t * 32 + co) * 16 + (ch ^ (((co >> 3) << 2) | (co & 3)))] = wreg[i];
-        }
-        __syncthreads();
-        if (ph < 3) wfetch(ph + 1);                                   // in flight while this phase computes
-        f32x4 acc[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int a = 0; a < 2; ++a) {
+                const int co = 8 * (pl >> 2) + 4 * a + (pl & 3);
+                aw[t][kk][a] = *reinterpret_cast<const uint4*>(wt + ((long)(co * 4 + kh) * 4 + kw) * 128 + (kk * 4 + g) * 8);
+            }
+    }
+    __syncthreads();                                                  // halo written
+#pragma unroll 1
+    for (int b = 0; b < 8; ++b) {
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int kh = kh0 + 2 * (t >> 1), kw = kw0 + 2 * (t & 1);
             const int dy = (py + 1 - kh) / 2, dx = (px + 1 - kw) / 2;  // input offset of this tap: -1, 0 or +1
+            const int pix = (b + 1 + dy) * HC + (pl + 1 + dx);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                uint4 af[2], bf[2];
-#pragma unroll
-                for (int a = 0; a < 2; ++a) af[a] = wl[(t * 32 + wrow[a]) * 16 + ((kk * 4 + g) ^ pl)];     // key(wrow[a]) == pl
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int pix = (wid * 2 + b + 1 + dy) * HC + (pl + 1 + dx);
-                    bf[b] = halo[pix * 16 + ((kk * 4 + g) ^ (pix & 15))];
-                }
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) Mma<T>::run(af[a], bf[b], acc[a][b]);
+                const uint4 bf = halo[pix * 16 + ((kk * 4 + g) ^ (pix & 15))];
+                Mma<T>::run(aw[t][kk][0], bf, acc[0]);
+                Mma<T>::run(aw[t][kk][1], bf, acc[1]);
             }
         }
+        const int oy = 2 * (qy0 + b) + py, ox = 2 * (qx0 + pl) + px;
+        const long opix = (long)(n * p.Ho + oy) * p.Wo + ox;
+        float v[8];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int oy = 2 * (qy0 + wid * 2 + b) + py, ox = 2 * (qx0 + pl) + px;
-            const long opix = (long)(n * p.Ho + oy) * p.Wo + ox;
-            float v[8];
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][r] * sc[a * 4 + r] + sh[a * 4 + r];
+        if (res) {
+            float rv[8];
+            Vec16<T>::load(res + opix * p.res_ld + c0, rv);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][b][r] * sc[a * 4 + r] + sh[a * 4 + r];
-            if (res) {
-                float rv[8];
-                Vec16<T>::load(res + opix * p.res_ld + c0, rv);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += rv[j];
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-            }
-            Vec16<T>::store(out + opix * p.out_ld + c0, v);
+            for (int j = 0; j < 8; ++j) v[j] += rv[j];
         }
+        if (p.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        Vec16<T>::store(out + opix * p.out_ld + c0, v);
     }
 }
 
