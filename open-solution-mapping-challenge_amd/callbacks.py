@@ -49,12 +49,14 @@ class Callback:
         self.model = self.optimizer = self.loss_function = self.output_names = None
         self.validation_datagen = self.lr_scheduler = None
         self.validation_loss = None
+        self.world = None                 # distributed.World of the transformer (one process per GPU); None = single process
 
     def set_params(self, transformer, validation_datagen, *args, **kwargs):
         self.model, self.optimizer = transformer.model, transformer.optimizer
         self.loss_function, self.output_names = transformer.loss_function, transformer.output_names
         self.validation_datagen = validation_datagen
         self.validation_loss = transformer.validation_loss
+        self.world = getattr(transformer, 'world', None)
 
     def on_train_begin(self, *args, **kwargs):
         self.epoch_id, self.batch_id = 0, 0
@@ -80,8 +82,14 @@ class Callback:
     def get_validation_loss(self):
         if self.epoch_id not in self.validation_loss:
             self.model.eval()
-            self.validation_loss[self.epoch_id] = score_model(self.model, self.loss_function, self.validation_datagen)
+            score = score_model(self.model, self.loss_function, self.validation_datagen)
             self.model.train()
+            # one process per GPU: every rank validates its own shard with its own BatchNorm running statistics; the
+            # decisions taken from the value (best checkpoint, early stopping) must be the same on every rank or a rank
+            # that stops alone leaves the others in the next gradient all-reduce -> mean over ranks
+            if self.world is not None and self.world.size > 1:
+                score = {k: self.world.all_reduce(v.detach().clone().float()) / self.world.size for k, v in score.items()}
+            self.validation_loss[self.epoch_id] = score
         return self.validation_loss[self.epoch_id]
 
 
@@ -232,9 +240,13 @@ class ModelCheckpoint(Callback):
                         or self.epoch_id == 0)
                 if save:
                     self.best_score = loss_sum
-            if save:
+            # one process per GPU: rank 0 writes (its BatchNorm running statistics are the ones kept, as DataParallel keeps
+            # replica 0's); the file appears atomically so a reader never sees a half-written archive
+            if save and (self.world is None or self.world.rank == 0):
                 self.model.eval()
-                torch.save(self.model.state_dict(), self.filepath)
+                tmp = '%s.tmp.%d' % (self.filepath, os.getpid())
+                torch.save(self.model.state_dict(), tmp)
+                os.replace(tmp, self.filepath)
                 self.model.train()
                 logger.info('epoch {0} model saved to {1}'.format(self.epoch_id, self.filepath))
         self.epoch_id += 1

@@ -25,6 +25,12 @@ import torch.distributed as dist
 GRAD_BUCKET_BYTES = 64 << 20
 
 
+def wire_for(compute_dtype):
+    """gradient wire format for a compute dtype: 16-bit compute -> 'bf16' (fp16 compute too: its gradients carry the static
+    loss scale until Adam divides it out, an fp16 wire would overflow above 65504 / scale), fp32 -> 'fp32'"""
+    return 'bf16' if compute_dtype in ('bf16', 'fp16') else 'fp32'
+
+
 class _Done:
     """handle of a gradient exchange issued on the communication stream: wait() orders the caller's stream after it"""
 

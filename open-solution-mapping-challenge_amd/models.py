@@ -21,7 +21,7 @@ import torch
 
 from . import _lib
 from .callbacks import callbacks_unet
-from .distributed import World
+from .distributed import World, wire_for
 from .postprocessing import _to_host
 from .steps import BaseTransformer
 from .trainer import HipAdam, HipLoss, LossSpec, TrainStep
@@ -72,6 +72,7 @@ class _TransformerView:
         self.optimizer, self.loss_function = t.optimizer, t.loss_function
         self.output_names, self.validation_loss = t.output_names, t.validation_loss
         self.callbacks = t.callbacks
+        self.world = t.world          # the product's callbacks average the validation loss over ranks and save on rank 0 only
 
 
 class BasePyTorchUNet(BaseTransformer):
@@ -90,8 +91,10 @@ class BasePyTorchUNet(BaseTransformer):
         self.optimizer = HipAdam(self.model, lr=opt.get('lr', 1e-3), weight_decay=wd)
         self.loss_spec = None
         self.loss_function = None                    # [(name, callable(output, target) -> loss, weight)] set by subclasses
-        # gradients travel in the compute dtype when that is a 16-bit one (distributed.World.all_reduce_grad_range)
-        self.world = World(grad_wire=self.model.compute_dtype)
+        # gradients travel in 16 bits when the network computes in 16 bits (distributed.World.all_reduce_grad_range) -- always
+        # as bf16: under fp16 compute the gradients still carry the static loss scale (divided out inside Adam), and an
+        # fp16 wire would overflow at |g| > 65504 / scale; bf16 has fp32's exponent range
+        self.world = World(grad_wire=wire_for(self.model.compute_dtype))
         self.callbacks = callbacks_unet(self.callbacks_config)     # replaceable by the reference's own CallbackList
         self.epoch_losses = []
 
@@ -154,11 +157,21 @@ class BasePyTorchUNet(BaseTransformer):
             if losses:
                 self.epoch_losses.append(float(torch.stack(losses).mean().item()))     # one D2H per epoch
             self.callbacks.on_epoch_end()
-            if self.callbacks.training_break():
+            if self._training_break():
                 break
         self.callbacks.on_train_end()
         self.model.weights_changed()
         return self
+
+    def _training_break(self):
+        """`callbacks.training_break()`, agreed between the ranks (max): whatever the callbacks are (the reference's own
+        decide from a rank-local validation loss), either every rank leaves the epoch loop or none does"""
+        stop = bool(self.callbacks.training_break())
+        if self.world.size > 1:
+            flag = torch.tensor([1.0 if stop else 0.0], device=self._device())
+            self.world.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            stop = bool(flag.item() > 0)
+        return stop
 
     def _fit_loop(self, data):
         """src/steps/pytorch/models.py:76-113 on the fused step (trainer.TrainStep); returns {'sum': loss[1]}"""

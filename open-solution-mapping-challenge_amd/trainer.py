@@ -193,6 +193,26 @@ class HipAdam(torch.optim.Optimizer):
         return {'m': self.m, 'v': self.v, 'steps': self.steps, 'lr': self.lr,
                 'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
 
+    def load_state_dict(self, state):
+        """restore what state_dict() returned: both moment buffers (flat, in the model's parameter order), the step count the
+        bias correction uses and the learning rate -- also into the device-resident state a captured graph reads"""
+        p = self._ensure()
+        for key in ('m', 'v'):
+            src = state[key]
+            if src is None:
+                getattr(self, key).zero_()
+            else:
+                if src.numel() != p.numel():
+                    raise ValueError('HipAdam.load_state_dict: %s has %d elements, the model has %d' % (key, src.numel(), p.numel()))
+                getattr(self, key).copy_(src.to(p.device, torch.float32).reshape(p.shape))
+        self.steps = int(state['steps'])
+        for g, saved in zip(self.param_groups, state.get('param_groups', [])):
+            g.update({k: v for k, v in saved.items() if k != 'params'})
+        g0 = self.param_groups[0]
+        self.betas, self.eps, self.weight_decay = tuple(g0['betas']), float(g0['eps']), float(g0['weight_decay'])
+        self.set_lr(float(state['lr']))
+        self.dev_state[0] = float(self.steps)
+
 
 def ddp_plan(prog, flat_grads, nchunks=4):
     """Cut the backward launch list into `nchunks` pieces and find, after each piece, the suffix of the flat
@@ -337,6 +357,7 @@ class TrainStep:
         else:
             st.graph.replay()
         self.opt.steps += 1
+        self.opt._opt_called = True       # torch's LR schedulers check that optimizer.step() ran before scheduler.step(): the replay was that step
         self.net._packed_version = -1     # the replay changed the master weights; packed copies are refreshed inside every replay
         self.net._version += 1
         return self.loss

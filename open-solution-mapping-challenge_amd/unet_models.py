@@ -477,9 +477,16 @@ class UNetResNet(nn.Module):
             _Program.run(prog.fold, stream)
             prog.fold_version = self._version
         _Program.run(prog.fwd, stream)
+        prog.bwd_pending = training
         return prog
 
     def _run_backward(self, prog, dlogits, zero_grads=True):
+        # ONE backward per forward: the BatchNorm backward overwrites the raw conv outputs it reads (dy in place of y), so a
+        # second pass over the same forward would differentiate garbage -- fail loudly instead
+        if not getattr(prog, 'bwd_pending', False):
+            raise _lib.MscError('UNetResNet backward called twice for one forward (or without a training forward): the backward '
+                                'consumes the saved activations in place; run the forward again')
+        prog.bwd_pending = False
         stream = _stream_of(dlogits.device)
         if zero_grads:
             self._flat[1].zero_()
@@ -645,8 +652,8 @@ class _Builder:
         return Act(self.buf(H, W, C))
 
     def slots(self, C_):
-        """device address of a fresh [BN_SLOTS][C][2] f64 block of the statistics arena (zeroed once per step by the first
-        forward launch)"""
+        """device address of a fresh [BN_SLOTS][C][2] f64 block of the statistics arena (forward blocks first, zeroed by the first
+        forward launch; the backward's blocks after them, zeroed by the first backward launch)"""
         n = _lib.BN_SLOTS * C_ * 2
         if self.slot_used + n > self.slot_arena.numel():
             raise RuntimeError('BatchNorm statistics arena too small')
@@ -1093,6 +1100,11 @@ class _Builder:
         self.emit(P.fwd, lib.msc_final_fwd, d0.ptr, d0.ld, fin.weight.data_ptr(), fin.bias.data_ptr(), P.logits.data_ptr(),
                   None if self.training else P.probs.data_ptr(), self.dt, N, H, W, nf)
         if self.training:
+            # the backward sums (BatchNorm-backward, bias gradients) are accumulated atomically into the arena's tail: zeroed at
+            # the head of EVERY backward, so a second backward for one forward (retain_graph, re-timing prog.bwd) starts clean
+            bwd_slots_from = self.slot_used
+            zero_at = len(P.bwd)
+            self.emit(P.bwd, lib.msc_memset_zero, 0, 0)      # extent known once the backward is built: patched below
             gd0 = self.grad_of(d0)
             self.grad_acc(d0)
             # final 1x1 backward also applies dec0's ReLU mask, so dec0's backward skips it
@@ -1103,6 +1115,7 @@ class _Builder:
             for op in reversed(self.ops):
                 op()
             self.flush_wgrads()
+            P.bwd[zero_at] = (lib.msc_memset_zero, (self.slot_arena.data_ptr() + 8 * bwd_slots_from, 8 * (self.slot_used - bwd_slots_from)))
         P.keep += [xp]
         P.acts = {'c1': s1, 'd0': d0, 'cat2': cat2, 'cat3': cat3, 'cat4': cat4, 'cat5': cat5}
         if self._tuned_new:

@@ -178,3 +178,73 @@ def test_product_backward_in_pieces_with_async_allreduce_matches_full_batch(wire
             # larger than the sum), then the sum once more: bounded relative to the tensor's largest element
             assert np.abs(g - gref).max() <= (2.0 ** -6 + 2e-3) * np.abs(gref).max() + 1e-12, (name, np.abs(g - gref).max() / np.abs(gref).max())
             assert np.array_equal(g, g.astype(np.float32)) and (g.view(np.uint32) & 0xffff == 0).all(), name   # bf16-representable
+
+
+def _fit_worker(rank, world_size, port, q, tmp):
+    """the PRODUCT's fit() (callback protocol, validation, best checkpoint, early stopping) as one of two ranks over gloo,
+    on the CPU interpreter of the launch lists; the ranks validate on DIFFERENT data, so rank-local decisions would diverge"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
+    import emu
+    import mapping_challenge_amd.unet_models as um
+    from mapping_challenge_amd import models as hip_models
+    from mapping_challenge_amd.distributed import World
+    from oracle import unet_ref, losses_ref
+    um._Program.run = staticmethod(emu.run)
+    hip_models._HOST_INTERPRETER = True
+    World.from_env(backend='gloo')
+    ckpt = os.path.join(tmp, 'checkpoints', 'best.torch')
+    arch = {'model_params': {'encoder': 'ResNet34', 'compute_dtype': 'fp32'}, 'optimizer_params': {'lr': 5e-4},
+            'regularizer_params': {'regularize': True, 'weight_decay_conv2d': 1e-4}}
+    cb = {'model_checkpoint': {'filepath': ckpt, 'epoch_every': 1, 'minimize': True},
+          'validation_monitor': {'epoch_every': 1}, 'early_stopping': {'patience': 0, 'minimize': True}}
+    t = hip_models.PyTorchUNet(arch, {'epochs': 3}, cb)
+    assert t.world.size == 2 and t.world.rank == rank
+    sd = unet_ref.seeded_state_dict(unet_ref.UNetResNetRef(34))
+    if rank == 1:                                   # fit() must start from rank 0's weights (World.sync_model)
+        sd = {k: (v + 0.5 if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    t.model.load_state_dict(sd)
+    hw = 64
+    train = [[unet_ref.synthetic_batch(1, hw, hw, seed=100 + 10 * b + rank), losses_ref.synthetic_target(1, hw, hw, seed=200 + 10 * b + rank)[:, :1].contiguous()]
+             for b in range(2)]
+    valid = [[unet_ref.synthetic_batch(1, hw, hw, seed=300 + rank), losses_ref.synthetic_target(1, hw, hw, seed=400 + rank)[:, :1].contiguous()]]
+    # the rank-LOCAL validation loss of the initial weights, to show below that what the callbacks saw was not it
+    t.fit((train, len(train)), validation_datagen=(valid, len(valid)))
+    vals = [float(t.validation_loss[e]['sum']) for e in sorted(t.validation_loss)]
+    es = [c for c in t.callbacks.callbacks if type(c).__name__ == 'EarlyStopping'][0]
+    q.put((rank, len(t.epoch_losses), vals, bool(es.training_break()), t.model.flat_params.clone().numpy(),
+           sorted(os.listdir(os.path.dirname(ckpt)))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_fit_agrees_on_validation_checkpoints_on_rank0_and_stops_together(tmp_path):
+    """every rank saw its own validation loss, saved the same file and could leave the epoch loop alone"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    threads = str(max(1, (os.cpu_count() or 2) // 2))
+    saved = {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS')}
+    os.environ.update({k: threads for k in saved})
+    try:
+        for p in procs:
+            p.start()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+    (r0, n0, v0, b0, p0, f0), (r1, n1, v1, b1, p1, f1) = res
+    assert n0 == n1 and 1 <= n0 <= 3                  # both ranks ran the same number of epochs
+    assert v0 == v1 and len(v0) == n0                 # ... on the same (rank-averaged) validation loss
+    assert b0 == b1                                   # ... and took the same early-stopping decision
+    assert np.array_equal(p0, p1)                     # parameters stayed in lock-step (broadcast at start, identical gradients)
+    assert f0 == ['best.torch'] and f1 == ['best.torch']      # one file, no temporaries left behind
+    ckpt = torch.load(os.path.join(str(tmp_path), 'checkpoints', 'best.torch'))
+    assert all(k.startswith('module.') for k in ckpt)

@@ -98,3 +98,50 @@ def test_ddp_plan_only_releases_finished_gradient_ranges(interpreted):
     assert covered[0][0] == 0 and covered[-1][1] == flat_g.numel()
     assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
     assert len(covered) >= 3          # the overlap is real: gradients are released in several pieces
+
+
+def test_backward_twice_for_one_forward_is_refused_and_backward_sums_start_clean(interpreted):
+    """the backward consumes the saved raw conv outputs in place (dy over y), so one forward supports ONE backward: a second
+    call fails loudly; the BatchNorm-backward / bias-gradient sums it accumulates atomically live in arena slots that the
+    backward zeroes at its own head (forward + backward again reproduces the gradients exactly)"""
+    from mapping_challenge_amd._lib import MscError
+    ref, net = build(34)
+    net.train()
+    x = unet_ref.synthetic_batch(1, 64, 64)
+    prog = net.train_forward(x)
+    dl = torch.randn_like(prog.logits) * 1e-3
+    net.train_backward(prog, dl)
+    g1 = net.flat_grads.clone()
+    with pytest.raises(MscError, match='twice'):
+        net.train_backward(prog, dl)
+    prog = net.train_forward(x)
+    net.train_backward(prog, dl)
+    assert torch.equal(g1, net.flat_grads)
+    assert prog.bwd[0][0].__name__ == 'msc_memset_zero' and prog.bwd[0][1][1] > 0
+
+
+def test_hipadam_state_dict_roundtrip_restores_moments_step_and_lr(interpreted):
+    from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
+    ref, net = build(34)
+    net.train()
+    opt = HipAdam(net, lr=1e-3, weight_decay=1e-4)
+    step = TrainStep(net, LossSpec.plain_ce(), opt)
+    x = unet_ref.synthetic_batch(1, 64, 64)
+    t = losses_ref.synthetic_target(1, 64, 64)[:, :1].contiguous()
+    step(x, t); step(x, t)
+    opt.set_lr(2.5e-4)
+    state = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state_dict().items()}
+    params = net.flat_params.clone()
+    step(x, t)
+    after = net.flat_params.clone()
+    # a fresh optimizer restored from the state continues identically from the same parameters
+    net.flat_params.copy_(params)
+    net.weights_changed()
+    opt2 = HipAdam(net, lr=9.0)
+    opt2.load_state_dict(state)
+    assert opt2.steps == 2 and opt2.lr == 2.5e-4 and opt2.param_groups[0]['lr'] == 2.5e-4
+    assert float(opt2.dev_state[0]) == 2.0 and abs(float(opt2.dev_state[1]) - 2.5e-4) < 1e-10
+    TrainStep(net, LossSpec.plain_ce(), opt2)(x, t)
+    assert torch.equal(after, net.flat_params)
+    with pytest.raises(ValueError):
+        opt2.load_state_dict(dict(state, m=torch.zeros(3)))
