@@ -208,6 +208,19 @@ def tile_text(hw):
             320: '300x300 tiles replicate-padded to 320x320 network input (reference loader_mode crop_and_pad)'}.get(hw, '%dx%d tiles' % (hw, hw))
 
 
+def reexec_argv(gpus, argv, port=None):
+    """argv that turns `python bench.py --gpus N ...` into N ranks on this node: the launch line the driver itself uses
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`),
+    with a free local port when none is given; the original flags follow unchanged"""
+    if port is None:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus),
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -232,12 +245,7 @@ def main():
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # `python bench.py --gpus N` on its own: become N ranks (one per GPU) under torch.distributed.run
-        import socket
-        with socket.socket() as sock:
-            sock.bind(('127.0.0.1', 0))
-            port = sock.getsockname()[1]
-        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-                                  '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:])
+        os.execv(sys.executable, reexec_argv(args.gpus, sys.argv[1:]))
 
     from mapping_challenge_amd.distributed import World
     world = World.from_env()

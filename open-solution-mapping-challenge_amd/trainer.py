@@ -214,11 +214,21 @@ class HipAdam(torch.optim.Optimizer):
         self.dev_state[0] = float(self.steps)
 
 
-def ddp_plan(prog, flat_grads, nchunks=4):
+DDP_FRACTIONS = (0.40, 0.65, 0.85)      # share of the gradient bytes that must be final before the first three exchanges
+
+
+def ddp_plan(prog, flat_grads, nchunks=4, fractions=None):
     """Cut the backward launch list into `nchunks` pieces and find, after each piece, the suffix of the flat
     gradient buffer that is final (parameters are laid out in forward order, backward finishes them from the
     tail): [(launch_end, grad_lo, grad_hi) ...] with grad_lo None when nothing new completed.  The gradient
-    all-reduce of a piece is issued as soon as its launches are enqueued, so RCCL overlaps the rest of backward."""
+    all-reduce of a piece is issued as soon as its launches are enqueued, so RCCL overlaps the rest of backward.
+
+    The cuts are placed by BYTES, not by launch count: piece c ends at the first launch after which `fractions[c]` of the
+    gradient buffer is final (default 40 / 65 / 85 %), the last piece takes the rest -- the LAST exchange has no compute
+    left to hide behind, so it gets the smallest share (<= 25 %: the stem, layer1 / layer2 and the head of layer3, whose
+    weight gradients complete with the last grouped launch), and the decoder's 45 % of the bytes, final after the first
+    third of backward, leaves early.  Falls back to equal launch counts when the program finishes (almost) everything
+    with its last launches (all weight gradients in one grouped launch: the single-process configuration)."""
     base, n = flat_grads.data_ptr(), flat_grads.numel()
     last = {}
     for idx, ptr in prog.grad_writes:
@@ -226,17 +236,33 @@ def ddp_plan(prog, flat_grads, nchunks=4):
         last[off] = max(last.get(off, -1), idx)
     offs = sorted(last)
     total = len(prog.bwd)
-    plan, done_from = [], n
-    for c in range(nchunks):
-        end = total * (c + 1) // nchunks
+
+    def final_from(end):
+        """start of the suffix of the buffer whose writers all lie in launches [0, end)"""
         s = n
         for off in reversed(offs):
             if last[off] < end:
                 s = off
             else:
                 break
-        if c == nchunks - 1:
-            s = 0
+        return s
+
+    fractions = DDP_FRACTIONS if fractions is None else tuple(fractions)
+    ends = []
+    if nchunks == len(fractions) + 1 and offs:
+        # the suffix start only moves at launches that are some parameter's last writer
+        marks = sorted(set(last.values()))
+        for f in fractions:
+            end = next((m + 1 for m in marks if (n - final_from(m + 1)) >= f * n), total)
+            ends.append(max(end, (ends[-1] + 1) if ends else 1))
+        if ends[-1] >= total or (n - final_from(ends[-1])) < 0.75 * n:      # nothing much is final before the end: by launch count
+            ends = []
+    if not ends:
+        ends = [total * (c + 1) // nchunks for c in range(nchunks - 1)]
+    ends.append(total)
+    plan, done_from = [], n
+    for c, end in enumerate(ends):
+        s = 0 if c == len(ends) - 1 else final_from(end)
         if s < done_from:
             plan.append((end, s, done_from))
             done_from = s

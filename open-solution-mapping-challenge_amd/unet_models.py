@@ -550,20 +550,26 @@ class _UNetFunction(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
-def _grad_views(self):
-    flat_g = self._flat[1]
+def _flat_views(self, flat):
+    """per-parameter views (torch-logical shapes, in _trainable() order) of a flat fp32 buffer laid out like the flat parameter
+    buffer: the gradients, or the optimizer's moment buffers"""
     out, total = [], 0
     for name, p in self._trainable():
         n = p.numel()
         if p.dim() == 4 and not name.endswith('encoder.conv1.weight') and p.shape[2] * p.shape[3] * p.shape[1] > 1:
             a, b, kh, kw = p.shape
-            out.append(flat_g[total:total + n].view(a, kh, kw, b).permute(0, 3, 1, 2))
+            out.append(flat[total:total + n].view(a, kh, kw, b).permute(0, 3, 1, 2))
         else:
-            out.append(flat_g[total:total + n].view(p.shape))
+            out.append(flat[total:total + n].view(p.shape))
         total += (n + 3) // 4 * 4
     return out
 
 
+def _grad_views(self):
+    return self._flat_views(self._flat[1])
+
+
+UNetResNet.flat_views = _flat_views
 UNetResNet._grad_views = _grad_views
 
 

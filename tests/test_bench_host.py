@@ -1,0 +1,46 @@
+"""CPU: the parts of bench.py that have never run on this pool (one GPU per gpurun box): the `--gpus N` self re-exec line and
+the distributed bench set-up (World.from_env under torch.distributed.run, gradient wire chosen after construction)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_gpus_n_reexec_argv_is_the_drivers_launch_line():
+    import bench
+    argv = bench.reexec_argv(4, ['--gpus', '4', '--steps', '7', '--warmup', '2'], port=29871)
+    assert argv[0] == sys.executable
+    assert argv[1:11] == ['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4', '--master-addr', '127.0.0.1',
+                          '--master-port', '29871', os.path.join(ROOT, 'bench.py')]
+    assert argv[11:] == ['--gpus', '4', '--steps', '7', '--warmup', '2']
+    port = int(bench.reexec_argv(2, [])[9])             # a free local port is picked when none is given
+    assert 1024 < port < 65536
+
+
+def test_reexec_line_really_starts_n_ranks_with_the_torchrun_environment(tmp_path):
+    """the same launch line with a stand-in script: torch.distributed.run starts 2 processes that see RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR = 127.0.0.1, and World.from_env turns them into a 2-rank gloo group"""
+    import bench
+    script = tmp_path / 'probe.py'
+    script.write_text(
+        'import os, sys\n'
+        'sys.path.insert(0, %r)\n'
+        'import torch\n'
+        'from mapping_challenge_amd.distributed import World, wire_for\n'
+        'w = World.from_env(backend="gloo")\n'
+        'w.grad_wire = os.environ.get("MSC_GRAD_WIRE", wire_for("fp16"))\n'      # as bench.py: chosen after construction
+        't = torch.tensor([float(w.rank + 1)])\n'
+        'w.all_reduce(t)\n'
+        'w.barrier()\n'
+        'print("RANK", w.rank, w.size, os.environ["LOCAL_RANK"], os.environ["MASTER_ADDR"], w.grad_wire, t.item(), flush=True)\n' % ROOT)
+    argv = bench.reexec_argv(2, [])
+    argv[argv.index(os.path.join(ROOT, 'bench.py'))] = str(script)
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = sorted(l for l in out.stdout.splitlines() if l.startswith('RANK'))
+    assert lines == ['RANK 0 2 0 127.0.0.1 bf16 3.0', 'RANK 1 2 1 127.0.0.1 bf16 3.0'], out.stdout

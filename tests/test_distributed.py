@@ -88,14 +88,19 @@ def _engine_worker(rank, world_size, port, q, wire='fp32'):
     gradient range each piece finishes) on the CPU interpreter of the launch lists, over gloo"""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size), MSC_GRAD_WIRE=wire)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
+    os.environ.pop('MSC_GRAD_WIRE', None)
     import emu
     import mapping_challenge_amd.unet_models as um
-    from mapping_challenge_amd.distributed import World
+    from mapping_challenge_amd.distributed import World, wire_for
     from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
     from oracle import unet_ref, losses_ref
     um._Program.run = staticmethod(emu.run)
     world = World.from_env(backend='gloo')
+    assert world.grad_wire == 'fp32'                # the constructor's default ...
+    if wire != 'fp32':
+        world.grad_wire = wire_for(wire)            # ... and, as bench.py does, the 16-bit wire chosen AFTER construction (W = 2: the
+        assert world.grad_wire == 'bf16'            # all_to_all_single / all_gather_into_tensor branch really runs between two ranks)
     n, hw = 4, 64
     x = unet_ref.synthetic_batch(n, hw, hw)
     tgt = losses_ref.synthetic_target(n, hw, hw)

@@ -98,6 +98,11 @@ def test_ddp_plan_only_releases_finished_gradient_ranges(interpreted):
     assert covered[0][0] == 0 and covered[-1][1] == flat_g.numel()
     assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
     assert len(covered) >= 3          # the overlap is real: gradients are released in several pieces
+    # cuts are placed by bytes: the LAST exchange (nothing left to overlap it with) carries at most a quarter of the buffer,
+    # and what leaves before it does so in launch order
+    assert [e for e, _, _ in plan] == sorted(e for e, _, _ in plan) and plan[-1][0] == len(prog.bwd)
+    last_lo, last_hi = plan[-1][1], plan[-1][2]
+    assert (last_hi - last_lo) <= 0.25 * flat_g.numel(), (last_lo, last_hi, flat_g.numel())
 
 
 def test_backward_twice_for_one_forward_is_refused_and_backward_sums_start_clean(interpreted):

@@ -50,18 +50,22 @@ def test_eval_logits_fp32_vs_oracle(depth, hw, n):
 
 
 @pytest.mark.parametrize('depth', [34, 101])
-def test_eval_bf16_close_and_masks_agree(depth):
+def test_eval_bf16_logits_within_the_derived_16bit_bound(depth):
+    """bf16 storage of every activation: d tensors stored one after the other on the longest path of the eval network (BatchNorm
+    folded: one per conv), independent roundings of unit roundoff u = 2^-8  =>  relative L2 error of the logits <= u * sqrt(d)
+    (the same derivation tests/test_gpu_parity_timed.py uses at the timed size)"""
+    import math
     ref, net = build(depth, 'bf16')
     x = unet_ref.synthetic_batch(2, 128, 128, seed=6)
     ref.eval()
     with torch.no_grad():
         yr = ref(x)
-    ph = net.predict_proba(x.cuda()).cpu()
-    pr = torch.softmax(yr, 1)
-    # bf16 storage of every activation (8 mantissa bits) through 35-100+ layers: tolerance on probabilities 0.1
-    # absolute, and >= 97% of thresholded mask pixels identical
-    assert (pr - ph).abs().max().item() < 0.15
-    assert ((pr[:, 1] > 0.5) == (ph[:, 1] > 0.5)).float().mean().item() > 0.97
+    yh = net.eval()(x.cuda()).cpu()
+    d = 1 + {34: 16 * 2, 101: 33 * 3}[depth] + 13
+    err = (yh.double() - yr.double()).norm().item() / yr.double().norm().item()
+    assert err < 2.0 ** -8 * math.sqrt(d), (err, d)
+    ph, pr = net.predict_proba(x.cuda()).cpu(), torch.softmax(yr, 1)
+    assert (pr - ph).abs().mean().item() < 2.0 ** -8 * math.sqrt(d) / 4          # softmax slope <= 1/4
 
 
 @pytest.mark.parametrize('depth', [34, 101])
@@ -89,8 +93,17 @@ def test_train_step_fp32_matches_reference_golden(golden_dir, depth):
     assert np.allclose(net.encoder.bn1.running_mean.cpu().numpy(), g['rm_bn1'], atol=1e-5)
     assert np.allclose(net.encoder.bn1.running_var.cpu().numpy(), g['rv_bn1'], atol=1e-5)
     if depth != 34:
-        return       # 64x64 tiles leave ResNet101's layer4 BatchNorms 8 samples per channel: its gradients are checked at
-                     # 128x128 / batch 4 below, against the golden the reference produced there
+        # 64x64 tiles leave ResNet101's layer4 BatchNorms 8 samples per channel (ill-conditioned: a rounding difference in a
+        # near-zero variance is amplified by 1/sqrt(var + eps)); the tight per-element checks run at 128x128 / batch 4 below,
+        # against the golden the reference produced there.  Here: every tensor against the oracle with a bound on the
+        # distribution of the per-tensor errors instead of on each one
+        ref.train()
+        losses_ref.mixed_dice_ce(ref(x), tgt).backward()
+        errs = sorted((grads[n_] - p.grad).norm().item() / (p.grad.norm().item() + 1e-12)
+                      for n_, p in ref.named_parameters() if n_ in grads and p.grad is not None)
+        assert len(errs) > 300 and all(np.isfinite(errs))
+        assert errs[len(errs) // 2] < 5e-3 and errs[int(0.9 * len(errs))] < 5e-2, (errs[len(errs) // 2], errs[int(0.9 * len(errs))], errs[-1])
+        return
 
     def close(a, b, rel=2e-3):
         return (a - torch.from_numpy(b)).abs().max().item() <= rel * (np.abs(b).max() + 1e-12)

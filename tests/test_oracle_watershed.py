@@ -54,3 +54,39 @@ def test_vectorised_oracle_equals_per_pixel_statement_and_properties():
                 for i in range(1, int(got.max()) + 1):          # every region is 4-connected and holds its marker
                     comp = post_ref.label(got == i)
                     assert comp.max() == 1 and (markers[got == i] == i).any()
+
+
+def test_independent_pin_scipy_watershed_ift_agreement():
+    """`scipy.ndimage.watershed_ift` (installed here; Falcao's image foresting transform as published in scipy) on the same 8-bit
+    relief + markers is an INDEPENDENT marker-controlled watershed.  It cannot be bit-matched by the immersion of WATERSHED.md:
+    its path cost is the largest |h(p) - h(q)| along the path (relief [0, 10, 1, 0] with markers at both ends floods
+    [1, 2, 2, 2]: the 10 goes to the right marker through the cheap 1 -> 10 climb), the immersion's is the largest h(p)
+    ([1, 1, 2, 2]: the 10 is reached at level 10 from both sides, the smaller label wins).  What is pinned is the AGREEMENT of
+    the two on the chain's own inputs, as measured when this was written: 99.1 % of the mask pixels (worst layer 97.8 %),
+    area-weighted instance IoU 0.985, mean IoU of the instances of >= 64 pixels 0.957."""
+    from scipy import ndimage as ndi
+    cross = ndi.generate_binary_structure(2, 1)
+    tiny = ndi.watershed_ift(np.array([[0, 10, 1, 0]], np.uint8), np.array([[1, 0, 0, 2]], np.int32), structure=cross)
+    ours = watershed_ref.flood(np.ones((1, 4), bool), np.array([[1, 0, 0, 2]]), np.array([[0, 10, 1, 0]], np.uint8))
+    assert tiny.tolist() == [[1, 2, 2, 2]] and ours.tolist() == [[1, 1, 2, 2]]       # the two definitions differ, by design
+    probs = post_ref.synthetic_probs(4, 256, 256, seed=77)
+    agree, ious, areas = [], [], []
+    for pr in probs:
+        r = post_ref.resize_image(pr, (300, 300)).astype(np.float32)
+        for layer, pch in zip(post_ref.categorize_multilayer_image(r), r):
+            for k in (3, 5):
+                markers = post_ref.label(post_ref.erode_image(layer, k) != 0)
+                h = watershed_ref.relief(pch)
+                got = watershed_ref.flood(layer, markers, h)
+                # outside the layer the relief is the maximum, so no minimax path to a mask pixel prefers to leave the mask
+                ift = ndi.watershed_ift(np.where(layer, h, 255).astype(np.uint8), markers.astype(np.int32), structure=cross)
+                ift = np.where(layer, ift, 0)
+                assert ((ift > 0) == layer).all() and (ift[markers > 0] == markers[markers > 0]).all()
+                agree.append((got == ift)[layer].mean())
+                for i in range(1, int(markers.max()) + 1):
+                    a, b = got == i, ift == i
+                    ious.append((a & b).sum() / max(1, (a | b).sum()))
+                    areas.append(a.sum())
+    ious, areas = np.array(ious), np.array(areas)
+    assert np.mean(agree) > 0.985 and np.min(agree) > 0.97, (np.mean(agree), np.min(agree))
+    assert (ious * areas).sum() / areas.sum() > 0.975 and ious[areas >= 64].mean() > 0.94, ((ious * areas).sum() / areas.sum(), ious[areas >= 64].mean())
