@@ -42,6 +42,11 @@ def conv_flops(d):
     return 2.0 * macs
 
 
+def bneck_flops(d):
+    """algorithmic FLOPs of one fused Bottleneck launch: its three convolutions (1x1 4C->C, 3x3 C->C, 1x1 C->4C), halo recompute not counted"""
+    return 2.0 * d.N * d.H * d.W * 17.0 * d.Cmid * d.Cmid
+
+
 def wgrad_flops(d):
     return 2.0 * d.N * d.Hp * d.Wp * d.A * d.B * d.KH * d.KW
 
@@ -51,7 +56,7 @@ def dump_launches(launches, stream, path, repeats=3):
     rows = []
     for fn, args in launches:
         name = fn.__name__
-        if name not in ('msc_conv_igemm', 'msc_conv_wgrad'):
+        if name not in ('msc_conv_igemm', 'msc_conv_wgrad', 'msc_bottleneck_fused'):
             continue
         best = 1e30
         for _ in range(repeats):
@@ -62,7 +67,9 @@ def dump_launches(launches, stream, path, repeats=3):
             torch.cuda.synchronize()
             best = min(best, a.elapsed_time(b))
         d = args[0]._obj
-        if name == 'msc_conv_igemm':
+        if name == 'msc_bottleneck_fused':
+            rows.append({'k': 'bottleneck', 'N': d.N, 'H': d.H, 'W': d.W, 'Cmid': d.Cmid, 'us': 1e3 * best, 'tflops': bneck_flops(d) / (best * 1e-3) / 1e12})
+        elif name == 'msc_conv_igemm':
             rows.append({'k': 'conv', 'mode': d.mode, 'flip': d.flip, 'N': d.N, 'Hi': d.Hi, 'Wi': d.Wi, 'Cin': d.Cin, 'Ho': d.Ho, 'Wo': d.Wo,
                          'Cout': d.Cout, 'KH': d.KH, 'KW': d.KW, 'stride': d.stride, 'stats': bool(d.stats), 'res': bool(d.res),
                          'us': 1e3 * best, 'tflops': conv_flops(d) / (best * 1e-3) / 1e12})
@@ -92,6 +99,8 @@ def family_times(launches, stream, repeats=2):
             f['launches'] += 1.0 / repeats
             if name == 'msc_conv_igemm':
                 f['flops'] += conv_flops(args[0]._obj) / repeats
+            elif name == 'msc_bottleneck_fused':
+                f['flops'] += bneck_flops(args[0]._obj) / repeats
             elif name == 'msc_conv_wgrad':
                 f['flops'] += wgrad_flops(args[0]._obj) / repeats
             elif name == 'msc_wgrad_group_run':
@@ -346,7 +355,8 @@ def main():
             fam = family_times(launches, stream)
             if args.dump_launches:
                 dump_launches(launches, stream, args.dump_launches)
-            conv = fam.get('msc_conv_igemm', {'ms': 0, 'launches': 0, 'flops': 0})
+            conv = {k: fam.get('msc_conv_igemm', {}).get(k, 0.0) + fam.get('msc_bottleneck_fused', {}).get(k, 0.0) for k in ('ms', 'launches', 'flops')}
+            fused = fam.get('msc_bottleneck_fused')
             wg = {'ms': 0.0, 'launches': 0.0, 'flops': 0.0}
             for name in ('msc_conv_wgrad', 'msc_wgrad_group_run'):
                 for key in wg:
@@ -361,8 +371,10 @@ def main():
                 traffic = json.load(open(pmc_file)).get('hbm_bytes_per_launch')
             result['roofline'] = {
                 'kernel': ('msc_conv_igemm family: conv3x3_halo_dma_kernel (3x3 stride-1 layers) + conv_igemm_dma_kernel (1x1, strided, transposed) '
-                           '+ the two 32-channel halo kernels; conv / dgrad / deconv, %d launches per step, per-layer autotuned configuration'
-                           % round(conv['launches'])),
+                           '+ the two 32-channel halo kernels%s; conv / dgrad / deconv, %d launches per step, per-layer autotuned configuration'
+                           % ((' + bottleneck_fused_kernel (%d eval-mode identity Bottlenecks, one launch each: %.3f ms, %.0f TFLOP/s)'
+                               % (round(fused['launches']), fused['ms'], fused['flops'] / (fused['ms'] * 1e-3) / 1e12)) if fused else '',
+                              round(conv['launches']))),
                 'bound': 'mfma', 'achieved': ach / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
                 'avg_launch_us': 1e3 * conv['ms'] / max(conv['launches'], 1),
                 'algorithmic_gflop_per_step': conv['flops'] / 1e9,

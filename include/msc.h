@@ -155,6 +155,29 @@ int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_t res_ld, v
 /* eval mode (model.eval(), src/steps/pytorch/models.py:116): scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
 int msc_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                 float eps, float* scale, float* shift, int C, void* stream);
+/* Eval-mode fused Bottleneck (ABI v5): one launch for the torchvision ResNet bottleneck block in its identity form (stride 1,
+ * no downsample branch) -- conv1x1 -> bn -> ReLU -> conv3x3 -> bn -> ReLU -> conv1x1 -> bn -> (+x) -> ReLU -- that the
+ * reference's encoder stages layer1..layer3 are made of (`self.encoder.layer1..3` used at src/unet_models.py:345-351,365-371:
+ * 27 of ResNet101's 33 blocks, 44 of ResNet152's 50).  BatchNorm is folded (msc_bn_fold); the two Cmid-channel intermediates
+ * stay in LDS.  x: NHWC [N][H][W][x_ld], 4*Cmid channels (also the residual); out likewise; Cmid in {64, 128, 256};
+ * W % 16 == 0, H % (patch rows) == 0; 16-bit dtypes.  wpk: the three weight tensors ([Cmid][4Cmid], [Cmid][3][3][Cmid],
+ * [4Cmid][Cmid] in dtype, as msc_conv_igemm takes them) re-ordered by msc_bottleneck_pack into the fragment-major stream the
+ * kernel reads (msc_bottleneck_pack_bytes bytes).  cfg: patch rows (0 = chosen by shape).  msc_bottleneck_ok: 1 if the fused
+ * kernel takes the descriptor (otherwise the caller runs the three msc_conv_igemm launches). */
+typedef struct msc_bneck_desc {
+    const void* x;
+    void* out;
+    const void* wpk;
+    const float* scale1; const float* shift1;
+    const float* scale2; const float* shift2;
+    const float* scale3; const float* shift3;
+    int64_t x_ld, out_ld;
+    int32_t dtype, N, H, W, Cmid, cfg;
+} msc_bneck_desc;
+int msc_bottleneck_ok(const msc_bneck_desc* d);
+int64_t msc_bottleneck_pack_bytes(int Cmid);
+int msc_bottleneck_pack(const void* w1, const void* w2, const void* w3, void* wpk, int Cmid, int dtype, void* stream);
+int msc_bottleneck_fused(const msc_bneck_desc* d, void* stream);
 /* backward of out = relu?(bn(y) (+res)):  dh = dout * [out>0] (relu 1) or dout * [scale*y+shift > 0] (relu 2);
  * reduce: slots[xcd][c] += (sum dh, sum dh*y)   (the data-gradient conv that writes dout can do this in its epilogue instead);
  * apply:  prologue: dbeta += sum dh, dgamma += sum dh*xhat (into the fp32 gradients), dy = a*dh + b*y + k per channel;

@@ -38,6 +38,14 @@ class WgradDesc(C.Structure):
                 ('stride', C.c_int32), ('pad', C.c_int32), ('cfg', C.c_int32)]
 
 
+class BneckDesc(C.Structure):             # == msc_bneck_desc
+    _fields_ = [('x', C.c_void_p), ('out', C.c_void_p), ('wpk', C.c_void_p),
+                ('scale1', C.c_void_p), ('shift1', C.c_void_p), ('scale2', C.c_void_p), ('shift2', C.c_void_p),
+                ('scale3', C.c_void_p), ('shift3', C.c_void_p),
+                ('x_ld', C.c_int64), ('out_ld', C.c_int64),
+                ('dtype', C.c_int32), ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('Cmid', C.c_int32), ('cfg', C.c_int32)]
+
+
 class BiasSlotsItem(C.Structure):         # == msc_bias_slots_item
     _fields_ = [('slots', C.c_void_p), ('db', C.c_void_p), ('Cs', C.c_int32), ('C', C.c_int32)]
 
@@ -78,6 +86,10 @@ SIGNATURES = {
     'msc_maxpool2_fwd': (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     'msc_maxpool2_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
     'msc_bn_fold': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
+    'msc_bottleneck_ok': (_i, [C.POINTER(BneckDesc)]),
+    'msc_bottleneck_pack_bytes': (_i64, [_i]),
+    'msc_bottleneck_pack': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'msc_bottleneck_fused': (_i, [C.POINTER(BneckDesc), _vp]),
     'msc_memset_zero': (_i, [_vp, _i64, _vp]),
     'msc_copy': (_i, [_vp, _vp, _i64, _vp]),
     'msc_bn_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp]),

@@ -12,8 +12,10 @@
 //   4. per segment, from its sorted neighbours: gap, length, trailing 0-run, their delta codes (x[i] -= x[i-2] for
 //      i > 2) and character counts (5 bits per char, continuation bit 0x20, +48); scan -> string offsets;
 //   5. emit characters, instance table (layer, label, string range, bounding box by atomic min/max).
-// Scan and sort are rocPRIM primitives (through hipCUB); the rest are the kernels below.
-#include <hipcub/hipcub.hpp>
+// Scan and sort are rocPRIM device primitives (rocprim::inclusive_scan / exclusive_scan / radix_sort_pairs); the rest are the kernels below.
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
 
 #include "common.h"
 #include "msc_internal.h"
@@ -165,7 +167,7 @@ struct Ws1 {                       // segment extraction
         key = o;  o += align256(cap * 8);
         val = o;  o += align256(cap * 4);
         tmp_bytes = 0;
-        (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, (unsigned*)nullptr, (unsigned*)nullptr, (int)px);
+        (void)rocprim::inclusive_scan(nullptr, tmp_bytes, (unsigned*)nullptr, (unsigned*)nullptr, px, rocprim::plus<unsigned>());
         tmp = o;  o += align256(tmp_bytes);
         total = o;
     }
@@ -185,10 +187,10 @@ struct Ws2 {                       // sort, codes, output
         table = o; o += align256(n * TABLE_W * 4);
         chars = o; o += align256(21 * n);
         size_t a = 0, b = 0, c = 0;
-        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr,
-                                                 (unsigned*)nullptr, (int)n, 0, 40);
-        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (unsigned*)nullptr, (unsigned*)nullptr, (int)(3 * n));
-        (void)hipcub::DeviceScan::InclusiveSum(nullptr, c, (unsigned*)nullptr, (unsigned*)nullptr, (int)n);
+        (void)rocprim::radix_sort_pairs(nullptr, a, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr,
+                                        (unsigned*)nullptr, n, 0u, 40u);
+        (void)rocprim::exclusive_scan(nullptr, b, (unsigned*)nullptr, (unsigned*)nullptr, 0u, 3 * n, rocprim::plus<unsigned>());
+        (void)rocprim::inclusive_scan(nullptr, c, (unsigned*)nullptr, (unsigned*)nullptr, n, rocprim::plus<unsigned>());
         tmp_bytes = a > b ? a : b;
         if (c > tmp_bytes) tmp_bytes = c;
         tmp = o;   o += align256(tmp_bytes);
@@ -228,7 +230,7 @@ extern "C" int msc_rle_segments(const int32_t* labels, int layers, int H, int W,
     hipLaunchKernelGGL(transpose_cm_kernel, dim3(ceil_div(W, 32), ceil_div(H, 32), layers), dim3(32, 8), 0, st, labels, cm, H, W);
     hipLaunchKernelGGL(seg_flags_kernel, dim3(grid_for(total)), dim3(256), 0, st, cm, incl, total, a);
     size_t tb = L.tmp_bytes;
-    HIP_OK(hipcub::DeviceScan::InclusiveSum(w + L.tmp, tb, incl, incl, (int)total, st), "msc_rle_segments: scan");
+    HIP_OK(rocprim::inclusive_scan(w + L.tmp, tb, incl, incl, (size_t)total, rocprim::plus<unsigned>(), st), "msc_rle_segments: scan");
     hipLaunchKernelGGL(seg_scatter_kernel, dim3(grid_for(total)), dim3(256), 0, st, cm, incl, (int*)(w + L.S), (int*)(w + L.E),
                        (unsigned long long*)(w + L.key), (unsigned*)(w + L.val), total, a);
     unsigned n = 0;
@@ -267,13 +269,13 @@ extern "C" int msc_rle_encode(const void* seg_ws, int layers, int H, int W, int 
     unsigned* off = (unsigned*)(w + L.off);
     unsigned* first = (unsigned*)(w + L.first);
     size_t tb = L.tmp_bytes;
-    HIP_OK(hipcub::DeviceRadixSort::SortPairs(w + L.tmp, tb, (const unsigned long long*)(w1 + L1.key), key, (const unsigned*)(w1 + L1.val), val,
-                                              nseg, 0, 40, st), "msc_rle_encode: sort");
+    HIP_OK(rocprim::radix_sort_pairs(w + L.tmp, tb, (const unsigned long long*)(w1 + L1.key), key, (const unsigned*)(w1 + L1.val), val,
+                                     (size_t)nseg, 0u, 40u, st), "msc_rle_encode: sort");
     hipLaunchKernelGGL(seg_codes_kernel, dim3(grid_for(nseg)), dim3(256), 0, st, key, val, S, E, xval, nch, first, nseg, H * W);
     tb = L.tmp_bytes;
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(w + L.tmp, tb, nch, off, 3 * nseg, st), "msc_rle_encode: scan");
+    HIP_OK(rocprim::exclusive_scan(w + L.tmp, tb, nch, off, 0u, (size_t)(3 * nseg), rocprim::plus<unsigned>(), st), "msc_rle_encode: scan");
     tb = L.tmp_bytes;
-    HIP_OK(hipcub::DeviceScan::InclusiveSum(w + L.tmp, tb, first, first, nseg, st), "msc_rle_encode: scan");
+    HIP_OK(rocprim::inclusive_scan(w + L.tmp, tb, first, first, (size_t)nseg, rocprim::plus<unsigned>(), st), "msc_rle_encode: scan");
     hipLaunchKernelGGL(table_init_kernel, dim3(grid_for(nseg)), dim3(256), 0, st, (int*)(w + L.table), nseg, H, W);
     hipLaunchKernelGGL(seg_emit_kernel, dim3(grid_for(nseg)), dim3(256), 0, st, key, val, S, E, xval, nch, off, first, w + L.chars,
                        (int*)(w + L.table), nseg, H);

@@ -22,18 +22,14 @@
 //                      fine[q] = sum_{t: (q+pad-t) even} coarse[(q+pad-t)/2] W[t]
 //                                                                     (convT fwd, stride-2 dgrad)
 //
-// Two generations of each kernel are kept:
-//   *_kernel      v1: operands staged HBM -> VGPR -> ds_write_b128 -> LDS, 2 LDS buffers, all addressing
-//                 recomputed every k-step.  Measured 0.23-0.25 PFLOP/s (9-10 % of the bf16 MFMA peak): the
-//                 64-bit address arithmetic of every k-step sits in front of the MFMAs of an in-order wave.
-//   *_dma_kernel  v2: operands go HBM -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per
-//                 wave-instruction) through a 4-stage LDS ring with counted s_waitcnt vmcnt(N) and one raw
-//                 s_barrier per k-step; per-lane byte offsets are 32-bit, computed once per filter tap, the
-//                 k-chunk advance is the instruction's scalar offset; out-of-image taps are out-of-range
-//                 buffer offsets, which the hardware returns as zeros (no zero-fill code, no branches).
-//                 The LDS image is linear (DMA destination = wave base + lane*16), so bank conflicts are
-//                 removed by permuting 16-byte k-chunks on the SOURCE side and applying the same involution
-//                 on the fragment reads.
+// Operands go HBM -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction) through an LDS ring with
+// counted s_waitcnt vmcnt(N) and one raw s_barrier per k-step; per-lane byte offsets are 32-bit, computed once per filter
+// tap, the k-chunk advance is the instruction's scalar offset; out-of-image taps are out-of-range buffer offsets, which the
+// hardware returns as zeros (no zero-fill code, no branches).  The LDS image is linear (DMA destination = wave base +
+// lane*16), so bank conflicts are removed by permuting 16-byte k-chunks on the SOURCE side and applying the same involution
+// on the fragment reads.  (The first generation staged HBM -> VGPR -> ds_write_b128 and recomputed all addressing every
+// k-step: 0.23-0.25 PFLOP/s, the 64-bit address arithmetic sat in front of the MFMAs of an in-order wave; removed in round 3.
+// Operands beyond the 31-bit offsets of a buffer descriptor are run as image ranges, one launch after the other.)
 #include <stdlib.h>
 
 #include <algorithm>
@@ -41,6 +37,7 @@
 #include <vector>
 
 #include "common.h"
+#include "dma.h"
 #include "msc_internal.h"
 
 namespace {
@@ -62,26 +59,6 @@ struct ConvK {
     float rcp_hw, rcp_w;             // 1/(Hq*Wq), 1/Wq for the pixel decode of the DMA kernel; 0 = pixel count >= 2^24: integer division
 };
 
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    }
-};
-template <> struct Mma<f16_t> {
-    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    }
-};
-template <> struct Mma<float> {
-    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
-    }
-};
-
 // floor(m / d) through the float reciprocal, exact for m < 2^24 (one correction step either way)
 __device__ __forceinline__ unsigned udiv_rcp(unsigned m, unsigned d, float rcp) {
     unsigned q = (unsigned)((float)m * rcp);
@@ -89,36 +66,6 @@ __device__ __forceinline__ unsigned udiv_rcp(unsigned m, unsigned d, float rcp) 
     if (r < 0) { --q; r += (int)d; }
     if (r >= (int)d) ++q;
     return q;
-}
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-constexpr unsigned OOB_OFF = 0x80000000u;   // >= any buffer extent we accept: the load returns zeros
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ void raw_barrier() {
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-// One LDS-DMA wave-instruction: 64 lanes x 16 bytes from buffer offsets `voff` (+ scalar `soff`) to LDS bytes
-// [lds_wave_base, +1024).  Issued through inline asm on purpose: a compiler-visible LDS-DMA makes hipcc put
-// s_waitcnt vmcnt(0) in front of every ds_read of the loop (it cannot disambiguate the ring slots), which
-// serialises the pipeline; hidden from it, the ring is ordered by our own counted vmcnt + s_barrier.
-// M0 (the DMA's LDS base) is compiler-reserved: saved, set and restored inside the one statement.
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4_t make_srd(const void* base, unsigned bytes) {
-    const unsigned long long b = (unsigned long long)base;
-    u32x4_t r;
-    r.x = (unsigned)b; r.y = (unsigned)(b >> 32) & 0xffffu; r.z = bytes; r.w = 0x00020000u;   // raw buffer, stride 0
-    return r;
-}
-__device__ __forceinline__ void dma16(u32x4_t srd, char* lds_wave_base, unsigned voff, int soff) {
-    const unsigned lds_addr = (unsigned)(size_t)(lds_ptr_t)lds_wave_base;
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
-                 : "memory");
 }
 
 // shared epilogue: lane holds NV consecutive channels cb.. of pixel rows (b*16+pl), b < FN
@@ -276,135 +223,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
     }
 }
 
-// ------------------------------------------------------------------------------------------------ v1
-constexpr int ROWB = 80;  // v1 LDS row pitch: 64 B of K + 16 B pad
-
-template <typename T, int TP, int TC, int WP, int WC, int MODE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
-    constexpr int ES = sizeof(T);
-    constexpr int KE = 64 / ES;   // K elements per step
-    constexpr int CE = 16 / ES;   // elements per 16-byte chunk
-    constexpr int WTP = TP / WP, WTC = TC / WC;
-    constexpr int FM = WTC / 16, FN = WTP / 16;
-    constexpr int NV = FM * 4;
-    constexpr int XI = TP / 64, WI = (TC + 63) / 64;
-    static_assert(WP * WC == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) char smem[2 * (TP + TC) * ROWB];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
-    const int wp = wid / WC, wc = wid % WC;
-    const int g = lane >> 4, pl = lane & 15;
-    const int m0 = blockIdx.x * TP;
-    const int c0 = blockIdx.y * TC;
-    const int ph = MODE ? (int)blockIdx.z : 0;
-    const int py = ph >> 1, px = ph & 1;
-
-    int kh0 = 0, kw0 = 0, nkh = p.KH, nkw = p.KW;
-    if (MODE) {
-        kh0 = (py + p.pad) & 1; kw0 = (px + p.pad) & 1;
-        nkh = p.KH > kh0 ? (p.KH - kh0 + 1) / 2 : 0;
-        nkw = p.KW > kw0 ? (p.KW - kw0 + 1) / 2 : 0;
-    }
-    const int cps = p.Cin / KE;            // k-steps per tap
-    const int nsteps = nkh * nkw * cps;
-
-    const int lrow = tid >> 2, kc = tid & 3;
-    int xn[XI], xby[XI], xbx[XI];
-    bool xv[XI];
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-        const int m = m0 + lrow + i * 64;
-        xv[i] = m < p.M;
-        const int mm = xv[i] ? m : 0;
-        const int n = mm / (p.Hq * p.Wq);
-        const int rem = mm - n * (p.Hq * p.Wq);
-        const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
-        xn[i] = n * p.Hi;
-        xby[i] = MODE ? qy : qy * p.stride;
-        xbx[i] = MODE ? qx : qx * p.stride;
-    }
-    const T* in = reinterpret_cast<const T*>(p.in);
-    const T* wt = reinterpret_cast<const T*>(p.wt);
-
-    uint4 xr[XI], wr[WI];
-    auto gload = [&](int s) {
-        const int tap = s / cps;
-        const int cch = s - tap * cps;
-        const int khi = tap / nkw, kwi = tap - khi * nkw;
-        const int kh = MODE ? kh0 + 2 * khi : khi;
-        const int kw = MODE ? kw0 + 2 * kwi : kwi;
-        int dy, dx;
-        if (MODE) { dy = (py + p.pad - kh) / 2; dx = (px + p.pad - kw) / 2; }
-        else if (p.flip) { dy = p.pad - kh; dx = p.pad - kw; }
-        else { dy = kh - p.pad; dx = kw - p.pad; }
-        const int coff = cch * KE + kc * CE;
-#pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            const int iy = xby[i] + dy, ix = xbx[i] + dx;
-            const bool ok = xv[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) v = *reinterpret_cast<const uint4*>(in + ((long)(xn[i] + iy) * p.Wi + ix) * p.in_ld + coff);
-            xr[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const int row = lrow + i * 64;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if ((TC >= 64 || row < TC) && c0 + row < p.Cout)
-                v = *reinterpret_cast<const uint4*>(wt + ((long)((c0 + row) * p.KH + kh) * p.KW + kw) * p.Cin + coff);
-            wr[i] = v;
-        }
-    };
-    auto lstore = [&](int buf) {
-        char* sx = smem + buf * (TP + TC) * ROWB;
-        char* sw = sx + TP * ROWB;
-#pragma unroll
-        for (int i = 0; i < XI; ++i) *reinterpret_cast<uint4*>(sx + (lrow + i * 64) * ROWB + kc * 16) = xr[i];
-#pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const int row = lrow + i * 64;
-            if (TC >= 64 || row < TC) *reinterpret_cast<uint4*>(sw + row * ROWB + kc * 16) = wr[i];
-        }
-    };
-
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int a = 0; a < FM; ++a)
-#pragma unroll
-        for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    if (nsteps > 0) {
-        gload(0);
-        lstore(0);
-        __syncthreads();
-        for (int s = 0; s < nsteps; ++s) {
-            if (s + 1 < nsteps) gload(s + 1);
-            const char* sx = smem + (s & 1) * (TP + TC) * ROWB;
-            const char* sw = sx + TP * ROWB;
-            uint4 af[FM], bf[FN];
-#pragma unroll
-            for (int a = 0; a < FM; ++a) {
-                // fragment row i=pl of fragment a carries local channel (i>>2)*NV + a*4 + (i&3)
-                const int row = wc * WTC + (pl >> 2) * NV + a * 4 + (pl & 3);
-                af[a] = *reinterpret_cast<const uint4*>(sw + row * ROWB + g * 16);
-            }
-#pragma unroll
-            for (int b = 0; b < FN; ++b)
-                bf[b] = *reinterpret_cast<const uint4*>(sx + (wp * WTP + b * 16 + pl) * ROWB + g * 16);
-#pragma unroll
-            for (int a = 0; a < FM; ++a)
-#pragma unroll
-                for (int b = 0; b < FN; ++b) Mma<T>::run(af[a], bf[b], acc[a][b]);
-            if (s + 1 < nsteps) lstore((s + 1) & 1);
-            __syncthreads();
-        }
-    }
-    conv_epilogue<T, FM, FN, WTP, WP, MODE, WC>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px, (int)blockIdx.x, (int)gridDim.x,
-                                                reinterpret_cast<float*>(smem), wc, c0);
-}
-
-// ------------------------------------------------------------------------------------------------ v2 (DMA)
+// ------------------------------------------------------------------------------------------------ implicit GEMM (DMA)
 // K step = KB bytes per row: 128 B (one full cache line per row) whenever Cin*sizeof(T) is a multiple of 128,
 // else 64 B.  Measured LDS-DMA fill rate with the operand's 512-byte row pitch (profiles/r1_dma_fill_probe.txt):
 // 64-byte row segments 9-16 TB/s, 128-byte segments 28-31 TB/s -- the 64-byte form bounded the whole kernel.
@@ -1099,144 +918,7 @@ __device__ __forceinline__ void wgrad_block(const WgK& p, int orig, int nwg, int
     tile = r - tap * p.ntiles;
 }
 
-// v1: register staging, element-wise (ds_read_u16) gather of the fragments
-template <typename T, int TA, int TB>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgK p) {
-    const int orig = blockIdx.x, nwg = gridDim.x;
-    constexpr int ES = sizeof(T);
-    constexpr int KP = 64 / ES;      // pixels per k-step
-    constexpr int CE = 16 / ES;
-    constexpr int WTA = TA / 2, WTB = TB / 2;
-    constexpr int FM = WTA / 16, FN = WTB / 16;
-    constexpr int CPA = TA / CE, CPB = TB / CE;            // 16-B chunks per pixel row
-    constexpr int PI = (KP * CPA + 255) / 256, QI = (KP * CPB + 255) / 256;
-    constexpr int LDA = TA * ES + 16, LDB = TB * ES + 16;  // LDS row pitch (bytes)
-    constexpr int BUF = KP * (LDA + LDB);
-    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
-    const int wa = wid >> 1, wb = wid & 1;
-    const int g = lane >> 4, pl = lane & 15;
-    int tile, tap, split;
-    wgrad_block(p, orig, nwg, tile, tap, split);
-    const int ta = tile / p.tiles_b, tb = tile - ta * p.tiles_b;
-    const int a0 = ta * TA, b0 = tb * TB;
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
-    const int mbeg = split * p.mchunk;
-    const int mend = min(p.M, mbeg + p.mchunk);
-    const int nsteps = mend > mbeg ? (mend - mbeg + KP - 1) / KP : 0;
-
-    const T* P = reinterpret_cast<const T*>(p.p);
-    const T* Q = reinterpret_cast<const T*>(p.q);
-    uint4 pr[PI], qr[QI];
-    auto gload = [&](int s) {
-        const int mb = mbeg + s * KP;
-#pragma unroll
-        for (int i = 0; i < PI; ++i) {
-            const int c = tid + i * 256;
-            const int row = c / CPA, cc = c - row * CPA;
-            const int m = mb + row;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < KP && m < mend) v = *reinterpret_cast<const uint4*>(P + (long)m * p.p_ld + a0 + cc * CE);
-            pr[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < QI; ++i) {
-            const int c = tid + i * 256;
-            const int row = c / CPB, cc = c - row * CPB;
-            const int m = mb + row;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < KP && m < mend) {
-                const int n = m / (p.Hp * p.Wp);
-                const int rem = m - n * (p.Hp * p.Wp);
-                const int y = rem / p.Wp, x = rem - y * p.Wp;
-                const int iy = y * p.stride - p.pad + kh, ix = x * p.stride - p.pad + kw;
-                if ((unsigned)iy < (unsigned)p.Hq && (unsigned)ix < (unsigned)p.Wq)
-                    v = *reinterpret_cast<const uint4*>(Q + ((long)(n * p.Hq + iy) * p.Wq + ix) * p.q_ld + b0 + cc * CE);
-            }
-            qr[i] = v;
-        }
-    };
-    auto lstore = [&](int buf) {
-        char* sp = smem + buf * BUF;
-        char* sq = sp + KP * LDA;
-#pragma unroll
-        for (int i = 0; i < PI; ++i) {
-            const int c = tid + i * 256;
-            const int row = c / CPA, cc = c - row * CPA;
-            if (row < KP) *reinterpret_cast<uint4*>(sp + row * LDA + cc * 16) = pr[i];
-        }
-#pragma unroll
-        for (int i = 0; i < QI; ++i) {
-            const int c = tid + i * 256;
-            const int row = c / CPB, cc = c - row * CPB;
-            if (row < KP) *reinterpret_cast<uint4*>(sq + row * LDB + cc * 16) = qr[i];
-        }
-    };
-    auto frag = [&](const char* base, int ld, int ch) -> uint4 {
-        uint4 r;
-        if (ES == 2) {
-            const uint16_t* s = reinterpret_cast<const uint16_t*>(base) + ch;
-            const int ldh = ld / 2;
-            uint32_t w[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t lo = s[(8 * g + 2 * j) * ldh];
-                const uint32_t hi = s[(8 * g + 2 * j + 1) * ldh];
-                w[j] = lo | (hi << 16);
-            }
-            r = make_uint4(w[0], w[1], w[2], w[3]);
-        } else {
-            const uint32_t* s = reinterpret_cast<const uint32_t*>(base) + ch;
-            const int ldw = ld / 4;
-            r = make_uint4(s[(4 * g) * ldw], s[(4 * g + 1) * ldw], s[(4 * g + 2) * ldw], s[(4 * g + 3) * ldw]);
-        }
-        return r;
-    };
-
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int a = 0; a < FM; ++a)
-#pragma unroll
-        for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    if (nsteps > 0) {
-        gload(0);
-        lstore(0);
-        __syncthreads();
-        for (int s = 0; s < nsteps; ++s) {
-            if (s + 1 < nsteps) gload(s + 1);
-            const char* sp = smem + (s & 1) * BUF;
-            const char* sq = sp + KP * LDA;
-            uint4 af[FM], bf[FN];
-#pragma unroll
-            for (int a = 0; a < FM; ++a) af[a] = frag(sp, LDA, wa * WTA + a * 16 + pl);
-#pragma unroll
-            for (int b = 0; b < FN; ++b) bf[b] = frag(sq, LDB, wb * WTB + b * 16 + pl);
-#pragma unroll
-            for (int a = 0; a < FM; ++a)
-#pragma unroll
-                for (int b = 0; b < FN; ++b) Mma<T>::run(af[a], bf[b], acc[a][b]);
-            if (s + 1 < nsteps) lstore((s + 1) & 1);
-            __syncthreads();
-        }
-        const long taps = (long)p.KH * p.KW;
-#pragma unroll
-        for (int a = 0; a < FM; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ia = a0 + wa * WTA + a * 16 + 4 * g + r;
-#pragma unroll
-                for (int b = 0; b < FN; ++b) {
-                    const int ib = b0 + wb * WTB + b * 16 + pl;
-                    if (ia < p.A && ib < p.B) atomicAdd(p.dw + (ia * taps + tap) * p.B + ib, acc[a][b][r]);
-                }
-            }
-    }
-}
-
-// v2: both operands HBM -> LDS by DMA (pixel rows of TA*ES / TB*ES contiguous bytes, 4-stage ring, counted
+// both operands HBM -> LDS by DMA (pixel rows of TA*ES / TB*ES contiguous bytes, 4-stage ring, counted
 // vmcnt), k-contiguous fragments by ds_read_b64_tr_b16 (bf16: the hardware transposes a [4 pixels][16 channels]
 // block per 16-lane group; probe: profiles/r1_tr_b16_probe.txt) or by ds_read_b32 (f32, one k element per lane).
 // Bank conflicts: 16-byte units of pixel row r are permuted with
@@ -1738,13 +1420,7 @@ __global__ __launch_bounds__(NWV * 64) void conv_wgrad3_group_kernel(const WgK* 
     }
 }
 
-bool env_flag(const char* name) {
-    const char* e = getenv(name);
-    return e && e[0] == '1';
-}
-bool use_v1_conv() { static int v = -1; if (v < 0) v = env_flag("MSC_CONV_V1") ? 1 : 0; return v == 1; }
 bool xcd_order_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("MSC_XCD_ORDER"); v = (e && e[0] == '0') ? 0 : 1; } return v == 1; }
-bool use_v1_wgrad() { static int v = -1; if (v < 0) v = env_flag("MSC_WGRAD_V1") ? 1 : 0; return v == 1; }
 
 // ---- kernel configurations.  A configuration = (pixel rows, channels, waves along pixels, waves along channels,
 // bytes of K per row and step, ring depth); LDS = NST*(TP+TC)*KB.  Which one is fastest depends on the layer
@@ -1856,14 +1532,6 @@ int launch_halo3(const ConvK& k0, hipStream_t st) {
     return msc_check_launch("conv3x3_halo_dma");
 }
 
-template <typename T, int TP, int TC, int WP, int WC>
-int launch_v1(const ConvK& k, int mode, hipStream_t st) {
-    dim3 grid(ceil_div(k.M, TP), ceil_div(k.Cout, TC), mode ? 4 : 1);
-    if (mode) hipLaunchKernelGGL((conv_igemm_kernel<T, TP, TC, WP, WC, 1>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((conv_igemm_kernel<T, TP, TC, WP, WC, 0>), grid, dim3(256), 0, st, k);
-    return msc_check_launch("conv_igemm");
-}
-
 bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
     if (cfg < 1 || cfg > N_CONV_CFG) return false;
     if (cfg == CFG_HALO)
@@ -1875,12 +1543,12 @@ bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
     const ConvCfg& c = CONV_CFGS[cfg];
     if (cfg_is_halo3(cfg))
         return es == 2 && k.mode == 0 && k.KH == 3 && k.KW == 3 && k.stride == 1 && k.pad == 1 && k.Hi == k.Ho && k.Wi == k.Wo &&
-               k.Wo % 16 == 0 && k.Ho % (c.tp / 16) == 0 && (k.Cin * es) % 128 == 0 && k.Cout % c.tc == 0 && k.in_bytes != 0;
+               k.Wo % 16 == 0 && k.Ho % (c.tp / 16) == 0 && (k.Cin * es) % 128 == 0 && k.Cout % c.tc == 0;
     if (k.Cout % c.tc) return false;
     if (k.span_bytes && (long)k.Cin * es != c.kb) return false;      // merged taps: the row is one k-step
     if (c.tc == 32 && k.Cout % 64 == 0) return false;        // a 32-channel tile only for the 32-channel layers
     if (((long)k.Cin * es) % c.kb) return false;
-    return k.in_bytes != 0;
+    return true;
 }
 
 // heuristic: largest tile that still gives every CU a block; 64-byte K steps (best on average over the network)
@@ -1898,11 +1566,6 @@ int pick_cfg(const ConvK& k) {
 
 template <typename T>
 int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
-    if (use_v1_conv() || k.in_bytes == 0) {      // register-staged fallback (also for operands beyond 2 GiB)
-        if (k.Cout % 128 == 0) return launch_v1<T, 128, 128, 2, 2>(k, mode, st);
-        if (k.Cout % 64 == 0) return launch_v1<T, 64, 64, 2, 2>(k, mode, st);
-        return launch_v1<T, 256, 32, 4, 1>(k, mode, st);
-    }
     if (cfg == 0) cfg = pick_cfg(k);
     if (!conv_cfg_ok(k, (int)sizeof(T), cfg)) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: configuration %d is not valid for this layer", cfg);
     if (cfg == CFG_HALO) {
@@ -2016,12 +1679,13 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
     k->M = (int)m;
     k->rcp_hw = m < (1L << 24) ? 1.0f / (float)(k->Hq * k->Wq) : 0.f;
     k->rcp_w = 1.0f / (float)k->Wq;
-    // extents for the DMA kernel's buffer descriptors; 0 = too large for 31-bit offsets -> v1 kernel
+    // extents of the buffer descriptors: 31-bit offsets (msc_conv_igemm hands over image ranges that fit, conv_image_chunk)
     const long in_b = (((long)d->N * d->Hi * d->Wi - 1) * d->in_ld + d->Cin) * es;
     const long wt_b = (long)d->Cout * d->KH * d->KW * d->Cin * es;
     const bool fits = in_b < 0x7fffffffL && wt_b < 0x7fffffffL;
-    k->in_bytes = fits ? (unsigned)in_b : 0;
-    k->wt_bytes = fits ? (unsigned)wt_b : 0;
+    if (!fits) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: one image (%ld bytes) or the weights (%ld bytes) exceed 2 GiB", in_b / d->N, wt_b);
+    k->in_bytes = (unsigned)in_b;
+    k->wt_bytes = (unsigned)wt_b;
     // Narrow compact inputs (32 channels = 64-byte rows, the slow LDS-DMA case): the KW taps of a kernel row read KW consecutive
     // pixels = KW*Cin contiguous elements, and the weights of those taps are contiguous too ([Cout][KH][KW][Cin]) -- run the layer
     // as KW' = 1 with Cin' = KW*Cin (one 256-byte k-step per kernel row instead of four 64-byte ones); the DMA kernel bounds-checks
@@ -2031,7 +1695,7 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
     // kernel row -- the merged rows start 64 bytes off the 128-byte lines (pixel 2x-1) and straddle three of them; OFF by default
     // (MSC_CONV_MERGE_KW=2 enables it).  The same merge in the weight gradient (wgrad_plan) is a gain and on by default.
     static const bool merge_on = [] { const char* e = getenv("MSC_CONV_MERGE_KW"); return e && e[0] == '2'; }();
-    if (merge_on && fits && !use_v1_conv() && d->mode == 0 && !d->flip && d->KW > 1 && d->in_ld == d->Cin && (long)d->KW * d->Cin * es == 256 &&
+    if (merge_on && fits && d->mode == 0 && !d->flip && d->KW > 1 && d->in_ld == d->Cin && (long)d->KW * d->Cin * es == 256 &&
         (d->Cin * es) % 16 == 0 && d->Cout % 64 == 0) {
         k->span_bytes = d->Cin * es;
         k->Cin = d->KW * d->Cin;
@@ -2040,34 +1704,69 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
     return MSC_OK;
 }
 
+// Images per launch: the kernels address their input with 31-bit byte offsets (buffer descriptors), so a tensor beyond 2 GiB
+// (fp32 mode, 512x512, batch 64: 2.1 GB at full resolution) runs as consecutive image ranges -- images are independent, the
+// statistics epilogues accumulate atomically.  Returns the number of images a launch may cover (>= 1; d->N when all fit).
+static int conv_image_chunk(const msc_conv_desc* d) {
+    if (!d || d->N <= 0 || !msc_dtype_ok(d->dtype)) return 1;
+    const long es = msc_dtype_size(d->dtype);
+    const long per_image = (long)d->Hi * d->Wi * d->in_ld * es;
+    if (per_image <= 0 || per_image * d->N < 0x7fff0000L) return d->N;
+    const long n = 0x7fff0000L / per_image;
+    return n < 1 ? 1 : (int)n;
+}
+
+// descriptor of the image range [n0, n0 + n) of *d
+static msc_conv_desc conv_image_range(const msc_conv_desc* d, int n0, int n) {
+    msc_conv_desc c = *d;
+    const long es = msc_dtype_size(d->dtype);
+    c.N = n;
+    c.in = (const char*)d->in + (long)n0 * d->Hi * d->Wi * d->in_ld * es;
+    c.out = (char*)d->out + (long)n0 * d->Ho * d->Wo * d->out_ld * es;
+    if (d->res) c.res = (const char*)d->res + (long)n0 * d->Ho * d->Wo * d->res_ld * es;
+    if (d->stats_y) c.stats_y = (const char*)d->stats_y + (long)n0 * d->Ho * d->Wo * d->stats_y_ld * es;
+    return c;
+}
+
 extern "C" int msc_conv_stats_slices(const msc_conv_desc* d) {
     ConvK probe;
-    return conv_fill(d, &probe) == MSC_OK ? MSC_BN_SLOTS : -1;      // one accumulation slot per XCD, whatever the tile
+    if (!d) return -1;
+    const msc_conv_desc first = conv_image_range(d, 0, conv_image_chunk(d));
+    return conv_fill(&first, &probe) == MSC_OK ? MSC_BN_SLOTS : -1;      // one accumulation slot per XCD, whatever the tile
 }
 
 extern "C" int msc_conv_num_cfgs(void) { return N_CONV_CFG; }
 
 extern "C" int msc_conv_cfg_ok(const msc_conv_desc* d, int cfg) {
     ConvK k;
-    if (conv_fill(d, &k) != MSC_OK) return 0;
+    if (!d) return 0;
+    const msc_conv_desc first = conv_image_range(d, 0, conv_image_chunk(d));
+    if (conv_fill(&first, &k) != MSC_OK) return 0;
     return conv_cfg_ok(k, msc_dtype_size(d->dtype), cfg) ? 1 : 0;
 }
 
 extern "C" int msc_conv_igemm(const msc_conv_desc* d, void* stream) {
-    ConvK k;
-    int rc = conv_fill(d, &k);
-    if (rc != MSC_OK) return rc;
+    if (!d) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: null descriptor");
     hipStream_t st = (hipStream_t)stream;
-    if (d->dtype == MSC_F16) return conv_dispatch<f16_t>(k, d->mode, d->cfg, st);
-    if (d->dtype == MSC_BF16) return conv_dispatch<bf16_t>(k, d->mode, d->cfg, st);
-    return conv_dispatch<float>(k, d->mode, d->cfg, st);
+    const int chunk = conv_image_chunk(d);
+    for (int n0 = 0; n0 < (d->N > 0 ? d->N : 1); n0 += chunk) {
+        const msc_conv_desc part = conv_image_range(d, n0, d->N - n0 < chunk ? d->N - n0 : chunk);
+        ConvK k;
+        int rc = conv_fill(&part, &k);
+        if (rc != MSC_OK) return rc;
+        if (d->dtype == MSC_F16) rc = conv_dispatch<f16_t>(k, d->mode, d->cfg, st);
+        else if (d->dtype == MSC_BF16) rc = conv_dispatch<bf16_t>(k, d->mode, d->cfg, st);
+        else rc = conv_dispatch<float>(k, d->mode, d->cfg, st);
+        if (rc != MSC_OK) return rc;
+    }
+    return MSC_OK;
 }
 
 extern "C" int msc_conv_wgrad_num_cfgs(void) { return WGRAD_NCFG; }
 
 namespace {
 
-struct WgPlan { WgK k; int dtype, ta, tb; bool dma, kw3; };
+struct WgPlan { WgK k; int dtype, ta, tb; bool kw3; };
 
 // Validates a descriptor and fixes tile shape and split-K.  steps_per_block > 0 (grouped launches: other problems
 // fill the chip, so a block just runs that many k-steps) overrides the per-launch policy selected by d->cfg.
@@ -2088,8 +1787,8 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
     static const bool merge_on = [] { const char* e = getenv("MSC_CONV_MERGE_KW"); return !(e && e[0] == '0'); }();
     const long m_all = (long)d->N * d->Hp * d->Wp;
     const bool dma_ok = m_all > 0 && m_all < (1L << 24) && ((m_all - 1) * d->p_ld + d->A) * es < 0x7fffffffL &&
-                        (((long)d->N * d->Hq * d->Wq - 1) * d->q_ld + (long)d->KW * d->B) * es < 0x7fffffffL;      // the DMA kernel will take it (see `fits` below)
-    if (merge_on && dma_ok && !use_v1_wgrad() && d->KW > 1 && d->q_ld == d->B && (long)d->KW * d->B * es == 256 && (d->B * es) % 16 == 0) {
+                        (((long)d->N * d->Hq * d->Wq - 1) * d->q_ld + (long)d->KW * d->B) * es < 0x7fffffffL;      // the merged row still fits (see `fits` below)
+    if (merge_on && dma_ok && d->KW > 1 && d->q_ld == d->B && (long)d->KW * d->B * es == 256 && (d->B * es) % 16 == 0) {
         span_bytes = d->B * es;
         merged.B = d->KW * d->B;
         merged.KW = 1;
@@ -2107,10 +1806,12 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
     k.M = (int)m;
     const long p_b = ((m - 1) * d->p_ld + d->A) * es;
     const long q_b = (((long)d->N * d->Hq * d->Wq - 1) * d->q_ld + d->B) * es;
-    // the float-reciprocal pixel decode of the DMA kernel is exact below 2^24 pixels
+    // 31-bit buffer offsets; the float-reciprocal pixel decode is exact below 2^24 pixels (callers hand over image ranges that
+    // fit: wgrad_image_chunk)
     const bool fits = p_b < 0x7fffffffL && q_b < 0x7fffffffL && m < (1L << 24);
-    k.p_bytes = fits ? (unsigned)p_b : 0;
-    k.q_bytes = fits ? (unsigned)q_b : 0;
+    if (!fits) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_wgrad: one image is beyond 2 GiB / 2^24 pixels (%ld pixels, %ld / %ld bytes)", m, p_b, q_b);
+    k.p_bytes = (unsigned)p_b;
+    k.q_bytes = (unsigned)q_b;
     k.rcp_hw = 1.0f / (float)(d->Hp * d->Wp);
     k.rcp_w = 1.0f / (float)d->Wp;
     const int kp = 64 / es;
@@ -2118,7 +1819,7 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
     // three taps of a kernel row per block (wgrad3_dma_body): 3x3 / stride 1 / pad 1 in a 16-bit type, image rows that a
     // 32-pixel k-step covers in whole segments
     static const bool kw3_on = [] { const char* e = getenv("MSC_WGRAD_KW3"); return !(e && e[0] == '0'); }();
-    const bool kw3 = kw3_on && !use_v1_wgrad() && fits && es == 2 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Hq == d->Hp &&
+    const bool kw3 = kw3_on && fits && es == 2 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Hq == d->Hp &&
                      d->Wq == d->Wp && (d->Wp % 32 == 0 || d->Wp == 16 || d->Wp == 8) && d->Hp >= 8 && k.M % 32 == 0;
     const int ntaps = kw3 ? d->KH : d->KH * d->KW;
     k.kw3 = kw3 ? 1 : 0;
@@ -2160,7 +1861,6 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
     k.ntiles = (d->A / ta) * (d->B / tbs); k.ntaps = ntaps; k.xcd_order = xcd_order_enabled() ? 1 : 0;
     k.nblocks = k.ntiles * k.ntaps * splits;
     out->dtype = d->dtype; out->ta = ta; out->tb = tbs;
-    out->dma = !use_v1_wgrad() && k.p_bytes != 0;
     out->kw3 = kw3;
     // 128x128 tiles: with 4 waves three accumulator sets leave one wave per SIMD and one block per CU -- measured 15 % slower
     // than the single-tap blocks at two blocks per CU (859 vs 745 us for the 3x3 layers of the ResNet101 step); the 8-wave form
@@ -2189,14 +1889,13 @@ void wgrad_tile_dispatch(int dtype, int ta, int tb, F&& f) {
 }
 
 struct WgLaunchOne {
-    const WgK& k; bool dma; hipStream_t st;
+    const WgK& k; hipStream_t st;
     template <typename T, int TA, int TB> void operator()() const {
-        if (dma && k.kw3) {
+        if (k.kw3) {
             if constexpr (TA == 128) hipLaunchKernelGGL((conv_wgrad3_dma_kernel<T, TA, TB, 4, 8>), dim3(k.nblocks), dim3(512), 0, st, k);
             else hipLaunchKernelGGL((conv_wgrad3_dma_kernel<T, TA, TB, 4>), dim3(k.nblocks), dim3(256), 0, st, k);
         }
-        else if (dma) hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, TA, TB, 4>), dim3(k.nblocks), dim3(256), 0, st, k);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<T, TA, TB>), dim3(k.nblocks), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, TA, TB, 4>), dim3(k.nblocks), dim3(256), 0, st, k);
     }
 };
 
@@ -2211,38 +1910,72 @@ struct WgLaunchGroup {
     }
 };
 
+// Images per problem (see conv_image_chunk): both operands within 31-bit byte offsets and fewer than 2^24 pixels; the weight
+// gradient is a sum over images, accumulated atomically, so image ranges are independent problems.
+int wgrad_image_chunk(const msc_wgrad_desc* d) {
+    if (!d || d->N <= 0 || !msc_dtype_ok(d->dtype)) return 1;
+    const long es = msc_dtype_size(d->dtype);
+    const long pp = (long)d->Hp * d->Wp, per_p = pp * d->p_ld * es, per_q = (long)d->Hq * d->Wq * d->q_ld * es;
+    if (pp <= 0 || per_p <= 0 || per_q <= 0) return d->N;
+    long n = d->N;
+    if (pp * n >= (1L << 24)) n = ((1L << 24) - 1) / pp;
+    if (per_p * n >= 0x7fff0000L) n = 0x7fff0000L / per_p;
+    if (per_q * n >= 0x7fff0000L) n = 0x7fff0000L / per_q;
+    return n < 1 ? 1 : (int)n;
+}
+
+msc_wgrad_desc wgrad_image_range(const msc_wgrad_desc* d, int n0, int n) {
+    msc_wgrad_desc c = *d;
+    const long es = msc_dtype_size(d->dtype);
+    c.N = n;
+    c.p = (const char*)d->p + (long)n0 * d->Hp * d->Wp * d->p_ld * es;
+    c.q = (const char*)d->q + (long)n0 * d->Hq * d->Wq * d->q_ld * es;
+    return c;
+}
+
 }  // namespace
 
 extern "C" int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream) {
-    WgPlan pl;
-    int rc = wgrad_plan(d, 0, 128, &pl);
-    if (rc != MSC_OK) return rc;
-    wgrad_tile_dispatch(pl.dtype, pl.ta, pl.tb, WgLaunchOne{pl.k, pl.dma, (hipStream_t)stream});
+    if (!d) return msc_fail(MSC_ERR_ARG, "msc_conv_wgrad: null descriptor");
+    const int chunk = wgrad_image_chunk(d);
+    for (int n0 = 0; n0 < (d->N > 0 ? d->N : 1); n0 += chunk) {
+        const msc_wgrad_desc part = wgrad_image_range(d, n0, d->N - n0 < chunk ? d->N - n0 : chunk);
+        WgPlan pl;
+        int rc = wgrad_plan(&part, 0, 128, &pl);
+        if (rc != MSC_OK) return rc;
+        wgrad_tile_dispatch(pl.dtype, pl.ta, pl.tb, WgLaunchOne{pl.k, (hipStream_t)stream});
+    }
     return msc_check_launch("conv_wgrad");
 }
 
 // ---- grouped weight gradients ---------------------------------------------------------------------
 struct msc_wgrad_group {
     struct Bucket { int dtype, ta, tb, n, blocks; WgK* tab; int* starts; bool kw3; };
-    std::vector<Bucket> buckets;      // DMA-kernel problems by (dtype, tile): one launch each
-    std::vector<WgPlan> singles;      // problems the DMA kernel cannot take (>= 2 GiB operands): launched one by one
+    std::vector<Bucket> buckets;      // problems by (dtype, tile): one launch each
     void* dev = nullptr;              // one allocation behind every table
 };
 
 extern "C" int msc_wgrad_group_create(const msc_wgrad_desc* descs, int n, int steps_per_block, int tile_cap, msc_wgrad_group** out) {
     if (!descs || n <= 0 || !out) return msc_fail(MSC_ERR_ARG, "msc_wgrad_group_create: bad argument");
-    std::vector<WgPlan> plans(n);
-    for (int i = 0; i < n; ++i) {
-        int rc = wgrad_plan(&descs[i], steps_per_block, tile_cap > 0 ? tile_cap : 128, &plans[i]);
-        if (rc != MSC_OK) return rc;
+    std::vector<WgPlan> plans;
+    plans.reserve(n);
+    for (int i = 0; i < n; ++i) {      // a layer beyond the 31-bit offsets enters the table as several image ranges
+        const int chunk = wgrad_image_chunk(&descs[i]);
+        for (int n0 = 0; n0 < (descs[i].N > 0 ? descs[i].N : 1); n0 += chunk) {
+            const msc_wgrad_desc part = wgrad_image_range(&descs[i], n0, descs[i].N - n0 < chunk ? descs[i].N - n0 : chunk);
+            WgPlan pl;
+            int rc = wgrad_plan(&part, steps_per_block, tile_cap > 0 ? tile_cap : 128, &pl);
+            if (rc != MSC_OK) return rc;
+            plans.push_back(pl);
+        }
     }
+    n = (int)plans.size();
     msc_wgrad_group* g = new msc_wgrad_group;
     // the longest-running blocks first: the launch ends when its slowest block does
     std::stable_sort(plans.begin(), plans.end(), [](const WgPlan& a, const WgPlan& b) { return a.k.mchunk > b.k.mchunk; });
     std::vector<std::vector<int>> members;
     for (int i = 0; i < n; ++i) {
         const WgPlan& p = plans[i];
-        if (!p.dma) { g->singles.push_back(p); continue; }
         size_t b = 0;
         for (; b < g->buckets.size(); ++b)
             if (g->buckets[b].dtype == p.dtype && g->buckets[b].ta == p.ta && g->buckets[b].tb == p.tb && g->buckets[b].kw3 == p.kw3) break;
@@ -2286,12 +2019,11 @@ extern "C" int msc_wgrad_group_run(const msc_wgrad_group* g, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     for (const auto& bk : g->buckets)
         wgrad_tile_dispatch(bk.dtype, bk.ta, bk.tb, WgLaunchGroup{bk.tab, bk.starts, bk.n, bk.blocks, st, bk.kw3});
-    for (const auto& p : g->singles) wgrad_tile_dispatch(p.dtype, p.ta, p.tb, WgLaunchOne{p.k, p.dma, st});
     return msc_check_launch("wgrad_group");
 }
 
 extern "C" int msc_wgrad_group_launches(const msc_wgrad_group* g) {
-    return g ? (int)(g->buckets.size() + g->singles.size()) : -1;
+    return g ? (int)g->buckets.size() : -1;
 }
 
 extern "C" void msc_wgrad_group_destroy(msc_wgrad_group* g) {

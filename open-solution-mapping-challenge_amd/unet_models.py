@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._lib import ConvDesc, WgradDesc, F32, BF16, F16
+from ._lib import BneckDesc, ConvDesc, WgradDesc, F32, BF16, F16
 
 _DTYPES = {'bf16': (torch.bfloat16, BF16), 'fp16': (torch.float16, F16), 'fp32': (torch.float32, F32)}
 
@@ -566,7 +566,7 @@ def _flat_views(self, flat):
 
 
 def _grad_views(self):
-    return self._flat_views(self._flat[1])
+    return self.flat_views(self._flat[1])
 
 
 UNetResNet.flat_views = _flat_views
@@ -640,6 +640,7 @@ class _Builder:
         self.fuse_relu_bwd = _os_env.environ.get('MSC_FUSE_RELU_BWD', '1') != '0'
         self.rwriter = {}             # id(activation buffer) -> (ConvDesc, c0, C) of that first writer
         self.bias_items = []          # (slots address, slot channel count, bias parameter, channels) awaiting flush_bias_slots
+        self.fuse_bneck = _os_env.environ.get('MSC_FUSE_BNECK', '1') != '0'
 
     # ---- memory
     def buf(self, H, W, C, dtype=None):
@@ -916,6 +917,39 @@ class _Builder:
         else:
             self.conv(bwd, dy, wt, gx, KH=k, KW=k, stride=2, pad=geo['pad'], mode=1, res=gx if acc else None)
 
+    def bottleneck_fused(self, base, x, blk, out):
+        """Eval mode, 16-bit compute: the identity Bottleneck `blk` (conv1x1-bn-relu, conv3x3-bn-relu, conv1x1-bn, + x, relu) as ONE
+        launch (msc_bottleneck_fused; csrc/bottleneck.hip) when the kernel takes the shape -- the intermediates never leave
+        LDS.  Returns False when the block has to run as three convolutions (training: batch statistics sit between them;
+        fp32 parity mode; 512-channel stage; map width not a multiple of 16).  MSC_FUSE_BNECK=0 switches it off (A/B)."""
+        if self.training or self.dev.type != 'cuda' or self.dt == F32 or not self.fuse_bneck:
+            return False
+        if blk.downsample is not None or blk.stride != 1 or x.C != out.C or x.C != 4 * blk.conv1.out_channels:
+            return False
+        net, lib, P = self.net, self.lib, self.prog
+        cmid = blk.conv1.out_channels
+        d = BneckDesc()
+        d.x, d.out, d.x_ld, d.out_ld = x.ptr, out.ptr, x.ld, out.ld
+        d.dtype, d.N, d.H, d.W, d.Cmid, d.cfg = self.dt, self.N, x.H, x.W, cmid, 0
+        if not lib.msc_bottleneck_ok(C.byref(d)):
+            return False
+        coef = []
+        for bn in (blk.bn1, blk.bn2, blk.bn3):
+            sc, sh = self.vec(bn.num_features), self.vec(bn.num_features)
+            self.emit(P.fold, lib.msc_bn_fold, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                      bn.running_var.data_ptr(), BN_EPS, sc.data_ptr(), sh.data_ptr(), bn.num_features)
+            coef += [sc, sh]
+        wpk = self.vec(int(lib.msc_bottleneck_pack_bytes(cmid)), dtype=torch.uint8)
+        w = net._pack['w']
+        # the fragment-major weight stream is rebuilt with the folded coefficients whenever the master weights changed
+        self.emit(P.fold, lib.msc_bottleneck_pack, w[base + '.conv1'].data_ptr(), w[base + '.conv2'].data_ptr(), w[base + '.conv3'].data_ptr(),
+                  wpk.data_ptr(), cmid, self.dt)
+        d.wpk = wpk.data_ptr()
+        d.scale1, d.shift1, d.scale2, d.shift2, d.scale3, d.shift3 = [t.data_ptr() for t in coef]
+        P.keep.append(d)
+        self.emit(P.fwd, lib.msc_bottleneck_fused, C.byref(d))
+        return True
+
     def _relu_writer(self, x, d, acc):
         """remember the data-gradient conv `d` as the first (non-accumulating) writer of grad(x)"""
         if self.fuse_relu_bwd and not acc and self.dev.type != 'meta':
@@ -1072,6 +1106,8 @@ class _Builder:
                     a = self.act(ho, wo, planes)
                     self.conv_bn(base + '.conv1', cur, blk.conv1, blk.bn1, s, True, a)
                     self.conv_bn(base + '.conv2', a, blk.conv2, blk.bn2, 1, True, out, res=idt)
+                elif self.bottleneck_fused(base, cur, blk, out):
+                    pass
                 else:
                     a = self.act(hh, ww, planes)
                     self.conv_bn(base + '.conv1', cur, blk.conv1, blk.bn1, 1, True, a)

@@ -1,7 +1,7 @@
-"""Tensor-level wrappers over single C-ABI entry points (include/msc.h), on NHWC cuda tensors.
+"""TEST SUPPORT -- tensor-level wrappers over single C-ABI entry points (include/msc.h), on NHWC cuda tensors.
 
-Used by the kernel parity tests and handy for experiments; the network itself drives the C ABI through
-pre-built descriptors (unet_models._Builder) and does not go through here.
+Used by the kernel parity tests (tests/test_gpu_kernels.py) and the probes; the product drives the C ABI through pre-built
+descriptors (unet_models._Builder) and does not go through here (moved out of the package in round 3).
 Activations: torch tensors of shape [N,H,W,C] (f32 or bf16), possibly channel slices of a wider buffer
 (`x[..., c0:c1]`) -- the channel stride is taken from `x.stride(2)`.
 """
@@ -9,8 +9,8 @@ import ctypes as C
 
 import torch
 
-from . import _lib
-from ._lib import ConvDesc, WgradDesc, F32, BF16, F16
+from mapping_challenge_amd import _lib
+from mapping_challenge_amd._lib import ConvDesc, WgradDesc, F32, BF16, F16
 
 
 def _dt(t):

@@ -34,7 +34,8 @@ def test_reexec_line_really_starts_n_ranks_with_the_torchrun_environment(tmp_pat
         't = torch.tensor([float(w.rank + 1)])\n'
         'w.all_reduce(t)\n'
         'w.barrier()\n'
-        'print("RANK", w.rank, w.size, os.environ["LOCAL_RANK"], os.environ["MASTER_ADDR"], w.grad_wire, t.item(), flush=True)\n' % ROOT)
+        'line = "RANK %%d %%d %%s %%s %%s %%.1f" %% (w.rank, w.size, os.environ["LOCAL_RANK"], os.environ["MASTER_ADDR"], w.grad_wire, t.item())\n'
+        'open(os.path.join(%r, "rank%%d.txt" %% w.rank), "w").write(line)\n' % (ROOT, str(tmp_path)))
     argv = bench.reexec_argv(2, [])
     argv[argv.index(os.path.join(ROOT, 'bench.py'))] = str(script)
     env = dict(os.environ, OMP_NUM_THREADS='1')
@@ -42,5 +43,5 @@ def test_reexec_line_really_starts_n_ranks_with_the_torchrun_environment(tmp_pat
         env.pop(k, None)
     out = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = sorted(l for l in out.stdout.splitlines() if l.startswith('RANK'))
-    assert lines == ['RANK 0 2 0 127.0.0.1 bf16 3.0', 'RANK 1 2 1 127.0.0.1 bf16 3.0'], out.stdout
+    lines = [open(str(tmp_path / ('rank%d.txt' % r))).read() for r in range(2)]      # one file per rank: stdout of the ranks interleaves
+    assert lines == ['RANK 0 2 0 127.0.0.1 bf16 3.0', 'RANK 1 2 1 127.0.0.1 bf16 3.0'], (lines, out.stdout)

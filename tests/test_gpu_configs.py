@@ -215,8 +215,9 @@ def test_bf16_training_trajectory_tracks_the_fp32_oracle_resnet101_256():
                                          'rel_mean': float(np.mean(rel)), 'final_mask_iou': iou, 'foreground': float(mr.mean()),
                                          'weight_rel_l2_median': float(np.median([rel_l2(final_w[n], pw[n].detach()) for n in names if final_w[n].dim() == 4]))})
     assert np.isfinite(hip_losses).all()
-    # the engine's curve follows the oracle's: every step within 10 %, 3 % on average (CPU emulation of the same experiment with
-    # 16-bit storage, ResNet34 128x128: 0.9 % / 0.4 %)
-    assert max(rel) < 0.10 and np.mean(rel) < 0.03, (max(rel), np.mean(rel), hip_losses[::5], ref_losses[::5])
-    assert hip_losses[-1] < warm[0] and ref_losses[-1] < warm[0]
-    assert 0.02 < mr.mean() < 0.9 and iou >= 0.98, (iou, mr.mean())
+    # the engine's curve follows the oracle's: every step within 2 %, 1 % on average, final masks IoU >= 0.99
+    # (measured on MI355X: 0.19 % worst step, 0.10 % mean, IoU 0.9989; a 30 % bias of the bf16 gradients -- which the per-tensor band of
+    # test_gpu_parity_timed.py would let through -- moves the loss curve by several per cent within ten steps)
+    assert max(rel) < 0.02 and np.mean(rel) < 0.01, (max(rel), np.mean(rel), hip_losses[::5], ref_losses[::5])
+    assert hip_losses[-1] < 0.6 * hip_losses[0] and ref_losses[-1] < 0.6 * ref_losses[0]      # and both still learn
+    assert 0.02 < mr.mean() < 0.9 and iou >= 0.99, (iou, mr.mean())

@@ -33,7 +33,7 @@ def to_nchw(t):
                                                     (64, 256, 1, 2, 14, 2), (32, 32, 3, 1, 20, 1), (320, 128, 3, 1, 8, 2),
                                                     (64, 64, 3, 1, 40, 4), (256, 512, 3, 1, 33, 2)])
 def test_conv_forward_epilogues(dtype, cin, cout, k, stride, hw, n):
-    from mapping_challenge_amd import ops
+    import hip_ops as ops
     pad = k // 2
     x = rnd((n, cin, hw, hw), dtype, 1)
     w = rnd((cout, cin, k, k), dtype, 2, (2.0 / (cin * k * k)) ** 0.5)
@@ -54,7 +54,7 @@ def test_conv_forward_epilogues(dtype, cin, cout, k, stride, hw, n):
 @pytest.mark.parametrize('dtype', DT)
 def test_conv_channel_slices_and_stats(dtype):
     """input / output / residual as channel slices of wider buffers; BN partial statistics"""
-    from mapping_challenge_amd import ops
+    import hip_ops as ops
     n, hw, cin, cout = 2, 10, 64, 64
     x = rnd((n, cin, hw, hw), dtype, 1)
     w = rnd((cout, cin, 3, 3), dtype, 2, 0.06)
@@ -76,7 +76,7 @@ def test_conv_channel_slices_and_stats(dtype):
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('cin,cout,hw', [(64, 64, 6), (512, 256, 4), (128, 32, 16)])
 def test_conv_transpose_forward(dtype, cin, cout, hw):
-    from mapping_challenge_amd import ops
+    import hip_ops as ops
     n = 2
     x = rnd((n, cin, hw, hw), dtype, 1)
     wt = rnd((cin, cout, 4, 4), dtype, 2, (2.0 / (cin * 4)) ** 0.5)
@@ -94,7 +94,7 @@ def test_conv_transpose_forward(dtype, cin, cout, hw):
                                                   (64, 256, 1, 2, 12), (128, 64, 4, 2, 16)])
 def test_data_gradient(dtype, cin, cout, k, stride, hw):
     """dgrad of conv (stride 1: flipped gather; stride 2: transposed mode) and of ConvTranspose2d (k4: gather s2)"""
-    from mapping_challenge_amd import ops
+    import hip_ops as ops
     n = 2
     deconv = k == 4
     if deconv:           # forward: x[cin, hw] -> out[cout, 2hw]; dgrad wrt x
@@ -136,7 +136,7 @@ def test_data_gradient(dtype, cin, cout, k, stride, hw):
 @pytest.mark.parametrize('cin,cout,k,stride,hw,n', [(64, 64, 3, 1, 12, 2), (64, 128, 1, 1, 9, 3), (128, 64, 3, 2, 16, 2),
                                                     (32, 32, 3, 1, 24, 2), (256, 128, 3, 1, 8, 4), (64, 32, 4, 2, 10, 2), (128, 32, 4, 2, 24, 3)])
 def test_weight_gradient(dtype, cin, cout, k, stride, hw, n):
-    from mapping_challenge_amd import ops
+    import hip_ops as ops
     if k == 4:           # ConvTranspose2d: dW[cin][kh][kw][cout]
         x = rnd((n, cin, hw, hw), dtype, 1)
         wt = rnd((cin, cout, 4, 4), dtype, 2, 0.05).requires_grad_(True)
@@ -168,7 +168,8 @@ def test_weight_gradient_three_taps_per_block(dtype, cin, cout, hw, n):
     a kernel row from ONE staged segment with a one-pixel halo (wgrad3_dma_body) -- every tile shape, every split-K policy, alone
     and grouped, channel slices of wider buffers, against torch; MSC_WGRAD_KW3=0 (single-tap blocks) must agree bit for bit in
     the structure of the result (same tolerance)"""
-    from mapping_challenge_amd import _lib, ops
+    from mapping_challenge_amd import _lib
+    import hip_ops as ops
     x = rnd((n, cin, hw, hw), dtype, 1)
     w = rnd((cout, cin, 3, 3), dtype, 2, 0.05).requires_grad_(True)
     y = F.conv2d(x, w, padding=1)
@@ -196,7 +197,7 @@ def test_weight_gradient_three_taps_per_block(dtype, cin, cout, hw, n):
 
 @pytest.mark.parametrize('dtype', DT)
 def test_maxpool_forward_backward(dtype):
-    from mapping_challenge_amd import ops
+    import hip_ops as ops
     x = rnd((2, 64, 12, 16), dtype, 1).requires_grad_(True)
     y = F.max_pool2d(x, 2, 2)
     dy = rnd(tuple(y.shape), dtype, 2)
@@ -207,7 +208,7 @@ def test_maxpool_forward_backward(dtype):
 
 
 def test_adam_matches_torch_optim():
-    from mapping_challenge_amd import ops
+    import hip_ops as ops
     torch.manual_seed(0)
     p0 = torch.randn(10007)
     pr = torch.nn.Parameter(p0.clone())
@@ -248,7 +249,7 @@ def test_loss_kernels_match_oracle_and_golden(golden_dir):
 def test_every_kernel_configuration_is_correct(dtype, cin, cout, k, stride, hw, n):
     """the per-layer autotuner may pick any valid configuration: each must give the same convolution (incl. BN partial
     statistics and the transposed mode), and each wgrad configuration the same weight gradient"""
-    from mapping_challenge_amd import ops
+    import hip_ops as ops
     pad = k // 2
     x = rnd((n, cin, hw, hw), dtype, 1)
     w = rnd((cout, cin, k, k), dtype, 2, (2.0 / (cin * k * k)) ** 0.5)
@@ -291,7 +292,7 @@ def test_every_kernel_configuration_is_correct(dtype, cin, cout, k, stride, hw, 
 def test_grouped_weight_gradients_equal_separate_ones(dtype, steps, cap):
     """msc_wgrad_group_*: layers of different shapes (several tile buckets, 1x1 / 3x3 / strided, ragged pixel counts) in one
     launch per bucket; each gradient equals torch's, also when the group is run twice into the same buffers (+=)"""
-    from mapping_challenge_amd import ops
+    import hip_ops as ops
     shapes = [(128, 128, 3, 1, 20, 3), (64, 256, 1, 1, 16, 4), (32, 32, 3, 1, 24, 2), (64, 64, 3, 2, 18, 2), (256, 128, 1, 1, 9, 3),
               (128, 256, 3, 1, 7, 1), (32, 96, 1, 2, 10, 2)]
     problems, refs = [], []
@@ -318,7 +319,8 @@ def test_conv_epilogue_batchnorm_backward_sums(dtype, cin, cout, k, hw, n, maske
     """stats_kind 1: a (data-gradient) conv also reduces (sum dh, sum dh*y), dh = out * [scale*y + shift > 0], per channel --
     what msc_bn_bwd_reduce would compute from the stored tensors; every configuration"""
     import ctypes as C
-    from mapping_challenge_amd import _lib, ops
+    from mapping_challenge_amd import _lib
+    import hip_ops as ops
     lib = _lib.load()
     pad = k // 2
     x = rnd((n, cin, hw, hw), dtype, 1)
@@ -361,7 +363,8 @@ def test_conv_epilogue_relu_backward_and_bias_sums(dtype, cin, cout, k, stride, 
     msc_bias_slots_finalize) -- the pass msc_relu_bias_grad would make over the tensors; every valid configuration, incl. the
     halo-tile kernel of the 32-channel layers and the stride-2 gather form of the ConvTranspose2d data gradient"""
     import ctypes as C
-    from mapping_challenge_amd import _lib, ops
+    from mapping_challenge_amd import _lib
+    import hip_ops as ops
     lib = _lib.load()
     pad = 1
     ho = (hw + 2 * pad - k) // stride + 1
@@ -421,7 +424,8 @@ def test_conv_epilogue_relu_backward_and_bias_sums(dtype, cin, cout, k, stride, 
 def test_final_1x1_backward(dtype, n, hw, c, with_bias_in):
     """msc_final_bwd against torch autograd of ReLU -> Conv2d(C, 2, 1): the input gradient masked by the producer's ReLU, the
     1x1 weight / bias gradients, and the producer's bias gradient summed from the stored (rounded) input gradient"""
-    from mapping_challenge_amd import _lib, ops
+    from mapping_challenge_amd import _lib
+    import hip_ops as ops
     lib = _lib.load()
     if c * (4 if dtype == torch.float32 else 2) % 16:
         pytest.skip('C must keep 16-byte channel vectors')
@@ -460,7 +464,8 @@ def test_halo_tile_kernel_for_3x3_convs_of_any_width(dtype, cin, cout, hw, n):
     flipped taps + accumulate (data gradient), folded BN + ReLU, channel slices of wider buffers, and the three kinds of
     epilogue statistics, against torch"""
     import ctypes as C
-    from mapping_challenge_amd import _lib, ops
+    from mapping_challenge_amd import _lib
+    import hip_ops as ops
     lib = _lib.load()
     st = torch.cuda.current_stream().cuda_stream
     x = rnd((n, cin, hw, hw), dtype, 1)
@@ -540,7 +545,8 @@ def test_halo_tile_kernel_for_3x3_convs_of_any_width(dtype, cin, cout, hw, n):
 def test_halo_tile_kernel_for_32_channel_3x3(hw, n, flip, with_res, relu, dtype):
     """the halo-tile configuration (last one) of the 32-channel 3x3 layers: bias / scale, ReLU, residual accumulate and the
     flipped-tap form used by the data gradient, against torch"""
-    from mapping_challenge_amd import _lib, ops
+    from mapping_challenge_amd import _lib
+    import hip_ops as ops
     lib = _lib.load()
     halo = _lib.CFG_HALO
     x = rnd((n, 32, hw, hw), dtype, 1)
@@ -572,7 +578,8 @@ def test_halo_tile_kernel_for_32_channel_3x3(hw, n, flip, with_res, relu, dtype)
 @pytest.mark.parametrize('hw,n,relu,with_res', [(16, 2, True, False), (32, 1, False, True), (8, 3, True, False)])
 def test_halo_tile_kernel_for_the_128_to_32_transposed_conv(hw, n, relu, with_res, dtype):
     """ConvTranspose2d(128, 32, k4, s2, p1) + bias (+ReLU) through the halo-tile configuration, against torch"""
-    from mapping_challenge_amd import _lib, ops
+    from mapping_challenge_amd import _lib
+    import hip_ops as ops
     cfg = _lib.CFG_HALO_T
     x = rnd((n, 128, hw, 2 * hw), dtype, 1)                     # non-square: 8 | H, 16 | W
     wt = rnd((128, 32, 4, 4), dtype, 2, 0.05)
@@ -655,3 +662,94 @@ def test_batchnorm_training_forward_and_backward_with_prologue_finalize(dtype, c
     assert (dbeta.cpu() - bn.bias.grad).abs().max().item() < (2e-4 if dtype == torch.float32 else 5e-2) * max(1.0, bn.bias.grad.abs().max().item())
     if with_res:
         assert (~torch.isclose(to_nchw(dresd), rr.grad, **t)).float().mean().item() <= (0.0 if dtype == torch.float32 else 2e-3)
+
+
+def test_conv_and_wgrad_beyond_2gib_run_as_image_ranges():
+    """the kernels address their operands with 31-bit byte offsets (buffer descriptors): a 2.4 GB input (9 images of
+    512 x 512 x 512 channels in bf16) is run as consecutive image ranges -- conv with a statistics epilogue (accumulated
+    across the ranges), and the weight gradient (a sum over images) -- against torch on the device"""
+    import hip_ops as ops
+    n, hw, cin, cout = 9, 512, 512, 32
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = (torch.randn((n, hw, hw, cin), generator=g, device='cuda') * 0.5).to(torch.bfloat16)      # 2.42 GB > 2 GiB
+    assert x.numel() * 2 > 2 ** 31
+    w = (torch.randn((cout, 1, 1, cin), generator=g, device='cuda') * (2.0 / cin) ** 0.5).to(torch.bfloat16)
+    out = torch.empty((n, hw, hw, cout), dtype=torch.bfloat16, device='cuda')
+    stats = torch.zeros(8 * cout * 2, dtype=torch.float64, device='cuda')
+    ops.conv_igemm(x, w, out, stride=1, pad=0, stats=stats)
+    ref = x.view(-1, cin).float() @ w.view(cout, cin).float().t()
+    assert torch.allclose(out.view(-1, cout).float(), ref, rtol=2e-2, atol=2e-2)
+    assert out[-1].float().abs().max().item() > 0        # the last image range was written
+    s = stats.view(8, cout, 2).sum(0)
+    assert torch.allclose(s[:, 0], ref.double().sum(0), rtol=1e-3, atol=1e-1) and torch.allclose(s[:, 1], (ref.double() ** 2).sum(0), rtol=1e-3)
+    # weight gradient dW[a][b] = sum_m dy[m][a] * x[m][b]: q (= x) is the operand beyond 2 GiB
+    dy = (torch.randn((n, hw, hw, cout), generator=g, device='cuda') * 0.05).to(torch.bfloat16)
+    dw = torch.zeros((cout, 1, 1, cin), dtype=torch.float32, device='cuda')
+    ops.conv_wgrad(dy, x, dw, 1, 1, stride=1, pad=0)
+    dref = dy.view(-1, cout).float().t() @ x.view(-1, cin).float()
+    assert (dw.view(cout, cin) - dref).abs().max().item() <= 2e-3 * dref.abs().max().item()
+    # ... also through a grouped launch (the table gets one problem per image range)
+    dw2 = torch.zeros_like(dw)
+    ops.conv_wgrad_group([(dy, x, dw2, 1, 1, 1, 0)], 128, 128)
+    assert (dw2.view(cout, cin) - dref).abs().max().item() <= 2e-3 * dref.abs().max().item()
+
+
+def _bottleneck_reference(x, w1, w2, w3, co, dtype):
+    """torch-CPU fp32 reference of the eval-mode identity Bottleneck with the kernel's storage points: both intermediates are
+    rounded to the 16-bit dtype (as the three-launch path stores them in HBM), accumulation in fp32"""
+    def store(t):
+        return t.to(dtype).float()
+    s1, b1, s2, b2, s3, b3 = [c.view(1, -1, 1, 1) for c in co]
+    y1 = store(torch.relu(F.conv2d(x, w1) * s1 + b1))
+    y2 = store(torch.relu(F.conv2d(y1, w2, padding=1) * s2 + b2))
+    return torch.relu(F.conv2d(y2, w3) * s3 + b3 + x)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('cmid,n,h,w,cfg,pad_ld', [(64, 3, 16, 32, 0, 0), (64, 1, 8, 16, 0, 64), (128, 2, 16, 16, 0, 0), (128, 1, 24, 32, 0, 256),
+                                                   (256, 2, 8, 16, 2, 0), (256, 2, 8, 16, 4, 0), (256, 1, 16, 32, 4, 128), (256, 1, 6, 16, 2, 0)])
+def test_fused_bottleneck_matches_the_three_convolutions(dtype, cmid, n, h, w, cfg, pad_ld):
+    """msc_bottleneck_fused (conv1x1-bn-relu, conv3x3-bn-relu, conv1x1-bn, + x, relu in one launch, intermediates in LDS) against
+    the composition of the three convolutions, for every kernel instantiation (Cmid 64 / 128 / 256, patch rows 8 / 2 / 4), several
+    patches per image in both directions (halo rows AND columns cross patch borders), image borders (zero padding of the 3x3
+    applies to conv1's OUTPUT: not ReLU(shift)), and input / output as channel slices of wider buffers"""
+    import ctypes as C
+    from mapping_challenge_amd import _lib
+    lib = _lib.load()
+    c4 = 4 * cmid
+    x = rnd((n, c4, h, w), dtype, 1)
+    w1 = rnd((cmid, c4, 1, 1), dtype, 2, (2.0 / c4) ** 0.5)
+    w2 = rnd((cmid, cmid, 3, 3), dtype, 3, (2.0 / (9 * cmid)) ** 0.5)
+    w3 = rnd((c4, cmid, 1, 1), dtype, 4, (2.0 / cmid) ** 0.5)
+    g = torch.Generator().manual_seed(5)
+    co = [torch.rand(cmid, generator=g) + 0.5, torch.randn(cmid, generator=g) * 0.2 + 0.1,       # positive shifts: a wrong padding value shows
+          torch.rand(cmid, generator=g) + 0.5, torch.randn(cmid, generator=g) * 0.2 + 0.1,
+          torch.rand(c4, generator=g) * 0.5 + 0.25, torch.randn(c4, generator=g) * 0.2]
+    ref = _bottleneck_reference(x, w1, w2, w3, co, dtype)
+    ld = c4 + pad_ld
+    xb = torch.full((n, h, w, ld), 7.0, dtype=dtype, device='cuda')
+    ob = torch.full((n, h, w, ld), -3.0, dtype=dtype, device='cuda')
+    xb[..., pad_ld:] = nhwc(x, dtype)
+    dt = {torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}[dtype]
+    wk = [t.permute(0, 2, 3, 1).contiguous().to(dtype).cuda() for t in (w1, w2, w3)]
+    wpk = torch.empty(int(lib.msc_bottleneck_pack_bytes(cmid)), dtype=torch.uint8, device='cuda')
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.msc_bottleneck_pack(wk[0].data_ptr(), wk[1].data_ptr(), wk[2].data_ptr(), wpk.data_ptr(), cmid, dt, stream), 'pack')
+    cod = [c.cuda() for c in co]
+    d = _lib.BneckDesc()
+    d.x, d.out, d.wpk = xb.data_ptr() + pad_ld * 2, ob.data_ptr() + pad_ld * 2, wpk.data_ptr()
+    d.scale1, d.shift1, d.scale2, d.shift2, d.scale3, d.shift3 = [c.data_ptr() for c in cod]
+    d.x_ld = d.out_ld = ld
+    d.dtype, d.N, d.H, d.W, d.Cmid, d.cfg = dt, n, h, w, cmid, cfg
+    assert lib.msc_bottleneck_ok(C.byref(d)) == 1
+    _lib.check(lib.msc_bottleneck_fused(C.byref(d), stream), 'msc_bottleneck_fused')
+    torch.cuda.synchronize()
+    got = to_nchw(ob[..., pad_ld:])
+    assert torch.allclose(got, ref, **tol(dtype)), (got - ref).abs().max().item()
+    if pad_ld:
+        assert (ob[..., :pad_ld].float() == -3.0).all()          # nothing written outside the channel slice
+    # shapes the kernel does not take are refused, not mis-run
+    d.W = w + 8
+    assert lib.msc_bottleneck_ok(C.byref(d)) == 0 and lib.msc_bottleneck_fused(C.byref(d), stream) != 0
+    d.W, d.Cmid = w, 512
+    assert lib.msc_bottleneck_ok(C.byref(d)) == 0
