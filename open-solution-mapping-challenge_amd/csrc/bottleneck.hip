@@ -34,6 +34,7 @@
 namespace {
 
 struct BnkK {
+    unsigned long long* dbg;      // probe only (ABL bit 3): per-phase shader-clock stamps of wave 0 of every block
     const char* x; char* out; const char* wpk;
     const float* sc1; const float* sh1; const float* sc2; const float* sh2; const float* sc3; const float* sh3;
     long x_ld, out_ld;
@@ -111,7 +112,10 @@ template <> __device__ __forceinline__ uint4 pack8<f16_t>(const float* v) { retu
 // ring (registers: 16 VGPRs per stage) -- RW-1 k-steps of weights are in flight per wave: the stream comes out of L2 (or, for
 // the first block of an XCD to touch a line, out of HBM) with a microsecond or more of latency, and 8 waves x 4 KB x (RW-1) per
 // CU is what has to cover it; MINB: resident blocks per CU the register allocation has to allow
-template <typename T, int CMID, int PH, int RX, int RW, int MINB>
+// ABL (tools/bneck_probe.py only, MSC_BNECK_ABL; 0 in the product): bit 0 = no MFMA (operands still fetched), bit 1 = weight loads go out
+// with an out-of-range offset (same instruction stream, no L2 traffic), bit 2 = no pixel-fragment reads from LDS, bit 3 = per-phase
+// shader-clock stamps into the debug buffer.  Only 7 and 8 are instantiated in the library (results: profiles/r3_bneck_probe.txt)
+template <typename T, int CMID, int PH, int RX, int RW, int MINB, int ABL = 0>
 __global__ __launch_bounds__(512, MINB * 2) void bottleneck_fused_kernel(BnkK p) {
     static_assert(sizeof(T) == 2, "16-bit types");
     constexpr int NW = 8;                                  // waves per block
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(512, MINB * 2) void bottleneck_fused_kernel(BnkK p)
     constexpr int PLANE1 = HPR * 128, MID1 = NCH * PLANE1;
     constexpr int PLANE2 = PH * 16 * 128, MID2 = NCH * PLANE2;
     constexpr int WSTEP = WC * NF * 1024;                  // bytes of the weight stream per k-step
-    static_assert(WC * WP == NW && PH % WP == 0 && K1S >= RX && RX >= 2 && RW >= 2 && RW <= 8, "tiling");
+    static_assert(WC * WP == NW && PH % WP == 0 && K1S >= RX && RX >= 2 && RW >= 2 && RW <= 8 && (K1S & (K1S - 1)) == 0, "tiling");
     static_assert(MID2 <= RX * XSTAGE, "phase-2 result reuses the pixel-row ring");
     constexpr int COEF = 12 * CMID * 4;                    // (scale, shift) of the three BatchNorms: 2 x (CMID + CMID + 4 CMID) floats
     static_assert(MID1 + RX * XSTAGE + COEF <= 160 * 1024, "LDS");
@@ -153,6 +157,10 @@ __global__ __launch_bounds__(512, MINB * 2) void bottleneck_fused_kernel(BnkK p)
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wid / WC, wc = wid % WC;
     const int g = lane >> 4, pl = lane & 15;
+    auto stamp = [&](int i) {
+        if ((ABL & 8) && p.dbg && tid == 0) p.dbg[blockIdx.x * 16 + i] = __builtin_readcyclecounter();
+    };
+    stamp(0);
     // XCD-aware order (block b runs on XCD b % 8): consecutive patches -- vertical neighbours share halo rows -- on one XCD
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int xcd = orig & 7, wq = nwg >> 3, wr_ = nwg & 7;
@@ -176,22 +184,35 @@ __global__ __launch_bounds__(512, MINB * 2) void bottleneck_fused_kernel(BnkK p)
         const bool ok = hp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         hoff[i] = ok ? (unsigned)((n * p.H + iy) * p.W + ix) * pix_bytes + (unsigned)(slot ^ ((hp >> 1) & 7)) * 16u : OOB_OFF;
     }
-    const unsigned wvoff = (unsigned)(wc * NF * 1024 + lane * 16);
+    const unsigned wvoff = (ABL & 2) ? OOB_OFF : (unsigned)(wc * NF * 1024 + lane * 16);
 
+    // Every CU needs the whole weight stream of a phase, in no particular order (only the fp32 summation order depends on it).
+    // Read in the SAME order by the 32 CUs of an XCD -- all started together, all at the same rate -- every line is asked for 32
+    // times within a few hundred cycles and the L2 channel that holds it serialises them while the other channels idle.  So each
+    // block starts the k-steps of phase 1 (its input-channel chunks) and of phase 2 (its (chunk, tap) pairs) at its own offset:
+    // at any time the CUs of an XCD pull different parts of the stream, and the first touches (HBM) are spread as well.
+    const int qx = (orig >> 3) & 31;                        // position among the blocks of this XCD that are resident together
+    const int rot1 = __builtin_amdgcn_readfirstlane((qx * K1S) >> 5);
+    const int rot2 = __builtin_amdgcn_readfirstlane((qx * S2) >> 5);
+    auto elem1 = [&](int t) { return (t + rot1) & (K1S - 1); };                                   // chunk of phase-1 k-step t
+    auto elem2 = [&](int i) { const int e = i + rot2; return e >= S2 ? e - S2 : e; };             // (chunk, tap) of phase-2 k-step i
+    auto wsoff = [&](int ts) {                              // byte offset of weight stage ts (ts is a compile-time constant at every call)
+        return ts < K1S ? elem1(ts) * WSTEP : ts < K1S + S2 ? (K1S + elem2(ts - K1S)) * WSTEP : ts * WSTEP;
+    };
     u32x4_t wring[RW][NF];
     // stage t of the stream: its pixel rows (phase 1 only; past K1S the instructions still go out, with an out-of-range offset:
     // every k-step of phase 1 issues the same number of memory instructions, so the counted waits are compile-time constants)
     auto x_piece = [&](int i, int t, int xs) {
         const bool live = t < K1S;
-        dma16(rx, xring + xs * XSTAGE + (i * NW + wid) * 1024, live ? hoff[i] : OOB_OFF, live ? t * 128 : 0);
+        dma16(rx, xring + xs * XSTAGE + (i * NW + wid) * 1024, live ? hoff[i] : OOB_OFF, live ? elem1(t) * 128 : 0);
     };
     // ---- prologue: weight stages 0 .. RW-2, pixel-row stages 0 .. RX-2
     static_for<RW - 1>([&](auto tt) {
         constexpr int t = decltype(tt)::value;
-        wload<0>(wring[t][0], rw, wvoff, t * WSTEP);
-        wload<1024>(wring[t][1], rw, wvoff, t * WSTEP);
-        wload<2048>(wring[t][2], rw, wvoff, t * WSTEP);
-        wload<3072>(wring[t][3], rw, wvoff, t * WSTEP);
+        wload<0>(wring[t][0], rw, wvoff, wsoff(t));
+        wload<1024>(wring[t][1], rw, wvoff, wsoff(t));
+        wload<2048>(wring[t][2], rw, wvoff, wsoff(t));
+        wload<3072>(wring[t][3], rw, wvoff, wsoff(t));
     });
 #pragma unroll
     for (int t = 0; t < RX - 1; ++t) {
@@ -199,6 +220,7 @@ __global__ __launch_bounds__(512, MINB * 2) void bottleneck_fused_kernel(BnkK p)
         for (int i = 0; i < XH; ++i) x_piece(i, t, t);
     }
 
+    stamp(1);
     // =============================================================== phase 1: conv1 over the halo
     {
         f32x4 acc[FM][FN1];
@@ -225,7 +247,7 @@ __global__ __launch_bounds__(512, MINB * 2) void bottleneck_fused_kernel(BnkK p)
             for (int kk = 0; kk < 2; ++kk) {
                 uint4 bf[FN1];
 #pragma unroll
-                for (int b = 0; b < FN1; ++b) bf[b] = *reinterpret_cast<const uint4*>(xb + (boff[b] ^ (kk * 64)));
+                for (int b = 0; b < FN1; ++b) bf[b] = (ABL & 4) ? make_uint4(1u, 2u, 3u, 4u) : *reinterpret_cast<const uint4*>(xb + (boff[b] ^ (kk * 64)));
 #pragma unroll
                 for (int a = 0; a < FM; ++a)
 #pragma unroll
@@ -235,15 +257,17 @@ __global__ __launch_bounds__(512, MINB * 2) void bottleneck_fused_kernel(BnkK p)
                         for (int i = 0; i < LPW; ++i)
                             if ((i * NM) / LPW == m) {
                                 if (i < XH) x_piece(i < XH ? i : 0, xs, jx);
-                                else if (i == XH) wload<0>(wring[js][0], rw, wvoff, ts * WSTEP);
-                                else if (i == XH + 1) wload<1024>(wring[js][1], rw, wvoff, ts * WSTEP);
-                                else if (i == XH + 2) wload<2048>(wring[js][2], rw, wvoff, ts * WSTEP);
-                                else wload<3072>(wring[js][3], rw, wvoff, ts * WSTEP);
+                                else if (i == XH) wload<0>(wring[js][0], rw, wvoff, wsoff(ts));
+                                else if (i == XH + 1) wload<1024>(wring[js][1], rw, wvoff, wsoff(ts));
+                                else if (i == XH + 2) wload<2048>(wring[js][2], rw, wvoff, wsoff(ts));
+                                else wload<3072>(wring[js][3], rw, wvoff, wsoff(ts));
                             }
-                        Mma<T>::run(as_u4(wring[j][kk * FM + a]), bf[b], acc[a][b]);
+                        if (!(ABL & 1)) Mma<T>::run(as_u4(wring[j][kk * FM + a]), bf[b], acc[a][b]);
+                        else asm volatile("" ::"v"(wring[j][kk * FM + a]), "v"(bf[b].x), "v"(bf[b].w));
                     }
             }
         });
+        stamp(2);
         // epilogue: ReLU(bn1(.)) -> LDS, zero outside the image (conv2's zero padding is of THIS tensor)
         const int cb = wc * 32 + g * 8;                    // lane holds channels cb .. cb+7 of its pixels
         float sc[8], sh[8];
@@ -265,6 +289,7 @@ __global__ __launch_bounds__(512, MINB * 2) void bottleneck_fused_kernel(BnkK p)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     raw_barrier();                                         // the halo of conv1 outputs is complete; the pixel-row ring is dead
+    stamp(3);
 
     // =============================================================== phase 2: conv2 (3x3) on the halo
     {
@@ -273,27 +298,29 @@ __global__ __launch_bounds__(512, MINB * 2) void bottleneck_fused_kernel(BnkK p)
         for (int a = 0; a < FM; ++a)
 #pragma unroll
             for (int b = 0; b < FN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        int boff[9][FN];                                   // byte offset within a chunk plane, sub-step 0 (sub-step 1: ^ 64)
+        int hp0[FN];                                       // halo pixel of the centre tap
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int dy = t / 3 - 1, dx = t % 3 - 1;
-#pragma unroll
-            for (int b = 0; b < FN; ++b) {
-                const int hp = (wp * FN + b + 1 + dy) * HCOLS + pl + 1 + dx;
-                boff[t][b] = hp * 128 + ((g ^ ((hp >> 1) & 7)) * 16);
-            }
-        }
+        for (int b = 0; b < FN; ++b) hp0[b] = (wp * FN + b + 1) * HCOLS + pl + 1;
         auto step2 = [&](auto ii) {
             constexpr int i = decltype(ii)::value;          // k-step of this phase: chunk i / 9, tap i % 9
             constexpr int gs = K1S + i, j = gs % RW, ts = gs + RW - 1, js = ts % RW;
-            constexpr int c = i / 9, t = i % 9;
+            const int e = elem2(i);                        // this block's i-th (chunk, tap) pair: uniform, in scalar registers
+            const int c = (e * 29) >> 8, t = e - 9 * c;    // e / 9, e % 9 for e < 36
+            const int dy = (t * 11) >> 5, dx = t - 3 * dy; // t / 3, t % 3
+            const int delta = (dy - 1) * HCOLS + dx - 1;
             wait_frags<pending_at<S, K1S, S2, NCH, NF, XH, FN, RX, RW>(0, gs)>(wring[j]);
             const char* hb = mid1 + c * PLANE1;
+            int boff[FN];
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
+                const int hp = hp0[b] + delta;
+                boff[b] = hp * 128 + ((g ^ ((hp >> 1) & 7)) * 16);
+            }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 uint4 bf[FN];
 #pragma unroll
-                for (int b = 0; b < FN; ++b) bf[b] = *reinterpret_cast<const uint4*>(hb + (boff[t][b] ^ (kk * 64)));
+                for (int b = 0; b < FN; ++b) bf[b] = (ABL & 4) ? make_uint4(1u, 2u, 3u, 4u) : *reinterpret_cast<const uint4*>(hb + (boff[b] ^ (kk * 64)));
 #pragma unroll
                 for (int a = 0; a < FM; ++a)
 #pragma unroll
@@ -301,16 +328,18 @@ __global__ __launch_bounds__(512, MINB * 2) void bottleneck_fused_kernel(BnkK p)
                         constexpr int NM = 2 * FM * FN;
                         const int m = (kk * FM + a) * FN + b;
                         if (ts < S) {
-                            if ((0 * NM) / NF == m) wload<0>(wring[js][0], rw, wvoff, ts * WSTEP);
-                            if ((1 * NM) / NF == m) wload<1024>(wring[js][1], rw, wvoff, ts * WSTEP);
-                            if ((2 * NM) / NF == m) wload<2048>(wring[js][2], rw, wvoff, ts * WSTEP);
-                            if ((3 * NM) / NF == m) wload<3072>(wring[js][3], rw, wvoff, ts * WSTEP);
+                            if ((0 * NM) / NF == m) wload<0>(wring[js][0], rw, wvoff, wsoff(ts));
+                            if ((1 * NM) / NF == m) wload<1024>(wring[js][1], rw, wvoff, wsoff(ts));
+                            if ((2 * NM) / NF == m) wload<2048>(wring[js][2], rw, wvoff, wsoff(ts));
+                            if ((3 * NM) / NF == m) wload<3072>(wring[js][3], rw, wvoff, wsoff(ts));
                         }
-                        Mma<T>::run(as_u4(wring[j][kk * FM + a]), bf[b], acc[a][b]);
+                        if (!(ABL & 1)) Mma<T>::run(as_u4(wring[j][kk * FM + a]), bf[b], acc[a][b]);
+                        else asm volatile("" ::"v"(wring[j][kk * FM + a]), "v"(bf[b].x), "v"(bf[b].w));
                     }
             }
         };
         static_for<S2>(step2);
+        stamp(4);
         // epilogue: ReLU(bn2(.)) -> LDS over the dead pixel-row ring
         const int cb = wc * 32 + g * 8;
         float sc[8], sh[8];
@@ -330,6 +359,7 @@ __global__ __launch_bounds__(512, MINB * 2) void bottleneck_fused_kernel(BnkK p)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     raw_barrier();
 
+    stamp(5);
     // =============================================================== phase 3: conv3 (1x1) + residual + ReLU -> HBM
     {
         int boff[FN];
@@ -363,7 +393,7 @@ __global__ __launch_bounds__(512, MINB * 2) void bottleneck_fused_kernel(BnkK p)
                 for (int kk = 0; kk < 2; ++kk) {
                     uint4 bf[FN];
 #pragma unroll
-                    for (int b = 0; b < FN; ++b) bf[b] = *reinterpret_cast<const uint4*>(hb + (boff[b] ^ (kk * 64)));
+                    for (int b = 0; b < FN; ++b) bf[b] = (ABL & 4) ? make_uint4(1u, 2u, 3u, 4u) : *reinterpret_cast<const uint4*>(hb + (boff[b] ^ (kk * 64)));
 #pragma unroll
                     for (int a = 0; a < FM; ++a)
 #pragma unroll
@@ -371,17 +401,19 @@ __global__ __launch_bounds__(512, MINB * 2) void bottleneck_fused_kernel(BnkK p)
                             constexpr int NM = 2 * FM * FN;
                             const int m = (kk * FM + a) * FN + b;
                             if (ts < S) {
-                                if ((0 * NM) / NF == m) wload<0>(wring[js][0], rw, wvoff, ts * WSTEP);
-                                if ((1 * NM) / NF == m) wload<1024>(wring[js][1], rw, wvoff, ts * WSTEP);
-                                if ((2 * NM) / NF == m) wload<2048>(wring[js][2], rw, wvoff, ts * WSTEP);
-                                if ((3 * NM) / NF == m) wload<3072>(wring[js][3], rw, wvoff, ts * WSTEP);
+                                if ((0 * NM) / NF == m) wload<0>(wring[js][0], rw, wvoff, wsoff(ts));
+                                if ((1 * NM) / NF == m) wload<1024>(wring[js][1], rw, wvoff, wsoff(ts));
+                                if ((2 * NM) / NF == m) wload<2048>(wring[js][2], rw, wvoff, wsoff(ts));
+                                if ((3 * NM) / NF == m) wload<3072>(wring[js][3], rw, wvoff, wsoff(ts));
                             }
-                            Mma<T>::run(as_u4(wring[j][kk * FM + a]), bf[b], acc[a][b]);
+                            if (!(ABL & 1)) Mma<T>::run(as_u4(wring[j][kk * FM + a]), bf[b], acc[a][b]);
+                        else asm volatile("" ::"v"(wring[j][kk * FM + a]), "v"(bf[b].x), "v"(bf[b].w));
                         }
                 }
             };
             static_for<NCH>(step3);
             wait_regs<pending_at<S, K1S, S2, NCH, NF, XH, FN, RX, RW>(1, ps)>(resv);
+            if (ps == 0) stamp(10);
             float sc[8], sh[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) { sc[q] = coef[4 * CMID + cb + q]; sh[q] = coef[8 * CMID + cb + q]; }
@@ -397,9 +429,13 @@ __global__ __launch_bounds__(512, MINB * 2) void bottleneck_fused_kernel(BnkK p)
             }
         };
         pass3(std::integral_constant<int, 0>{});
+        stamp(6);
         pass3(std::integral_constant<int, 1>{});
+        stamp(7);
         pass3(std::integral_constant<int, 2>{});
+        stamp(8);
         pass3(std::integral_constant<int, 3>{});
+        stamp(9);
     }
 }
 
@@ -436,10 +472,12 @@ long pack_units(int cmid) {       // 16-byte units of the stream
 
 bool xcd_on() { static int v = -1; if (v < 0) { const char* e = getenv("MSC_XCD_ORDER"); v = (e && e[0] == '0') ? 0 : 1; } return v == 1; }
 
-// patch rows for a block.  CMID = 64 (HBM-bound, 140 KB of weights): 4 -- 78 KB of LDS, two resident blocks per CU, so one block's
-// loads overlap the other's MFMAs; CMID = 128: 8; CMID = 256: 4 when that still gives every CU a block, else 2
+// patch rows for a block (d->cfg selects explicitly; the caller may time the valid ones).  CMID = 64 (HBM-bound, 140 KB of weights): 8 or
+// 4, two resident blocks per CU either way (one block's loads overlap the other's MFMAs) -- measured on ResNet101's layer1
+// (32 x 64 x 64): 52 us with 8 rows, 65 us with 4 (twice the blocks, twice the weight traffic); CMID = 128: 8; CMID = 256: 4 when
+// that still gives every CU a block, else 2
 int pick_ph(const msc_bneck_desc* d) {
-    if (d->Cmid == 64) return 4;
+    if (d->Cmid == 64) return d->H % 8 == 0 ? 8 : 4;
     if (d->Cmid == 128) return 8;
     return (long)d->N * (d->H / 4) * (d->W / 16) >= 256 && d->H % 4 == 0 ? 4 : 2;
 }
@@ -447,14 +485,26 @@ int pick_ph(const msc_bneck_desc* d) {
 template <typename T>
 int launch_bneck(const msc_bneck_desc* d, const BnkK& k, int ph, hipStream_t st) {
     const int blocks = d->N * (d->H / ph) * (d->W / 16);
-    if (d->Cmid == 64) hipLaunchKernelGGL((bottleneck_fused_kernel<T, 64, 4, 3, 4, 2>), dim3(blocks), dim3(512), 0, st, k);
+    if (d->Cmid == 64 && ph == 4) hipLaunchKernelGGL((bottleneck_fused_kernel<T, 64, 4, 3, 4, 2>), dim3(blocks), dim3(512), 0, st, k);
+    else if (d->Cmid == 64) hipLaunchKernelGGL((bottleneck_fused_kernel<T, 64, 8, 2, 4, 2>), dim3(blocks), dim3(512), 0, st, k);
     else if (d->Cmid == 128) hipLaunchKernelGGL((bottleneck_fused_kernel<T, 128, 8, 4, 5, 1>), dim3(blocks), dim3(512), 0, st, k);
     else if (ph == 4) hipLaunchKernelGGL((bottleneck_fused_kernel<T, 256, 4, 4, 6, 1>), dim3(blocks), dim3(512), 0, st, k);
-    else hipLaunchKernelGGL((bottleneck_fused_kernel<T, 256, 2, 4, 8, 1>), dim3(blocks), dim3(512), 0, st, k);
+    else {
+        static const int abl = [] { const char* e = getenv("MSC_BNECK_ABL"); return e ? atoi(e) : 0; }();      // probe only
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            if (abl == 8) { hipLaunchKernelGGL((bottleneck_fused_kernel<T, 256, 2, 4, 8, 1, 8>), dim3(blocks), dim3(512), 0, st, k); return msc_check_launch("bottleneck_fused"); }
+            if (abl == 7) { hipLaunchKernelGGL((bottleneck_fused_kernel<T, 256, 2, 4, 8, 1, 7>), dim3(blocks), dim3(512), 0, st, k); return msc_check_launch("bottleneck_fused"); }
+        }
+        hipLaunchKernelGGL((bottleneck_fused_kernel<T, 256, 2, 4, 8, 1>), dim3(blocks), dim3(512), 0, st, k);
+    }
     return msc_check_launch("bottleneck_fused");
 }
 
 }  // namespace
+
+static unsigned long long* g_bneck_dbg = nullptr;
+// probe hook (tools/bneck_probe.py; not part of the C ABI of include/msc.h): device buffer of 16 stamps per block for MSC_BNECK_ABL=8
+extern "C" void msc_bottleneck_debug_buffer(void* buf) { g_bneck_dbg = (unsigned long long*)buf; }
 
 extern "C" int msc_bottleneck_ok(const msc_bneck_desc* d) {
     if (!d) return 0;
@@ -462,7 +512,7 @@ extern "C" int msc_bottleneck_ok(const msc_bneck_desc* d) {
     if (d->Cmid != 64 && d->Cmid != 128 && d->Cmid != 256) return 0;
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->W % 16) return 0;
     const int ph = d->cfg > 0 ? d->cfg : pick_ph(d);
-    if (d->Cmid == 64 ? ph != 4 : d->Cmid == 128 ? ph != 8 : (ph != 2 && ph != 4)) return 0;
+    if (d->Cmid == 64 ? (ph != 4 && ph != 8) : d->Cmid == 128 ? ph != 8 : (ph != 2 && ph != 4)) return 0;
     if (d->H % ph) return 0;
     if (d->x_ld < 4 * d->Cmid || d->out_ld < 4 * d->Cmid || (d->x_ld * 2) % 16 || (d->out_ld * 2) % 16) return 0;
     if ((((long)d->N * d->H * d->W - 1) * d->x_ld + 4L * d->Cmid) * 2 >= 0x7fffffffL) return 0;       // 31-bit buffer offsets
@@ -492,6 +542,7 @@ extern "C" int msc_bottleneck_fused(const msc_bneck_desc* d, void* stream) {
                         d->dtype, d->Cmid, d->N, d->H, d->W, (long)d->x_ld, (long)d->out_ld, d->cfg);
     if (((uintptr_t)d->x | (uintptr_t)d->out | (uintptr_t)d->wpk) & 15) return msc_fail(MSC_ERR_ARG, "msc_bottleneck_fused: pointers must be 16-byte aligned");
     BnkK k;
+    k.dbg = g_bneck_dbg;
     k.x = (const char*)d->x; k.out = (char*)d->out; k.wpk = (const char*)d->wpk;
     k.sc1 = d->scale1; k.sh1 = d->shift1; k.sc2 = d->scale2; k.sh2 = d->shift2; k.sc3 = d->scale3; k.sh3 = d->shift3;
     k.x_ld = d->x_ld; k.out_ld = d->out_ld; k.N = d->N; k.H = d->H; k.W = d->W;

@@ -25,6 +25,9 @@ all)    pt all 2400 tests;;
 infer)  bench_line infer_r101 600 --workload infer --encoder 101 --no-cpu-baseline --dump-launches gpurun_out/launches_infer_r101.json
         MSC_FUSE_BNECK=0 bench_line infer_r101_unfused 600 --workload infer --encoder 101 --no-cpu-baseline;;
 trainq) bench_line train 900 --no-cpu-baseline --steps 50;;
+stamps) MSC_BNECK_ABL=8 timeout 120 python tools/bneck_probe.py 2>&1 | tail -16;;
+probe)  for a in 0 7; do MSC_BNECK_ABL=$a timeout 120 python tools/bneck_probe.py 2>&1 | tail -1; done
+        CMID=128 HW=32 timeout 120 python tools/bneck_probe.py 2>&1 | tail -1; CMID=64 HW=64 timeout 120 python tools/bneck_probe.py 2>&1 | tail -1;;
 smoke)  timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 gpurun_out/smoke.log;;
 esac
 done
