@@ -10,7 +10,9 @@ One "step" = one pass of the hot path over one synthetic batch resident in HBM:
   infer (configs[1]): ResNet34-U-Net eval forward + fused softmax, batch 32 (--encoder 101: the north-star forward line)
   tta   (configs[4]): ResNet152-U-Net fp16, batch 64, 512x512 tiles, test-time augmentation x4 (identity, two flips, both
         -- the reference's elif chain, src/loaders.py:478-481), aggregated on the device
-  post  (configs[3]): resize 256->300, threshold, 4-connected labelling, 2x2 label dilation, scoring, batch 64 masks
+  post  (configs[3], the chain alone): resize 256->300, threshold, 4-connected labelling, 2x2 label dilation, scoring, batch 64 masks
+  e2e   (configs[3] as written): ResNet101-U-Net inference -> post-processing on the device -> COCO annotations, with the variants
+        + watershed (extension), + dense CRF, + both; value = the FULL chain (morphology + watershed + dense CRF)
 --size: network input edge; 256 = the reference's default loader (300x300 tiles resized, neptune.yaml:23,27-28), 320 = its
 crop_and_pad loader (tiles replicate-padded by 10 px, neptune.yaml:77-79).
 N > 1: one rank per GPU, batch sharded (weak scaling), loss sums and gradients all-reduced over RCCL.  Started without a
@@ -209,7 +211,106 @@ def cpu_baseline_annot(layers, budget_s=15.0):
             'sample': 'oracle/annot_ref.py (numpy restatement of src/utils.py:61-127 + maskApi.c) on %d images of 2 layers' % k}
 
 
-DEFAULT_STEPS = {'train': 200, 'infer': 200, 'tta': 20, 'post': 100, 'annot': 50}     # seconds of GPU work, not milliseconds
+def bench_e2e(args, world, dev, stream, timed):
+    """BASELINE.json configs[3] as written: inference + full HIP post-processing (morphology + watershed + dense CRF) on 256x256
+    masks, ending in the COCO annotations (src/pipelines.py:248-304 -> src/utils.py:76-115).  The network is first trained
+    for 40 steps on inputs that carry their target (untimed), so that its masks are building-like blobs -- the cost of labelling,
+    flooding and encoding depends on the number and shape of the instances, and random weights give 0.5-noise."""
+    from mapping_challenge_amd import postprocessing as post, utils
+    from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
+    from mapping_challenge_amd.unet_models import UNetResNet
+    from oracle import losses_ref, unet_ref
+    enc = args.encoder or 101
+    batch = args.batch or 32
+    hw = args.size
+    net = UNetResNet(enc, 2, num_filters=32, dropout_2d=0.0, is_deconv=True, compute_dtype=args.dtype)
+    net.load_state_dict(unet_ref.seeded_state_dict(net))
+    net.flatten_parameters(dev)
+    tgt = losses_ref.synthetic_target(min(batch, 8), hw, hw, seed=31 + world.rank)
+    tgt = tgt.repeat((batch + tgt.shape[0] - 1) // tgt.shape[0], 1, 1, 1)[:batch].contiguous()
+    x = (unet_ref.synthetic_batch(batch, hw, hw, seed=1234 + world.rank) * 0.5 + 2.0 * tgt[:, :1]).to(dev)
+    net.train()
+    step = TrainStep(net, LossSpec.mixed(ARCH), HipAdam(net, lr=5e-4, weight_decay=1e-4), use_graph=False)
+    for _ in range(40):
+        step(x, tgt.to(dev))
+    del step
+    net.eval()
+    # the de-normalised RGB tiles the CRF compares colours on (src/postprocessing.py:203-204, src/utils.py:324-325)
+    mean = torch.tensor(post.MEAN, device=dev).view(1, 3, 1, 1)
+    std = torch.tensor(post.STD, device=dev).view(1, 3, 1, 1)
+    rgb = ((x * std + mean) * 255.0).clamp(0, 255).permute(0, 2, 3, 1).contiguous().to(torch.uint8)
+    # The tail (device chain -> annotations) has four host synchronisations, ~60 launches and the Python that builds the annotation
+    # dicts: a cost per CALL that one network batch does not amortise (4.5 ms per call of 32 images, 0.5 ms of it GPU time).  The
+    # chain is batched and device-resident, so it takes the probabilities of TB network batches per call (TB = 4: 128 images).
+    TB = int(os.environ.get('MSC_E2E_TAIL_BATCHES', '4'))
+    ids = list(range(batch * TB))
+    cat_ids, layers = [None, 100], [1, 1]            # src/pipeline_config.py:17-18
+    rgb_t = rgb.repeat(TB, 1, 1, 1)
+
+    def tail(probs, ws=0, crf=False):
+        return utils.annotations_from_probabilities(ids, probs, cat_ids, layers, (300, 300), 0, 2, watershed_selem_size=ws,
+                                                    crf_images=rgb_t if crf else None)
+    probs_t = torch.empty((batch * TB, 2, hw, hw), dtype=torch.float32, device=dev)
+
+    def forward_all():
+        for k in range(TB):
+            probs_t[k * batch:(k + 1) * batch].copy_(net.predict_proba(x))
+        return probs_t
+    probs0 = forward_all().clone()
+    fg = float((probs0[:, 1] > 0.5).float().mean().item())
+    ann = tail(probs0)
+    variants = {'plain': dict(ws=0, crf=False), 'watershed': dict(ws=5, crf=False), 'crf': dict(ws=0, crf=True), 'full': dict(ws=5, crf=True)}
+    out = {}
+    imgs = batch * TB * world.size * args.steps
+    dt_net = timed(lambda: net.predict_proba(x))
+    out['inference_only_img_s'] = batch * world.size * args.steps / dt_net
+    out['images_per_tail_call'] = batch * TB
+    for name, kw in variants.items():
+        dt_tail = timed(lambda: tail(probs0, **kw))                                  # the post-processing + annotation part alone
+        dt_all = timed(lambda: tail(forward_all(), **kw))                            # TB network batches + one tail call, on one stream
+        out[name] = {'post_only_img_s': imgs / dt_tail, 'post_only_ms_per_img': 1e3 * dt_tail / (batch * TB * args.steps),
+                     'end_to_end_img_s': imgs / dt_all, 'end_to_end_ms_per_step': 1e3 * dt_all / args.steps,
+                     'post_not_slower_than_network': imgs / dt_tail >= out['inference_only_img_s']}
+    # dense CRF alone: HIP events around the launches of one call on the launch stream
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    post.dense_crf_batch(probs0[:batch], rgb)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(5):
+        post.dense_crf_batch(probs0[:batch], rgb)
+    b.record()
+    torch.cuda.synchronize()
+    crf_ms = a.elapsed_time(b) / 5
+    # algorithmic work of the exact windowed mean field (oracle/crf_ref.py): per pixel a normalisation pass and 5 iterations over the
+    # 11x11 window; Gaussian tap = 2 FMA (4 flop), bilateral tap = 3 sub + 3 FMA + scale + exp + weight + 2 FMA (16 flop)
+    taps = 121
+    crf_flop = batch * hw * hw * (taps * (1 + 12) + 5 * taps * (4 + 16))
+    full = out['full']
+    prog = net._program(batch, hw, hw, False, dev)
+    fam = family_times(list(prog.fwd), stream)
+    conv = {k: fam.get('msc_conv_igemm', {}).get(k, 0.0) + fam.get('msc_bottleneck_fused', {}).get(k, 0.0) for k in ('ms', 'launches', 'flops')}
+    ach = conv['flops'] / (conv['ms'] * 1e-3)
+    res = {'metric': 'images/sec (inference + full HIP post-processing: morphology + watershed + dense CRF -> annotations) ResNet%d-U-Net 256x256' % enc,
+           'unit': 'img/s', 'value': full['end_to_end_img_s'], 'ms_per_step': full['end_to_end_ms_per_step'],
+           'config': {'workload': 'ResNet%d-U-Net eval forward (batch %d/GPU, %s, %s) -> dense CRF (5 iterations, sxy 1, srgb 50) -> resize 256->300, threshold, '
+                                  'erosion-marker watershed (extension, k=5), 2x2 label dilation, scoring -> COCO RLE + bbox annotations; weights '
+                                  'trained 40 steps on synthetic blobs (foreground %.2f, %d annotations per tail call of %d images in the plain variant); '
+                                  'one step = %d network batches + one tail call'
+                                  % (enc, batch, tile_text(hw), args.dtype, fg, len(ann), batch * TB, TB),
+                      'global_batch': batch * world.size, 'parallelism': 'dp%d' % world.size, 'images_per_step': batch * TB, 'variants': out},
+           'roofline': {'kernel': 'conv family of the forward (dominant: %.2f of %.2f ms per step are the network)' % (1e3 * TB * dt_net / args.steps, full['end_to_end_ms_per_step']),
+                        'bound': 'mfma', 'achieved': ach / 1e12, 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16, 'traffic': None,
+                        'dense_crf': {'kernel': 'crf_norm / crf_iter (exact 11x11 windowed mean field, 5 iterations)', 'bound': 'valu-fp32',
+                                      'ms_per_batch': crf_ms, 'us_per_img': 1e3 * crf_ms / batch, 'achieved': crf_flop / (crf_ms * 1e-3) / 1e12,
+                                      'peak': PEAK_F32 / 1e12, 'unit': 'TFLOP/s', 'frac': crf_flop / (crf_ms * 1e-3) / PEAK_F32,
+                                      'algorithmic_gflop_per_batch': crf_flop / 1e9}}}
+    if world.rank == 0 and world.size == 1 and not args.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline_post(probs0[:batch].cpu().numpy(), (300, 300), 2)
+        res['cpu_baseline']['sample'] += ' (the plain chain without network, watershed, CRF and annotation encoding: the part of this workload the reference runs on the CPU in every shipped pipeline)'
+    return res
+
+
+DEFAULT_STEPS = {'train': 200, 'infer': 200, 'tta': 20, 'post': 100, 'annot': 50, 'e2e': 30}     # seconds of GPU work, not milliseconds
 
 
 def tile_text(hw):
@@ -235,7 +336,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default='train', choices=['train', 'infer', 'tta', 'post', 'annot'])
+    ap.add_argument('--workload', default='train', choices=['train', 'infer', 'tta', 'post', 'annot', 'e2e'])
     ap.add_argument('--encoder', type=int, default=None)
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--size', type=int, default=None)
@@ -390,6 +491,8 @@ def main():
                 'whole_step_frac_of_mfma_peak': (conv['flops'] + wg['flops']) * result['config'].get('tta_variants', 1) * (args.steps / dt) / peak}
         if world.rank == 0 and world.size == 1 and not args.no_cpu_baseline:      # reported at N=1 only
             result['cpu_baseline'] = cpu_baseline_train(enc, hw) if args.workload == 'train' else cpu_baseline_infer(enc, hw, n=4 if hw <= 320 else 1)
+    elif args.workload == 'e2e':
+        result.update(bench_e2e(args, world, dev, stream, timed))
     elif args.workload == 'annot':
         # labelled 300x300 layers (2 per image, on the device) -> COCO RLE strings + boxes on the host
         from mapping_challenge_amd import postprocessing as post, utils

@@ -5,6 +5,8 @@
 //
 // Integer results (threshold layers, labels, erosion/dilation, dropped objects) are bit-exact
 // against oracle/post_ref.py; float results (resize, score, CRF) within the tolerances in tests/.
+#include <stdlib.h>
+
 #include "common.h"
 #include "msc_internal.h"
 
@@ -238,62 +240,163 @@ __global__ void dropped_apply_kernel(const uint8_t* __restrict__ processed, cons
 
 // ------------------------------------------------------------------ watershed (EXTENSION: WATERSHED.md; no reference function)
 // Synchronous immersion flood of the 8-bit relief of 1 - P inside the mask, from labelled markers; one workgroup per
-// image-layer.  A round = candidates from the labels as they are (phase A), barrier, apply (phase B): simultaneous update,
-// ties to the smaller label, so the result does not depend on any traversal order.
-__global__ __launch_bounds__(1024) void watershed_flood_kernel(const float* __restrict__ prob, const uint8_t* __restrict__ mask,
-                                                               int32_t* labels, uint8_t* hq, int32_t* cand, int32_t* list, int H, int W) {
+// image-layer.  The definition (WATERSHED.md) is a sequence of synchronous rounds, level by level; run literally it is
+// 256 levels x (rounds until nothing changes) block-wide barriers -- hundreds of L2 round trips per layer (round 2: 85 us).
+// The same result without walking the levels: the round in which a pixel is labelled is its ARRIVAL TIME
+//     T(p) = (level, round), markers at (-1, 0);   T(p) = min over 4-neighbours q of  next(T(q), h(p)),
+//     next((l, r), h) = (l, r + 1) if h <= l  (p is eligible already: the round after q)   else (h, 1)  (first round of p's own level)
+// -- a shortest-path problem with a strictly increasing step, so plain relaxation in ANY order reaches its unique solution --
+// and the label it takes in that round is the smallest one among the neighbours labelled BEFORE it:
+//     label(p) = min { label(q) : T(q) < T(p) },
+// a second monotone fixed point over the (acyclic) order T defines.  Both are swept over the work list of unlabelled mask pixels
+// until nothing changes: the number of sweeps is the flood DISTANCE in pixels (a few for the eroded-mask markers), not the number
+// of grey levels.  Bit-identical to the round-by-round oracle (tests/test_gpu_post.py; the arrival-time form is also checked
+// against it on the CPU in tests/test_oracle_watershed.py).  T is packed as ((level + 1) << 20) | round: 0 for markers.
+constexpr int WS_INF = 0x7fffffff;
+constexpr int WS_TILE = 64, WS_HALO = WS_TILE + 2;
+
+__device__ __forceinline__ int ws_step(int tq, int h1) {      // arrival time of a pixel of relief h1 - 1 reached from a neighbour that arrived at tq
+    return h1 > (tq >> 20) ? ((h1 << 20) | 1) : tq + 1;
+}
+
+// relief, arrival times of the markers (0) / everything else (infinity), the work list of unlabelled mask pixels: one workgroup per layer
+__global__ __launch_bounds__(1024) void watershed_init_kernel(const float* __restrict__ prob, const uint8_t* __restrict__ mask, int32_t* labels,
+                                                              uint8_t* hq, int32_t* tarr, int32_t* list, int32_t* nlist, int H, int W) {
     __shared__ int n_list;
-    __shared__ int hist[256];
     const long HW = (long)H * W;
     const long base = (long)blockIdx.x * HW;
-    const float* P = prob + base;
-    const uint8_t* M = mask + base;
-    int32_t* L = labels + base;
-    uint8_t* Hq = hq + base;
-    int32_t* C = cand + base;
-    int32_t* Q = list + base;                     // the unlabelled mask pixels: only they ever change (order irrelevant: rounds are synchronous)
-    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) n_list = 0;
     __syncthreads();
     for (long p = threadIdx.x; p < HW; p += blockDim.x) {
-        float v = floorf((1.0f - P[p]) * 255.0f);
+        float v = floorf((1.0f - prob[base + p]) * 255.0f);
         v = fminf(fmaxf(v, 0.f), 255.f);
-        Hq[p] = (uint8_t)v;
-        C[p] = 0;
-        if (!M[p]) L[p] = 0;
-        else if (L[p] == 0) {
-            Q[atomicAdd(&n_list, 1)] = (int32_t)p;
-            atomicAdd(&hist[(int)v], 1);
-        }
+        hq[base + p] = (uint8_t)v;
+        int t = WS_INF;
+        if (!mask[base + p]) labels[base + p] = 0;
+        else if (labels[base + p] != 0) t = 0;
+        else list[base + atomicAdd(&n_list, 1)] = (int32_t)p;
+        tarr[base + p] = t;
     }
     __syncthreads();
-    const int n = n_list;
-    int todo = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) ++todo;
-    for (int level = 0; level < 256; ++level) {
-        if (hist[level] == 0) continue;            // nothing new is eligible: the state is the fixed point the previous level ended in
-        if (!__syncthreads_or(todo > 0)) break;    // every mask pixel is labelled
-        for (;;) {
-            int found = 0;
-            for (int i = threadIdx.x; i < n; i += blockDim.x) {
-                const long p = Q[i];
-                if (L[p] != 0 || Hq[p] > level) continue;
-                const int y = (int)(p / W), x = (int)(p - (long)y * W);
-                int best = 0x7fffffff;
-                if (y > 0) { const int q = L[p - W]; if (q > 0 && q < best) best = q; }
-                if (y + 1 < H) { const int q = L[p + W]; if (q > 0 && q < best) best = q; }
-                if (x > 0) { const int q = L[p - 1]; if (q > 0 && q < best) best = q; }
-                if (x + 1 < W) { const int q = L[p + 1]; if (q > 0 && q < best) best = q; }
-                if (best != 0x7fffffff) { C[p] = best; found = 1; }
-            }
-            if (!__syncthreads_or(found)) break;   // also orders phase A's reads before phase B's writes
-            for (int i = threadIdx.x; i < n; i += blockDim.x) {
-                const long p = Q[i];
-                const int c = C[p];
-                if (c > 0) { L[p] = c; C[p] = 0; --todo; }
-            }
-            __syncthreads();
+    if (threadIdx.x == 0) nlist[blockIdx.x] = n_list;
+}
+
+// Block-Jacobi pass of either fixed point (both are order-independent): a block takes a 64x64 tile with a one-pixel ring of its
+// neighbours' current values into LDS, relaxes it to ITS fixed point there (a sweep is ~100 cycles instead of an L2 round trip),
+// and writes the tile back.  Values only ever decrease towards the solution, so stale ring values are harmless; what a pass cannot
+// do is carry information across more than one tile border -- a few passes cover the flood distances of eroded-mask markers, and
+// the finish kernels below complete whatever is left, so the result does not depend on the number of passes.
+template <bool LABELS>
+__global__ __launch_bounds__(256) void watershed_tile_kernel(const uint8_t* __restrict__ mask, const uint8_t* __restrict__ hq, int32_t* tarr,
+                                                             int32_t* labels, int H, int W) {
+    __shared__ int sT[WS_HALO * WS_HALO];
+    __shared__ int sL[LABELS ? WS_HALO * WS_HALO : 1];
+    __shared__ uint8_t sH[WS_HALO * WS_HALO];
+    __shared__ uint16_t sQ[WS_TILE * WS_TILE];       // the tile's own work list: the unlabelled mask pixels (typically a fifth of the tile)
+    __shared__ int nQ;
+    const long HW = (long)H * W;
+    const long base = (long)blockIdx.z * HW;
+    const int x0 = blockIdx.x * WS_TILE, y0 = blockIdx.y * WS_TILE;
+    if (threadIdx.x == 0) nQ = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < WS_HALO * WS_HALO; i += blockDim.x) {
+        const int hy = i / WS_HALO, hx = i - hy * WS_HALO;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        int t = WS_INF, l = 0, h = 0, wk = 0;
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+            const long p = base + (long)y * W + x;
+            t = tarr[p];
+            h = hq[p];
+            if (LABELS) l = labels[p];
+            const bool interior = hy >= 1 && hy <= WS_TILE && hx >= 1 && hx <= WS_TILE;
+            wk = interior && mask[p] && t != 0 && (!LABELS || t != WS_INF);      // markers (t == 0) never change
         }
+        sT[i] = t; sH[i] = (uint8_t)h;
+        if (LABELS) sL[i] = l;
+        if (wk) sQ[atomicAdd(&nQ, 1)] = (uint16_t)i;
+    }
+    __syncthreads();
+    const int n = nQ;
+    if (n == 0) return;                              // no unlabelled mask pixel in this tile
+    for (;;) {
+        int changed = 0;
+        for (int k = threadIdx.x; k < n; k += blockDim.x) {
+            const int i = sQ[k];
+            if (!LABELS) {
+                const int h1 = (int)sH[i] + 1, cur = sT[i];
+                int best = cur;
+                const int nb[4] = {sT[i - WS_HALO], sT[i + WS_HALO], sT[i - 1], sT[i + 1]};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (nb[q] != WS_INF) { const int c = ws_step(nb[q], h1); best = c < best ? c : best; }
+                if (best < cur) { sT[i] = best; changed = 1; }
+            } else {
+                const int t = sT[i], cur = sL[i];
+                int best = cur > 0 ? cur : WS_INF;
+                const int off[4] = {-WS_HALO, WS_HALO, -1, 1};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (sT[i + off[q]] < t) { const int lq = sL[i + off[q]]; if (lq > 0 && lq < best) best = lq; }
+                if (best != WS_INF && best != cur) { sL[i] = best; changed = 1; }
+            }
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const int i = sQ[k];
+        const int ty = i / WS_HALO - 1, tx = i % WS_HALO - 1;
+        const long p = base + (long)(y0 + ty) * W + x0 + tx;
+        if (LABELS) labels[p] = sL[i];
+        else tarr[p] = sT[i];
+    }
+}
+
+// the same two relaxations over a layer's work list by ONE workgroup, swept until nothing changes: after the tiled passes this is
+// normally a single confirming sweep; on masks whose flood paths wind through many tiles it does the remaining work
+template <bool LABELS>
+__global__ __launch_bounds__(1024) void watershed_finish_kernel(const uint8_t* __restrict__ hq, int32_t* tarr, int32_t* labels,
+                                                                const int32_t* __restrict__ list, const int32_t* __restrict__ nlist, int H, int W) {
+    const long HW = (long)H * W;
+    const long base = (long)blockIdx.x * HW;
+    int32_t* L = labels + base;
+    const uint8_t* Hq = hq + base;
+    int32_t* T = tarr + base;
+    const int32_t* Q = list + base;
+    const int n = nlist[blockIdx.x];
+    for (;;) {
+        int changed = 0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const long p = Q[i];
+            const int y = (int)(p / W), x = (int)(p - (long)y * W);
+            if (!LABELS) {
+                const int h1 = (int)Hq[p] + 1;
+                const int cur = T[p];
+                int best = cur;
+                auto relax = [&](long q) {
+                    const int tq = T[q];
+                    if (tq != WS_INF) { const int c = ws_step(tq, h1); best = c < best ? c : best; }
+                };
+                if (y > 0) relax(p - W);
+                if (y + 1 < H) relax(p + W);
+                if (x > 0) relax(p - 1);
+                if (x + 1 < W) relax(p + 1);
+                if (best < cur) { T[p] = best; changed = 1; }
+            } else {
+                const int t = T[p];
+                if (t == WS_INF) continue;             // not reachable from any marker (cannot happen for masks from erode_image)
+                const int cur = L[p];
+                int best = cur > 0 ? cur : WS_INF;
+                auto take = [&](long q) {
+                    if (T[q] < t) { const int lq = L[q]; if (lq > 0 && lq < best) best = lq; }
+                };
+                if (y > 0) take(p - W);
+                if (y + 1 < H) take(p + W);
+                if (x > 0) take(p - 1);
+                if (x + 1 < W) take(p + 1);
+                if (best != WS_INF && best != cur) { L[p] = best; changed = 1; }
+            }
+        }
+        if (!__syncthreads_or(changed)) break;
     }
 }
 
@@ -422,6 +525,117 @@ __global__ void crf_iter_kernel(const float* __restrict__ probs, const uint8_t* 
         const float t1 = -u1 + c.compat_g * g1 * n_g + c.compat_b * b1 * n_b;
         softmax2(t0, t1, &qout[(b * 2) * HW + p], &qout[(b * 2 + 1) * HW + p]);
     }
+}
+
+// ---- tiled form (window radius <= CRF_RMAX): a block owns a 16x16 tile; the (16+2r)^2 halo of what every tap needs -- the
+// neighbour's Q already multiplied by its two normalisers, and its colour -- goes to LDS once per iteration and the 121 taps
+// read it from there.  The naive kernels above load 5 global values per tap (605 per pixel and kernel): 672 us per iteration for
+// 32 images of 256x256; tiled, the iteration is bound by the per-tap arithmetic (3 colour differences, a dot product, one exp2,
+// four FMAs) and the LDS reads (two ds_read_b128 per tap).  Spatial weights are tables of (2r+1)^2 floats in LDS (broadcast
+// reads), folded into the exponent for the bilateral kernel: k = exp2(c_sp[t] - |dI|^2 * inv2rgb * log2(e)).
+constexpr int CRF_T = 16, CRF_RMAX = 8, CRF_HMAX = CRF_T + 2 * CRF_RMAX;
+
+struct CrfHalo {
+    float4 a[CRF_HMAX * CRF_HMAX];      // (q0*ng, q1*ng, q0*nb, q1*nb) of the halo pixel (zeros outside the image)
+    float4 c[CRF_HMAX * CRF_HMAX];      // (r, g, b, inside)
+    float gsp[(2 * CRF_RMAX + 1) * (2 * CRF_RMAX + 1)];      // Gaussian kernel: exp(-d^2 * inv2g)
+    float bsp[(2 * CRF_RMAX + 1) * (2 * CRF_RMAX + 1)];      // bilateral kernel, spatial part as an exponent of 2: -d^2 * inv2b * log2(e)
+};
+
+__device__ __forceinline__ void crf_tables(CrfHalo& s, const CrfP& c, int r) {
+    const int w = 2 * r + 1;
+    for (int i = threadIdx.x; i < w * w; i += blockDim.x) {
+        const int dy = i / w - r, dx = i % w - r;
+        const float d2 = (float)(dy * dy + dx * dx);
+        s.gsp[i] = (abs(dy) <= c.rg && abs(dx) <= c.rg) ? expf(-d2 * c.inv2g) : 0.f;
+        s.bsp[i] = (abs(dy) <= c.rb && abs(dx) <= c.rb) ? -d2 * c.inv2b * 1.44269504f : -1e30f;
+    }
+}
+
+// normalisers n = 1 / sqrt(sum_j k(i, j) + 1e-20) of both kernels (NORMALIZE_SYMMETRIC), window clipped to the image
+__global__ __launch_bounds__(256) void crf_norm_tiled_kernel(const uint8_t* __restrict__ rgb, float* __restrict__ ng, float* __restrict__ nb, CrfP c, int r) {
+    __shared__ CrfHalo s;
+    const long HW = (long)c.H * c.W, b = blockIdx.z;
+    const int x0 = blockIdx.x * CRF_T, y0 = blockIdx.y * CRF_T, hw = CRF_T + 2 * r;
+    crf_tables(s, c, r);
+    for (int i = threadIdx.x; i < hw * hw; i += blockDim.x) {
+        const int yy = y0 - r + i / hw, xx = x0 - r + i % hw;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)yy < (unsigned)c.H && (unsigned)xx < (unsigned)c.W) {
+            const uint8_t* px = rgb + (b * HW + (long)yy * c.W + xx) * 3;
+            v = make_float4((float)px[0], (float)px[1], (float)px[2], 1.f);
+        }
+        s.c[i] = v;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= c.W || y >= c.H) return;
+    const float4 me = s.c[(ty + r) * hw + tx + r];
+    const float krgb = c.inv2rgb * 1.44269504f;
+    float sg = 0.f, sb = 0.f;
+    const int w = 2 * r + 1;
+    for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -r; dx <= r; ++dx) {
+            const float4 o = s.c[(ty + r + dy) * hw + tx + r + dx];
+            const int t = (dy + r) * w + dx + r;
+            const float d0 = o.x - me.x, d1 = o.y - me.y, d2 = o.z - me.z;
+            sg += s.gsp[t] * o.w;
+            sb += exp2f(s.bsp[t] - (d0 * d0 + d1 * d1 + d2 * d2) * krgb) * o.w;
+        }
+    ng[b * HW + (long)y * c.W + x] = 1.f / sqrtf(sg + 1e-20f);
+    nb[b * HW + (long)y * c.W + x] = 1.f / sqrtf(sb + 1e-20f);
+}
+
+// one mean-field iteration: Q <- softmax(-U + compat_g * K_g Q + compat_b * K_b Q)
+__global__ __launch_bounds__(256) void crf_iter_tiled_kernel(const float* __restrict__ probs, const uint8_t* __restrict__ rgb, const float* __restrict__ ng,
+                                                             const float* __restrict__ nb, const float* __restrict__ qin, float* __restrict__ qout, CrfP c, int r) {
+    __shared__ CrfHalo s;
+    const long HW = (long)c.H * c.W, b = blockIdx.z;
+    const int x0 = blockIdx.x * CRF_T, y0 = blockIdx.y * CRF_T, hw = CRF_T + 2 * r;
+    const float* q0 = qin + (b * 2) * HW;
+    const float* q1 = q0 + HW;
+    crf_tables(s, c, r);
+    for (int i = threadIdx.x; i < hw * hw; i += blockDim.x) {
+        const int yy = y0 - r + i / hw, xx = x0 - r + i % hw;
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vc = va;
+        if ((unsigned)yy < (unsigned)c.H && (unsigned)xx < (unsigned)c.W) {
+            const long j = (long)yy * c.W + xx;
+            const float a0 = q0[j], a1 = q1[j], n_g = ng[b * HW + j], n_b = nb[b * HW + j];
+            const uint8_t* px = rgb + (b * HW + j) * 3;
+            va = make_float4(a0 * n_g, a1 * n_g, a0 * n_b, a1 * n_b);
+            vc = make_float4((float)px[0], (float)px[1], (float)px[2], 1.f);
+        }
+        s.a[i] = va;
+        s.c[i] = vc;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= c.W || y >= c.H) return;
+    const float4 me = s.c[(ty + r) * hw + tx + r];
+    const float krgb = c.inv2rgb * 1.44269504f;
+    float g0 = 0.f, g1 = 0.f, b0 = 0.f, b1 = 0.f;
+    const int w = 2 * r + 1;
+    for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -r; dx <= r; ++dx) {
+            const int h = (ty + r + dy) * hw + tx + r + dx;
+            const float4 o = s.c[h];
+            const float4 qv = s.a[h];
+            const int t = (dy + r) * w + dx + r;
+            const float d0 = o.x - me.x, d1 = o.y - me.y, d2 = o.z - me.z;
+            const float kg = s.gsp[t];
+            const float kb = exp2f(s.bsp[t] - (d0 * d0 + d1 * d1 + d2 * d2) * krgb);      // out-of-image neighbours carry Q = 0
+            g0 += kg * qv.x; g1 += kg * qv.y;
+            b0 += kb * qv.z; b1 += kb * qv.w;
+        }
+    const long p = (long)y * c.W + x;
+    const float u0 = -logf(fminf(fmaxf(probs[(b * 2) * HW + p], 1e-5f), 1.f));
+    const float u1 = -logf(fminf(fmaxf(probs[(b * 2 + 1) * HW + p], 1e-5f), 1.f));
+    const float n_g = ng[b * HW + p], n_b = nb[b * HW + p];
+    const float t0 = -u0 + c.compat_g * g0 * n_g + c.compat_b * b0 * n_b;
+    const float t1 = -u1 + c.compat_g * g1 * n_g + c.compat_b * b1 * n_b;
+    softmax2(t0, t1, &qout[(b * 2) * HW + p], &qout[(b * 2 + 1) * HW + p]);
 }
 
 // ------------------------------------------------------------------ test-time augmentation (src/loaders.py:401-517)
@@ -588,7 +802,7 @@ extern "C" int msc_label4(const uint8_t* mask, int32_t* labels, int32_t* counts,
 
 extern "C" int64_t msc_watershed_workspace_bytes(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return -1;
-    return (int64_t)B * H * W * 9;          // int32 candidates + int32 work list + 8-bit relief
+    return (int64_t)B * H * W * 9 + (int64_t)B * 4 + 16;          // int32 arrival times + int32 work list + 8-bit relief + work-list lengths
 }
 
 extern "C" int msc_watershed(const float* prob, const uint8_t* mask, int32_t* labels, void* workspace, int B, int H, int W, void* stream) {
@@ -596,10 +810,18 @@ extern "C" int msc_watershed(const float* prob, const uint8_t* mask, int32_t* la
     if (!prob || !mask || !labels || !workspace) return msc_fail(MSC_ERR_ARG, "msc_watershed: null pointer");
     if (((uintptr_t)workspace) & 3) return msc_fail(MSC_ERR_ARG, "msc_watershed: workspace must be 4-byte aligned");
     const long n = (long)B * H * W;
-    int32_t* cand = (int32_t*)workspace;
-    int32_t* list = cand + n;
-    uint8_t* hq = (uint8_t*)workspace + n * 8;
-    hipLaunchKernelGGL(watershed_flood_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, prob, mask, labels, hq, cand, list, H, W);
+    int32_t* tarr = (int32_t*)workspace;
+    int32_t* list = tarr + n;
+    int32_t* nlist = list + n;
+    uint8_t* hq = (uint8_t*)(nlist + B + ((4 - (B & 3)) & 3));
+    hipStream_t st = (hipStream_t)stream;
+    static const int passes = [] { const char* e = getenv("MSC_WS_PASSES"); return e ? atoi(e) : 3; }();      // 0: the single-workgroup kernels alone (A/B)
+    const dim3 gt(ceil_div(W, WS_TILE), ceil_div(H, WS_TILE), B);
+    hipLaunchKernelGGL(watershed_init_kernel, dim3(B), dim3(1024), 0, st, prob, mask, labels, hq, tarr, list, nlist, H, W);
+    for (int p = 0; p < passes; ++p) hipLaunchKernelGGL(watershed_tile_kernel<false>, gt, dim3(256), 0, st, mask, hq, tarr, labels, H, W);
+    hipLaunchKernelGGL(watershed_finish_kernel<false>, dim3(B), dim3(1024), 0, st, hq, tarr, labels, list, nlist, H, W);
+    for (int p = 0; p < passes; ++p) hipLaunchKernelGGL(watershed_tile_kernel<true>, gt, dim3(256), 0, st, mask, hq, tarr, labels, H, W);
+    hipLaunchKernelGGL(watershed_finish_kernel<true>, dim3(B), dim3(1024), 0, st, hq, tarr, labels, list, nlist, H, W);
     return msc_check_launch("msc_watershed");
 }
 
@@ -653,12 +875,18 @@ extern "C" int msc_dense_crf(const float* probs, const uint8_t* rgb, float* out,
     float* qa = nb + (long)B * HW;
     float* qb = qa + 2L * B * HW;
     const dim3 g = plane_grid(HW, B);
-    hipLaunchKernelGGL(crf_norm_kernel, g, dim3(256), 0, st, rgb, ng, nb, c);
+    const int r = c.rg > c.rb ? c.rg : c.rb;
+    static const bool naive = [] { const char* e = getenv("MSC_CRF_NAIVE"); return e && e[0] == '1'; }();      // A/B: the global-memory kernels
+    const bool tiled = r <= CRF_RMAX && !naive;
+    const dim3 gt(ceil_div(W, CRF_T), ceil_div(H, CRF_T), B);
+    if (tiled) hipLaunchKernelGGL(crf_norm_tiled_kernel, gt, dim3(256), 0, st, rgb, ng, nb, c, r);
+    else hipLaunchKernelGGL(crf_norm_kernel, g, dim3(256), 0, st, rgb, ng, nb, c);
     hipLaunchKernelGGL(crf_init_kernel, g, dim3(256), 0, st, probs, iterations == 0 ? out : qa, HW);
     float* cur = qa;
     for (int it = 0; it < iterations; ++it) {
         float* dst = (it == iterations - 1) ? out : (cur == qa ? qb : qa);
-        hipLaunchKernelGGL(crf_iter_kernel, g, dim3(256), 0, st, probs, rgb, ng, nb, cur, dst, c);
+        if (tiled) hipLaunchKernelGGL(crf_iter_tiled_kernel, gt, dim3(256), 0, st, probs, rgb, ng, nb, cur, dst, c, r);
+        else hipLaunchKernelGGL(crf_iter_kernel, g, dim3(256), 0, st, probs, rgb, ng, nb, cur, dst, c);
         cur = dst;
     }
     return msc_check_launch("msc_dense_crf");

@@ -168,10 +168,11 @@ LABEL_CAPACITY = 512          # instances per image layer the score table is siz
 
 
 def postprocess_device(probs, target_size=None, erode_selem_size=0, dilate_selem_size=0, category_layers=CATEGORY_LAYERS,
-                       watershed_selem_size=0):
+                       watershed_selem_size=0, raw_scores=False):
     """postprocess_batch without the final copy of the label images: returns (labels cuda i32 [B,L,H,W], per-image
-    per-layer score lists) -- for consumers that stay on the device (utils.annotations_from_probabilities)."""
-    return _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, category_layers, False, watershed_selem_size)
+    per-layer score lists) -- for consumers that stay on the device (utils.annotations_from_probabilities).
+    raw_scores: (labels, counts i32 [B,L], scores f64 [B,n_scored,cap]) as numpy arrays instead of the nested lists."""
+    return _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, category_layers, False, watershed_selem_size, raw_scores)
 
 
 def postprocess_batch(probs, target_size=None, erode_selem_size=0, dilate_selem_size=0, category_layers=CATEGORY_LAYERS,
@@ -189,7 +190,7 @@ def _layer_classes(category_layers):
     return [c for c, n in enumerate(category_layers) for _ in range(n)]
 
 
-def _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, category_layers, to_host, watershed_selem_size=0):
+def _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, category_layers, to_host, watershed_selem_size=0, raw_scores=False):
     if not probs.is_cuda:
         probs = probs.to(_device())
     probs = probs.contiguous().float()
@@ -223,6 +224,8 @@ def _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, catego
     scores_h = got[1].reshape(B, n_scored, cap)
     if max_labels > cap:
         scores_h = score_batch(sl, sp, max_labels).cpu().numpy().reshape(B, n_scored, max_labels)
+    if raw_scores and not to_host:
+        return lab4, counts_h, scores_h
     scores = []
     for b in range(B):
         total = []

@@ -947,6 +947,21 @@ class _Builder:
         d.wpk = wpk.data_ptr()
         d.scale1, d.shift1, d.scale2, d.shift2, d.scale3, d.shift3 = [t.data_ptr() for t in coef]
         P.keep.append(d)
+        if net.autotune:                  # patch rows: time the instantiations that take this shape (like tune_conv)
+            key = repr(('b', self.tune_dt, self.N, x.H, x.W, cmid, x.ld, out.ld))
+            if key not in _TUNE_CACHE:
+                best, best_t = 0, 1e30
+                for cfg in (2, 4, 8):
+                    d.cfg = cfg
+                    if lib.msc_bottleneck_ok(C.byref(d)):
+                        t = self._time(lib.msc_bottleneck_fused, C.byref(d))
+                        if t is not None and t < best_t:
+                            best, best_t = cfg, t
+                _TUNE_CACHE[key] = best
+                self._tuned_new = True
+            d.cfg = int(_TUNE_CACHE[key])
+            if not lib.msc_bottleneck_ok(C.byref(d)):
+                d.cfg = 0
         self.emit(P.fwd, lib.msc_bottleneck_fused, C.byref(d))
         return True
 

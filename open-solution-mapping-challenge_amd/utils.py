@@ -36,9 +36,11 @@ def _count_chars(x):
     return bytes(out)
 
 
-def encode_labels(labels):
+def encode_labels(labels, trusted=False):
     """labels: int32 [L,H,W] (numpy or cuda tensor), 0 = background.  Returns a list of L dicts
-    {instance id: (counts bytes, [x, y, w, h])} holding every id that owns at least one pixel."""
+    {instance id: (counts bytes, [x, y, w, h])} holding every id that owns at least one pixel.
+    trusted: the label images come from msc_label4 / msc_dilate_i32 / msc_watershed (ids in [0, H*W]): skip the range check
+    (two reductions and two host synchronisations)."""
     lib = _lib.load()
     dev = _device()
     t = torch.as_tensor(labels)
@@ -49,9 +51,10 @@ def encode_labels(labels):
     out = [dict() for _ in range(L)]
     if L == 0:
         return out
-    lo, hi = int(t.min().item()), int(t.max().item())
-    if lo < 0 or hi >= (1 << 24):          # the run sort key packs (layer << 24) | label
-        raise ValueError('encode_labels: instance ids must lie in [0, 2^24) (got %d..%d)' % (lo, hi))
+    if not (trusted and H * W < (1 << 24)):
+        lo, hi = int(t.min().item()), int(t.max().item())
+        if lo < 0 or hi >= (1 << 24):          # the run sort key packs (layer << 24) | label
+            raise ValueError('encode_labels: instance ids must lie in [0, 2^24) (got %d..%d)' % (lo, hi))
     stream = torch.cuda.current_stream(dev).cuda_stream
     b1 = lib.msc_rle_segments_workspace(L, H, W)
     if b1 < 0:
@@ -143,25 +146,38 @@ def bounding_box_from_rle(rle):
 
 
 def annotations_from_probabilities(image_ids, probs, category_ids, category_layers, target_size=None, erode_selem_size=0,
-                                   dilate_selem_size=0):
+                                   dilate_selem_size=0, watershed_selem_size=0, crf_images=None, crf_params=None):
     """The inference tail without a host round trip: softmax maps (cuda f32 [B,2,h,w]) -> mask_postprocessing
     (src/pipelines.py:248-304) -> create_annotations (src/utils.py:76-115).  The label images stay on the device
     (they are 46 MB per 64 images, the strings a few hundred KB); the result equals
-    create_annotations(meta, postprocessing.postprocess_batch(probs, ...), ...)."""
+    create_annotations(meta, postprocessing.postprocess_batch(probs, ...), ...).
+    crf_images (cuda u8 [B,h,w,3], the de-normalised tiles): the probabilities first go through `dense_crf`
+    (src/postprocessing.py:183-225, which no shipped pipeline calls) with `crf_params` (keyword arguments of
+    postprocessing.dense_crf_batch); watershed_selem_size > 0: the labelling step is the watershed extension (WATERSHED.md)."""
     from . import postprocessing as post
-    lab4, scores = post.postprocess_device(probs, target_size, erode_selem_size, dilate_selem_size, category_layers)
+    if crf_images is not None:
+        probs = post.dense_crf_batch(probs.contiguous().float(), crf_images, **(crf_params or {}))
+    lab4, counts_h, scores_h = post.postprocess_device(probs, target_size, erode_selem_size, dilate_selem_size, category_layers,
+                                                       watershed_selem_size=watershed_selem_size, raw_scores=True)
     B, L, H, W = lab4.shape
-    encoded = encode_labels(lab4.view(B * L, H, W))
     inds = np.cumsum(category_layers)
+    n_scored = scores_h.shape[1]
+    # only the layers of categories that HAVE an id become annotations (src/utils.py:97-99 drops the background class): the others
+    # are neither encoded nor copied
+    keep = [l for l in range(min(L, n_scored)) if category_ids[int(np.searchsorted(inds, l, side='right'))] is not None]
+    if not keep:
+        return []
+    sel = lab4 if len(keep) == L else lab4[:, keep].contiguous()
+    encoded = encode_labels(sel.view(B * len(keep), H, W), trusted=True)
     size = [int(H), int(W)]
     annotations = []
     for b, image_id in enumerate(image_ids):
-        for category_ind, category_scores in enumerate(scores[b]):          # zip(prediction, image_scores), src/utils.py:96
-            category_nr = int(np.searchsorted(inds, category_ind, side='right'))
-            if category_ids[category_nr] is None:
-                continue
-            for (counts, bbox), score in zip(_instances(encoded[b * L + category_ind], size), category_scores):
-                annotations.append({'image_id': int(image_id), 'category_id': category_ids[category_nr], 'score': score,
+        image_id = int(image_id)
+        for k, l in enumerate(keep):                  # zip(prediction, image_scores), src/utils.py:96
+            category_id = category_ids[int(np.searchsorted(inds, l, side='right'))]
+            category_scores = scores_h[b, l, :int(counts_h[b, l])].tolist()
+            for (counts, bbox), score in zip(_instances(encoded[b * len(keep) + k], size), category_scores):
+                annotations.append({'image_id': image_id, 'category_id': category_id, 'score': score,
                                     'segmentation': {'size': size, 'counts': counts.decode('UTF-8')}, 'bbox': bbox})
     return annotations
 

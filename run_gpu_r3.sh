@@ -28,6 +28,15 @@ trainq) bench_line train 900 --no-cpu-baseline --steps 50;;
 stamps) MSC_BNECK_ABL=8 timeout 120 python tools/bneck_probe.py 2>&1 | tail -16;;
 probe)  for a in 0 7; do MSC_BNECK_ABL=$a timeout 120 python tools/bneck_probe.py 2>&1 | tail -1; done
         CMID=128 HW=32 timeout 120 python tools/bneck_probe.py 2>&1 | tail -1; CMID=64 HW=64 timeout 120 python tools/bneck_probe.py 2>&1 | tail -1;;
+post)   pt post 900 tests/test_gpu_post.py tests/test_gpu_pipeline.py tests/test_gpu_annot.py;;
+postq)  pt postq 600 tests/test_gpu_post.py tests/test_gpu_annot.py;;
+e2e)    bench_line e2e 900 --workload e2e --no-cpu-baseline; python -c "import json; d=json.load(open('gpurun_out/bench_e2e.json')); print(json.dumps(d['config']['variants'], indent=1)); print(d['roofline']['dense_crf'])";;
+postb)  bench_line post 600 --workload post --no-cpu-baseline;;
+prof_e2e) ( cd /tmp; export TMPDIR=/tmp; rm -rf "$R/gpurun_out/prof_e2e"; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_e2e" -- python "$R/bench.py" --workload e2e --steps 5 --warmup 2 --no-cpu-baseline > "$R/gpurun_out/prof_e2e.log" 2>&1; echo "prof e2e rc=$?" )
+        python tools/kernel_stats_summary.py gpurun_out/prof_e2e > gpurun_out/kernel_stats_e2e.txt 2>&1; head -60 gpurun_out/kernel_stats_e2e.txt | cut -c1-180;;
+tailprof) timeout 300 python tools/tail_profile.py 0 2>&1 | grep -v '^$' | head -50 | cut -c1-150; timeout 300 python tools/tail_profile.py 5 2>&1 | grep -v '^$' | head -45 | cut -c1-150;;
+hiptrace) ( cd /tmp; export TMPDIR=/tmp; rm -rf "$R/gpurun_out/hip_tail"; timeout 600 rocprofv3 --hip-trace --kernel-trace --stats --output-format csv -d "$R/gpurun_out/hip_tail" -- python "$R/tools/tail_profile.py" 0 > "$R/gpurun_out/hip_tail.log" 2>&1; echo rc=$? )
+        f=$(ls gpurun_out/hip_tail/*/*hip_api_stats.csv 2>/dev/null | head -1); echo $f; head -25 "$f" | cut -c1-160; f2=$(ls gpurun_out/hip_tail/*/*kernel_stats.csv | head -1); head -30 "$f2" | cut -c1-200;;
 smoke)  timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 gpurun_out/smoke.log;;
 esac
 done

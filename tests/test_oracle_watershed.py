@@ -90,3 +90,68 @@ def test_independent_pin_scipy_watershed_ift_agreement():
     ious, areas = np.array(ious), np.array(areas)
     assert np.mean(agree) > 0.985 and np.min(agree) > 0.97, (np.mean(agree), np.min(agree))
     assert (ious * areas).sum() / areas.sum() > 0.975 and ious[areas >= 64].mean() > 0.94, ((ious * areas).sum() / areas.sum(), ious[areas >= 64].mean())
+
+
+def flood_by_arrival_time(mask, markers, h):
+    """the form the HIP kernel computes (csrc/post.hip): arrival time T(p) = (level, round) as a shortest-path fixed point,
+    then label(p) = min label of the neighbours that arrived earlier -- Jacobi sweeps in numpy"""
+    mask = np.asarray(mask) != 0
+    lab = np.where(mask, markers, 0).astype(np.int64)
+    H, W = mask.shape
+    INF = np.int64(1) << 40
+    T = np.where(lab > 0, 0, INF).astype(np.int64)
+    hh = h.astype(np.int64)
+    work = mask & (lab == 0)
+
+    def shifted(a, fill):
+        out = []
+        for dy, dx in ((-1, 0), (1, 0), (0, -1), (0, 1)):
+            b = np.full_like(a, fill)
+            b[max(-dy, 0):H + min(-dy, 0), max(-dx, 0):W + min(-dx, 0)] = a[max(dy, 0):H + min(dy, 0), max(dx, 0):W + min(dx, 0)]
+            out.append(b)
+        return out
+    while True:
+        best = np.full((H, W), INF, np.int64)
+        for Tq in shifted(T, INF):
+            cand = np.where((hh + 1) > (Tq >> 20), ((hh + 1) << 20) | 1, Tq + 1)
+            best = np.minimum(best, np.where(Tq >= INF, INF, cand))
+        new = np.where(work, np.minimum(T, best), T)
+        if (new == T).all():
+            break
+        T = new
+    L = np.where(lab > 0, lab, INF)
+    while True:
+        best = np.full((H, W), INF, np.int64)
+        for Tq, Lq in zip(shifted(T, INF), shifted(L, INF)):
+            best = np.minimum(best, np.where(Tq < T, Lq, INF))
+        new = np.where(work & (T < INF), np.minimum(L, best), L)
+        if (new == L).all():
+            break
+        L = new
+    return np.where(L >= INF, 0, L).astype(np.int32)
+
+
+def test_arrival_time_form_equals_the_round_by_round_definition():
+    """the kernel does not walk the 256 levels: it solves for the round in which each pixel is labelled.  That form must give
+    the definition's result on the chain's inputs and on adversarial cases (random masks, several markers per component, reliefs
+    with 2 / 8 / 256 levels: long plateaus and ties)"""
+    probs = post_ref.synthetic_probs(2, 96, 96, seed=7, smooth=3.0)
+    for pr in probs:
+        for layer, pch in zip(post_ref.categorize_multilayer_image(pr), pr):
+            for k in (2, 3, 5, 9):
+                markers = post_ref.label(post_ref.erode_image(layer, k) != 0)
+                h = watershed_ref.relief(pch)
+                assert (flood_by_arrival_time(layer, markers, h) == watershed_ref.flood(layer, markers, h)).all(), k
+    rng = np.random.default_rng(0)
+    for trial in range(40):
+        H, W = int(rng.integers(5, 40)), int(rng.integers(5, 40))
+        mask = rng.random((H, W)) > 0.3
+        markers = np.zeros((H, W), np.int32)
+        comp = post_ref.label(mask)
+        for i in range(1, comp.max() + 1):
+            ys, xs = np.nonzero(comp == i)
+            for _ in range(int(rng.integers(1, 4))):
+                t = int(rng.integers(len(ys)))
+                markers[ys[t], xs[t]] = int(rng.integers(1, 50))
+        h = rng.integers(0, int(rng.choice([2, 8, 256])), (H, W)).astype(np.uint8)
+        assert (flood_by_arrival_time(mask, markers, h) == watershed_ref.flood(mask, markers, h)).all(), trial
