@@ -247,9 +247,11 @@ def bench_e2e(args, world, dev, stream, timed):
     cat_ids, layers = [None, 100], [1, 1]            # src/pipeline_config.py:17-18
     rgb_t = rgb.repeat(TB, 1, 1, 1)
 
-    def tail(probs, ws=0, crf=False):
-        return utils.annotations_from_probabilities(ids, probs, cat_ids, layers, (300, 300), 0, 2, watershed_selem_size=ws,
-                                                    crf_images=rgb_t if crf else None)
+    def tail(probs, ws=0, crf=False, as_list=False):
+        # the product of the tail is the JSON document of submission.json (src/utils.py:105-110), written natively from the encoder's
+        # table; as_list: the same annotations as Python dicts (what create_annotations returns when it does not save)
+        fn = utils.annotations_from_probabilities if as_list else utils.annotations_json_from_probabilities
+        return fn(ids, probs, cat_ids, layers, (300, 300), 0, 2, watershed_selem_size=ws, crf_images=rgb_t if crf else None)
     probs_t = torch.empty((batch * TB, 2, hw, hw), dtype=torch.float32, device=dev)
 
     def forward_all():
@@ -258,13 +260,17 @@ def bench_e2e(args, world, dev, stream, timed):
         return probs_t
     probs0 = forward_all().clone()
     fg = float((probs0[:, 1] > 0.5).float().mean().item())
-    ann = tail(probs0)
+    ann = tail(probs0, as_list=True)
+    import json as _json
+    assert _json.loads(tail(probs0)) == ann
     variants = {'plain': dict(ws=0, crf=False), 'watershed': dict(ws=5, crf=False), 'crf': dict(ws=0, crf=True), 'full': dict(ws=5, crf=True)}
     out = {}
     imgs = batch * TB * world.size * args.steps
     dt_net = timed(lambda: net.predict_proba(x))
     out['inference_only_img_s'] = batch * world.size * args.steps / dt_net
     out['images_per_tail_call'] = batch * TB
+    dt_list = timed(lambda: tail(probs0, as_list=True))
+    out['plain_as_python_dicts_post_only_img_s'] = imgs / dt_list      # the same tail building one dict per instance in Python
     for name, kw in variants.items():
         dt_tail = timed(lambda: tail(probs0, **kw))                                  # the post-processing + annotation part alone
         dt_all = timed(lambda: tail(forward_all(), **kw))                            # TB network batches + one tail call, on one stream

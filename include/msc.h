@@ -319,6 +319,15 @@ int64_t msc_rle_encode_workspace(int nseg);
 int msc_rle_encode(const void* seg_ws, int layers, int H, int W, int nseg, void* ws, int64_t ws_bytes, int32_t* n_inst,
                    int64_t* n_chars, const int32_t** table, const char** chars, void* stream);
 
+/* The annotation list as JSON text -- what create_annotations (src/utils.py:76-115) passes to json.dumps for submission.json --
+ * written on the HOST from the encoder's table (copied from the device): table i32 [n_inst][8] and chars as msc_rle_encode
+ * returns them; per encoded layer k: image_ids[k], category_ids[k], counts[k] scores at scores[score_off[k] ...] (instance id - 1
+ * indexes them).  Instances 1 .. min(largest id present, counts[k]) per layer, ids without pixels as empty masks (decompose(),
+ * src/utils.py:61-73).  Returns the number of bytes of the document; it is written to `out` when that is <= cap. */
+int64_t msc_annotations_json(const int32_t* table, int n_inst, const char* chars, int layers, const int64_t* image_ids,
+                             const int32_t* category_ids, const int32_t* counts, const double* scores, const int64_t* score_off,
+                             int H, int W, char* out, int64_t cap);
+
 /* ---------------------------------------------------------------- target preparation -------------
  * overlay_mask_one_image (src/preparation.py:44-84) for erode = dilate = 0 (neptune.yaml:69-70) from the decoded
  * instance masks of ONE image, masks u8 [n,H,W] in annotation order, category_nr i32 [n] (NULL: all 1):

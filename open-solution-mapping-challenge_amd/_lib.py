@@ -90,6 +90,7 @@ SIGNATURES = {
     'msc_bottleneck_pack_bytes': (_i64, [_i]),
     'msc_bottleneck_pack': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     'msc_bottleneck_fused': (_i, [C.POINTER(BneckDesc), _vp]),
+    'msc_annotations_json': (_i64, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64]),
     'msc_memset_zero': (_i, [_vp, _i64, _vp]),
     'msc_copy': (_i, [_vp, _vp, _i64, _vp]),
     'msc_bn_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp]),

@@ -288,3 +288,93 @@ extern "C" int msc_rle_encode(const void* seg_ws, int layers, int H, int W, int 
     *n_chars = (int64_t)tail[1] + tail[2];
     return msc_check_launch("msc_rle_encode");
 }
+
+
+// ------------------------------------------------------------------ annotations as JSON text (host)
+// What create_annotations (src/utils.py:76-115) hands to json.dumps -- [{"image_id", "category_id", "score", "segmentation":
+// {"size", "counts"}, "bbox"}, ...] -- written directly from the encoder's table: the reference builds one Python dict per
+// instance, which at a few dozen instances per tile costs more than the whole device chain (0.2 ms per image on the GPU box's
+// host).  Host memory in, host memory out; no device work.
+#include <charconv>
+
+namespace {
+struct JsonOut {
+    char* p; char* end; int64_t need;
+    void raw(const char* s, size_t n) { need += (int64_t)n; if (p + n <= end) { memcpy(p, s, n); p += n; } else p = end; }
+    void lit(const char* s) { raw(s, strlen(s)); }
+    void i64(long long v) { char b[24]; auto r = std::to_chars(b, b + sizeof(b), v); raw(b, (size_t)(r.ptr - b)); }
+    void f64(double v) {                   // shortest text that reads back as the same double (what Python's repr gives json.dumps)
+        char b[40];
+        auto r = std::to_chars(b, b + sizeof(b), v);
+        size_t n = (size_t)(r.ptr - b);
+        bool plain = true;
+        for (size_t i = 0; i < n; ++i) if (b[i] == '.' || b[i] == 'e' || b[i] == 'n' || b[i] == 'i') plain = false;
+        raw(b, n);
+        if (plain) lit(".0");
+    }
+    void str(const char* s, size_t n) {    // COCO count strings use the characters '0' .. 'o' (48 .. 111): '\\' (92) needs escaping, '"' cannot occur
+        raw("\"", 1);
+        size_t a = 0;
+        for (size_t i = 0; i < n; ++i)
+            if (s[i] == '\\') { raw(s + a, i - a); raw("\\\\", 2); a = i + 1; }
+        raw(s + a, n - a);
+        raw("\"", 1);
+    }
+};
+}  // namespace
+
+// table: i32 [n_inst][8] (layer, label, string begin, string end, xs, ys, xe, ye) sorted by (layer, label) as msc_rle_encode returns
+// it (copied to the host); per encoded layer k < layers: image_ids[k], category_ids[k], counts[k] = number of score entries,
+// scores + score_off[k] = its scores (label id - 1 indexes them).  Instances 1 .. min(largest id present, counts[k]) of every layer
+// are written in id order, ids without pixels as empty masks (decompose(), src/utils.py:61-73, zip-truncated like :96-104); a layer
+// without any instance contributes one empty mask if it has a score.  Returns the bytes the document needs (written if <= cap).
+extern "C" int64_t msc_annotations_json(const int32_t* table, int n_inst, const char* chars, int layers, const int64_t* image_ids,
+                                        const int32_t* category_ids, const int32_t* counts, const double* scores, const int64_t* score_off,
+                                        int H, int W, char* out, int64_t cap) {
+    if ((n_inst > 0 && (!table || !chars)) || layers < 0 || (layers > 0 && (!image_ids || !category_ids || !counts || !scores || !score_off)) || cap < 0)
+        return msc_fail(MSC_ERR_ARG, "msc_annotations_json: bad argument");
+    JsonOut o{out, out ? out + cap : out, 0};
+    // the single count of an all-background mask (maskApi.c rleToString of [H*W])
+    char empty[16];
+    size_t ne = 0;
+    {
+        long x = (long)H * W;
+        bool more = true;
+        while (more) {
+            long c = x & 0x1f;
+            x >>= 5;
+            more = (c & 0x10) ? x != -1 : x != 0;
+            if (more) c |= 0x20;
+            empty[ne++] = (char)(c + 48);
+        }
+    }
+    o.lit("[");
+    bool first = true;
+    int row = 0;
+    for (int k = 0; k < layers; ++k) {
+        int r0 = row;
+        while (row < n_inst && table[(long)row * 8] == k) ++row;
+        const int present = row - r0;
+        const int max_id = present ? table[(long)(row - 1) * 8 + 1] : 1;      // decompose() of an instance-free layer yields ONE empty mask
+        const int m = max_id < counts[k] ? max_id : counts[k];
+        int r = r0;
+        for (int id = 1; id <= m; ++id) {
+            while (r < row && table[(long)r * 8 + 1] < id) ++r;
+            const bool have = r < row && table[(long)r * 8 + 1] == id;
+            const int32_t* t = table + (long)r * 8;
+            if (!first) o.lit(", ");
+            first = false;
+            o.lit("{\"image_id\": "); o.i64(image_ids[k]);
+            o.lit(", \"category_id\": "); o.i64(category_ids[k]);
+            o.lit(", \"score\": "); o.f64(scores[score_off[k] + id - 1]);
+            o.lit(", \"segmentation\": {\"size\": ["); o.i64(H); o.lit(", "); o.i64(W); o.lit("], \"counts\": ");
+            if (have) o.str(chars + t[2], (size_t)(t[3] - t[2])); else o.str(empty, ne);
+            o.lit("}, \"bbox\": [");
+            if (have) { o.f64((double)t[4]); o.lit(", "); o.f64((double)t[5]); o.lit(", "); o.f64((double)(t[6] - t[4] + 1)); o.lit(", "); o.f64((double)(t[7] - t[5] + 1)); }
+            else o.lit("0.0, 0.0, 0.0, 0.0");
+            o.lit("]}");
+        }
+    }
+    o.lit("]");
+    return o.need;
+}

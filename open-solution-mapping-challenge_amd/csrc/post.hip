@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void crf_norm_tiled_kernel(const uint8_t* __re
             const int t = (dy + r) * w + dx + r;
             const float d0 = o.x - me.x, d1 = o.y - me.y, d2 = o.z - me.z;
             sg += s.gsp[t] * o.w;
-            sb += exp2f(s.bsp[t] - (d0 * d0 + d1 * d1 + d2 * d2) * krgb) * o.w;
+            sb += __builtin_amdgcn_exp2f(s.bsp[t] - (d0 * d0 + d1 * d1 + d2 * d2) * krgb) * o.w;      // v_exp_f32: the argument is <= 0, a flushed denormal is 0
         }
     ng[b * HW + (long)y * c.W + x] = 1.f / sqrtf(sg + 1e-20f);
     nb[b * HW + (long)y * c.W + x] = 1.f / sqrtf(sb + 1e-20f);
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256) void crf_iter_tiled_kernel(const float* __rest
             const int t = (dy + r) * w + dx + r;
             const float d0 = o.x - me.x, d1 = o.y - me.y, d2 = o.z - me.z;
             const float kg = s.gsp[t];
-            const float kb = exp2f(s.bsp[t] - (d0 * d0 + d1 * d1 + d2 * d2) * krgb);      // out-of-image neighbours carry Q = 0
+            const float kb = __builtin_amdgcn_exp2f(s.bsp[t] - (d0 * d0 + d1 * d1 + d2 * d2) * krgb);      // out-of-image neighbours carry Q = 0
             g0 += kg * qv.x; g1 += kg * qv.y;
             b0 += kb * qv.z; b1 += kb * qv.w;
         }

@@ -36,11 +36,12 @@ def _count_chars(x):
     return bytes(out)
 
 
-def encode_labels(labels, trusted=False):
+def encode_labels(labels, trusted=False, raw=False):
     """labels: int32 [L,H,W] (numpy or cuda tensor), 0 = background.  Returns a list of L dicts
     {instance id: (counts bytes, [x, y, w, h])} holding every id that owns at least one pixel.
     trusted: the label images come from msc_label4 / msc_dilate_i32 / msc_watershed (ids in [0, H*W]): skip the range check
-    (two reductions and two host synchronisations)."""
+    (two reductions and two host synchronisations).  raw: (table i32 [n,8] = layer, label, string begin / end, xs, ys, xe, ye sorted by
+    (layer, label); the concatenated count strings) as the encoder returns them, for msc_annotations_json."""
     lib = _lib.load()
     dev = _device()
     t = torch.as_tensor(labels)
@@ -50,7 +51,7 @@ def encode_labels(labels, trusted=False):
     L, H, W = t.shape
     out = [dict() for _ in range(L)]
     if L == 0:
-        return out
+        return (np.zeros((0, 8), np.int32), b'') if raw else out
     if not (trusted and H * W < (1 << 24)):
         lo, hi = int(t.min().item()), int(t.max().item())
         if lo < 0 or hi >= (1 << 24):          # the run sort key packs (layer << 24) | label
@@ -63,7 +64,7 @@ def encode_labels(labels, trusted=False):
     nseg = C.c_int32(0)
     _lib.check(lib.msc_rle_segments(t.data_ptr(), L, H, W, ws1.data_ptr(), b1, C.byref(nseg), stream), 'msc_rle_segments')
     if nseg.value == 0:
-        return out
+        return (np.zeros((0, 8), np.int32), b'') if raw else out
     b2 = lib.msc_rle_encode_workspace(nseg.value)
     ws2 = torch.empty(b2, dtype=torch.uint8, device=dev)
     n_inst, n_chars = C.c_int32(0), C.c_int64(0)
@@ -73,6 +74,8 @@ def encode_labels(labels, trusted=False):
     t0, c0 = table_p.value - ws2.data_ptr(), chars_p.value - ws2.data_ptr()
     table = ws2[t0:t0 + n_inst.value * 32].cpu().numpy().view(np.int32).reshape(-1, 8)
     chars = ws2[c0:c0 + n_chars.value].cpu().numpy().tobytes()
+    if raw:
+        return table, chars
     for layer, label, s0, s1, xs, ys, xe, ye in table.tolist():
         out[layer][label] = (chars[s0:s1], [float(xs), float(ys), float(xe - xs + 1), float(ye - ys + 1)])
     return out
@@ -180,6 +183,53 @@ def annotations_from_probabilities(image_ids, probs, category_ids, category_laye
                 annotations.append({'image_id': image_id, 'category_id': category_id, 'score': score,
                                     'segmentation': {'size': size, 'counts': counts.decode('UTF-8')}, 'bbox': bbox})
     return annotations
+
+
+def annotations_json(table, chars, image_ids, category_ids, counts, scores, score_off, size):
+    """msc_annotations_json: the annotation list of `layers = len(image_ids)` encoded label layers as JSON text (bytes), straight from
+    the encoder's table -- json.loads() of it equals the list of dicts create_annotations builds (src/utils.py:76-115)"""
+    lib = _lib.load()
+    table = np.ascontiguousarray(table, np.int32)
+    ids = np.ascontiguousarray(image_ids, np.int64)
+    cats = np.ascontiguousarray(category_ids, np.int32)
+    cnts = np.ascontiguousarray(counts, np.int32)
+    sc = np.ascontiguousarray(scores, np.float64)
+    offs = np.ascontiguousarray(score_off, np.int64)
+    cap = 64 + 2 * len(chars) + 220 * int(cnts.sum() + len(ids))
+    while True:
+        buf = C.create_string_buffer(cap)
+        need = lib.msc_annotations_json(table.ctypes.data, int(table.shape[0]), chars, len(ids), ids.ctypes.data, cats.ctypes.data, cnts.ctypes.data,
+                                        sc.ctypes.data, offs.ctypes.data, int(size[0]), int(size[1]), buf, cap)
+        if need < 0:
+            _lib.check(int(need), 'msc_annotations_json')
+        if need <= cap:
+            return buf.raw[:need]
+        cap = int(need)
+
+
+def annotations_json_from_probabilities(image_ids, probs, category_ids, category_layers, target_size=None, erode_selem_size=0,
+                                        dilate_selem_size=0, watershed_selem_size=0, crf_images=None, crf_params=None):
+    """annotations_from_probabilities with the result as the JSON document `create_annotations(..., save=True)` writes to
+    submission.json (src/utils.py:105-110): no Python object per instance -- the device chain, one table copy, one native pass."""
+    from . import postprocessing as post
+    if crf_images is not None:
+        probs = post.dense_crf_batch(probs.contiguous().float(), crf_images, **(crf_params or {}))
+    lab4, counts_h, scores_h = post.postprocess_device(probs, target_size, erode_selem_size, dilate_selem_size, category_layers,
+                                                       watershed_selem_size=watershed_selem_size, raw_scores=True)
+    B, L, H, W = lab4.shape
+    inds = np.cumsum(category_layers)
+    n_scored, cap = scores_h.shape[1], scores_h.shape[2]
+    keep = [l for l in range(min(L, n_scored)) if category_ids[int(np.searchsorted(inds, l, side='right'))] is not None]
+    if not keep:
+        return b'[]'
+    sel = lab4 if len(keep) == L else lab4[:, keep].contiguous()
+    table, chars = encode_labels(sel.view(B * len(keep), H, W), trusted=True, raw=True)
+    keep_a = np.asarray(keep)
+    ids = np.repeat(np.asarray(image_ids, np.int64), len(keep))
+    cats = np.tile(np.asarray([category_ids[int(np.searchsorted(inds, l, side='right'))] for l in keep], np.int32), B)
+    cnts = counts_h[:, keep_a].reshape(-1)
+    offs = ((np.arange(B, dtype=np.int64)[:, None] * n_scored + keep_a[None, :]) * cap).reshape(-1)
+    return annotations_json(table, chars, ids, cats, cnts, scores_h, offs, (H, W))
 
 
 def create_annotations(meta, predictions, logger, category_ids, category_layers, save=False, experiment_dir='./', chunk=64):

@@ -143,3 +143,30 @@ def test_string_coding_round_trips_for_arbitrary_counts():
     assert len(annot_ref.rle_to_string([15])) == 1 and len(annot_ref.rle_to_string([16])) == 2
     assert len(annot_ref.rle_to_string([511])) == 2 and len(annot_ref.rle_to_string([512])) == 3
     assert annot_ref.rle_from_string(annot_ref.rle_to_string([0, 90000])) == [0, 90000]
+
+
+def test_native_json_writer_equals_json_dumps_of_the_reference_style_list():
+    """msc_annotations_json (host code of the C-ABI library: no GPU involved): the JSON text it writes parses to exactly the list of
+    dicts the Python path builds -- ids without pixels as empty masks, instance-free layers as one empty mask, zip-truncation by
+    the number of scores, a count string with a backslash (character 92 is in the COCO alphabet) escaped, floats that read back
+    bit-identically"""
+    import json
+    from mapping_challenge_amd import utils
+    H, W = 30, 20
+    strings = [b'0a1', b'4\\7' , b'n<0O', b'11']            # the second holds ONE backslash
+    chars = b''.join(strings)
+    offs = np.cumsum([0] + [len(x) for x in strings])
+    # layer 0: ids 1 and 3 present (2 missing); layer 1: no instance; layer 2: id 2 present, but only one score
+    table = np.array([[0, 1, offs[0], offs[1], 2, 3, 5, 9], [0, 3, offs[1], offs[2], 0, 0, 19, 29], [2, 2, offs[2], offs[3], 7, 7, 7, 7]], np.int32)
+    scores = np.array([0.1, 1.0 / 3.0, 12345.678, 7.5e-06, 2.0, 1e+22], np.float64)
+    got = json.loads(utils.annotations_json(table, chars, [11, 12, 13], [100, 100, 7], [3, 1, 1], scores, [0, 3, 4], (H, W)))
+    empty = utils._count_chars(H * W).decode()
+
+    def ann(i, c, s, counts, bbox):
+        return {'image_id': i, 'category_id': c, 'score': s, 'segmentation': {'size': [H, W], 'counts': counts}, 'bbox': bbox}
+    exp = [ann(11, 100, 0.1, '0a1', [2.0, 3.0, 4.0, 7.0]), ann(11, 100, 1.0 / 3.0, empty, [0.0, 0.0, 0.0, 0.0]),
+           ann(11, 100, 12345.678, '4\\7', [0.0, 0.0, 20.0, 30.0]), ann(12, 100, 7.5e-06, empty, [0.0, 0.0, 0.0, 0.0]),
+           ann(13, 7, 2.0, empty, [0.0, 0.0, 0.0, 0.0])]
+    assert got == exp
+    assert json.loads(json.dumps(exp)) == got and all(isinstance(a['bbox'][0], float) for a in got)
+    assert utils.annotations_json(np.zeros((0, 8), np.int32), b'', [], [], [], np.zeros(0), [], (H, W)) == b'[]'
