@@ -66,6 +66,16 @@ typedef struct msc_conv_desc {
     int32_t stats_kind;
     const void* stats_y;
     int64_t stats_y_ld;
+    /* ABI v5, eval mode: the network's last two layers in one launch.  When final_w is set (only with the 32-channel 3x3 halo kernel,
+     * cfg 27: Cin = Cout = 32, 3x3, stride 1) the epilogue also applies the final 1x1 convolution 32 -> 2 + bias to the stored
+     * (16-bit rounded) ReLU output and writes logits / softmax probabilities as f32 NCHW planes [N][2][Ho][Wo] -- what msc_final_fwd
+     * would read the tensor back for (Conv2d(32, 2, 1) + the host softmax, src/unet_models.py:383,403, src/models.py:88-92);
+     * final_logits or final_probs may be NULL.  final_skip_store: do not write `out` (nothing else reads dec0's output in eval). */
+    const float* final_w;
+    const float* final_b;
+    float* final_logits;
+    float* final_probs;
+    int32_t final_skip_store;
 } msc_conv_desc;
 int msc_conv_igemm(const msc_conv_desc* d, void* stream);
 int msc_conv_stats_slices(const msc_conv_desc* d);   /* depends on d->cfg */

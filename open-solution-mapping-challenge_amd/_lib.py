@@ -27,7 +27,9 @@ class ConvDesc(C.Structure):
                 ('N', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32), ('Cin', C.c_int32),
                 ('Ho', C.c_int32), ('Wo', C.c_int32), ('Cout', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32),
                 ('stride', C.c_int32), ('pad', C.c_int32), ('flip', C.c_int32), ('relu', C.c_int32), ('cfg', C.c_int32),
-                ('stats_kind', C.c_int32), ('stats_y', C.c_void_p), ('stats_y_ld', C.c_int64)]
+                ('stats_kind', C.c_int32), ('stats_y', C.c_void_p), ('stats_y_ld', C.c_int64),
+                ('final_w', C.c_void_p), ('final_b', C.c_void_p), ('final_logits', C.c_void_p), ('final_probs', C.c_void_p),
+                ('final_skip_store', C.c_int32)]
 
 
 class WgradDesc(C.Structure):

@@ -54,6 +54,7 @@ struct ConvK {
                                      // a compact narrow tensor merged into one tap, conv_fill); the lanes of the later pixels are bounds-checked on their own
     unsigned in_bytes, wt_bytes;     // extents for the buffer descriptors of the DMA kernel
     int ntc;                         // channel tiles (DMA kernel: 1-D grid of ntm*ntc blocks, XCD-aware order)
+    const float* fin_w; const float* fin_b; float* fin_logits; float* fin_probs; int fin_skip;      // fused final 1x1 + softmax (conv3x3_c32_halo_kernel)
     int mode;                        // 0 gather, 1 transposed
     int xcd_order;                   // 1: XCD-aware tile order, 0: pixel tile fastest (for A/B measurements)
     float rcp_hw, rcp_w;             // 1/(Hq*Wq), 1/Wq for the pixel decode of the DMA kernel; 0 = pixel count >= 2^24: integer division
@@ -744,6 +745,12 @@ __global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
     float sc[8], sh[8], bs[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = p.scale ? p.scale[c0 + j] : 1.f; sh[j] = p.shift ? p.shift[c0 + j] : 0.f; bs[j] = 0.f; }
+    // eval: the final 1x1 convolution 32 -> 2 + softmax on the values this epilogue stores (rounded to T first, as msc_final_fwd
+    // would read them back): the lane's 8 channels against its 16 weights, then the four channel groups of a pixel (lanes pl,
+    // pl+16, pl+32, pl+48) are folded by two cross-lane adds
+    float fw0[8], fw1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { fw0[j] = p.fin_w ? p.fin_w[c0 + j] : 0.f; fw1[j] = p.fin_w ? p.fin_w[32 + c0 + j] : 0.f; }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const long opix = (long)(n * p.Ho + y0 + wid * 4 + b) * p.Wo + x0 + pl;
@@ -771,7 +778,32 @@ __global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
                 bs[j] += v[j];
             }
         }
-        Vec16<T>::store(out + opix * p.out_ld + c0, v);
+        if (!p.fin_skip) Vec16<T>::store(out + opix * p.out_ld + c0, v);
+        if (p.fin_w) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const T tv = ElemIO<T>::from(v[j]);
+                const float r = ElemIO<T>::load(&tv);
+                a0 = fmaf(r, fw0[j], a0);
+                a1 = fmaf(r, fw1[j], a1);
+            }
+            a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64);
+            a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64);
+            if (g == 0) {
+                a0 += p.fin_b ? p.fin_b[0] : 0.f;
+                a1 += p.fin_b ? p.fin_b[1] : 0.f;
+                const long hw = (long)p.Ho * p.Wo;
+                const long o0 = (long)n * 2 * hw + (long)(y0 + wid * 4 + b) * p.Wo + x0 + pl;
+                if (p.fin_logits) { p.fin_logits[o0] = a0; p.fin_logits[o0 + hw] = a1; }
+                if (p.fin_probs) {      // numpy softmax of src/utils.py:231-273: subtract max, exp, divide by the sum
+                    const float m = fmaxf(a0, a1);
+                    const float e0 = expf(a0 - m), e1 = expf(a1 - m);
+                    const float sden = e0 + e1;
+                    p.fin_probs[o0] = e0 / sden; p.fin_probs[o0 + hw] = e1 / sden;
+                }
+            }
+        }
     }
     if (rlb) {
         // fold the 16 pixel lanes of a channel group, then the four waves through LDS (the halo is no longer read), and add the
@@ -1534,6 +1566,7 @@ int launch_halo3(const ConvK& k0, hipStream_t st) {
 
 bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
     if (cfg < 1 || cfg > N_CONV_CFG) return false;
+    if (k.fin_w && cfg != CFG_HALO) return false;           // the fused final 1x1 lives in the 32-channel halo kernel's epilogue only
     if (cfg == CFG_HALO)
         return es == 2 && k.mode == 0 && k.KH == 3 && k.KW == 3 && k.stride == 1 && k.pad == 1 && k.Cin == 32 && k.Cout == 32 &&
                k.Ho % 16 == 0 && k.Wo % 16 == 0 && k.Hi == k.Ho && k.Wi == k.Wo && (!k.stats || k.stats_kind == 2) && k.res_ld % 8 == 0 && k.out_ld % 8 == 0;
@@ -1566,7 +1599,7 @@ int pick_cfg(const ConvK& k) {
 
 template <typename T>
 int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
-    if (cfg == 0) cfg = pick_cfg(k);
+    if (cfg == 0) cfg = k.fin_w ? CFG_HALO : pick_cfg(k);
     if (!conv_cfg_ok(k, (int)sizeof(T), cfg)) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: configuration %d is not valid for this layer", cfg);
     if (cfg == CFG_HALO) {
         if constexpr (sizeof(T) == 2) hipLaunchKernelGGL(conv3x3_c32_halo_kernel<T>, dim3(k.N * (k.Ho / 16) * (k.Wo / 16)), dim3(256), 0, st, k);
@@ -1663,6 +1696,10 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
     k->N = d->N; k->Hi = d->Hi; k->Wi = d->Wi; k->Cin = d->Cin; k->Ho = d->Ho; k->Wo = d->Wo; k->Cout = d->Cout;
     k->KH = d->KH; k->KW = d->KW; k->stride = d->stride; k->pad = d->pad; k->flip = d->flip; k->relu = d->relu;
     k->mode = d->mode;
+    k->fin_w = d->final_w; k->fin_b = d->final_b; k->fin_logits = d->final_logits; k->fin_probs = d->final_probs;
+    k->fin_skip = d->final_w ? d->final_skip_store : 0;
+    if (d->final_w && (d->res || d->stats || (!d->final_logits && !d->final_probs)))
+        return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: the fused final 1x1 takes no residual / statistics and needs a logits or probabilities output");
     k->span_bytes = 0;
     if (d->mode == 1) {
         if (d->stride != 2 || (d->Ho & 1) || (d->Wo & 1)) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: transposed mode needs stride 2 and even output size");
@@ -1725,6 +1762,8 @@ static msc_conv_desc conv_image_range(const msc_conv_desc* d, int n0, int n) {
     c.out = (char*)d->out + (long)n0 * d->Ho * d->Wo * d->out_ld * es;
     if (d->res) c.res = (const char*)d->res + (long)n0 * d->Ho * d->Wo * d->res_ld * es;
     if (d->stats_y) c.stats_y = (const char*)d->stats_y + (long)n0 * d->Ho * d->Wo * d->stats_y_ld * es;
+    if (d->final_logits) c.final_logits = d->final_logits + (long)n0 * 2 * d->Ho * d->Wo;
+    if (d->final_probs) c.final_probs = d->final_probs + (long)n0 * 2 * d->Ho * d->Wo;
     return c;
 }
 

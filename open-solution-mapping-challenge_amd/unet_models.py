@@ -1152,10 +1152,23 @@ class _Builder:
             self.deconv_relu(dn + '.block.1', mid, d.block[1], up)
             x = up
         d0 = self.act(H, W, nf)
-        self.conv(P.fwd, x, net._pack['w']['dec0.conv'], d0, KH=3, KW=3, stride=1, pad=1, relu=1, shift=net.dec0.conv.bias)
         fin = net.final
-        self.emit(P.fwd, lib.msc_final_fwd, d0.ptr, d0.ld, fin.weight.data_ptr(), fin.bias.data_ptr(), P.logits.data_ptr(),
-                  None if self.training else P.probs.data_ptr(), self.dt, N, H, W, nf)
+        dd = self.conv_desc(x, net._pack['w']['dec0.conv'], d0, KH=3, KW=3, stride=1, pad=1, relu=1, shift=net.dec0.conv.bias)
+        fused_final = False
+        if not self.training and self.dev.type == 'cuda' and nf == 32 and _os_env.environ.get('MSC_FUSE_FINAL', '1') != '0':
+            # eval: dec0's 3x3 conv + ReLU, the final 1x1 conv and the channel softmax in ONE launch (src/unet_models.py:401-403 +
+            # src/models.py:88-92): dec0's 134 MB output is neither written nor read back
+            dd.final_w, dd.final_b = fin.weight.data_ptr(), fin.bias.data_ptr()
+            dd.final_logits, dd.final_probs, dd.final_skip_store = P.logits.data_ptr(), P.probs.data_ptr(), 1
+            if lib.msc_conv_cfg_ok(C.byref(dd), _lib.CFG_HALO):
+                dd.cfg, fused_final = _lib.CFG_HALO, True
+            else:
+                dd.final_w = dd.final_b = dd.final_logits = dd.final_probs = None
+                dd.final_skip_store = 0
+        self.emit(P.fwd, lib.msc_conv_igemm, C.byref(dd))
+        if not fused_final:
+            self.emit(P.fwd, lib.msc_final_fwd, d0.ptr, d0.ld, fin.weight.data_ptr(), fin.bias.data_ptr(), P.logits.data_ptr(),
+                      None if self.training else P.probs.data_ptr(), self.dt, N, H, W, nf)
         if self.training:
             # the backward sums (BatchNorm-backward, bias gradients) are accumulated atomically into the arena's tail: zeroed at
             # the head of EVERY backward, so a second backward for one forward (retain_graph, re-timing prog.bwd) starts clean

@@ -33,13 +33,15 @@ bench) # every line DESIGN.md quotes; the default command (BASELINE.json's metri
        bench_line tta_r152_fp16 900 --workload tta
        bench_line post 600 --workload post
        bench_line annot 600 --workload annot
+       bench_line e2e 900 --workload e2e
        bench_line train 1200;;
 benchq) bench_line train 1200 --no-cpu-baseline;;
 prof)  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1   # fills the tune cache so the profile holds no tuning launches
        prof_stats train --steps 20 --warmup 2
        python bench.py --workload infer --encoder 101 --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
        prof_stats infer_r101 --workload infer --encoder 101 --steps 20 --warmup 2
-       prof_stats post --workload post --steps 20 --warmup 2;;
+       prof_stats post --workload post --steps 20 --warmup 2
+       prof_stats e2e --workload e2e --steps 5 --warmup 2;;
 pmc)   python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
        cd /tmp; export TMPDIR=/tmp
        for c in FETCH_SIZE WRITE_SIZE; do

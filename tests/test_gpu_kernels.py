@@ -753,3 +753,45 @@ def test_fused_bottleneck_matches_the_three_convolutions(dtype, cmid, n, h, w, c
     assert lib.msc_bottleneck_ok(C.byref(d)) == 0 and lib.msc_bottleneck_fused(C.byref(d), stream) != 0
     d.W, d.Cmid = w, 512
     assert lib.msc_bottleneck_ok(C.byref(d)) == 0
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_dec0_conv_with_fused_final_1x1_and_softmax(dtype):
+    """eval: ConvRelu(32, 32) + Conv2d(32, 2, 1) + channel softmax in one launch (msc_conv_desc.final_*; src/unet_models.py:401-403,
+    src/models.py:88-92) against conv -> ReLU -> 16-bit rounding -> 1x1 -> softmax; `out` is left untouched with final_skip_store"""
+    import ctypes as C
+    from mapping_challenge_amd import _lib
+    lib = _lib.load()
+    n, hw = 2, 48
+    x = rnd((n, 32, hw, hw), dtype, 1)
+    w = rnd((32, 32, 3, 3), dtype, 2, (2.0 / 288) ** 0.5)
+    bias = torch.randn(32) * 0.1
+    fw, fb = torch.randn(2, 32) * 0.3, torch.randn(2) * 0.1
+    act = torch.relu(F.conv2d(x, w, bias, padding=1)).to(dtype).float()
+    logits = torch.einsum('nchw,kc->nkhw', act, fw) + fb.view(1, 2, 1, 1)
+    xd, wk = nhwc(x, dtype), w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    out = torch.full((n, hw, hw, 32), 5.0, dtype=dtype, device='cuda')
+    lg = torch.empty((n, 2, hw, hw), dtype=torch.float32, device='cuda')
+    pr = torch.empty_like(lg)
+    bd, fwd_, fbd = bias.cuda(), fw.contiguous().cuda(), fb.cuda()
+    d = _lib.ConvDesc()
+    d.in_, d.wt, d.out, d.shift = xd.data_ptr(), wk.data_ptr(), out.data_ptr(), bd.data_ptr()
+    d.in_ld = d.out_ld = 32
+    d.dtype, d.mode = {torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}[dtype], 0
+    d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = n, hw, hw, 32, hw, hw, 32
+    d.KH, d.KW, d.stride, d.pad, d.relu = 3, 3, 1, 1, 1
+    d.final_w, d.final_b, d.final_logits, d.final_probs, d.final_skip_store = fwd_.data_ptr(), fbd.data_ptr(), lg.data_ptr(), pr.data_ptr(), 1
+    assert lib.msc_conv_cfg_ok(C.byref(d), _lib.CFG_HALO) == 1 and lib.msc_conv_cfg_ok(C.byref(d), 10) == 0
+    _lib.check(lib.msc_conv_igemm(C.byref(d), torch.cuda.current_stream().cuda_stream), 'msc_conv_igemm')
+    torch.cuda.synchronize()
+    assert (lg.cpu() - logits).abs().max().item() < 2e-2 * max(1.0, logits.abs().max().item())
+    assert (pr.cpu() - torch.softmax(lg.cpu(), 1)).abs().max().item() < 1e-6 and (pr.sum(1) - 1).abs().max().item() < 1e-6
+    assert (out.float() == 5.0).all()                    # final_skip_store: dec0's activation is not written
+    d.final_skip_store = 0
+    _lib.check(lib.msc_conv_igemm(C.byref(d), torch.cuda.current_stream().cuda_stream), 'msc_conv_igemm')
+    assert torch.allclose(to_nchw(out), act, **tol(dtype))
+    # the logits are computed from the ROUNDED activation: comparable with the two-launch path up to the order of 32 fp32 additions
+    lg2 = torch.empty_like(lg)
+    _lib.call('msc_final_fwd', out.data_ptr(), 32, fwd_.data_ptr(), fbd.data_ptr(), lg2.data_ptr(), None, d.dtype, n, hw, hw, 32,
+              torch.cuda.current_stream().cuda_stream)
+    assert (lg - lg2).abs().max().item() < 1e-5 * max(1.0, lg2.abs().max().item())
