@@ -64,7 +64,7 @@ if os.environ.get('MSC_BNECK_ABL') == '8':
     rel = (t[:, 1:11] - t[:, :1])
     names = ['prologue issued', 'phase-1 k-loop done', 'phase-1 epilogue + barrier', 'phase-2 k-loop done', 'phase-2 epilogue + barrier',
              'pass 0 done', 'pass 1 done', 'pass 2 done', 'pass 3 done', 'pass-0 k-steps + residual wait']
-    print('shader-clock stamps since block start, median over %d blocks (100 MHz counter: x10 ns):' % blocks)
+    print('shader-clock stamps since block start, median over %d blocks (shader clock, ~2 GHz):' % blocks)
     for k, nm in enumerate(names):
         print('  %-32s median %8.0f   min %8.0f   max %8.0f' % (nm, np.median(rel[:, k]), rel[:, k].min(), rel[:, k].max()))
     print('  block start spread: %.0f' % (t[:, 0].max() - t[:, 0].min()))
