@@ -527,13 +527,15 @@ __global__ void crf_iter_kernel(const float* __restrict__ probs, const uint8_t* 
     }
 }
 
-// ---- tiled form (window radius <= CRF_RMAX): a block owns a 16x16 tile; the (16+2r)^2 halo of what every tap needs -- the
+// ---- tiled form (window radius <= CRF_RMAX): a block owns a 32x32 tile; the (32+2r)^2 halo of what every tap needs -- the
 // neighbour's Q already multiplied by its two normalisers, and its colour -- goes to LDS once per iteration and the 121 taps
 // read it from there.  The naive kernels above load 5 global values per tap (605 per pixel and kernel): 672 us per iteration for
 // 32 images of 256x256; tiled, the iteration is bound by the per-tap arithmetic (3 colour differences, a dot product, one exp2,
-// four FMAs) and the LDS reads (two ds_read_b128 per tap).  Spatial weights are tables of (2r+1)^2 floats in LDS (broadcast
+// four FMAs): a thread owns FOUR vertically adjacent pixels, so a halo value it loads serves up to four (pixel, tap) pairs -- with
+// one pixel per thread the two ds_read_b128 per tap, not the VALU, set the pace (222 us per iteration for 32 images; the LDS pipe
+// moves 128 B/clk for the whole CU).  Spatial weights are tables of (2r+1)^2 floats in LDS (broadcast
 // reads), folded into the exponent for the bilateral kernel: k = exp2(c_sp[t] - |dI|^2 * inv2rgb * log2(e)).
-constexpr int CRF_T = 16, CRF_RMAX = 8, CRF_HMAX = CRF_T + 2 * CRF_RMAX;
+constexpr int CRF_T = 32, CRF_PV = 4, CRF_RMAX = 8, CRF_HMAX = CRF_T + 2 * CRF_RMAX;      // 32x32 tile, 256 threads x 4 vertical pixels
 
 struct CrfHalo {
     float4 a[CRF_HMAX * CRF_HMAX];      // (q0*ng, q1*ng, q0*nb, q1*nb) of the halo pixel (zeros outside the image)
@@ -568,23 +570,35 @@ __global__ __launch_bounds__(256) void crf_norm_tiled_kernel(const uint8_t* __re
         s.c[i] = v;
     }
     __syncthreads();
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int x = x0 + tx, y = y0 + ty;
-    if (x >= c.W || y >= c.H) return;
-    const float4 me = s.c[(ty + r) * hw + tx + r];
+    const int tx = threadIdx.x & 31, ty = (threadIdx.x >> 5) * CRF_PV;      // this thread's pixels: (tx, ty .. ty+3) of the tile
+    const int x = x0 + tx;
+    if (x >= c.W || y0 + ty >= c.H) return;
+    float4 me[CRF_PV];
+#pragma unroll
+    for (int k = 0; k < CRF_PV; ++k) me[k] = s.c[(ty + k + r) * hw + tx + r];
     const float krgb = c.inv2rgb * 1.44269504f;
-    float sg = 0.f, sb = 0.f;
+    float sg[CRF_PV] = {0.f, 0.f, 0.f, 0.f}, sb[CRF_PV] = {0.f, 0.f, 0.f, 0.f};
     const int w = 2 * r + 1;
-    for (int dy = -r; dy <= r; ++dy)
+    for (int hy = 0; hy < CRF_PV + 2 * r; ++hy)            // halo rows this thread's four windows cover
         for (int dx = -r; dx <= r; ++dx) {
-            const float4 o = s.c[(ty + r + dy) * hw + tx + r + dx];
-            const int t = (dy + r) * w + dx + r;
-            const float d0 = o.x - me.x, d1 = o.y - me.y, d2 = o.z - me.z;
-            sg += s.gsp[t] * o.w;
-            sb += __builtin_amdgcn_exp2f(s.bsp[t] - (d0 * d0 + d1 * d1 + d2 * d2) * krgb) * o.w;      // v_exp_f32: the argument is <= 0, a flushed denormal is 0
+            const float4 o = s.c[(ty + hy) * hw + tx + r + dx];
+#pragma unroll
+            for (int k = 0; k < CRF_PV; ++k) {
+                const int dy = hy - k - r;                  // offset of this halo row from pixel k
+                if (dy < -r || dy > r) continue;
+                const int t = (dy + r) * w + dx + r;
+                const float d0 = o.x - me[k].x, d1 = o.y - me[k].y, d2 = o.z - me[k].z;
+                sg[k] += s.gsp[t] * o.w;
+                sb[k] += __builtin_amdgcn_exp2f(s.bsp[t] - (d0 * d0 + d1 * d1 + d2 * d2) * krgb) * o.w;      // v_exp_f32: the argument is <= 0
+            }
         }
-    ng[b * HW + (long)y * c.W + x] = 1.f / sqrtf(sg + 1e-20f);
-    nb[b * HW + (long)y * c.W + x] = 1.f / sqrtf(sb + 1e-20f);
+#pragma unroll
+    for (int k = 0; k < CRF_PV; ++k) {
+        const int y = y0 + ty + k;
+        if (y >= c.H) break;
+        ng[b * HW + (long)y * c.W + x] = 1.f / sqrtf(sg[k] + 1e-20f);
+        nb[b * HW + (long)y * c.W + x] = 1.f / sqrtf(sb[k] + 1e-20f);
+    }
 }
 
 // one mean-field iteration: Q <- softmax(-U + compat_g * K_g Q + compat_b * K_b Q)
@@ -610,32 +624,44 @@ __global__ __launch_bounds__(256) void crf_iter_tiled_kernel(const float* __rest
         s.c[i] = vc;
     }
     __syncthreads();
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int x = x0 + tx, y = y0 + ty;
-    if (x >= c.W || y >= c.H) return;
-    const float4 me = s.c[(ty + r) * hw + tx + r];
+    const int tx = threadIdx.x & 31, ty = (threadIdx.x >> 5) * CRF_PV;
+    const int x = x0 + tx;
+    if (x >= c.W || y0 + ty >= c.H) return;
+    float4 me[CRF_PV];
+#pragma unroll
+    for (int k = 0; k < CRF_PV; ++k) me[k] = s.c[(ty + k + r) * hw + tx + r];
     const float krgb = c.inv2rgb * 1.44269504f;
-    float g0 = 0.f, g1 = 0.f, b0 = 0.f, b1 = 0.f;
+    float g0[CRF_PV] = {0.f, 0.f, 0.f, 0.f}, g1[CRF_PV] = {0.f, 0.f, 0.f, 0.f}, b0[CRF_PV] = {0.f, 0.f, 0.f, 0.f}, b1[CRF_PV] = {0.f, 0.f, 0.f, 0.f};
     const int w = 2 * r + 1;
-    for (int dy = -r; dy <= r; ++dy)
+    for (int hy = 0; hy < CRF_PV + 2 * r; ++hy)
         for (int dx = -r; dx <= r; ++dx) {
-            const int h = (ty + r + dy) * hw + tx + r + dx;
+            const int h = (ty + hy) * hw + tx + r + dx;
             const float4 o = s.c[h];
-            const float4 qv = s.a[h];
-            const int t = (dy + r) * w + dx + r;
-            const float d0 = o.x - me.x, d1 = o.y - me.y, d2 = o.z - me.z;
-            const float kg = s.gsp[t];
-            const float kb = __builtin_amdgcn_exp2f(s.bsp[t] - (d0 * d0 + d1 * d1 + d2 * d2) * krgb);      // out-of-image neighbours carry Q = 0
-            g0 += kg * qv.x; g1 += kg * qv.y;
-            b0 += kb * qv.z; b1 += kb * qv.w;
+            const float4 qv = s.a[h];                       // out-of-image neighbours carry Q = 0
+#pragma unroll
+            for (int k = 0; k < CRF_PV; ++k) {
+                const int dy = hy - k - r;
+                if (dy < -r || dy > r) continue;
+                const int t = (dy + r) * w + dx + r;
+                const float d0 = o.x - me[k].x, d1 = o.y - me[k].y, d2 = o.z - me[k].z;
+                const float kg = s.gsp[t];
+                const float kb = __builtin_amdgcn_exp2f(s.bsp[t] - (d0 * d0 + d1 * d1 + d2 * d2) * krgb);
+                g0[k] += kg * qv.x; g1[k] += kg * qv.y;
+                b0[k] += kb * qv.z; b1[k] += kb * qv.w;
+            }
         }
-    const long p = (long)y * c.W + x;
-    const float u0 = -logf(fminf(fmaxf(probs[(b * 2) * HW + p], 1e-5f), 1.f));
-    const float u1 = -logf(fminf(fmaxf(probs[(b * 2 + 1) * HW + p], 1e-5f), 1.f));
-    const float n_g = ng[b * HW + p], n_b = nb[b * HW + p];
-    const float t0 = -u0 + c.compat_g * g0 * n_g + c.compat_b * b0 * n_b;
-    const float t1 = -u1 + c.compat_g * g1 * n_g + c.compat_b * b1 * n_b;
-    softmax2(t0, t1, &qout[(b * 2) * HW + p], &qout[(b * 2 + 1) * HW + p]);
+#pragma unroll
+    for (int k = 0; k < CRF_PV; ++k) {
+        const int y = y0 + ty + k;
+        if (y >= c.H) break;
+        const long p = (long)y * c.W + x;
+        const float u0 = -logf(fminf(fmaxf(probs[(b * 2) * HW + p], 1e-5f), 1.f));
+        const float u1 = -logf(fminf(fmaxf(probs[(b * 2 + 1) * HW + p], 1e-5f), 1.f));
+        const float n_g = ng[b * HW + p], n_b = nb[b * HW + p];
+        const float t0 = -u0 + c.compat_g * g0[k] * n_g + c.compat_b * b0[k] * n_b;
+        const float t1 = -u1 + c.compat_g * g1[k] * n_g + c.compat_b * b1[k] * n_b;
+        softmax2(t0, t1, &qout[(b * 2) * HW + p], &qout[(b * 2 + 1) * HW + p]);
+    }
 }
 
 // ------------------------------------------------------------------ test-time augmentation (src/loaders.py:401-517)

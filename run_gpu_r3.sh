@@ -31,6 +31,7 @@ probe)  for a in 0 7; do MSC_BNECK_ABL=$a timeout 120 python tools/bneck_probe.p
 post)   pt post 900 tests/test_gpu_post.py tests/test_gpu_pipeline.py tests/test_gpu_annot.py;;
 postq)  pt postq 600 tests/test_gpu_post.py tests/test_gpu_annot.py;;
 e2e)    bench_line e2e 900 --workload e2e --no-cpu-baseline; python -c "import json; d=json.load(open('gpurun_out/bench_e2e.json')); print(json.dumps(d['config']['variants'], indent=1)); print(d['roofline']['dense_crf'])";;
+e2e_ws2) MSC_WS_PASSES=2 bench_line e2e_ws2 900 --workload e2e --no-cpu-baseline; python -c "import json; d=json.load(open('gpurun_out/bench_e2e_ws2.json')); print({k:(round(v['post_only_img_s']),round(v['end_to_end_img_s'])) for k,v in d['config']['variants'].items() if isinstance(v,dict)})";;
 postb)  bench_line post 600 --workload post --no-cpu-baseline;;
 prof_e2e) ( cd /tmp; export TMPDIR=/tmp; rm -rf "$R/gpurun_out/prof_e2e"; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_e2e" -- python "$R/bench.py" --workload e2e --steps 5 --warmup 2 --no-cpu-baseline > "$R/gpurun_out/prof_e2e.log" 2>&1; echo "prof e2e rc=$?" )
         python tools/kernel_stats_summary.py gpurun_out/prof_e2e > gpurun_out/kernel_stats_e2e.txt 2>&1; head -60 gpurun_out/kernel_stats_e2e.txt | cut -c1-180;;
