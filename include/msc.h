@@ -76,6 +76,12 @@ typedef struct msc_conv_desc {
     float* final_logits;
     float* final_probs;
     int32_t final_skip_store;
+    /* ABI v5, split-K (mode 0, no statistics): splitk > 1 runs the reduction (filter taps x channel chunks) as `splitk` slices, each
+     * block storing its fp32 partial tile into its plane of splitk_ws (f32 [splitk][pixels][Cout], scratch); a finishing pass adds
+     * the planes in slice order, applies the epilogue and stores `out`.  For layers with few output tiles and a long reduction -- the decoder's
+     * centre / dec5 ConvRelu on 4x4 and 8x8 maps (src/unet_models.py:373-374): 512 pixels x 512 channels x 18432 is 32 tiles. */
+    int32_t splitk;
+    float* splitk_ws;
 } msc_conv_desc;
 int msc_conv_igemm(const msc_conv_desc* d, void* stream);
 int msc_conv_stats_slices(const msc_conv_desc* d);   /* depends on d->cfg */

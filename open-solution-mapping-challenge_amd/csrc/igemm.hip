@@ -55,6 +55,7 @@ struct ConvK {
     unsigned in_bytes, wt_bytes;     // extents for the buffer descriptors of the DMA kernel
     int ntc;                         // channel tiles (DMA kernel: 1-D grid of ntm*ntc blocks, XCD-aware order)
     const float* fin_w; const float* fin_b; float* fin_logits; float* fin_probs; int fin_skip;      // fused final 1x1 + softmax (conv3x3_c32_halo_kernel)
+    int ksplit; float* kws;          // split-K: slices of the reduction, fp32 partial sums (conv_igemm_dma_kernel, mode 0)
     int mode;                        // 0 gather, 1 transposed
     int xcd_order;                   // 1: XCD-aware tile order, 0: pixel tile fastest (for A/B measurements)
     float rcp_hw, rcp_w;             // 1/(Hq*Wq), 1/Wq for the pixel decode of the DMA kernel; 0 = pixel count >= 2^24: integer division
@@ -278,7 +279,8 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
     // XCD-aware tile order: workgroup b runs on XCD b%8 (observed dispatch order; only speed depends on it).  Each
     // XCD gets a contiguous run of tiles with the channel tile varying fastest, so the blocks that re-read one pixel
     // tile (one per channel tile) and one weight tile share that XCD's L2 close in time.
-    const int nwg = gridDim.x, orig = blockIdx.x;
+    // split-K: the grid holds ksplit copies of the tile grid, slice slowest
+    const int nwg = (int)gridDim.x / p.ksplit, kslice = (int)blockIdx.x / nwg, orig = (int)blockIdx.x - kslice * nwg;
     const int xcd = orig & 7, wq = nwg >> 3, wr = nwg & 7;
     const int wgid = (xcd < wr ? xcd * (wq + 1) : wr * (wq + 1) + (xcd - wr) * wq) + (orig >> 3);
     const int ntm_ = nwg / p.ntc;
@@ -296,7 +298,11 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
         nkw = p.KW > kw0 ? (p.KW - kw0 + 1) / 2 : 0;
     }
     const int cps = p.Cin / KE;
-    const int nsteps = nkh * nkw * cps;
+    const int nsteps_all = nkh * nkw * cps;
+    // this block's slice of the k-steps (all of them without split-K)
+    const int sper = (nsteps_all + p.ksplit - 1) / p.ksplit;
+    const int sbeg = kslice * sper;
+    const int nsteps = max(0, min(nsteps_all, sbeg + sper) - sbeg);
 
     const u32x4_t rx = make_srd(p.in, p.in_bytes);
     const u32x4_t rw = make_srd(p.wt, p.wt_bytes);
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
     }
 
     // ---- issue iterator: (tap, k-chunk) of the next stage to fetch; per-lane offsets refreshed once per tap
-    int itap = 0, icch = 0, istage = 0;
+    int itap = sbeg / cps, icch = sbeg - itap * cps, istage = 0;
     unsigned xoff[XI], woff[WI];
     auto set_tap = [&](int tap) {
         const int khi = tap / nkw, kwi = tap - khi * nkw;
@@ -457,6 +463,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
     };
 
     if (nsteps > 0) {
+        if (icch != 0) set_tap(itap);            // a slice that starts inside a tap (issue() refreshes the offsets at chunk 0 only)
 #pragma unroll
         for (int st = 0; st < NST - 1; ++st)
             if (st < nsteps) issue();
@@ -478,8 +485,65 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
             if (++cstage == NST) cstage = 0;
         }
     }
+    if (p.ksplit > 1) {
+        // split-K: the fp32 partial tile goes to this slice's plane of the workspace [slice][pixel][Cout] with plain 16-byte stores (a
+        // lane's NV channels are consecutive); splitk_finish_kernel adds the planes in slice order -- deterministic -- and applies the
+        // epilogue.  (fp32 atomics into one plane were 2x SLOWER than the unsplit launch: 16 slices hammering the same lines.)
+        if (MODE == 0) {
+            const int cb = c0 + wc * WTC + g * NV;
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
+                const int m = m0 + wp * WTP + b * 16 + pl;
+                if (m < p.M) {
+                    float* dst = p.kws + ((long)kslice * p.M + m) * p.Cout + cb;
+#pragma unroll
+                    for (int a = 0; a < FM; ++a)
+                        *reinterpret_cast<float4*>(dst + a * 4) = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+                }
+            }
+        }
+        return;
+    }
     conv_epilogue<T, FM, FN, WTP, WP, MODE, WC>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px, mtile, nwg / p.ntc,
                                                 reinterpret_cast<float*>(smem), wc, c0);
+}
+
+// second pass of a split-K convolution: out = relu?(sum over slices of ws[slice] * scale + shift (+ res)), 8 channels per lane
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, int slices, T* __restrict__ out, long out_ld,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift, const T* __restrict__ res,
+                                                            long res_ld, int relu, long M, int Cout) {
+    const int cpp = Cout / 8;                         // 8-channel groups per pixel
+    const long total = M * cpp;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / cpp;
+        const int c = (int)(i - m * cpp) * 8;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < slices; ++sl) {
+            const float4* w4 = reinterpret_cast<const float4*>(ws + ((long)sl * M + m) * Cout + c);
+            const float4 a = w4[0], b = w4[1];
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * (scale ? scale[c + j] : 1.f) + (shift ? shift[c + j] : 0.f);
+        if (res) {
+            constexpr int CE = 16 / (int)sizeof(T);
+#pragma unroll
+            for (int j = 0; j < 8; j += CE) {
+                float rv[CE];
+                Vec16<T>::load(res + m * res_ld + c + j, rv);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) v[j + e] += rv[e];
+            }
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        constexpr int CE = 16 / (int)sizeof(T);
+#pragma unroll
+        for (int j = 0; j < 8; j += CE) Vec16<T>::store(out + m * out_ld + c + j, v + j);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ halo tile, any width
@@ -1545,10 +1609,16 @@ int launch_dma(const ConvK& k0, int mode, hipStream_t st) {
     ConvK k = k0;
     k.ntc = ceil_div(k.Cout, TC);
     k.xcd_order = xcd_order_enabled() ? 1 : 0;
-    dim3 grid(ceil_div(k.M, TP) * k.ntc, 1, mode ? 4 : 1);
+    dim3 grid(ceil_div(k.M, TP) * k.ntc * k.ksplit, 1, mode ? 4 : 1);
     constexpr int NT = WP * WC * 64;
     if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1, NST, KB, ABL>), grid, dim3(NT), 0, st, k);
     else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, NST, KB, ABL>), grid, dim3(NT), 0, st, k);
+    if (k.ksplit > 1) {
+        const long units = (long)k.M * (k.Cout / 8);
+        const int blocks = (int)(units / 256 < 2048 ? (units + 255) / 256 : 2048);
+        hipLaunchKernelGGL((splitk_finish_kernel<T>), dim3(blocks), dim3(256), 0, st, (const float*)k.kws, k.ksplit, (T*)k.out, k.out_ld, k.scale, k.shift, (const T*)k.res, k.res_ld,
+                           k.relu, (long)k.M, k.Cout);
+    }
     return msc_check_launch("conv_igemm_dma");
 }
 
@@ -1567,6 +1637,7 @@ int launch_halo3(const ConvK& k0, hipStream_t st) {
 bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
     if (cfg < 1 || cfg > N_CONV_CFG) return false;
     if (k.fin_w && cfg != CFG_HALO) return false;           // the fused final 1x1 lives in the 32-channel halo kernel's epilogue only
+    if (k.ksplit > 1 && (cfg == CFG_HALO || cfg == CFG_HALO_T || cfg_is_halo3(cfg))) return false;      // split-K: the implicit-GEMM kernel only
     if (cfg == CFG_HALO)
         return es == 2 && k.mode == 0 && k.KH == 3 && k.KW == 3 && k.stride == 1 && k.pad == 1 && k.Cin == 32 && k.Cout == 32 &&
                k.Ho % 16 == 0 && k.Wo % 16 == 0 && k.Hi == k.Ho && k.Wi == k.Wo && (!k.stats || k.stats_kind == 2) && k.res_ld % 8 == 0 && k.out_ld % 8 == 0;
@@ -1587,6 +1658,7 @@ bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
 // heuristic: largest tile that still gives every CU a block; 64-byte K steps (best on average over the network)
 int pick_cfg(const ConvK& k) {
     const int M = k.M, Cout = k.Cout;
+    if (k.ksplit > 1 && Cout % 128 == 0 && ((long)k.Cin * 2) % 128 == 0) return 3;      // split-K: 128x128 tiles, 128-byte k-steps
     if (k.span_bytes) return Cout % 128 == 0 ? 23 : 20;      // merged taps: 256-byte k-steps only
     if (Cout % 128 == 0) {
         if ((long)ceil_div(M, 256) * (Cout / 128) >= 512) return 2;
@@ -1698,6 +1770,10 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
     k->mode = d->mode;
     k->fin_w = d->final_w; k->fin_b = d->final_b; k->fin_logits = d->final_logits; k->fin_probs = d->final_probs;
     k->fin_skip = d->final_w ? d->final_skip_store : 0;
+    k->ksplit = d->splitk > 1 ? d->splitk : 1;
+    k->kws = d->splitk_ws;
+    if (k->ksplit > 1 && (d->mode != 0 || d->stats || d->final_w || !d->splitk_ws || ((uintptr_t)d->splitk_ws & 15) || d->Cout % 8 || k->ksplit > 64))
+        return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: split-K needs mode 0, no statistics, a 16-byte aligned fp32 workspace and at most 64 slices");
     if (d->final_w && (d->res || d->stats || (!d->final_logits && !d->final_probs)))
         return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: the fused final 1x1 takes no residual / statistics and needs a logits or probabilities output");
     k->span_bytes = 0;

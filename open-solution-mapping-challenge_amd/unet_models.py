@@ -641,6 +641,7 @@ class _Builder:
         self.rwriter = {}             # id(activation buffer) -> (ConvDesc, c0, C) of that first writer
         self.bias_items = []          # (slots address, slot channel count, bias parameter, channels) awaiting flush_bias_slots
         self.fuse_bneck = _os_env.environ.get('MSC_FUSE_BNECK', '1') != '0'
+        self.split_k = _os_env.environ.get('MSC_SPLIT_K', '1') != '0'
 
     # ---- memory
     def buf(self, H, W, C, dtype=None):
@@ -714,7 +715,7 @@ class _Builder:
         lst.append((fn, args))
 
     def conv_desc(self, x, wt, out, KH, KW, stride, pad, mode=0, flip=0, relu=0, scale=None, shift=None, res=None,
-                  stats=None, in_hw=None, in_ld=None, cin=None, out_hw=None, want_stats=False):
+                  stats=None, in_hw=None, in_ld=None, cin=None, out_hw=None, want_stats=False, allow_split=False):
         d = ConvDesc()
         d.in_, d.wt, d.out = x.ptr, wt.data_ptr(), out.ptr
         d.res = res.ptr if res is not None else None
@@ -731,6 +732,16 @@ class _Builder:
         d.KH, d.KW, d.stride, d.pad, d.flip, d.relu = KH, KW, stride, pad, flip, relu
         d.cfg = 0
         self.prog.keep.append(d)
+        if allow_split and self.split_k and self.dev.type == 'cuda' and mode == 0 and not want_stats and stats is None:
+            # few output tiles, long reduction (the decoder's centre / dec5 ConvRelu on the 4x4 / 8x8 maps: 512 pixels x 512 channels x
+            # 18432 = 32 tiles of 128x128 for 256 CUs): the reduction runs in slices, a finishing pass applies the epilogue
+            pixels, ksteps = self.N * d.Ho * d.Wo, d.Cin * KH * KW * self.es // 128
+            tiles = ((pixels + 127) // 128) * ((d.Cout + 127) // 128)
+            split = min(16, 256 // max(tiles, 1), ksteps // 16)
+            if tiles <= 64 and split >= 2 and d.Cout % 8 == 0:
+                d.splitk = split
+                ws = self.vec(split * pixels * d.Cout)
+                d.splitk_ws = ws.data_ptr()
         self.tune_conv(d, want_stats)
         return d
 
@@ -797,7 +808,7 @@ class _Builder:
         if not self.net.autotune or self.dev.type != 'cuda':
             return
         key = repr(('c', self.tune_dt, d.mode, d.flip, d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad,
-                    bool(d.res), want_stats, d.in_ld, d.out_ld, bool(d.relu)))
+                    bool(d.res), want_stats, d.in_ld, d.out_ld, bool(d.relu)) + ((int(d.splitk),) if d.splitk > 1 else ()))
         cache = _TUNE_CACHE
         lib = self.lib
         if key not in cache or (cache[key] and not lib.msc_conv_cfg_ok(C.byref(d), int(cache[key]))):
@@ -1006,7 +1017,7 @@ class _Builder:
     def conv_relu(self, name, x, conv, out):
         """ConvRelu (src/unet_models.py:25-34): 3x3, pad 1, bias, ReLU."""
         net, lib, P = self.net, self.lib, self.prog
-        self.conv(P.fwd, x, net._pack['w'][name], out, KH=3, KW=3, stride=1, pad=1, relu=1, shift=conv.bias)
+        self.conv(P.fwd, x, net._pack['w'][name], out, KH=3, KW=3, stride=1, pad=1, relu=1, shift=conv.bias, allow_split=True)
         if self.training:
             self.ops.append(lambda: self._conv_relu_bwd(name, x, conv, out))
 

@@ -39,6 +39,7 @@ tailprof) timeout 300 python tools/tail_profile.py 0 2>&1 | grep -v '^$' | head 
 hiptrace) ( cd /tmp; export TMPDIR=/tmp; rm -rf "$R/gpurun_out/hip_tail"; timeout 600 rocprofv3 --hip-trace --kernel-trace --stats --output-format csv -d "$R/gpurun_out/hip_tail" -- python "$R/tools/tail_profile.py" 0 > "$R/gpurun_out/hip_tail.log" 2>&1; echo rc=$? )
         f=$(ls gpurun_out/hip_tail/*/*hip_api_stats.csv 2>/dev/null | head -1); echo $f; head -25 "$f" | cut -c1-160; f2=$(ls gpurun_out/hip_tail/*/*kernel_stats.csv | head -1); head -30 "$f2" | cut -c1-200;;
 fin)    pt fin 900 tests/test_gpu_kernels.py -k 'fused_final or epilogues'; pt fin2 900 tests/test_gpu_unet.py tests/test_gpu_fullsize.py;;
+splitk) pt splitk 600 tests/test_gpu_kernels.py -k 'split_k or epilogues or every_kernel'; pt splitk2 900 tests/test_gpu_unet.py tests/test_gpu_parity_timed.py;;
 smoke)  timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 gpurun_out/smoke.log;;
 esac
 done

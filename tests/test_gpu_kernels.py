@@ -795,3 +795,42 @@ def test_dec0_conv_with_fused_final_1x1_and_softmax(dtype):
     _lib.call('msc_final_fwd', out.data_ptr(), 32, fwd_.data_ptr(), fbd.data_ptr(), lg2.data_ptr(), None, d.dtype, n, hw, hw, 32,
               torch.cuda.current_stream().cuda_stream)
     assert (lg - lg2).abs().max().item() < 1e-5 * max(1.0, lg2.abs().max().item())
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('cin,cout,hw,n,split', [(512, 128, 4, 2, 4), (256, 256, 8, 1, 3), (192, 64, 6, 3, 16), (64, 128, 4, 1, 2)])
+def test_split_k_convolution(dtype, cin, cout, hw, n, split):
+    """msc_conv_desc.splitk: the reduction of a 3x3 convolution on a tiny map in `split` slices (partial tiles stored into the slice's plane of an
+    fp32 workspace, a finishing pass that adds the planes and applies the epilogue) equals the single-pass launch and torch; slices that start inside a filter tap,
+    a last slice shorter than the others (or empty), residual + scale / shift + ReLU in the finishing pass"""
+    import ctypes as C
+    from mapping_challenge_amd import _lib
+    lib = _lib.load()
+    x = rnd((n, cin, hw, hw), dtype, 1)
+    w = rnd((cout, cin, 3, 3), dtype, 2, (2.0 / (9 * cin)) ** 0.5)
+    res = rnd((n, cout, hw, hw), dtype, 3)
+    scale, shift = torch.rand(cout) + 0.5, torch.randn(cout) * 0.1
+    ref = torch.relu(F.conv2d(x, w, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    xd, wk, rd = nhwc(x, dtype), w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda(), nhwc(res, dtype)
+    out = torch.empty((n, hw, hw, cout), dtype=dtype, device='cuda')
+    ws = torch.full((split * n * hw * hw * cout,), float('nan'), dtype=torch.float32, device='cuda')      # scratch: every plane is written before it is read
+    sc, sh = scale.cuda(), shift.cuda()
+    d = _lib.ConvDesc()
+    d.in_, d.wt, d.out, d.res, d.scale, d.shift = xd.data_ptr(), wk.data_ptr(), out.data_ptr(), rd.data_ptr(), sc.data_ptr(), sh.data_ptr()
+    d.in_ld, d.out_ld, d.res_ld = cin, cout, cout
+    d.dtype, d.mode = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}[dtype], 0
+    d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = n, hw, hw, cin, hw, hw, cout
+    d.KH, d.KW, d.stride, d.pad, d.relu = 3, 3, 1, 1, 1
+    d.splitk, d.splitk_ws = split, ws.data_ptr()
+    stream = torch.cuda.current_stream().cuda_stream
+    cfgs = [c for c in range(1, lib.msc_conv_num_cfgs() + 1) if lib.msc_conv_cfg_ok(C.byref(d), c)]
+    assert cfgs and not any(42 <= c <= 46 or 51 <= c <= 56 or c in (27, 28) for c in cfgs)       # the halo-tile kernels do not split
+    for cfg in [0] + cfgs[:6]:
+        d.cfg = cfg
+        out.fill_(7.0)
+        _lib.check(lib.msc_conv_igemm(C.byref(d), stream), 'msc_conv_igemm')
+        torch.cuda.synchronize()
+        assert torch.allclose(to_nchw(out), ref, **tol(dtype)), (cfg, (to_nchw(out) - ref).abs().max().item())
+    # statistics / transposed mode are refused with split-K
+    d.mode = 1
+    assert lib.msc_conv_igemm(C.byref(d), stream) != 0
