@@ -902,18 +902,8 @@ __global__ __launch_bounds__(256, 2) void deconv4_c128_c32_halo_kernel(ConvK p) 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, pl = lane & 15;
     const int tiles_x = p.Wi / 16, tiles_y = p.Hi / 8;
-    const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, n = blockIdx.x / (tiles_x * tiles_y);
-    const int qy0 = by * 8, qx0 = bx * 16;
+    const int npatch = p.N * tiles_x * tiles_y;
     const T* in = reinterpret_cast<const T*>(p.in);
-    for (int c = tid; c < HR * HC * 16; c += 256) {
-        const int pix = c >> 4, ch = c & 15;
-        const int hy = pix / HC, hx = pix - hy * HC;
-        const int iy = qy0 - 1 + hy, ix = qx0 - 1 + hx;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-            v = *reinterpret_cast<const uint4*>(in + ((long)(n * p.Hi + iy) * p.Wi + ix) * p.in_ld + ch * 8);
-        halo[pix * 16 + (ch ^ (pix & 15))] = v;
-    }
     const T* wt = reinterpret_cast<const T*>(p.wt);          // [Cout][4][4][Cin]
     T* out = reinterpret_cast<T*>(p.out);
     const T* res = reinterpret_cast<const T*>(p.res);
@@ -925,6 +915,9 @@ __global__ __launch_bounds__(256, 2) void deconv4_c128_c32_halo_kernel(ConvK p) 
     // its phase are 32 weight fragments = 128 VGPRs, fetched ONCE straight from L2 and held; only the pixel fragments come from
     // LDS (one read per two MFMAs).  With the weights in LDS too (the first version: one phase at a time for all waves) every
     // MFMA cost one fragment read and the LDS port, not the matrix pipe, set the pace.
+    // Round 3: the block is PERSISTENT -- it walks patches blockIdx.x, + gridDim.x, ... with the weights of its phases kept in
+    // registers: with one patch per block the 128 KB of weight fragments were re-fetched 4096 times per launch (512 MB of L2 -> CU
+    // traffic, as much as input and output together).
     // row pl of weight fragment a is output channel 8*(pl>>2) + 4a + (pl&3): a lane ends with channels 8g..8g+7
     const int ph = wid, py = ph >> 1, px = ph & 1;
     const int kh0 = (py + 1) & 1, kw0 = (px + 1) & 1;                 // taps kh0, kh0+2 / kw0, kw0+2
@@ -940,40 +933,54 @@ __global__ __launch_bounds__(256, 2) void deconv4_c128_c32_halo_kernel(ConvK p) 
                 aw[t][kk][a] = *reinterpret_cast<const uint4*>(wt + ((long)(co * 4 + kh) * 4 + kw) * 128 + (kk * 4 + g) * 8);
             }
     }
-    __syncthreads();                                                  // halo written
+    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
+        const int bx = patch % tiles_x, by = (patch / tiles_x) % tiles_y, n = patch / (tiles_x * tiles_y);
+        const int qy0 = by * 8, qx0 = bx * 16;
+        __syncthreads();                                              // every wave is done with the previous patch's halo
+        for (int c = tid; c < HR * HC * 16; c += 256) {
+            const int pix = c >> 4, ch = c & 15;
+            const int hy = pix / HC, hx = pix - hy * HC;
+            const int iy = qy0 - 1 + hy, ix = qx0 - 1 + hx;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+                v = *reinterpret_cast<const uint4*>(in + ((long)(n * p.Hi + iy) * p.Wi + ix) * p.in_ld + ch * 8);
+            halo[pix * 16 + (ch ^ (pix & 15))] = v;
+        }
+        __syncthreads();                                              // halo written
 #pragma unroll 1
-    for (int b = 0; b < 8; ++b) {
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        for (int b = 0; b < 8; ++b) {
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int kh = kh0 + 2 * (t >> 1), kw = kw0 + 2 * (t & 1);
-            const int dy = (py + 1 - kh) / 2, dx = (px + 1 - kw) / 2;  // input offset of this tap: -1, 0 or +1
-            const int pix = (b + 1 + dy) * HC + (pl + 1 + dx);
+            for (int t = 0; t < 4; ++t) {
+                const int kh = kh0 + 2 * (t >> 1), kw = kw0 + 2 * (t & 1);
+                const int dy = (py + 1 - kh) / 2, dx = (px + 1 - kw) / 2;  // input offset of this tap: -1, 0 or +1
+                const int pix = (b + 1 + dy) * HC + (pl + 1 + dx);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const uint4 bf = halo[pix * 16 + ((kk * 4 + g) ^ (pix & 15))];
-                Mma<T>::run(aw[t][kk][0], bf, acc[0]);
-                Mma<T>::run(aw[t][kk][1], bf, acc[1]);
+                for (int kk = 0; kk < 4; ++kk) {
+                    const uint4 bf = halo[pix * 16 + ((kk * 4 + g) ^ (pix & 15))];
+                    Mma<T>::run(aw[t][kk][0], bf, acc[0]);
+                    Mma<T>::run(aw[t][kk][1], bf, acc[1]);
+                }
             }
+            const int oy = 2 * (qy0 + b) + py, ox = 2 * (qx0 + pl) + px;
+            const long opix = (long)(n * p.Ho + oy) * p.Wo + ox;
+            float v[8];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][r] * sc[a * 4 + r] + sh[a * 4 + r];
+            if (res) {
+                float rv[8];
+                Vec16<T>::load(res + opix * p.res_ld + c0, rv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += rv[j];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            Vec16<T>::store(out + opix * p.out_ld + c0, v);
         }
-        const int oy = 2 * (qy0 + b) + py, ox = 2 * (qx0 + pl) + px;
-        const long opix = (long)(n * p.Ho + oy) * p.Wo + ox;
-        float v[8];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][r] * sc[a * 4 + r] + sh[a * 4 + r];
-        if (res) {
-            float rv[8];
-            Vec16<T>::load(res + opix * p.res_ld + c0, rv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += rv[j];
-        }
-        if (p.relu) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-        }
-        Vec16<T>::store(out + opix * p.out_ld + c0, v);
     }
 }
 
@@ -1678,7 +1685,11 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
         return msc_check_launch("conv3x3_c32_halo");
     }
     if (cfg == CFG_HALO_T) {
-        if constexpr (sizeof(T) == 2) hipLaunchKernelGGL(deconv4_c128_c32_halo_kernel<T>, dim3(k.N * (k.Hi / 8) * (k.Wi / 16)), dim3(256), 0, st, k);
+        if constexpr (sizeof(T) == 2) {
+            const int patches = k.N * (k.Hi / 8) * (k.Wi / 16);
+            static const int persist = [] { const char* e = getenv("MSC_DECONV_BLOCKS"); return e ? atoi(e) : 1024; }();     // measured: 0 (one block per patch) 151 us, 512 117 us, 1024 113 us
+            hipLaunchKernelGGL(deconv4_c128_c32_halo_kernel<T>, dim3(persist > 0 && patches > persist ? persist : patches), dim3(256), 0, st, k);
+        }
         return msc_check_launch("deconv4_c128_c32_halo");
     }
     switch (cfg) {
