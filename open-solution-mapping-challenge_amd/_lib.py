@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get('MSC_HIP_LIB', os.path.join(_HERE, 'lib', 'libmsc_hip.
 F32, BF16, F16 = 0, 1, 2
 BN_SLOTS = 8                      # MSC_BN_SLOTS: per-XCD accumulation slots of the BatchNorm sums
 CFG_HALO, CFG_HALO_T = 27, 28     # msc_conv_igemm configurations that are halo-tile kernels, not tiles of the DMA kernel
+CFG_STREAM = 57                   # ... the persistent streaming kernel for 1x1 / stride 1 layers
 
 
 class MscError(RuntimeError):

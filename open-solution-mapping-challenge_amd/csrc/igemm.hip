@@ -39,191 +39,11 @@
 #include "common.h"
 #include "dma.h"
 #include "msc_internal.h"
+#include "conv_common.h"
 
 namespace {
 
-struct ConvK {
-    const char* in; const char* wt; char* out; const char* res;
-    const float* scale; const float* shift; double* stats;
-    const char* sy; long sy_ld; int stats_kind;     // stats_kind 1: BatchNorm-backward sums against the tensor sy;
-                                                    // 2: ReLU backward (mask [sy > 0] applied to the output) + bias-gradient sums
-    long in_ld, out_ld, res_ld;
-    int N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, flip, relu;
-    int M, Hq, Wq;
-    int span_bytes;                  // > 0: a K row of Cin*ES bytes spans several consecutive input pixels of span_bytes each (the KW taps of
-                                     // a compact narrow tensor merged into one tap, conv_fill); the lanes of the later pixels are bounds-checked on their own
-    unsigned in_bytes, wt_bytes;     // extents for the buffer descriptors of the DMA kernel
-    int ntc;                         // channel tiles (DMA kernel: 1-D grid of ntm*ntc blocks, XCD-aware order)
-    const float* fin_w; const float* fin_b; float* fin_logits; float* fin_probs; int fin_skip;      // fused final 1x1 + softmax (conv3x3_c32_halo_kernel)
-    int ksplit; float* kws;          // split-K: slices of the reduction, fp32 partial sums (conv_igemm_dma_kernel, mode 0)
-    int mode;                        // 0 gather, 1 transposed
-    int xcd_order;                   // 1: XCD-aware tile order, 0: pixel tile fastest (for A/B measurements)
-    float rcp_hw, rcp_w;             // 1/(Hq*Wq), 1/Wq for the pixel decode of the DMA kernel; 0 = pixel count >= 2^24: integer division
-};
-
-// floor(m / d) through the float reciprocal, exact for m < 2^24 (one correction step either way)
-__device__ __forceinline__ unsigned udiv_rcp(unsigned m, unsigned d, float rcp) {
-    unsigned q = (unsigned)((float)m * rcp);
-    int r = (int)(m - q * d);
-    if (r < 0) { --q; r += (int)d; }
-    if (r >= (int)d) ++q;
-    return q;
-}
-
-// shared epilogue: lane holds NV consecutive channels cb.. of pixel rows (b*16+pl), b < FN
-// PATCH (halo-tile kernels): fragment b of pixel wave wp is row wp*FN + b of a 16-pixel-wide image patch whose first pixel
-// is m0, i.e. pixel m0 + (wp*FN + b)*Wo + pl -- otherwise the tile is M-linear
-template <typename T, int FM, int FN, int WTP, int WP, int MODE, int WC = 1, bool PATCH = false>
-__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][FN], int m0, int wp, int cb, int pl, int py, int px,
-                                              int mtile, int ntm, float* red = nullptr, int wc = 0, int c0 = 0) {
-    constexpr int NV = FM * 4;
-    constexpr int CE = 16 / (int)sizeof(T);
-    // stats_kind 1 (a data-gradient conv that also produces the BatchNorm-backward sums of the layer whose output
-    // gradient it writes): scale/shift are that layer's forward coefficients, used for the ReLU mask only
-    // stats_kind 2 (a data-gradient conv whose output is the gradient w.r.t. a bias+ReLU layer's activation sy): the stored
-    // value is dh = acc * [sy > 0] and the sums are (sum dh, -) = that layer's bias gradient -- the separate
-    // ReLU-backward / bias-gradient pass over the tensor (msc_relu_bias_grad) is not launched
-    const bool bnb = p.stats && p.stats_kind == 1;
-    const bool rlb = p.stats && p.stats_kind == 2;
-    float sc[NV], sh[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        sc[j] = p.scale ? p.scale[cb + j] : 1.f;
-        sh[j] = p.shift ? p.shift[cb + j] : 0.f;
-    }
-    float s1[NV], s2[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    T* out = reinterpret_cast<T*>(p.out);
-    const T* res = reinterpret_cast<const T*>(p.res);
-    // the tensor the epilogue reads (residual / BatchNorm-backward y) is fetched for all fragments before the first use --
-    // nothing else is left to hide its latency behind -- where the wave tile is small enough to afford the registers
-    constexpr bool PRE = FN * (NV / CE) <= 8;
-    const T* side = (bnb || rlb) ? reinterpret_cast<const T*>(p.sy) : res;
-    const long side_ld = (bnb || rlb) ? p.sy_ld : p.res_ld;
-    uint4 pre[PRE ? FN : 1][PRE ? NV / CE : 1];
-    if (PRE && side) {
-#pragma unroll
-        for (int b = 0; b < FN; ++b) {
-            const int m = PATCH ? m0 + (wp * FN + b) * p.Wo + pl : m0 + wp * WTP + b * 16 + pl;
-            if (m < p.M) {
-                long opix = m;
-                if (MODE) {
-                    const int n = m / (p.Hq * p.Wq);
-                    const int rem = m - n * (p.Hq * p.Wq);
-                    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
-                    opix = ((long)n * p.Ho + 2 * qy + py) * p.Wo + 2 * qx + px;
-                }
-#pragma unroll
-                for (int j = 0; j < NV; j += CE) pre[PRE ? b : 0][PRE ? j / CE : 0] = *reinterpret_cast<const uint4*>(side + opix * side_ld + cb + j);
-            }
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < FN; ++b) {
-        const int m = PATCH ? m0 + (wp * FN + b) * p.Wo + pl : m0 + wp * WTP + b * 16 + pl;
-        float v[NV];
-#pragma unroll
-        for (int a = 0; a < FM; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][b][r];
-        if (p.stats && !bnb && !rlb) {
-#pragma unroll
-            for (int j = 0; j < NV; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
-        }
-        if (rlb && m < p.M) {          // dh = acc * [sy > 0], stored below; sum dh
-#pragma unroll
-            for (int j = 0; j < NV; j += CE) {
-                float yv[CE];
-                if (PRE) Vec16<T>::unpack(pre[PRE ? b : 0][PRE ? j / CE : 0], yv);
-                else Vec16<T>::load(side + (long)m * side_ld + cb + j, yv);
-#pragma unroll
-                for (int e = 0; e < CE; ++e) {
-                    v[j + e] = yv[e] > 0.f ? v[j + e] : 0.f;
-                    s1[j + e] += v[j + e];
-                }
-            }
-        }
-        if (bnb && m < p.M) {          // (sum dh, sum dh*y), dh = dout * [scale*y + shift > 0] (no mask without scale)
-#pragma unroll
-            for (int j = 0; j < NV; j += CE) {
-                float yv[CE];
-                if (PRE) Vec16<T>::unpack(pre[PRE ? b : 0][PRE ? j / CE : 0], yv);
-                else Vec16<T>::load(side + (long)m * side_ld + cb + j, yv);
-#pragma unroll
-                for (int e = 0; e < CE; ++e) {
-                    const float dh = (!p.scale || fmaf(yv[e], sc[j + e], sh[j + e]) > 0.f) ? v[j + e] : 0.f;
-                    s1[j + e] += dh;
-                    s2[j + e] += dh * yv[e];
-                }
-            }
-        }
-        if (m < p.M) {
-            long opix = m;
-            if (MODE) {
-                const int n = m / (p.Hq * p.Wq);
-                const int rem = m - n * (p.Hq * p.Wq);
-                const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
-                opix = ((long)n * p.Ho + 2 * qy + py) * p.Wo + 2 * qx + px;
-            }
-            if (!bnb && !rlb) {
-#pragma unroll
-                for (int j = 0; j < NV; ++j) v[j] = v[j] * sc[j] + sh[j];
-            }
-            if (res) {
-#pragma unroll
-                for (int j = 0; j < NV; j += CE) {
-                    float rv[CE];
-                    if (PRE) Vec16<T>::unpack(pre[PRE ? b : 0][PRE ? j / CE : 0], rv);
-                    else Vec16<T>::load(res + opix * p.res_ld + cb + j, rv);
-#pragma unroll
-                    for (int e = 0; e < CE; ++e) v[j + e] += rv[e];
-                }
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int j = 0; j < NV; ++j) v[j] = fmaxf(v[j], 0.f);
-            }
-#pragma unroll
-            for (int j = 0; j < NV; j += CE) Vec16<T>::store(out + opix * p.out_ld + cb + j, v + j);
-        }
-    }
-    if (p.stats) {
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                s1[j] += __shfl_xor(s1[j], o, 64);
-                s2[j] += __shfl_xor(s2[j], o, 64);
-            }
-        }
-        // One slot per XCD, layout [MSC_BN_SLOTS][Cout][2] (common.h); the consumer (msc_bn_apply / msc_bn_bwd_apply) sums the
-        // slots in its prologue.  The block's waves fold their sums through LDS and ONE coalesced atomic instruction per
-        // 64 consecutive floats goes out: an atomic costs the L2 per touched line, not per lane (4 scattered lanes per
-        // instruction cost 5 ms per train step), and ops on one line serialise, so the fewer per block the better.
-        constexpr int WTC = FM * 16, TC = WTC * WC;
-        raw_barrier();                               // every wave is done reading the operand ring
-        if (pl == 0) {
-            float* mine = red + ((wp * WC + wc) * WTC + (lane_id() >> 4) * NV) * 2;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) *reinterpret_cast<float2*>(mine + 2 * j) = make_float2(s1[j], s2[j]);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        raw_barrier();
-        // double accumulation: the fp32 partial of a block is exact enough, a running fp32 total over all blocks is not -- the
-        // consumer forms sum(dh*y) - mean*sum(dh) and E[y^2] - mean^2, which cancel by orders of magnitude
-        double* slot = p.stats + ((long)msc_xcc_id() * p.Cout + c0) * 2;
-        for (int f = threadIdx.x; f < TC * 2; f += WP * WC * 64) {
-            const int ch = f >> 1, k = f & 1;
-            if (rlb && k) continue;                  // only the first sum exists
-            const int wcs = ch / WTC, chw = ch - wcs * WTC;
-            float a = 0.f;
-#pragma unroll
-            for (int w = 0; w < WP; ++w) a += red[((w * WC + wcs) * WTC + chw) * 2 + k];
-            atomicAdd(slot + f, (double)a);
-        }
-    }
-}
+using namespace msc_conv;
 
 // ------------------------------------------------------------------------------------------------ implicit GEMM (DMA)
 // K step = KB bytes per row: 128 B (one full cache line per row) whenever Cin*sizeof(T) is a multiple of 128,
@@ -1531,7 +1351,7 @@ bool xcd_order_enabled() { static int v = -1; if (v < 0) { const char* e = geten
 // heuristic (cfg 0) the caller may pick one explicitly -- UNetResNet times the valid ones per layer when it builds
 // a program (msc_conv_cfg_ok enumerates them).
 struct ConvCfg { int tp, tc, wp, wc, kb, nst; };
-constexpr int N_CONV_CFG = 56;
+constexpr int N_CONV_CFG = 57;
 static inline bool cfg_is_halo3(int cfg) { return (cfg >= 42 && cfg <= 46) || (cfg >= 51 && cfg <= 56); }      // conv3x3_halo_dma_kernel
 constexpr int CFG_HALO = 27;          // conv3x3_c32_halo_kernel (not a tile of the DMA kernel)
 constexpr int CFG_HALO_T = 28;        // deconv4_c128_c32_halo_kernel
@@ -1609,6 +1429,7 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {128, 128, 2, 4, 128, 2},   // 54:  8x16 patch x 128 ch, 8 waves, 3 taps per k-step, 144 KB
     {128, 128, 2, 4, 128, 2},   // 55:  8x16 patch x 128 ch, 8 waves, 80 KB, 2 blocks/CU
     {256, 128, 4, 2, 128, 2},   // 56: 16x16 patch x 128 ch, 8 waves, 128 KB
+    {64, 256, 1, 8, 128, 2},    // 57: persistent streaming kernel for 1x1 / stride 1 layers of 64..512 input channels (tile shape per layer: STREAM_VARS)
 };
 
 template <typename T, int TP, int TC, int WP, int WC, int KB, int NST, int ABL = 0>
@@ -1644,7 +1465,8 @@ int launch_halo3(const ConvK& k0, hipStream_t st) {
 bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
     if (cfg < 1 || cfg > N_CONV_CFG) return false;
     if (k.fin_w && cfg != CFG_HALO) return false;           // the fused final 1x1 lives in the 32-channel halo kernel's epilogue only
-    if (k.ksplit > 1 && (cfg == CFG_HALO || cfg == CFG_HALO_T || cfg_is_halo3(cfg))) return false;      // split-K: the implicit-GEMM kernel only
+    if (k.ksplit > 1 && (cfg == CFG_HALO || cfg == CFG_HALO_T || cfg == CFG_STREAM || cfg_is_halo3(cfg))) return false;      // split-K: the implicit-GEMM kernel only
+    if (cfg == CFG_STREAM) return conv1x1_cfg_ok(k, es);
     if (cfg == CFG_HALO)
         return es == 2 && k.mode == 0 && k.KH == 3 && k.KW == 3 && k.stride == 1 && k.pad == 1 && k.Cin == 32 && k.Cout == 32 &&
                k.Ho % 16 == 0 && k.Wo % 16 == 0 && k.Hi == k.Ho && k.Wi == k.Wo && (!k.stats || k.stats_kind == 2) && k.res_ld % 8 == 0 && k.out_ld % 8 == 0;
@@ -1692,6 +1514,7 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
         }
         return msc_check_launch("deconv4_c128_c32_halo");
     }
+    if (cfg == CFG_STREAM) return conv1x1_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     switch (cfg) {
         case 1: return launch_dma<T, 256, 128, 4, 2, 128, 3>(k, mode, st);
         case 2: return launch_dma<T, 256, 128, 4, 2, 64, 4>(k, mode, st);

@@ -834,3 +834,88 @@ def test_split_k_convolution(dtype, cin, cout, hw, n, split):
     # statistics / transposed mode are refused with split-K
     d.mode = 1
     assert lib.msc_conv_igemm(C.byref(d), stream) != 0
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('cin,cout', [(64, 256), (64, 64), (128, 512), (128, 128), (256, 128), (256, 64), (512, 128), (256, 1024)])
+def test_streaming_1x1_kernel(dtype, cin, cout):
+    """conv1x1_stream_kernel (configuration 57): persistent blocks with the weights as register fragments and the pixel tiles streamed
+    through two LDS buffers -- more tiles than blocks (the carried loop), channel slices of wider buffers on both sides, folded-BN
+    coefficients + residual + ReLU, the three statistics epilogues (sums carried across the tiles of a block), against torch"""
+    import ctypes as C
+    from mapping_challenge_amd import _lib
+    lib = _lib.load()
+    n, hw = 5, 128                                    # 81 920 pixels: 2.5 tiles of 64 per block at 512 blocks
+    if cin * cout >= 256 * 512:
+        n = 3
+    x = rnd((n, cin, hw, hw), dtype, 1)
+    w = rnd((cout, cin, 1, 1), dtype, 2, (2.0 / cin) ** 0.5)
+    res = rnd((n, cout, hw, hw), dtype, 3)
+    y = rnd((n, cout, hw, hw), dtype, 4)
+    scale, shift = torch.rand(cout, generator=torch.Generator().manual_seed(5)) + 0.5, rnd((cout,), torch.float32, 6) * 0.3
+    raw = F.conv2d(x, w)
+    wide_in = torch.zeros((n, hw, hw, cin + 64), dtype=dtype, device='cuda')
+    wide_in[..., 32:32 + cin] = nhwc(x, dtype)
+    xd = wide_in[..., 32:32 + cin]
+    wide_out = torch.zeros((n, hw, hw, cout + 32), dtype=dtype, device='cuda')
+    od = wide_out[..., 16:16 + cout]
+    wk = w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    rd, yd = nhwc(res, dtype), nhwc(y, dtype)
+    sc, sh = scale.cuda(), shift.cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    dt = {torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}[dtype]
+
+    def desc(cfg):
+        d = _lib.ConvDesc()
+        d.in_, d.wt, d.out = xd.data_ptr(), wk.data_ptr(), od.data_ptr()
+        d.in_ld, d.out_ld, d.dtype, d.mode = cin + 64, cout + 32, dt, 0
+        d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.cfg = n, hw, hw, cin, hw, hw, cout, 1, 1, 1, 0, cfg
+        return d
+
+    tried = 0
+    t2 = dict(rtol=2e-3, atol=5e-1) if dtype == torch.float16 else dict(rtol=2e-2, atol=2.0)
+    for cfg in (_lib.CFG_STREAM,):
+        if not lib.msc_conv_cfg_ok(C.byref(desc(cfg)), cfg):
+            continue
+        tried += 1
+        # (a) raw output + forward statistics
+        d = desc(cfg)
+        stats = torch.zeros((_lib.BN_SLOTS, cout, 2), dtype=torch.float64, device='cuda')
+        d.stats = stats.data_ptr()
+        wide_out.fill_(3.0)
+        _lib.check(lib.msc_conv_igemm(C.byref(d), stream), 'conv')
+        assert torch.allclose(to_nchw(od), raw, **tol(dtype)), cfg
+        assert (wide_out[..., :16] == 3).all() and (wide_out[..., 16 + cout:] == 3).all()
+        s = stats.sum(0).float().cpu()
+        assert torch.allclose(s[:, 0], raw.sum((0, 2, 3)), **t2) and torch.allclose(s[:, 1], (raw * raw).sum((0, 2, 3)), rtol=2e-2, atol=2.0), cfg
+        # (b) folded BatchNorm + residual + ReLU
+        d = desc(cfg)
+        d.scale, d.shift, d.res, d.res_ld, d.relu = sc.data_ptr(), sh.data_ptr(), rd.data_ptr(), cout, 1
+        _lib.check(lib.msc_conv_igemm(C.byref(d), stream), 'conv')
+        ref = torch.relu(raw * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+        assert torch.allclose(to_nchw(od), ref, **tol(dtype)), cfg
+        # (c) BatchNorm-backward sums against y under the ReLU mask of (scale, shift)
+        d = desc(cfg)
+        stats.zero_()
+        d.stats, d.stats_kind, d.stats_y, d.stats_y_ld, d.scale, d.shift = stats.data_ptr(), 1, yd.data_ptr(), cout, sc.data_ptr(), sh.data_ptr()
+        _lib.check(lib.msc_conv_igemm(C.byref(d), stream), 'conv')
+        m = ((y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) > 0).float()
+        s = stats.sum(0).float().cpu()
+        assert torch.allclose(to_nchw(od), raw, **tol(dtype)), cfg
+        assert torch.allclose(s[:, 0], (raw * m).sum((0, 2, 3)), **t2) and torch.allclose(s[:, 1], (raw * m * y).sum((0, 2, 3)), **t2), cfg
+        # (d) ReLU backward + bias-gradient sums
+        d = desc(cfg)
+        stats.zero_()
+        d.stats, d.stats_kind, d.stats_y, d.stats_y_ld = stats.data_ptr(), 2, yd.data_ptr(), cout
+        _lib.check(lib.msc_conv_igemm(C.byref(d), stream), 'conv')
+        assert torch.allclose(to_nchw(od), raw * (y > 0), **tol(dtype)), cfg
+        assert torch.allclose(stats.sum(0)[:, 0].float().cpu(), (raw * (y > 0)).sum((0, 2, 3)), **t2), cfg
+    assert tried >= 1
+    # not for other filter sizes / strides / ragged pixel counts
+    d = desc(_lib.CFG_STREAM)
+    d.stride, d.Ho, d.Wo = 2, hw // 2, hw // 2
+    assert not lib.msc_conv_cfg_ok(C.byref(d), _lib.CFG_STREAM)
+    d = desc(_lib.CFG_STREAM)
+    d.Hi = d.Ho = 3
+    d.Wi = d.Wo = 5
+    assert not lib.msc_conv_cfg_ok(C.byref(d), _lib.CFG_STREAM)
