@@ -251,4 +251,8 @@ constexpr int CFG_STREAM = 57;        // conv1x1_stream_kernel (pixel tiles thro
 bool conv1x1_cfg_ok(const ConvK& k, int es);
 int conv1x1_launch(const ConvK& k, int dtype, hipStream_t st);
 
+// halo32.hip: the halo-tile kernels of the 32-channel full-resolution layers (configurations 27 / 28)
+int halo32_conv_launch(const ConvK& k, int dtype, hipStream_t st);
+int halo32_deconv_launch(const ConvK& k, int dtype, hipStream_t st);
+
 }  // namespace msc_conv

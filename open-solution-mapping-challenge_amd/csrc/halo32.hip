@@ -1,0 +1,395 @@
+// Halo-tile kernels of the two 32-channel full-resolution layers of the decoder (gfx950): dec0's 3x3 convolution 32 -> 32 (+ its data
+// gradient, + the fused final 1x1 and softmax in inference) and dec1's ConvTranspose2d(k4, s2, p1) 128 -> 32
+// (src/unet_models.py:136-141, 400-403).  Configurations 27 / 28 of msc_conv_igemm (igemm.hip validates and dispatches here).
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "conv_common.h"
+#include "msc_internal.h"
+
+namespace msc_conv {
+namespace {
+
+// ------------------------------------------------------------------------------------------------ halo tile
+// 3x3 / stride 1 / pad 1 convolutions of the 32-channel full-resolution layers (dec0 and its data gradient): as an
+// implicit GEMM every filter tap re-reads the pixel's 64-byte channel row from L2, and 64-byte row segments are the
+// slow LDS-DMA case -- the DMA kernel sits at ~12 TB/s of fill with the MFMA pipes idle.  Here a block owns a 16x16
+// pixel patch: the 18x18 halo of input rows goes to LDS once (20 KB), the nine taps read shifted windows of it, the
+// 18 KB of weights stay in registers (every block reads the same ones from L2).  bf16, Cin = Cout = 32.
+// Persistent over the patches (round 3): the weight fragments, the coefficients and the per-thread halo addressing are set up once per
+// block, the filter orientation is a template parameter (the 36 shifted-window reads are immediates) and the epilogue has one
+// straight-line body per use (statistics / fused final 1x1 / plain) behind uniform branches.  Before that the kernel issued 1142 VALU
+// instructions per wave and patch for 72 MFMAs -- 4x the matrix time in address arithmetic and predicated options.
+template <typename T, bool FLIP>
+__global__ __launch_bounds__(256, 2) void conv3x3_c32_halo_kernel(ConvK p, int npatch) {      // 2 blocks per CU: 256 VGPRs
+    constexpr int HCH = (18 * 18 * 4 + 255) / 256;   // halo chunks per thread (the last one of most threads is past the end)
+    constexpr int HBUF = HCH * 256;                  // chunks per halo buffer, padded to whole DMA instructions
+    __shared__ uint4 halo2[2 * HBUF];                // two halo buffers of [18][18] pixels x 4 chunks of 8 channels
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, pl = lane & 15;
+    const int tiles_x = p.Wo / 16, tiles_y = p.Ho / 16;
+    const u32x4_t rx = make_srd(p.in, p.in_bytes);
+    // weights [Cout][3][3][Cin]: lane (g, pl) of fragment a holds input channels 8g..8g+7 of ONE output channel; row pl of
+    // fragment a is output channel 8*(pl>>2) + 4a + (pl&3), so that the D rows a lane ends up with (4g..4g+3 of both
+    // fragments) are the 8 consecutive channels 8g..8g+7 -> one 16-byte store per pixel
+    const T* wt = reinterpret_cast<const T*>(p.wt);
+    uint4 wf[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+            wf[t][a] = *reinterpret_cast<const uint4*>(wt + ((long)(8 * (pl >> 2) + 4 * a + (pl & 3)) * 9 + t) * 32 + g * 8);
+    // the thread's halo chunks: position in the halo and byte offset from the patch's first pixel
+    int hyx[HCH], hrel[HCH];                         // (hy << 16 | hx + 1); the tensor is below 2 GiB (conv_fill)
+#pragma unroll
+    for (int i = 0; i < HCH; ++i) {
+        const int c = tid + 256 * i, pix = c >> 2;
+        const int hy = pix / 18 - 1, hx = pix - (pix / 18) * 18 - 1;
+        hrel[i] = ((hy * p.Wi + hx) * (int)p.in_ld + (c & 3) * 8) * 2;
+        hyx[i] = c >= 18 * 18 * 4 ? -(1 << 28) : hy * 65536 + hx + 1;       // past the end: never inside the image
+    }
+    T* out = reinterpret_cast<T*>(p.out);
+    const T* res = reinterpret_cast<const T*>(p.res);
+    const int c0 = 8 * g;
+    const bool rlb = p.stats && p.stats_kind == 2;
+    const bool has_sc = p.scale != nullptr, has_sh = p.shift != nullptr, fin = p.fin_w != nullptr;
+    // per-channel coefficients (scale, shift, the two rows of the final 1x1) live in LDS and are read per patch: in registers they
+    // would be 32 more live values next to the 72 of the weights
+    __shared__ float coef[4][32];
+    if (tid < 128) {
+        const int k = tid >> 5, ch = tid & 31;
+        float v = k == 0 ? 1.f : 0.f;
+        if (k == 0 && has_sc) v = p.scale[ch];
+        if (k == 1 && has_sh) v = p.shift[ch];
+        if (k >= 2 && fin) v = p.fin_w[(k - 2) * 32 + ch];
+        coef[k][ch] = v;
+    }
+    __syncthreads();
+    float bs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bs[j] = 0.f;
+    // eval: the final 1x1 convolution 32 -> 2 + softmax on the values this epilogue stores (rounded to T first, as msc_final_fwd
+    // would read them back): the lane's 8 channels against its 16 weights, then the four channel groups of a pixel (lanes pl,
+    // pl+16, pl+32, pl+48) are folded by two cross-lane adds
+    float fb0 = 0.f, fb1 = 0.f;
+    if (fin && p.fin_b) { fb0 = p.fin_b[0]; fb1 = p.fin_b[1]; }
+    const int lbase = ((wid * 4 + 1) * 18 + pl + 1) * 4 + g;      // halo chunk of (patch row 4*wid, pixel pl), this lane's input channels
+    const long hw = (long)p.Ho * p.Wo;
+
+    // The halo goes HBM -> LDS by DMA (out-of-image chunks as out-of-range offsets: zeros), the NEXT patch's into the other buffer as
+    // soon as this patch's has landed: the HBM latency of a patch hides behind the work of the one before it, and one barrier per patch
+    // covers both "my halo is complete" and "everyone is done with the buffer the next DMA overwrites".
+    auto request = [&](int patch, int buf) {
+        const int bx = patch % tiles_x, by = (patch / tiles_x) % tiles_y, n = patch / (tiles_x * tiles_y);
+        const int y0 = by * 16, x0 = bx * 16;
+        const int org = (((n * p.Hi + y0) * p.Wi + x0) * (int)p.in_ld) * 2;
+#pragma unroll
+        for (int i = 0; i < HCH; ++i) {
+            const int hy = hyx[i] >> 16, hx = (hyx[i] & 0xffff) - 1;
+            const bool ok = (unsigned)(y0 + hy) < (unsigned)p.Hi && (unsigned)(x0 + hx) < (unsigned)p.Wi;
+            dma16(rx, reinterpret_cast<char*>(halo2 + buf * HBUF + 256 * i + 64 * wid), ok ? (unsigned)(org + hrel[i]) : OOB_OFF, 0);
+        }
+    };
+    if ((int)blockIdx.x < npatch) request(blockIdx.x, 0);
+    int buf = 0;
+    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x, buf ^= 1) {
+        const int bx = patch % tiles_x, by = (patch / tiles_x) % tiles_y, n = patch / (tiles_x * tiles_y);
+        const int y0 = by * 16, x0 = bx * 16;
+        wait_vmcnt<0>();
+        raw_barrier();
+        if (patch + (int)gridDim.x < npatch) request(patch + gridDim.x, buf ^ 1);
+        const uint4* halo = halo2 + buf * HBUF;
+        // stats_kind 2: the activation rows the epilogue masks by are requested before the tap loop (nothing after it could hide them)
+        uint4 ypre[4];
+        if (rlb) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                ypre[b] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.sy) + ((long)(n * p.Ho + y0 + wid * 4 + b) * p.Wo + x0 + pl) * p.sy_ld + 8 * g);
+        }
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the fragments of tap t+1 are read while tap t is multiplied; the scheduling barrier keeps the compiler from hoisting all 36 reads
+        // (144 registers) to the top
+        uint4 bf[2][4];
+        auto rd = [&](auto tt) {
+            constexpr int t = decltype(tt)::value;
+            constexpr int kh = t / 3, kw = t - kh * 3;
+            constexpr int dy = FLIP ? 1 - kh : kh - 1, dx = FLIP ? 1 - kw : kw - 1;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bf[t & 1][b] = halo[lbase + ((b + dy) * 18 + dx) * 4];
+        };
+        auto tap = [&](auto tt) {
+            constexpr int t = decltype(tt)::value;
+            if constexpr (t < 8) rd(std::integral_constant<int, (t < 8 ? t + 1 : 8)>{});
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) Mma<T>::run(wf[t][a], bf[t & 1][b], acc[a][b]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        rd(std::integral_constant<int, 0>{});
+        tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
+        tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
+        tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+        // D: column = pixel x0+pl; rows 4g..4g+3 of fragments 0 and 1 = output channels 8g..8g+3 and 8g+4..8g+7
+        const long opix0 = (long)(n * p.Ho + y0 + wid * 4) * p.Wo + x0 + pl;
+        if (rlb) {                      // stats_kind 2: ReLU backward of the layer whose activation is sy, and its bias-gradient sums
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                float v[8], yv[8];
+                Vec16<T>::unpack(ypre[b], yv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[j] = yv[j] > 0.f ? acc[j >> 2][b][j & 3] : 0.f;
+                    bs[j] += v[j];
+                }
+                Vec16<T>::store(out + (opix0 + (long)b * p.Wo) * p.out_ld + c0, v);
+            }
+        } else {
+            float fa0 = 0.f, fa1 = 0.f;
+            int cofs = c0;
+            asm volatile("" : "+v"(cofs));                   // opaque per patch: the reads below stay in the loop
+            float sc[8], sh[8], fw0[8], fw1[8];
+            if (has_sc || has_sh) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { sc[j] = coef[0][cofs + j]; sh[j] = coef[1][cofs + j]; }
+            }
+            if (fin) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { fw0[j] = coef[2][cofs + j]; fw1[j] = coef[3][cofs + j]; }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const long opix = opix0 + (long)b * p.Wo;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = acc[j >> 2][b][j & 3];
+                if (has_sc) {
+                    asm volatile("" ::: "memory");          // keeps the options as branches (conv_common.h)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
+                } else if (has_sh) {
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = v[j] + sh[j];
+                }
+                if (res) {
+                    float rv[8];
+                    Vec16<T>::load(res + opix * p.res_ld + c0, rv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += rv[j];
+                }
+                if (p.relu) {
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                if (!p.fin_skip) Vec16<T>::store(out + opix * p.out_ld + c0, v);
+                if (fin) {
+                    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const T tv = ElemIO<T>::from(v[j]);
+                        const float r = ElemIO<T>::load(&tv);
+                        a0 = fmaf(r, fw0[j], a0);
+                        a1 = fmaf(r, fw1[j], a1);
+                    }
+                    a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64);
+                    a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64);
+                    // every lane group now holds the pixel's two logits: group b keeps row b, so the softmax below runs once for the four rows
+                    if (g == b) { fa0 = a0; fa1 = a1; }
+                }
+            }
+            if (fin) {
+                const float a0 = fa0 + fb0, a1 = fa1 + fb1;
+                const long o0 = (long)n * 2 * hw + (long)(y0 + wid * 4 + g) * p.Wo + x0 + pl;
+                if (p.fin_logits) { p.fin_logits[o0] = a0; p.fin_logits[o0 + hw] = a1; }
+                if (p.fin_probs) {      // numpy softmax of src/utils.py:231-273: subtract max, exp, divide by the sum
+                    const float m = fmaxf(a0, a1);
+                    const float e0 = expf(a0 - m), e1 = expf(a1 - m);
+                    const float sden = e0 + e1;
+                    p.fin_probs[o0] = e0 / sden; p.fin_probs[o0 + hw] = e1 / sden;
+                }
+            }
+        }
+    }
+    if (rlb) {
+        // fold the 16 pixel lanes of a channel group, then the four waves through LDS (the halo is no longer read), and add the
+        // block's 32 sums (of all its patches) to this XCD's slot ([MSC_BN_SLOTS][32][2] doubles, first of each pair) with one coalesced atomic
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) bs[j] += __shfl_xor(bs[j], o, 64);
+        }
+        float* red = reinterpret_cast<float*>(halo2);
+        __syncthreads();
+        if (pl == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[wid * 32 + c0 + j] = bs[j];
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const float a = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
+            atomicAdd(p.stats + ((long)msc_xcc_id() * 32 + tid) * 2, (double)a);
+        }
+    }
+}
+
+// ConvTranspose2d(k4, s2, p1) 128 -> 32 channels (dec1's up-sampling to full resolution): per output-parity phase the DMA
+// kernel re-reads four taps of 256-byte input rows for a 32-channel output tile.  Here a block owns 8x16 input pixels
+// (16x32 outputs): their 10x18 halo goes to LDS once (46 KB), each phase's four taps of weights (32 KB) follow, both with
+// the 16-byte chunks of a row XOR-swizzled by the row index so that 16 lanes reading 16 different rows hit 16 bank groups.
+template <typename T>
+__global__ __launch_bounds__(512) void deconv4_c128_c32_halo_kernel(ConvK p) {      // one block of 8 waves per CU (two halo buffers): up to 256 VGPRs
+    constexpr int HR = 10, HC = 18;                   // halo rows / columns
+    constexpr int NCH = HR * HC * 16;                 // 16-byte chunks of a halo: [pixel][16 chunks of 8 channels], chunk ^= pixel & 15
+    constexpr int HCH = (NCH + 511) / 512;            // ... per thread (DMA wave-instructions per wave)
+    constexpr int HBUF = HCH * 512;                   // chunks per buffer, padded to whole instructions
+    __shared__ uint4 halo2[2 * HBUF];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, pl = lane & 15;
+    const int tiles_x = p.Wi / 16, tiles_y = p.Hi / 8;
+    const int npatch = p.N * tiles_x * tiles_y;
+    const u32x4_t rx = make_srd(p.in, p.in_bytes);
+    const T* wt = reinterpret_cast<const T*>(p.wt);          // [Cout][4][4][Cin]
+    T* out = reinterpret_cast<T*>(p.out);
+    const T* res = reinterpret_cast<const T*>(p.res);
+    const int c0 = 8 * g;
+    const bool has_sc = p.scale != nullptr, has_sh = p.shift != nullptr;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
+    if (has_sc) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sc[j] = p.scale[c0 + j];
+    }
+    if (has_sh) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sh[j] = p.shift[c0 + j];
+    }
+    // Two waves = one output-parity phase (rows 0-3 and 4-7 of the 8 x 16 patch: two waves per SIMD, so that the epilogue and the
+    // fragment reads of one overlap the MFMAs of the other).  The 4 taps x 128 input channels x 32 output channels of
+    // its phase are 32 weight fragments = 128 VGPRs, fetched ONCE straight from L2 and held; only the pixel fragments come from
+    // LDS (one read per two MFMAs).  With the weights in LDS too (the first version: one phase at a time for all waves) every
+    // MFMA cost one fragment read and the LDS port, not the matrix pipe, set the pace.
+    // Round 3: the block is PERSISTENT -- it walks patches blockIdx.x, + gridDim.x, ... with the weights of its phases kept in
+    // registers (with one patch per block the 128 KB of weight fragments were re-fetched 4096 times per launch: 512 MB of L2 -> CU
+    // traffic, as much as input and output together) -- and the halo of the next patch arrives by DMA in the second buffer while this
+    // one is multiplied (before: a synchronous load between two barriers, with 25 VALU instructions of index arithmetic per chunk).
+    // row pl of weight fragment a is output channel 8*(pl>>2) + 4a + (pl&3): a lane ends with channels 8g..8g+7
+    const int ph = wid & 3, py = ph >> 1, px = ph & 1, b0 = (wid >> 2) * 4;
+    const int kh0 = (py + 1) & 1, kw0 = (px + 1) & 1;                 // taps kh0, kh0+2 / kw0, kw0+2
+    uint4 aw[4][4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int kh = kh0 + 2 * (t >> 1), kw = kw0 + 2 * (t & 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int co = 8 * (pl >> 2) + 4 * a + (pl & 3);
+                aw[t][kk][a] = *reinterpret_cast<const uint4*>(wt + ((long)(co * 4 + kh) * 4 + kw) * 128 + (kk * 4 + g) * 8);
+            }
+    }
+    // the thread's halo chunks: LDS slot c = 256 i + tid is chunk (c & 15) ^ (pix & 15) of halo pixel pix = c >> 4
+    int hyx[HCH], hrel[HCH];                         // (hy << 16 | hx + 1), byte offset from the patch's first pixel (the tensor is below 2 GiB)
+#pragma unroll
+    for (int i = 0; i < HCH; ++i) {
+        const int c = tid + 512 * i, pix = c >> 4;
+        const int hy = pix / HC - 1, hx = pix - (pix / HC) * HC - 1;
+        hrel[i] = ((hy * p.Wi + hx) * (int)p.in_ld + ((c & 15) ^ (pix & 15)) * 8) * 2;
+        hyx[i] = c >= NCH ? -(1 << 28) : hy * 65536 + hx + 1;          // past the end: never inside the image
+    }
+    auto request = [&](int patch, int buf) {
+        const int bx = patch % tiles_x, by = (patch / tiles_x) % tiles_y, n = patch / (tiles_x * tiles_y);
+        const int qy0 = by * 8, qx0 = bx * 16;
+        const int org = (((n * p.Hi + qy0) * p.Wi + qx0) * (int)p.in_ld) * 2;
+#pragma unroll
+        for (int i = 0; i < HCH; ++i) {
+            const int hy = hyx[i] >> 16, hx = (hyx[i] & 0xffff) - 1;
+            const bool ok = (unsigned)(qy0 + hy) < (unsigned)p.Hi && (unsigned)(qx0 + hx) < (unsigned)p.Wi;
+            dma16(rx, reinterpret_cast<char*>(halo2 + buf * HBUF + 512 * i + 64 * wid), ok ? (unsigned)(org + hrel[i]) : OOB_OFF, 0);
+        }
+    };
+    if ((int)blockIdx.x < npatch) request(blockIdx.x, 0);
+    int buf = 0;
+    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x, buf ^= 1) {
+        const int bx = patch % tiles_x, by = (patch / tiles_x) % tiles_y, n = patch / (tiles_x * tiles_y);
+        const int qy0 = by * 8, qx0 = bx * 16;
+        wait_vmcnt<0>();                                              // this patch's halo has landed ...
+        raw_barrier();                                                // ... for every wave, and everyone is done with the other buffer
+        if (patch + (int)gridDim.x < npatch) request(patch + gridDim.x, buf ^ 1);
+        const uint4* halo = halo2 + buf * HBUF;
+#pragma unroll 1
+        for (int b = b0; b < b0 + 4; ++b) {
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int kh = kh0 + 2 * (t >> 1), kw = kw0 + 2 * (t & 1);
+                const int dy = (py + 1 - kh) / 2, dx = (px + 1 - kw) / 2;  // input offset of this tap: -1, 0 or +1
+                const int pix = (b + 1 + dy) * HC + (pl + 1 + dx);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const uint4 bf = halo[pix * 16 + ((kk * 4 + g) ^ (pix & 15))];
+                    Mma<T>::run(aw[t][kk][0], bf, acc[0]);
+                    Mma<T>::run(aw[t][kk][1], bf, acc[1]);
+                }
+            }
+            const int oy = 2 * (qy0 + b) + py, ox = 2 * (qx0 + pl) + px;
+            const long opix = (long)(n * p.Ho + oy) * p.Wo + ox;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = acc[j >> 2][j & 3];
+            if (has_sc) {
+                asm volatile("" ::: "memory");                        // the options stay branches (conv_common.h)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
+            } else if (has_sh) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += sh[j];
+            }
+            if (res) {
+                float rv[8];
+                Vec16<T>::load(res + opix * p.res_ld + c0, rv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += rv[j];
+            }
+            if (p.relu) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            Vec16<T>::store(out + opix * p.out_ld + c0, v);
+        }
+    }
+}
+
+template <typename T>
+int conv_launch(const ConvK& k, hipStream_t st) {
+    const int patches = k.N * (k.Ho / 16) * (k.Wo / 16);
+    static const int persist = [] { const char* e = getenv("MSC_C32_BLOCKS"); return e ? atoi(e) : 512; }();       // 0: one block per patch (measured 100 us; 512: 68, 1024: 71, 2048: 78)
+    const dim3 grid(persist > 0 && patches > persist ? persist : patches);
+    if (k.flip) hipLaunchKernelGGL((conv3x3_c32_halo_kernel<T, true>), grid, dim3(256), 0, st, k, patches);
+    else hipLaunchKernelGGL((conv3x3_c32_halo_kernel<T, false>), grid, dim3(256), 0, st, k, patches);
+    return msc_check_launch("conv3x3_c32_halo");
+}
+
+template <typename T>
+int deconv_launch(const ConvK& k, hipStream_t st) {
+    const int patches = k.N * (k.Hi / 8) * (k.Wi / 16);
+    static const int persist = [] { const char* e = getenv("MSC_DECONV_BLOCKS"); return e ? atoi(e) : 256; }();      // one resident block per CU (98 KB of LDS)
+    hipLaunchKernelGGL(deconv4_c128_c32_halo_kernel<T>, dim3(persist > 0 && patches > persist ? persist : patches), dim3(512), 0, st, k);
+    return msc_check_launch("deconv4_c128_c32_halo");
+}
+
+}  // namespace
+
+int halo32_conv_launch(const ConvK& k, int dtype, hipStream_t st) { return dtype == MSC_F16 ? conv_launch<f16_t>(k, st) : conv_launch<bf16_t>(k, st); }
+int halo32_deconv_launch(const ConvK& k, int dtype, hipStream_t st) { return dtype == MSC_F16 ? deconv_launch<f16_t>(k, st) : deconv_launch<bf16_t>(k, st); }
+
+}  // namespace msc_conv

@@ -562,248 +562,6 @@ __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo
                                                         reinterpret_cast<float*>(smem), wc, c0);
 }
 
-// ------------------------------------------------------------------------------------------------ halo tile
-// 3x3 / stride 1 / pad 1 convolutions of the 32-channel full-resolution layers (dec0 and its data gradient): as an
-// implicit GEMM every filter tap re-reads the pixel's 64-byte channel row from L2, and 64-byte row segments are the
-// slow LDS-DMA case -- the DMA kernel sits at ~12 TB/s of fill with the MFMA pipes idle.  Here a block owns a 16x16
-// pixel patch: the 18x18 halo of input rows goes to LDS once (20 KB), the nine taps read shifted windows of it, the
-// 18 KB of weights stay in registers (every block reads the same ones from L2).  bf16, Cin = Cout = 32.
-template <typename T>
-__global__ __launch_bounds__(256) void conv3x3_c32_halo_kernel(ConvK p) {
-    __shared__ uint4 halo[18 * 18 * 4];              // [18][18] pixels x 4 chunks of 8 channels
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int g = lane >> 4, pl = lane & 15;
-    const int tiles_x = p.Wo / 16, tiles_y = p.Ho / 16;
-    const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, n = blockIdx.x / (tiles_x * tiles_y);
-    const int y0 = by * 16, x0 = bx * 16;
-    const T* in = reinterpret_cast<const T*>(p.in);
-    for (int c = tid; c < 18 * 18 * 4; c += 256) {
-        const int pix = c >> 2, ch = c & 3;
-        const int hy = pix / 18, hx = pix - hy * 18;
-        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-            v = *reinterpret_cast<const uint4*>(in + ((long)(n * p.Hi + iy) * p.Wi + ix) * p.in_ld + ch * 8);
-        halo[c] = v;
-    }
-    // weights [Cout][3][3][Cin]: lane (g, pl) of fragment a holds input channels 8g..8g+7 of ONE output channel; row pl of
-    // fragment a is output channel 8*(pl>>2) + 4a + (pl&3), so that the D rows a lane ends up with (4g..4g+3 of both
-    // fragments) are the 8 consecutive channels 8g..8g+7 -> one 16-byte store per pixel
-    const T* wt = reinterpret_cast<const T*>(p.wt);
-    uint4 wf[9][2];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-            wf[t][a] = *reinterpret_cast<const uint4*>(wt + ((long)(8 * (pl >> 2) + 4 * a + (pl & 3)) * 9 + t) * 32 + g * 8);
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // stats_kind 2: the activation rows the epilogue masks by are requested before the tap loop (nothing after it could hide them)
-    const bool rlb0 = p.stats && p.stats_kind == 2;
-    uint4 ypre[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        ypre[b] = make_uint4(0u, 0u, 0u, 0u);
-        if (rlb0) ypre[b] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.sy) + ((long)(n * p.Ho + y0 + wid * 4 + b) * p.Wo + x0 + pl) * p.sy_ld + 8 * g);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int kh = t / 3, kw = t - kh * 3;
-        const int dy = p.flip ? 1 - kh : kh - 1, dx = p.flip ? 1 - kw : kw - 1;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const uint4 bf = halo[((wid * 4 + b + 1 + dy) * 18 + (pl + 1 + dx)) * 4 + g];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) Mma<T>::run(wf[t][a], bf, acc[a][b]);
-        }
-    }
-    // D: column = pixel x0+pl; rows 4g..4g+3 of fragments 0 and 1 = output channels 8g..8g+3 and 8g+4..8g+7
-    T* out = reinterpret_cast<T*>(p.out);
-    const T* res = reinterpret_cast<const T*>(p.res);
-    const int c0 = 8 * g;
-    const bool rlb = p.stats && p.stats_kind == 2;
-    float sc[8], sh[8], bs[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { sc[j] = p.scale ? p.scale[c0 + j] : 1.f; sh[j] = p.shift ? p.shift[c0 + j] : 0.f; bs[j] = 0.f; }
-    // eval: the final 1x1 convolution 32 -> 2 + softmax on the values this epilogue stores (rounded to T first, as msc_final_fwd
-    // would read them back): the lane's 8 channels against its 16 weights, then the four channel groups of a pixel (lanes pl,
-    // pl+16, pl+32, pl+48) are folded by two cross-lane adds
-    float fw0[8], fw1[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { fw0[j] = p.fin_w ? p.fin_w[c0 + j] : 0.f; fw1[j] = p.fin_w ? p.fin_w[32 + c0 + j] : 0.f; }
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const long opix = (long)(n * p.Ho + y0 + wid * 4 + b) * p.Wo + x0 + pl;
-        float v[8];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][b][r] * sc[a * 4 + r] + sh[a * 4 + r];
-        if (res) {
-            float rv[8];
-            Vec16<T>::load(res + opix * p.res_ld + c0, rv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += rv[j];
-        }
-        if (p.relu) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-        }
-        if (rlb) {                  // stats_kind 2: ReLU backward of the layer whose activation is sy, and its bias-gradient sums
-            float yv[8];
-            Vec16<T>::unpack(ypre[b], yv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                v[j] = yv[j] > 0.f ? v[j] : 0.f;
-                bs[j] += v[j];
-            }
-        }
-        if (!p.fin_skip) Vec16<T>::store(out + opix * p.out_ld + c0, v);
-        if (p.fin_w) {
-            float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const T tv = ElemIO<T>::from(v[j]);
-                const float r = ElemIO<T>::load(&tv);
-                a0 = fmaf(r, fw0[j], a0);
-                a1 = fmaf(r, fw1[j], a1);
-            }
-            a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64);
-            a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64);
-            if (g == 0) {
-                a0 += p.fin_b ? p.fin_b[0] : 0.f;
-                a1 += p.fin_b ? p.fin_b[1] : 0.f;
-                const long hw = (long)p.Ho * p.Wo;
-                const long o0 = (long)n * 2 * hw + (long)(y0 + wid * 4 + b) * p.Wo + x0 + pl;
-                if (p.fin_logits) { p.fin_logits[o0] = a0; p.fin_logits[o0 + hw] = a1; }
-                if (p.fin_probs) {      // numpy softmax of src/utils.py:231-273: subtract max, exp, divide by the sum
-                    const float m = fmaxf(a0, a1);
-                    const float e0 = expf(a0 - m), e1 = expf(a1 - m);
-                    const float sden = e0 + e1;
-                    p.fin_probs[o0] = e0 / sden; p.fin_probs[o0 + hw] = e1 / sden;
-                }
-            }
-        }
-    }
-    if (rlb) {
-        // fold the 16 pixel lanes of a channel group, then the four waves through LDS (the halo is no longer read), and add the
-        // block's 32 sums to this XCD's slot ([MSC_BN_SLOTS][32][2] doubles, first of each pair) with one coalesced atomic
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) bs[j] += __shfl_xor(bs[j], o, 64);
-        }
-        float* red = reinterpret_cast<float*>(halo);
-        __syncthreads();
-        if (pl == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) red[wid * 32 + c0 + j] = bs[j];
-        }
-        __syncthreads();
-        if (tid < 32) {
-            const float a = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
-            atomicAdd(p.stats + ((long)msc_xcc_id() * 32 + tid) * 2, (double)a);
-        }
-    }
-}
-
-// ConvTranspose2d(k4, s2, p1) 128 -> 32 channels (dec1's up-sampling to full resolution): per output-parity phase the DMA
-// kernel re-reads four taps of 256-byte input rows for a 32-channel output tile.  Here a block owns 8x16 input pixels
-// (16x32 outputs): their 10x18 halo goes to LDS once (46 KB), each phase's four taps of weights (32 KB) follow, both with
-// the 16-byte chunks of a row XOR-swizzled by the row index so that 16 lanes reading 16 different rows hit 16 bank groups.
-template <typename T>
-__global__ __launch_bounds__(256, 2) void deconv4_c128_c32_halo_kernel(ConvK p) {      // 2 blocks per CU (LDS): up to 256 VGPRs, no spills
-    constexpr int HR = 10, HC = 18;                   // halo rows / columns
-    __shared__ uint4 halo[HR * HC * 16];              // [pixel][16 chunks of 8 channels], chunk ^= pixel & 15
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int g = lane >> 4, pl = lane & 15;
-    const int tiles_x = p.Wi / 16, tiles_y = p.Hi / 8;
-    const int npatch = p.N * tiles_x * tiles_y;
-    const T* in = reinterpret_cast<const T*>(p.in);
-    const T* wt = reinterpret_cast<const T*>(p.wt);          // [Cout][4][4][Cin]
-    T* out = reinterpret_cast<T*>(p.out);
-    const T* res = reinterpret_cast<const T*>(p.res);
-    const int c0 = 8 * g;
-    float sc[8], sh[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { sc[j] = p.scale ? p.scale[c0 + j] : 1.f; sh[j] = p.shift ? p.shift[c0 + j] : 0.f; }
-    // One wave = one output-parity phase, for the whole 8 x 16 patch.  The 4 taps x 128 input channels x 32 output channels of
-    // its phase are 32 weight fragments = 128 VGPRs, fetched ONCE straight from L2 and held; only the pixel fragments come from
-    // LDS (one read per two MFMAs).  With the weights in LDS too (the first version: one phase at a time for all waves) every
-    // MFMA cost one fragment read and the LDS port, not the matrix pipe, set the pace.
-    // Round 3: the block is PERSISTENT -- it walks patches blockIdx.x, + gridDim.x, ... with the weights of its phases kept in
-    // registers: with one patch per block the 128 KB of weight fragments were re-fetched 4096 times per launch (512 MB of L2 -> CU
-    // traffic, as much as input and output together).
-    // row pl of weight fragment a is output channel 8*(pl>>2) + 4a + (pl&3): a lane ends with channels 8g..8g+7
-    const int ph = wid, py = ph >> 1, px = ph & 1;
-    const int kh0 = (py + 1) & 1, kw0 = (px + 1) & 1;                 // taps kh0, kh0+2 / kw0, kw0+2
-    uint4 aw[4][4][2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int kh = kh0 + 2 * (t >> 1), kw = kw0 + 2 * (t & 1);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int co = 8 * (pl >> 2) + 4 * a + (pl & 3);
-                aw[t][kk][a] = *reinterpret_cast<const uint4*>(wt + ((long)(co * 4 + kh) * 4 + kw) * 128 + (kk * 4 + g) * 8);
-            }
-    }
-    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
-        const int bx = patch % tiles_x, by = (patch / tiles_x) % tiles_y, n = patch / (tiles_x * tiles_y);
-        const int qy0 = by * 8, qx0 = bx * 16;
-        __syncthreads();                                              // every wave is done with the previous patch's halo
-        for (int c = tid; c < HR * HC * 16; c += 256) {
-            const int pix = c >> 4, ch = c & 15;
-            const int hy = pix / HC, hx = pix - hy * HC;
-            const int iy = qy0 - 1 + hy, ix = qx0 - 1 + hx;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-                v = *reinterpret_cast<const uint4*>(in + ((long)(n * p.Hi + iy) * p.Wi + ix) * p.in_ld + ch * 8);
-            halo[pix * 16 + (ch ^ (pix & 15))] = v;
-        }
-        __syncthreads();                                              // halo written
-#pragma unroll 1
-        for (int b = 0; b < 8; ++b) {
-            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int kh = kh0 + 2 * (t >> 1), kw = kw0 + 2 * (t & 1);
-                const int dy = (py + 1 - kh) / 2, dx = (px + 1 - kw) / 2;  // input offset of this tap: -1, 0 or +1
-                const int pix = (b + 1 + dy) * HC + (pl + 1 + dx);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const uint4 bf = halo[pix * 16 + ((kk * 4 + g) ^ (pix & 15))];
-                    Mma<T>::run(aw[t][kk][0], bf, acc[0]);
-                    Mma<T>::run(aw[t][kk][1], bf, acc[1]);
-                }
-            }
-            const int oy = 2 * (qy0 + b) + py, ox = 2 * (qx0 + pl) + px;
-            const long opix = (long)(n * p.Ho + oy) * p.Wo + ox;
-            float v[8];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][r] * sc[a * 4 + r] + sh[a * 4 + r];
-            if (res) {
-                float rv[8];
-                Vec16<T>::load(res + opix * p.res_ld + c0, rv);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += rv[j];
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-            }
-            Vec16<T>::store(out + opix * p.out_ld + c0, v);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // weight gradient:  dW[a][kh][kw][b] += sum_m P[m][a] * Q[pix(m)*stride - pad + (kh,kw)][b]
 //   conv  wgrad: P = dY (a = cout), Q = X  (b = cin)
@@ -1502,18 +1260,8 @@ template <typename T>
 int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
     if (cfg == 0) cfg = k.fin_w ? CFG_HALO : pick_cfg(k);
     if (!conv_cfg_ok(k, (int)sizeof(T), cfg)) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: configuration %d is not valid for this layer", cfg);
-    if (cfg == CFG_HALO) {
-        if constexpr (sizeof(T) == 2) hipLaunchKernelGGL(conv3x3_c32_halo_kernel<T>, dim3(k.N * (k.Ho / 16) * (k.Wo / 16)), dim3(256), 0, st, k);
-        return msc_check_launch("conv3x3_c32_halo");
-    }
-    if (cfg == CFG_HALO_T) {
-        if constexpr (sizeof(T) == 2) {
-            const int patches = k.N * (k.Hi / 8) * (k.Wi / 16);
-            static const int persist = [] { const char* e = getenv("MSC_DECONV_BLOCKS"); return e ? atoi(e) : 1024; }();     // measured: 0 (one block per patch) 151 us, 512 117 us, 1024 113 us
-            hipLaunchKernelGGL(deconv4_c128_c32_halo_kernel<T>, dim3(persist > 0 && patches > persist ? persist : patches), dim3(256), 0, st, k);
-        }
-        return msc_check_launch("deconv4_c128_c32_halo");
-    }
+    if (cfg == CFG_HALO) return halo32_conv_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
+    if (cfg == CFG_HALO_T) return halo32_deconv_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     if (cfg == CFG_STREAM) return conv1x1_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     switch (cfg) {
         case 1: return launch_dma<T, 256, 128, 4, 2, 128, 3>(k, mode, st);
