@@ -21,7 +21,7 @@ struct ConvK {
     int ksplit; float* kws;          // split-K: slices of the reduction, fp32 partial sums (conv_igemm_dma_kernel, mode 0)
     int mode;                        // 0 gather, 1 transposed
     int xcd_order;                   // 1: XCD-aware tile order, 0: pixel tile fastest (for A/B measurements)
-    float rcp_hw, rcp_w;             // 1/(Hq*Wq), 1/Wq for the pixel decode of the DMA kernel; 0 = pixel count >= 2^24: integer division
+    float rcp_hw, rcp_w;             // 1/(Hq*Wq), 1/Wq for the pixel decode of the DMA kernel (a launch has fewer than 2^24 pixels)
 };
 
 // floor(m / d) through the float reciprocal, exact for m < 2^24 (one correction step either way)
@@ -32,6 +32,9 @@ __device__ __forceinline__ unsigned udiv_rcp(unsigned m, unsigned d, float rcp) 
     if (r >= (int)d) ++q;
     return q;
 }
+
+// floor(a / d) for a, d < 2^24 through v_rcp_f32 (1 ulp: the correction steps of udiv_rcp absorb it)
+__device__ __forceinline__ unsigned udiv24(unsigned a, unsigned d) { return udiv_rcp(a, d, __builtin_amdgcn_rcpf((float)d)); }
 
 // shared epilogue: lane holds NV consecutive channels cb.. of pixel rows (b*16+pl), b < FN
 // PATCH (halo-tile kernels): fragment b of pixel wave wp is row wp*FN + b of a 16-pixel-wide image patch whose first pixel

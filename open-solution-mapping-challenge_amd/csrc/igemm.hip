@@ -100,12 +100,21 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
     // XCD gets a contiguous run of tiles with the channel tile varying fastest, so the blocks that re-read one pixel
     // tile (one per channel tile) and one weight tile share that XCD's L2 close in time.
     // split-K: the grid holds ksplit copies of the tile grid, slice slowest
-    const int nwg = (int)gridDim.x / p.ksplit, kslice = (int)blockIdx.x / nwg, orig = (int)blockIdx.x - kslice * nwg;
+    // (the block-index arithmetic divides small uniform numbers: through v_rcp_f32, udiv24 -- a 32-bit integer division is a 25-instruction
+    // sequence, and nine of them stood at the head of every block)
+    const int nwg = p.ksplit > 1 ? (int)udiv24(gridDim.x, (unsigned)p.ksplit) : (int)gridDim.x;
+    const int kslice = p.ksplit > 1 ? (int)udiv24(blockIdx.x, (unsigned)nwg) : 0, orig = (int)blockIdx.x - kslice * nwg;
     const int xcd = orig & 7, wq = nwg >> 3, wr = nwg & 7;
     const int wgid = (xcd < wr ? xcd * (wq + 1) : wr * (wq + 1) + (xcd - wr) * wq) + (orig >> 3);
-    const int ntm_ = nwg / p.ntc;
-    const int mtile = p.xcd_order ? wgid / p.ntc : orig % ntm_;
-    const int ctile = p.xcd_order ? wgid - mtile * p.ntc : orig / ntm_;
+    int mtile, ctile;
+    if (p.xcd_order) {
+        mtile = (int)udiv24((unsigned)wgid, (unsigned)p.ntc);
+        ctile = wgid - mtile * p.ntc;
+    } else {
+        const int ntm_ = (int)udiv24((unsigned)nwg, (unsigned)p.ntc);
+        ctile = (int)udiv24((unsigned)orig, (unsigned)ntm_);
+        mtile = orig - ctile * ntm_;
+    }
     const int m0 = mtile * TP;
     const int c0 = ctile * TC;
     const int ph = MODE ? (int)blockIdx.z : 0;
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
     const int cps = p.Cin / KE;
     const int nsteps_all = nkh * nkw * cps;
     // this block's slice of the k-steps (all of them without split-K)
-    const int sper = (nsteps_all + p.ksplit - 1) / p.ksplit;
+    const int sper = p.ksplit > 1 ? (int)udiv24((unsigned)(nsteps_all + p.ksplit - 1), (unsigned)p.ksplit) : nsteps_all;
     const int sbeg = kslice * sper;
     const int nsteps = max(0, min(nsteps_all, sbeg + sper) - sbeg);
 
@@ -131,32 +140,35 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
     const int lr = lane / LPR, slot = lane % LPR;
     const unsigned pix_bytes = (unsigned)p.in_ld * ES;
     const unsigned tap_bytes = (unsigned)p.Cin * ES;
+    // 1x1 / stride 1 / pad 0 (half of the network's launches): output pixel m reads input pixel m -- no decode, no bounds but m < M,
+    // one tap; everything else decodes (image, row, column) through float reciprocals (a launch covers fewer than 2^24 pixels:
+    // conv_image_chunk).  The prologue stands in front of the first fill: the first form (both division flavours, a division per
+    // tap, the decode also for 1x1) was 1200 instructions deep before the first DMA of a 13 us kernel.
+    const bool lin = !MODE && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && !p.span_bytes;
     int xn[XI], xby[XI], xbx[XI];
     unsigned xkc[XI];
     bool xv[XI];
+    unsigned xoff[XI], woff[WI];
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
         const int j = NIX >= NW ? i * NW + wid : wid % NIX;
         const int row = j * RPI + lr;
         const int m = m0 + row;
         xv[i] = m < p.M;
-        const int mm = xv[i] ? m : 0;
-        // two divisions per row and DMA instruction: a microsecond of integer-division VALU code at the head of a 10-20 us
-        // kernel unless they go through the float reciprocal
-        int n, qy;
-        if (p.rcp_hw != 0.f) {
-            n = (int)udiv_rcp((unsigned)mm, (unsigned)(p.Hq * p.Wq), p.rcp_hw);
-            qy = (int)udiv_rcp((unsigned)(mm - n * (p.Hq * p.Wq)), (unsigned)p.Wq, p.rcp_w);
-        } else {
-            n = mm / (p.Hq * p.Wq);
-            qy = (mm - n * (p.Hq * p.Wq)) / p.Wq;
-        }
-        const int qx = mm - n * (p.Hq * p.Wq) - qy * p.Wq;
-        xn[i] = n * p.Hi;
-        xby[i] = MODE ? qy : qy * p.stride;
-        xbx[i] = MODE ? qx : qx * p.stride;
         xkc[i] = (unsigned)(slot ^ swz_x<KB>(row)) * 16u;
-        if (p.span_bytes) xbx[i] += (int)(xkc[i] / (unsigned)p.span_bytes);      // merged taps (one k-step per tap row): this lane's own pixel
+        xn[i] = 0; xby[i] = 0; xbx[i] = 0;
+        if (lin) {
+            xoff[i] = xv[i] ? (unsigned)m * pix_bytes + xkc[i] : OOB_OFF;
+        } else {
+            const int mm = xv[i] ? m : 0;
+            const int n = (int)udiv_rcp((unsigned)mm, (unsigned)(p.Hq * p.Wq), p.rcp_hw);
+            const int qy = (int)udiv_rcp((unsigned)(mm - n * (p.Hq * p.Wq)), (unsigned)p.Wq, p.rcp_w);
+            const int qx = mm - n * (p.Hq * p.Wq) - qy * p.Wq;
+            xn[i] = n * p.Hi;
+            xby[i] = MODE ? qy : qy * p.stride;
+            xbx[i] = MODE ? qx : qx * p.stride;
+            if (p.span_bytes) xbx[i] += (int)(xkc[i] / (unsigned)p.span_bytes);      // merged taps (one k-step per tap row): this lane's own pixel
+        }
     }
     unsigned wrow[WI];
 #pragma unroll
@@ -167,11 +179,18 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
         wrow[i] = co < p.Cout ? (unsigned)co * (unsigned)(p.KH * p.KW) * tap_bytes + (unsigned)(slot ^ swz_w<KB, NV>(row)) * 16u : OOB_OFF;
     }
 
-    // ---- issue iterator: (tap, k-chunk) of the next stage to fetch; per-lane offsets refreshed once per tap
-    int itap = sbeg / cps, icch = sbeg - itap * cps, istage = 0;
-    unsigned xoff[XI], woff[WI];
+    if (lin) {
+#pragma unroll
+        for (int i = 0; i < WI; ++i) woff[i] = wrow[i];
+    }
+    // ---- issue iterator: (tap, k-chunk) of the next stage to fetch; per-lane offsets refreshed once per tap.  (khi, kwi) of the next
+    // set_tap are carried along (taps come in order, from the slice's first one): no division per tap
+    int itap = sbeg ? (int)udiv24((unsigned)sbeg, (unsigned)cps) : 0, icch = sbeg - itap * cps, istage = 0;
+    int tkh = itap ? (int)udiv24((unsigned)itap, (unsigned)nkw) : 0, tkw = itap - tkh * nkw;
     auto set_tap = [&](int tap) {
-        const int khi = tap / nkw, kwi = tap - khi * nkw;
+        if (lin) return;
+        const int khi = tkh, kwi = tkw;
+        if (++tkw == nkw) { tkw = 0; ++tkh; }
         const int kh = MODE ? kh0 + 2 * khi : khi;
         const int kw = MODE ? kw0 + 2 * kwi : kwi;
         int dy, dx;
@@ -324,7 +343,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
         }
         return;
     }
-    conv_epilogue<T, FM, FN, WTP, WP, MODE, WC>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px, mtile, nwg / p.ntc,
+    conv_epilogue<T, FM, FN, WTP, WP, MODE, WC>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, py, px, mtile, 0,
                                                 reinterpret_cast<float*>(smem), wc, c0);
 }
 
@@ -417,9 +436,10 @@ __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int xcd = orig & 7, wq = nwg >> 3, wr = nwg & 7;
     const int wgid = p.xcd_order ? (xcd < wr ? xcd * (wq + 1) : wr * (wq + 1) + (xcd - wr) * wq) + (orig >> 3) : orig;
-    const int patch = wgid / p.ntc, ctile = wgid - patch * p.ntc;
+    const int patch = (int)udiv24((unsigned)wgid, (unsigned)p.ntc), ctile = wgid - patch * p.ntc;
     const int tiles_x = p.Wo / 16, tiles_y = p.Ho / PH;
-    const int bx = patch % tiles_x, by = (patch / tiles_x) % tiles_y, n = patch / (tiles_x * tiles_y);
+    const int prow = (int)udiv24((unsigned)patch, (unsigned)tiles_x), bx = patch - prow * tiles_x;       // (small uniform numbers: udiv24, conv_common.h)
+    const int n = (int)udiv24((unsigned)prow, (unsigned)tiles_y), by = prow - n * tiles_y;
     const int y0 = by * PH, x0 = bx * 16;
     const int c0 = ctile * TC;
     const int nchunks = (p.Cin * ES) / KB;
@@ -558,7 +578,7 @@ __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo
     }
     wait_vmcnt<0>();                                  // the trailing out-of-range pieces still write zeros into the ring
     const int m0 = (n * p.Ho + y0) * p.Wo + x0;
-    conv_epilogue<T, FM, FN, FN * 16, WP, 0, WC, true>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, 0, 0, patch, nwg / p.ntc,
+    conv_epilogue<T, FM, FN, FN * 16, WP, 0, WC, true>(p, acc, m0, wp, c0 + wc * WTC + g * NV, pl, 0, 0, patch, 0,
                                                         reinterpret_cast<float*>(smem), wc, c0);
 }
 
@@ -1372,7 +1392,10 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
     const long m = (long)d->N * k->Hq * k->Wq;
     if (m <= 0 || m > 0x7fffffffL) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: bad pixel count %ld", m);
     k->M = (int)m;
-    k->rcp_hw = m < (1L << 24) ? 1.0f / (float)(k->Hq * k->Wq) : 0.f;
+    // the kernels decode pixel -> (image, row, column) through float reciprocals, exact below 2^24 pixels: msc_conv_igemm hands over image
+    // ranges that stay below (conv_image_chunk)
+    if (m >= (1L << 24)) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: one image has %ld output pixels (>= 2^24)", m / d->N);
+    k->rcp_hw = 1.0f / (float)(k->Hq * k->Wq);
     k->rcp_w = 1.0f / (float)k->Wq;
     // extents of the buffer descriptors: 31-bit offsets (msc_conv_igemm hands over image ranges that fit, conv_image_chunk)
     const long in_b = (((long)d->N * d->Hi * d->Wi - 1) * d->in_ld + d->Cin) * es;
@@ -1399,15 +1422,18 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
     return MSC_OK;
 }
 
-// Images per launch: the kernels address their input with 31-bit byte offsets (buffer descriptors), so a tensor beyond 2 GiB
+// Images per launch: the kernels address their input with 31-bit byte offsets (buffer descriptors) and decode pixels through float
+// reciprocals (exact below 2^24 pixels), so a tensor beyond 2 GiB
 // (fp32 mode, 512x512, batch 64: 2.1 GB at full resolution) runs as consecutive image ranges -- images are independent, the
 // statistics epilogues accumulate atomically.  Returns the number of images a launch may cover (>= 1; d->N when all fit).
 static int conv_image_chunk(const msc_conv_desc* d) {
     if (!d || d->N <= 0 || !msc_dtype_ok(d->dtype)) return 1;
     const long es = msc_dtype_size(d->dtype);
     const long per_image = (long)d->Hi * d->Wi * d->in_ld * es;
-    if (per_image <= 0 || per_image * d->N < 0x7fff0000L) return d->N;
-    const long n = 0x7fff0000L / per_image;
+    const long out_pixels = d->mode == 1 ? (long)(d->Ho / 2) * (d->Wo / 2) : (long)d->Ho * d->Wo;      // per image and launch grid (transposed: per parity phase)
+    long n = d->N;
+    if (per_image > 0 && per_image * n >= 0x7fff0000L) n = 0x7fff0000L / per_image;
+    if (out_pixels > 0 && out_pixels * n >= (1L << 24)) n = ((1L << 24) - 1) / out_pixels;
     return n < 1 ? 1 : (int)n;
 }
 
