@@ -257,5 +257,6 @@ int conv1x1_launch(const ConvK& k, int dtype, hipStream_t st);
 // halo32.hip: the halo-tile kernels of the 32-channel full-resolution layers (configurations 27 / 28)
 int halo32_conv_launch(const ConvK& k, int dtype, hipStream_t st);
 int halo32_deconv_launch(const ConvK& k, int dtype, hipStream_t st);
+int halo32_stem_launch(const ConvK& k, int dtype, hipStream_t st);       // configuration 58: the 7x7 / stride 2 stem on the prepared input
 
 }  // namespace msc_conv

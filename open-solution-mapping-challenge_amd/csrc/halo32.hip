@@ -369,6 +369,75 @@ __global__ __launch_bounds__(512) void deconv4_c128_c32_halo_kernel(ConvK p) {  
     }
 }
 
+// The stem: Conv2d(3, 64, k7, s2, p3) on the prepared input xp [N][H+6][W+8][4] (msc_stem_prepare: the image at (3,3), a zero fourth
+// channel), which msc_conv_igemm sees as KH = 7, KW = 1, Cin = 32 (8 pixels x 4 channels of a row), stride 2, in_ld = 4, and the
+// weights packed [64][7][32] (msc_stem_pack) -- src/unet_models.py:360 via torchvision's resnet conv1.  As an implicit GEMM that is
+// seven 64-byte k-steps per tile (the slow LDS-DMA case) for 67 MB of output: 58-65 us.  Here a block owns 8 x 16 output pixels: the
+// 21 x 38 input pixels under them (6.4 KB) go to LDS once per patch by DMA, double-buffered over the patches of a persistent block, and
+// the B fragment of (kernel row kh, output pixel x, k-chunk g) is the 16 bytes at input row 2y + kh, pixel pair x + g -- 16-byte aligned
+// whatever x, because the stride of 2 pixels is 16 bytes.  Eight waves: four pairs of output rows x two halves of the 64 channels,
+// each with its 2 x 7 weight fragments in registers.
+template <typename T>
+__global__ __launch_bounds__(512) void stem7_halo_kernel(ConvK p, int npatch) {
+    constexpr int HR = 21, HCK = 19;                  // halo rows; 16-byte chunks (pixel pairs) per row
+    constexpr int NCH = HR * HCK;                     // 399 chunks
+    constexpr int HBUF = 512;                         // chunks per buffer: one DMA instruction per wave
+    __shared__ uint4 halo2[2 * HBUF];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, pl = lane & 15;
+    const int wp = wid >> 1, wc = wid & 1;
+    const int tiles_x = p.Wo / 16, tiles_y = p.Ho / 8;
+    const u32x4_t rx = make_srd(p.in, p.in_bytes);
+    const T* wt = reinterpret_cast<const T*>(p.wt);          // [64][7][32]
+    // row pl of weight fragment a is output channel 32 wc + 8*(pl>>2) + 4a + (pl&3): a lane ends with channels 32 wc + 8g .. + 7
+    uint4 wf[7][2];
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+            wf[kh][a] = *reinterpret_cast<const uint4*>(wt + ((long)(32 * wc + 8 * (pl >> 2) + 4 * a + (pl & 3)) * 7 + kh) * 32 + g * 8);
+    // the thread's halo chunk: LDS slot c = tid is pixel pair c % 19 of halo row c / 19
+    const int hr = tid / HCK, hj = tid - hr * HCK;
+    const int hrel = (hr * p.Wi * 4 + hj * 8) * 2;            // bytes from the patch's first input pixel (in_ld = 4)
+    auto request = [&](int patch, int buf) {
+        const int bx = patch % tiles_x, by = (patch / tiles_x) % tiles_y, n = patch / (tiles_x * tiles_y);
+        const int org = (((n * p.Hi + 16 * by) * p.Wi + 32 * bx) * 4) * 2;
+        dma16(rx, reinterpret_cast<char*>(halo2 + buf * HBUF + 64 * wid), tid < NCH ? (unsigned)(org + hrel) : OOB_OFF, 0);
+    };
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const int lbase = (4 * wp * HCK + pl + g);                // chunk of (kernel row 0, first of the wave's two output rows, pixel pl)
+    if ((int)blockIdx.x < npatch) request(blockIdx.x, 0);
+    int buf = 0;
+    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x, buf ^= 1) {
+        const int bx = patch % tiles_x, by = (patch / tiles_x) % tiles_y, n = patch / (tiles_x * tiles_y);
+        wait_vmcnt<0>();
+        raw_barrier();
+        if (patch + (int)gridDim.x < npatch) request(patch + gridDim.x, buf ^ 1);
+        const uint4* halo = halo2 + buf * HBUF;
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const uint4 bf = halo[lbase + (2 * b + kh) * HCK];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) Mma<T>::run(wf[kh][a], bf, acc[a][b]);
+            }
+        const int m0 = (n * p.Ho + 8 * by) * p.Wo + 16 * bx;
+        conv_epilogue_tile<T, 2, 2, 32, 4, 0, true>(p, acc, m0, wp, 32 * wc + 8 * g, pl, 0, 0, s1, s2);
+    }
+    if (p.stats) {
+        __syncthreads();
+        conv_epilogue_stats<T, 2, 4, 2>(p, s1, s2, wp, wc, pl, 0, reinterpret_cast<float*>(halo2));
+    }
+}
+
 template <typename T>
 int conv_launch(const ConvK& k, hipStream_t st) {
     const int patches = k.N * (k.Ho / 16) * (k.Wo / 16);
@@ -387,8 +456,17 @@ int deconv_launch(const ConvK& k, hipStream_t st) {
     return msc_check_launch("deconv4_c128_c32_halo");
 }
 
+template <typename T>
+int stem_launch(const ConvK& k, hipStream_t st) {
+    const int patches = k.N * (k.Ho / 8) * (k.Wo / 16);
+    static const int persist = [] { const char* e = getenv("MSC_STEM_BLOCKS"); return e ? atoi(e) : 256; }();      // measured: 0 (one block per patch) 52 us, 256: 36, 512: 39, 1024: 43
+    hipLaunchKernelGGL(stem7_halo_kernel<T>, dim3(persist > 0 && patches > persist ? persist : patches), dim3(512), 0, st, k, patches);
+    return msc_check_launch("stem7_halo");
+}
+
 }  // namespace
 
+int halo32_stem_launch(const ConvK& k, int dtype, hipStream_t st) { return dtype == MSC_F16 ? stem_launch<f16_t>(k, st) : stem_launch<bf16_t>(k, st); }
 int halo32_conv_launch(const ConvK& k, int dtype, hipStream_t st) { return dtype == MSC_F16 ? conv_launch<f16_t>(k, st) : conv_launch<bf16_t>(k, st); }
 int halo32_deconv_launch(const ConvK& k, int dtype, hipStream_t st) { return dtype == MSC_F16 ? deconv_launch<f16_t>(k, st) : deconv_launch<bf16_t>(k, st); }
 

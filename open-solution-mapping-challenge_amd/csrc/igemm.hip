@@ -1129,10 +1129,11 @@ bool xcd_order_enabled() { static int v = -1; if (v < 0) { const char* e = geten
 // heuristic (cfg 0) the caller may pick one explicitly -- UNetResNet times the valid ones per layer when it builds
 // a program (msc_conv_cfg_ok enumerates them).
 struct ConvCfg { int tp, tc, wp, wc, kb, nst; };
-constexpr int N_CONV_CFG = 57;
+constexpr int N_CONV_CFG = 58;
 static inline bool cfg_is_halo3(int cfg) { return (cfg >= 42 && cfg <= 46) || (cfg >= 51 && cfg <= 56); }      // conv3x3_halo_dma_kernel
 constexpr int CFG_HALO = 27;          // conv3x3_c32_halo_kernel (not a tile of the DMA kernel)
 constexpr int CFG_HALO_T = 28;        // deconv4_c128_c32_halo_kernel
+constexpr int CFG_STEM = 58;          // stem7_halo_kernel (halo32.hip)
 static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {0, 0, 0, 0, 0, 0},
     {256, 128, 4, 2, 128, 3},   //  1: 144 KB, 8 waves, 1 block/CU
@@ -1208,6 +1209,7 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {128, 128, 2, 4, 128, 2},   // 55:  8x16 patch x 128 ch, 8 waves, 80 KB, 2 blocks/CU
     {256, 128, 4, 2, 128, 2},   // 56: 16x16 patch x 128 ch, 8 waves, 128 KB
     {64, 256, 1, 8, 128, 2},    // 57: persistent streaming kernel for 1x1 / stride 1 layers of 64..512 input channels (tile shape per layer: STREAM_VARS)
+    {128, 64, 4, 2, 64, 2},     // 58: halo-tile kernel for the stem (7x7 / stride 2 on the prepared 4-channel input)
 };
 
 template <typename T, int TP, int TC, int WP, int WC, int KB, int NST, int ABL = 0>
@@ -1243,8 +1245,12 @@ int launch_halo3(const ConvK& k0, hipStream_t st) {
 bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
     if (cfg < 1 || cfg > N_CONV_CFG) return false;
     if (k.fin_w && cfg != CFG_HALO) return false;           // the fused final 1x1 lives in the 32-channel halo kernel's epilogue only
-    if (k.ksplit > 1 && (cfg == CFG_HALO || cfg == CFG_HALO_T || cfg == CFG_STREAM || cfg_is_halo3(cfg))) return false;      // split-K: the implicit-GEMM kernel only
+    if (k.ksplit > 1 && (cfg == CFG_HALO || cfg == CFG_HALO_T || cfg == CFG_STREAM || cfg == CFG_STEM || cfg_is_halo3(cfg))) return false;      // split-K: the implicit-GEMM kernel only
     if (cfg == CFG_STREAM) return conv1x1_cfg_ok(k, es);
+    if (cfg == CFG_STEM)
+        return es == 2 && k.mode == 0 && k.KH == 7 && k.KW == 1 && k.stride == 2 && k.pad == 0 && k.Cin == 32 && k.in_ld == 4 && k.Cout == 64 && !k.flip &&
+               !k.span_bytes && k.ksplit == 1 && k.Ho % 8 == 0 && k.Wo % 16 == 0 && k.Hi >= 2 * k.Ho + 5 && k.Wi >= 2 * k.Wo + 6 &&
+               (!k.stats || k.stats_kind == 0) && k.out_ld % 8 == 0 && k.res_ld % 8 == 0;
     if (cfg == CFG_HALO)
         return es == 2 && k.mode == 0 && k.KH == 3 && k.KW == 3 && k.stride == 1 && k.pad == 1 && k.Cin == 32 && k.Cout == 32 &&
                k.Ho % 16 == 0 && k.Wo % 16 == 0 && k.Hi == k.Ho && k.Wi == k.Wo && (!k.stats || k.stats_kind == 2) && k.res_ld % 8 == 0 && k.out_ld % 8 == 0;
@@ -1282,6 +1288,7 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
     if (!conv_cfg_ok(k, (int)sizeof(T), cfg)) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: configuration %d is not valid for this layer", cfg);
     if (cfg == CFG_HALO) return halo32_conv_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     if (cfg == CFG_HALO_T) return halo32_deconv_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
+    if (cfg == CFG_STEM) return halo32_stem_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     if (cfg == CFG_STREAM) return conv1x1_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     switch (cfg) {
         case 1: return launch_dma<T, 256, 128, 4, 2, 128, 3>(k, mode, st);

@@ -919,3 +919,55 @@ def test_streaming_1x1_kernel(dtype, cin, cout):
     d.Hi = d.Ho = 3
     d.Wi = d.Wo = 5
     assert not lib.msc_conv_cfg_ok(C.byref(d), _lib.CFG_STREAM)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('n,hw', [(3, 64), (2, 256)])
+def test_stem_halo_kernel(dtype, n, hw):
+    """stem7_halo_kernel (configuration 58): the 7x7 / stride 2 / pad 3 stem on the prepared 4-channel input equals torch's conv and the
+    implicit-GEMM configurations of the same descriptor: raw output + BatchNorm statistics (training), folded coefficients + ReLU (eval)"""
+    import ctypes as C
+    from mapping_challenge_amd import _lib
+    lib = _lib.load()
+    x = rnd((n, 3, hw, hw), dtype, 1)
+    w = rnd((64, 3, 7, 7), dtype, 2, (2.0 / 147) ** 0.5)
+    raw = F.conv2d(x, w, stride=2, padding=3)
+    ho = hw // 2
+    dt = {torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}[dtype]
+    stream = torch.cuda.current_stream().cuda_stream
+    xd, wd = x.cuda().contiguous(), w.cuda().contiguous()
+    xp = torch.empty((n, hw + 6, hw + 8, 4), dtype=dtype, device='cuda')
+    wp = torch.empty((64, 7, 32), dtype=dtype, device='cuda')
+    _lib.check(lib.msc_stem_prepare(xd.data_ptr(), xp.data_ptr(), dt, n, hw, hw, stream), 'prepare')
+    _lib.check(lib.msc_stem_pack(wd.data_ptr(), wp.data_ptr(), dt, 64, stream), 'pack')
+    out = torch.empty((n, ho, ho, 64), dtype=dtype, device='cuda')
+    scale, shift = torch.rand(64, generator=torch.Generator().manual_seed(3)) + 0.5, rnd((64,), torch.float32, 4) * 0.3
+    sc, sh = scale.cuda(), shift.cuda()
+
+    def desc(cfg):
+        d = _lib.ConvDesc()
+        d.in_, d.wt, d.out = xp.data_ptr(), wp.data_ptr(), out.data_ptr()
+        d.in_ld, d.out_ld, d.dtype, d.mode = 4, 64, dt, 0
+        d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.cfg = n, hw + 6, hw + 8, 32, ho, ho, 64, 7, 1, 2, 0, cfg
+        return d
+
+    assert lib.msc_conv_cfg_ok(C.byref(desc(58)), 58)
+    cfgs = [c for c in range(1, lib.msc_conv_num_cfgs() + 1) if lib.msc_conv_cfg_ok(C.byref(desc(c)), c)]
+    assert 58 in cfgs and len(cfgs) > 1
+    for cfg in (58, cfgs[0]):
+        d = desc(cfg)
+        stats = torch.zeros((_lib.BN_SLOTS, 64, 2), dtype=torch.float64, device='cuda')
+        d.stats = stats.data_ptr()
+        out.fill_(5.0)
+        _lib.check(lib.msc_conv_igemm(C.byref(d), stream), 'conv')
+        assert torch.allclose(to_nchw(out), raw, **tol(dtype)), cfg
+        s = stats.sum(0).float().cpu()
+        assert torch.allclose(s[:, 0], raw.sum((0, 2, 3)), rtol=2e-2, atol=1.0) and torch.allclose(s[:, 1], (raw * raw).sum((0, 2, 3)), rtol=2e-2, atol=1.0), cfg
+        d = desc(cfg)
+        d.scale, d.shift, d.relu = sc.data_ptr(), sh.data_ptr(), 1
+        _lib.check(lib.msc_conv_igemm(C.byref(d), stream), 'conv')
+        assert torch.allclose(to_nchw(out), torch.relu(raw * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)), **tol(dtype)), cfg
+    # other geometries do not qualify
+    d = desc(58)
+    d.in_ld = 8
+    assert not lib.msc_conv_cfg_ok(C.byref(d), 58)
