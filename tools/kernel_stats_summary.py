@@ -35,7 +35,7 @@ def main():
     print('source: %s' % os.path.relpath(path, root))
     print('%-10s %7s %8s %11s %11s %11s  %s' % ('total_ms', 'pct', 'calls', 'avg_us', 'min_us', 'max_us', 'kernel'))
     for name, calls, total, avg, mn, mx in rows[:top]:
-        name = re.sub(r'\(anonymous namespace\)::', '', name)
+        name = re.sub(r'\(anonymous namespace\)::|msc_conv::', '', name)
         name = re.sub(r'^void ', '', name)
         name = re.sub(r'\((?:[^()]|\([^()]*\))*\)$', '', name)
         print('%-10.3f %6.2f%% %8d %11.1f %11.1f %11.1f  %s' % (total / 1e6, 100.0 * total / tot, calls, avg / 1e3, mn / 1e3, mx / 1e3, name[:140]))

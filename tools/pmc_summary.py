@@ -19,7 +19,7 @@ def main():
     calls = defaultdict(lambda: defaultdict(int))
     for f in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
-            name = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
+            name = re.sub(r'\(anonymous namespace\)::|msc_conv::', '', r['Kernel_Name'])
             name = re.sub(r'^void ', '', name).split('(')[0]
             acc[name][r['Counter_Name']] += float(r['Counter_Value'])
             calls[name][r['Counter_Name']] += 1
@@ -31,7 +31,8 @@ def main():
         rows.append({'kernel': name, 'launches': max(n_f, n_w), 'fetch_bytes_per_launch': fetch, 'write_bytes_per_launch': write,
                      'hbm_bytes_per_launch': fetch + write})
     rows.sort(key=lambda r: -r['hbm_bytes_per_launch'] * r['launches'])
-    FAMILY = ('conv_igemm_dma_kernel', 'conv3x3_halo_dma_kernel', 'conv3x3_c32_halo_kernel', 'deconv4_c128_c32_halo_kernel')      # = msc_conv_igemm
+    FAMILY = ('conv_igemm_dma_kernel', 'conv3x3_halo_dma_kernel', 'conv3x3_c32_halo_kernel', 'deconv4_c128_c32_halo_kernel', 'conv1x1_stream_kernel',
+              'stem7_halo_kernel', 'splitk_finish_kernel')      # = msc_conv_igemm
     fam = [r for r in rows if r['kernel'].startswith(FAMILY)]
     tot_l = sum(r['launches'] for r in fam)
     summary = {'family': 'msc_conv_igemm (conv_igemm_dma_kernel + halo-tile kernels)', 'launches': tot_l,
