@@ -1594,8 +1594,10 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
     out->kw3 = kw3;
     // 128x128 tiles: with 4 waves three accumulator sets leave one wave per SIMD and one block per CU -- measured 15 % slower
     // than the single-tap blocks at two blocks per CU (859 vs 745 us for the 3x3 layers of the ResNet101 step); the 8-wave form
-    // (two waves per SIMD, 96 accumulator registers) is what MSC_WGRAD_KW3=2 selects
-    static const bool kw3_big = [] { const char* e = getenv("MSC_WGRAD_KW3"); return e && e[0] == '2'; }();
+    // (two waves per SIMD, 96 accumulator registers) was neutral in round 2 and is 4 % ahead since the epilogue / prologue work of
+    // round 3 (grouped launches 2.14-2.16 -> 2.05-2.06 ms, two A/B pairs on one box): the default.  MSC_WGRAD_KW3=1 keeps the
+    // 128x128 tiles single-tap.
+    static const bool kw3_big = [] { const char* e = getenv("MSC_WGRAD_KW3"); return !(e && e[0] == '1'); }();
     if (kw3 && ta == 128 && !kw3_big) {
         out->kw3 = false;
         k.kw3 = 0;
