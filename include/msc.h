@@ -46,6 +46,9 @@ int msc_abi_version(void);
  *   is the gradient w.r.t. a BatchNorm+ReLU layer's activation, stats_y that layer's pre-BN tensor (same shape as
  *   out), scale/shift its forward coefficients (used for the ReLU mask only, NULL = no ReLU; no affine is applied):
  *   stats[slot][c] += (sum dh, sum dh*y), dh = acc*[scale*y+shift > 0].  Same layout, consumed by msc_bn_bwd_apply.
+ *   ABI v6: with stats_z set the mask is [stats_z > 0] instead (the layer's OUTPUT: a residual block's ReLU sits after the add, so the
+ *   pre-BN tensor alone does not give it) and a residual is allowed: the conv that ACCUMULATES the last addend of a residual join's
+ *   gradient (out = acc + res) reduces dh = out*[stats_z > 0] -- the msc_bn_bwd_reduce launch of the join's BatchNorm is not needed.
  *   stats_kind 2 (data-gradient convs; no scale/shift/res/relu): the output is the gradient w.r.t. the activation of a
  *   bias+ReLU layer (ConvRelu, ConvTranspose2d+ReLU: src/unet_models.py:25-34,138-140), stats_y that activation: the
  *   launch STORES out = acc*[stats_y > 0] (the ReLU backward) and adds stats[slot][c][0] += sum_p out[p][c] (the layer's
@@ -82,6 +85,9 @@ typedef struct msc_conv_desc {
      * centre / dec5 ConvRelu on 4x4 and 8x8 maps (src/unet_models.py:373-374): 512 pixels x 512 channels x 18432 is 32 tiles. */
     int32_t splitk;
     float* splitk_ws;
+    /* ABI v6: stats_kind 1 with the ReLU mask taken from a stored activation (see above); same shape as out, stats_z_ld elements per pixel */
+    const void* stats_z;
+    int64_t stats_z_ld;
 } msc_conv_desc;
 int msc_conv_igemm(const msc_conv_desc* d, void* stream);
 int msc_conv_stats_slices(const msc_conv_desc* d);   /* depends on d->cfg */

@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):
                 ('stride', C.c_int32), ('pad', C.c_int32), ('flip', C.c_int32), ('relu', C.c_int32), ('cfg', C.c_int32),
                 ('stats_kind', C.c_int32), ('stats_y', C.c_void_p), ('stats_y_ld', C.c_int64),
                 ('final_w', C.c_void_p), ('final_b', C.c_void_p), ('final_logits', C.c_void_p), ('final_probs', C.c_void_p),
-                ('final_skip_store', C.c_int32), ('splitk', C.c_int32), ('splitk_ws', C.c_void_p)]
+                ('final_skip_store', C.c_int32), ('splitk', C.c_int32), ('splitk_ws', C.c_void_p),
+                ('stats_z', C.c_void_p), ('stats_z_ld', C.c_int64)]        # ABI v6: stats_kind 1 masked by a stored activation, residual allowed
 
 
 class WgradDesc(C.Structure):

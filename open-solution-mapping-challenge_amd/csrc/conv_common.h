@@ -8,6 +8,7 @@ namespace msc_conv {
 struct ConvK {
     const char* in; const char* wt; char* out; const char* res;
     const float* scale; const float* shift; double* stats;
+    const char* sz; long sz_ld;                     // stats_kind 1: the activation the ReLU mask is taken from (0: from scale*sy + shift, or none)
     const char* sy; long sy_ld; int stats_kind;     // stats_kind 1: BatchNorm-backward sums against the tensor sy;
                                                     // 2: ReLU backward (mask [sy > 0] applied to the output) + bias-gradient sums
     long in_ld, out_ld, res_ld;
@@ -47,7 +48,9 @@ __device__ __forceinline__ unsigned udiv24(unsigned a, unsigned d) { return udiv
 //   3 forward BatchNorm statistics (sum, sum of squares) of the raw accumulators, stored as they are (scale / shift / res / relu as in 0)
 //   1 stats_kind 1 (a data-gradient conv that also produces the BatchNorm-backward sums of the layer whose output gradient it
 //     writes): (sum dh, sum dh*y), dh = acc * [scale*y + shift > 0] (no mask without scale); scale/shift are that layer's forward
-//     coefficients, used for the mask only; the stored value is the raw accumulator
+//     coefficients, used for the mask only; the stored value is the raw accumulator.  With sz (ABI v6) the mask is [sz > 0] -- the ReLU
+//     of a residual join sits after the add -- and a residual is added first: the conv that accumulates the last addend of the
+//     join's gradient (out = acc + res) reduces what msc_bn_bwd_reduce would read the three tensors back for
 //   2 stats_kind 2 (a data-gradient conv whose output is the gradient w.r.t. a bias+ReLU layer's activation sy): the stored value is
 //     dh = acc * [sy > 0] and the sum is that layer's bias gradient -- the separate ReLU-backward / bias-gradient pass over the
 //     tensor (msc_relu_bias_grad) is not launched
@@ -129,11 +132,36 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvK& p, f32x4 (&acc)[
                 if (PRE) Vec16<T>::unpack(pre[PRE ? b : 0][PRE ? j / CE : 0], yv + j);
                 else Vec16<T>::load(side + opixs[b] * side_ld + cb + j, yv + j);
             }
+            if (KIND == 1 && p.res) {              // the accumulating writer of a gradient: out = acc + res, reduced and stored
+                asm volatile("" ::: "memory");
+                const T* res = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+                for (int j = 0; j < NV; j += CE) {
+                    float rv[CE];
+                    Vec16<T>::load(res + opixs[b] * p.res_ld + cb + j, rv);
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) v[j + e] += m < p.M ? rv[e] : 0.f;      // rows past the end stay zero (they are summed, not stored)
+                }
+            }
             if (KIND == 2) {
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
                     v[j] = yv[j] > 0.f ? v[j] : 0.f;
                     s1[j] += v[j];
+                }
+            } else if (p.sz) {
+                asm volatile("" ::: "memory");
+                const T* sz = reinterpret_cast<const T*>(p.sz);
+#pragma unroll
+                for (int j = 0; j < NV; j += CE) {
+                    float zv[CE];
+                    Vec16<T>::load(sz + opixs[b] * p.sz_ld + cb + j, zv);
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) {
+                        const float dh = zv[e] > 0.f ? v[j + e] : 0.f;
+                        s1[j + e] += dh;
+                        s2[j + e] = fmaf(dh, yv[j + e], s2[j + e]);
+                    }
                 }
             } else if (has_sc) {
                 asm volatile("" ::: "memory");           // a real branch (see above)

@@ -635,6 +635,10 @@ class _Builder:
         self.gcount = {}              # activation slice -> number of launches that write its gradient
         self.gwriter = {}             # activation slice -> ConvDesc of the (mode 0, no residual) dgrad conv that wrote it first
         self.fuse_bn_bwd = _os_env.environ.get('MSC_FUSE_BN_BWD', '1') != '0'
+        # residual joins: the data-gradient conv that ACCUMULATES the last addend of the join's gradient also reduces the sums of the
+        # join's BatchNorm backward (stats_kind 1 with stats_z, ABI v6) -- no msc_bn_bwd_reduce pass over three tensors
+        self.fuse_join_bwd = _os_env.environ.get('MSC_FUSE_JOIN_BWD', '1') != '0'
+        self.glast = {}               # gradient slice -> ConvDesc of its most recent writer, while that is a mode-0 / stride-1 data-gradient conv
         # decoder: the data-gradient conv that writes the gradient of a bias+ReLU layer's activation first also applies that
         # layer's ReLU mask and sums its bias gradient (stats_kind 2) -- no msc_relu_bias_grad pass over the tensor
         self.fuse_relu_bwd = _os_env.environ.get('MSC_FUSE_RELU_BWD', '1') != '0'
@@ -702,6 +706,8 @@ class _Builder:
         marks it (and every registered sub-slice it covers) written and returns 0."""
         key = (id(a.buf), a.c0, a.C)
         self.gcount[key] = self.gcount.get(key, 0) + 1
+        for k in [k for k in self.glast if k[0] == key[0] and k[1] < a.c0 + a.C and a.c0 < k[1] + k[2]]:
+            del self.glast[k]         # whoever writes next is the last writer of everything it overlaps (the dgrad site re-registers itself)
         if key in self.gwritten:
             return 1
         self.gwritten.add(key)
@@ -891,7 +897,16 @@ class _Builder:
         gkey = (id(out.buf), out.c0, out.C)      # grad_acc() keys gradient slices by their activation
         wd = self.gwriter.get(gkey) if (self.fuse_bn_bwd and mask != 1 and self.gcount.get(gkey, 0) == 1) else None
         bslots = self.slots(cout)                # (sum dh, sum dh*y) per XCD slot, summed in bn_bwd_apply's prologue
-        if wd is not None:
+        wl = self.glast.get(gkey) if (wd is None and mask == 1 and self.fuse_bn_bwd and self.fuse_join_bwd) else None
+        if wl is not None and not wl.stats and not wl.relu and not wl.scale and not wl.shift and wl.Cout == cout:
+            # residual join: the last writer of dout accumulated onto the other addend(s) (out = acc + res); its epilogue reduces
+            # dh = out * [block output > 0] against y -- the block output is the ReLU output that follows the add
+            wl.stats_kind, wl.stats_y, wl.stats_y_ld = 1, y.ptr, y.ld
+            wl.stats_z, wl.stats_z_ld = out.ptr, out.ld
+            wl.stats = bslots
+            if wl.cfg and not lib.msc_conv_cfg_ok(C.byref(wl), int(wl.cfg)):
+                wl.cfg = 0
+        elif wd is not None:
             # dout has exactly one writer, a data-gradient conv that ran earlier in this backward: its epilogue also
             # accumulates (sum dh, sum dh*y), so the column-reduce pass over dout and y is not launched
             wd.stats_kind, wd.stats_y, wd.stats_y_ld = 1, y.ptr, y.ld
@@ -925,6 +940,7 @@ class _Builder:
             d = self.conv(bwd, dy, wt, gx, KH=k, KW=k, stride=1, pad=geo['pad'], flip=1, res=gx if acc else None)
             if not acc:
                 self.gwriter[(id(x.buf), x.c0, x.C)] = d
+            self.glast[(id(x.buf), x.c0, x.C)] = d
         else:
             self.conv(bwd, dy, wt, gx, KH=k, KW=k, stride=2, pad=geo['pad'], mode=1, res=gx if acc else None)
 

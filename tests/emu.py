@@ -70,7 +70,14 @@ def conv_igemm(dref):
     if d.stats and d.stats_kind == 1:
         st = _arr(d.stats, SLOTS * Cout * 2, np.float64).reshape(SLOTS, Cout, 2)          # accumulated (caller zeroes): all into slot 0
         yy = _rows(d.stats_y, N * Ho * Wo, Cout, d.stats_y_ld).astype(np.float64)
-        dh = acc * (yy * _arr(d.scale, Cout) + _arr(d.shift, Cout) > 0) if d.scale else acc
+        if res is not None:              # ABI v6: the accumulating writer of a residual join's gradient, masked by the stored activation
+            assert d.stats_z and not d.scale
+            acc = acc + res
+            res = None
+        if d.stats_z:
+            dh = acc * (_rows(d.stats_z, N * Ho * Wo, Cout, d.stats_z_ld) > 0)
+        else:
+            dh = acc * (yy * _arr(d.scale, Cout) + _arr(d.shift, Cout) > 0) if d.scale else acc
         st[0, :, 0] += dh.sum(0)
         st[0, :, 1] += (dh * yy).sum(0)
         scale, shift = 1.0, 0.0          # the coefficients only define the mask

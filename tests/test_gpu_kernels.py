@@ -971,3 +971,53 @@ def test_stem_halo_kernel(dtype, n, hw):
     d = desc(58)
     d.in_ld = 8
     assert not lib.msc_conv_cfg_ok(C.byref(d), 58)
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('cin,cout,k,hw,n,with_res', [(256, 1024, 1, 16, 4, True), (64, 64, 3, 20, 2, True), (128, 64, 1, 16, 3, False), (64, 256, 1, 32, 2, True)])
+def test_conv_epilogue_batchnorm_backward_sums_of_a_residual_join(dtype, cin, cout, k, hw, n, with_res):
+    """stats_kind 1 with stats_z (ABI v6): the data-gradient conv that accumulates the last addend of a residual join's gradient stores
+    out = acc + res and reduces (sum dh, sum dh*y), dh = out * [z > 0] with z the block's (post-add, post-ReLU) output -- what
+    msc_bn_bwd_reduce (mask mode 1) would compute from the stored tensors; in place (res == out), every valid configuration"""
+    import ctypes as C
+    from mapping_challenge_amd import _lib
+    import hip_ops as ops
+    lib = _lib.load()
+    pad = k // 2
+    x = rnd((n, cin, hw, hw), dtype, 1)
+    w = rnd((cout, cin, k, k), dtype, 2, (2.0 / (cin * k * k)) ** 0.5)
+    y = rnd((n, cout, hw, hw), dtype, 3)
+    z = torch.relu(rnd((n, cout, hw, hw), dtype, 4))
+    g0 = rnd((n, cout, hw, hw), dtype, 5)
+    tot = F.conv2d(x, w, padding=pad) + (g0 if with_res else 0)
+    m = (z > 0).float()
+    e1, e2 = (tot * m).sum((0, 2, 3)), (tot * m * y).sum((0, 2, 3))
+    xd, yd, zd = nhwc(x, dtype), nhwc(y, dtype), nhwc(z, dtype)
+    wk = w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    out = torch.empty((n, hw, hw, cout), dtype=dtype, device='cuda')
+    stream = torch.cuda.current_stream().cuda_stream
+    tried = 0
+    for c in [0] + ops.conv_valid_cfgs(xd, wk, out, 1, pad):
+        d = ops.ConvDesc()
+        d.in_, d.wt, d.out = xd.data_ptr(), wk.data_ptr(), out.data_ptr()
+        d.in_ld, d.out_ld, d.dtype, d.mode = cin, cout, ops._dt(xd), 0
+        d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.cfg = n, hw, hw, cin, hw, hw, cout, k, k, 1, pad, c
+        d.stats_kind, d.stats_y, d.stats_y_ld, d.stats_z, d.stats_z_ld = 1, yd.data_ptr(), cout, zd.data_ptr(), cout
+        stats = torch.zeros((_lib.BN_SLOTS, cout, 2), dtype=torch.float64, device='cuda')
+        d.stats = stats.data_ptr()
+        if c and not lib.msc_conv_cfg_ok(C.byref(d), c):
+            continue
+        tried += 1
+        out.copy_(nhwc(g0, dtype))
+        if with_res:
+            d.res, d.res_ld = out.data_ptr(), cout          # accumulate in place, as the engine does
+        _lib.check(lib.msc_conv_igemm(C.byref(d), stream), 'conv')
+        assert torch.allclose(to_nchw(out), tot, **tol(dtype)), c
+        s = stats.sum(0).float().cpu()
+        t = dict(rtol=2e-3, atol=5e-2) if dtype == torch.float32 else dict(rtol=2e-2, atol=0.7)
+        assert torch.allclose(s[:, 0], e1, **t) and torch.allclose(s[:, 1], e2, **t), c
+    assert tried >= 2
+    # a residual without stats_z, or stats_z together with coefficients, is refused
+    d.stats_z = None
+    d.res, d.res_ld = out.data_ptr(), cout
+    assert lib.msc_conv_igemm(C.byref(d), stream) != 0
