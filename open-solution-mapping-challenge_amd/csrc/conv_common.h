@@ -113,6 +113,25 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvK& p, f32x4 (&acc)[
 #pragma unroll
             for (int j = 0; j < NV; j += CE) pre[PRE ? b : 0][PRE ? j / CE : 0] = *reinterpret_cast<const uint4*>(side + opixs[b] * side_ld + cb + j);
     }
+    // KIND 1 at a residual join reads two more tensors (the addend and the mask's activation): requested up front as well -- fetched
+    // fragment by fragment inside the loop they were FN dependent round trips to HBM at the end of every block (+8-16 us per launch)
+    constexpr bool JOIN = KIND == 1 && FM * FN <= 16;      // the residual-join form (sz / res) is compiled for wave tiles of up to 16 fragments (msc_conv_cfg_ok)
+    constexpr bool PRE2 = JOIN && PRE;
+    uint4 prez[PRE2 ? FN : 1][PRE2 ? NV / CE : 1], prer[PRE2 ? FN : 1][PRE2 ? NV / CE : 1];
+    if (PRE2 && p.sz) {
+        const T* sz = reinterpret_cast<const T*>(p.sz);
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+            for (int j = 0; j < NV; j += CE) prez[PRE2 ? b : 0][PRE2 ? j / CE : 0] = *reinterpret_cast<const uint4*>(sz + opixs[b] * p.sz_ld + cb + j);
+    }
+    if (PRE2 && p.res) {
+        const T* res = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+            for (int j = 0; j < NV; j += CE) prer[PRE2 ? b : 0][PRE2 ? j / CE : 0] = *reinterpret_cast<const uint4*>(res + opixs[b] * p.res_ld + cb + j);
+    }
 #pragma unroll
     for (int b = 0; b < FN; ++b) {
         const int m = PATCH ? m0 + (wp * FN + b) * p.Wo + pl : m0 + wp * WTP + b * 16 + pl;
@@ -132,13 +151,14 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvK& p, f32x4 (&acc)[
                 if (PRE) Vec16<T>::unpack(pre[PRE ? b : 0][PRE ? j / CE : 0], yv + j);
                 else Vec16<T>::load(side + opixs[b] * side_ld + cb + j, yv + j);
             }
-            if (KIND == 1 && p.res) {              // the accumulating writer of a gradient: out = acc + res, reduced and stored
+            if (JOIN && p.res) {                   // the accumulating writer of a gradient: out = acc + res, reduced and stored
                 asm volatile("" ::: "memory");
                 const T* res = reinterpret_cast<const T*>(p.res);
 #pragma unroll
                 for (int j = 0; j < NV; j += CE) {
                     float rv[CE];
-                    Vec16<T>::load(res + opixs[b] * p.res_ld + cb + j, rv);
+                    if (PRE2) Vec16<T>::unpack(prer[PRE2 ? b : 0][PRE2 ? j / CE : 0], rv);
+                    else Vec16<T>::load(res + opixs[b] * p.res_ld + cb + j, rv);
 #pragma unroll
                     for (int e = 0; e < CE; ++e) v[j + e] += m < p.M ? rv[e] : 0.f;      // rows past the end stay zero (they are summed, not stored)
                 }
@@ -149,13 +169,14 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvK& p, f32x4 (&acc)[
                     v[j] = yv[j] > 0.f ? v[j] : 0.f;
                     s1[j] += v[j];
                 }
-            } else if (p.sz) {
+            } else if (JOIN && p.sz) {
                 asm volatile("" ::: "memory");
                 const T* sz = reinterpret_cast<const T*>(p.sz);
 #pragma unroll
                 for (int j = 0; j < NV; j += CE) {
                     float zv[CE];
-                    Vec16<T>::load(sz + opixs[b] * p.sz_ld + cb + j, zv);
+                    if (PRE2) Vec16<T>::unpack(prez[PRE2 ? b : 0][PRE2 ? j / CE : 0], zv);
+                    else Vec16<T>::load(sz + opixs[b] * p.sz_ld + cb + j, zv);
 #pragma unroll
                     for (int e = 0; e < CE; ++e) {
                         const float dh = zv[e] > 0.f ? v[j + e] : 0.f;

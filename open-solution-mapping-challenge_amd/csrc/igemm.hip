@@ -1245,6 +1245,7 @@ int launch_halo3(const ConvK& k0, hipStream_t st) {
 bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
     if (cfg < 1 || cfg > N_CONV_CFG) return false;
     if (k.fin_w && cfg != CFG_HALO) return false;           // the fused final 1x1 lives in the 32-channel halo kernel's epilogue only
+    if (k.sz && cfg >= 29 && cfg <= 32) return false;       // the residual-join epilogue (stats_z) is not compiled for the 32-fragment wave tiles
     if (k.ksplit > 1 && (cfg == CFG_HALO || cfg == CFG_HALO_T || cfg == CFG_STREAM || cfg == CFG_STEM || cfg_is_halo3(cfg))) return false;      // split-K: the implicit-GEMM kernel only
     if (cfg == CFG_STREAM) return conv1x1_cfg_ok(k, es);
     if (cfg == CFG_STEM)
