@@ -38,8 +38,14 @@ PRETRAINED_NETWORKS = {
 }
 
 
-_HOST_INTERPRETER = False     # tests only: build programs on the CPU for tests/emu.py (there is still no CPU compute path)
 
+
+
+def _compute_device():
+    """the device the transformers compute on: the current ROCm GPU -- the product has no CPU path"""
+    if not torch.cuda.is_available():
+        raise _lib.MscError('HIP transformers need a ROCm GPU: the product has no CPU path')
+    return torch.device('cuda', torch.cuda.current_device())
 
 class _ModuleView(torch.nn.Module):
     """What the callbacks get as `transformer.model`: the reference hands them the nn.DataParallel wrapper
@@ -114,15 +120,9 @@ class BasePyTorchUNet(BaseTransformer):
         self.model = config.pop('model', UNetResNet)(compute_dtype=dtype, **config)
         if params.get('encoder_weights'):            # local torchvision checkpoint standing in for the model-zoo download
             self.model.load_encoder_state_dict(params['encoder_weights'])
-        if _HOST_INTERPRETER:
-            self.model._host_interpreter = True
 
     def _device(self):
-        if _HOST_INTERPRETER:
-            return torch.device('cpu')
-        if not torch.cuda.is_available():
-            raise _lib.MscError('HIP transformers need a ROCm GPU: the product has no CPU path')
-        return torch.device('cuda', torch.cuda.current_device())
+        return _compute_device()
 
     def fit(self, datagen, validation_datagen=None, meta_valid=None):
         """src/models.py:62-86: the callback-driven epoch / batch loop around `_fit_loop`; nn.DataParallel is replaced by

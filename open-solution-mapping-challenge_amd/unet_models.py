@@ -457,9 +457,7 @@ class UNetResNet(nn.Module):
 
     # ------------------------------------------------------------------ execution
     def _run_forward(self, x, training):
-        if not x.is_cuda and not getattr(self, '_host_interpreter', False):
-            # tests/emu.py sets _host_interpreter and swaps _Program.run to check the HOST logic without a GPU
-            raise _lib.MscError('UNetResNet (HIP) needs a CUDA/ROCm tensor; there is no CPU path in the product')
+        _require_device(x)
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError('expected input of shape [N,3,H,W], got %s' % (tuple(x.shape),))
         if x.shape[2] % 64 or x.shape[3] % 64:
@@ -571,6 +569,12 @@ def _grad_views(self):
 
 UNetResNet.flat_views = _flat_views
 UNetResNet._grad_views = _grad_views
+
+
+def _require_device(x):
+    """the product computes on the GPU only: a host tensor is an error, not a fallback"""
+    if not x.is_cuda:
+        raise _lib.MscError('UNetResNet (HIP) needs a CUDA/ROCm tensor; there is no CPU path in the product')
 
 
 # ----------------------------------------------------------------------------- program builder

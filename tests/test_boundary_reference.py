@@ -21,8 +21,7 @@ needs_ref = pytest.mark.skipif(not ref_import.available(), reason='/root/referen
 
 @pytest.fixture()
 def interpreted(monkeypatch):
-    monkeypatch.setattr(um._Program, 'run', staticmethod(emu.run))
-    monkeypatch.setattr(hip_models, '_HOST_INTERPRETER', True)
+    emu.install(monkeypatch.setattr, models=True)
 
 
 def configs(tmp_path, encoder='ResNet34', epochs=3, patience=0):
@@ -205,7 +204,6 @@ def test_train_step_keeps_state_per_batch_shape(interpreted):
     from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
     net = um.UNetResNet(34, 2, num_filters=32, dropout_2d=0.0, is_deconv=True, compute_dtype='fp32')
     net.load_state_dict(unet_ref.seeded_state_dict(unet_ref.UNetResNetRef(34)))
-    net._host_interpreter = True
     net.flatten_parameters('cpu')
     net.train()
     step = TrainStep(net, LossSpec.plain_ce(), HipAdam(net, lr=1e-3))

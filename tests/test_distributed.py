@@ -95,7 +95,7 @@ def _engine_worker(rank, world_size, port, q, wire='fp32'):
     from mapping_challenge_amd.distributed import World, wire_for
     from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
     from oracle import unet_ref, losses_ref
-    um._Program.run = staticmethod(emu.run)
+    emu.install()
     world = World.from_env(backend='gloo')
     assert world.grad_wire == 'fp32'                # the constructor's default ...
     if wire != 'fp32':
@@ -107,7 +107,6 @@ def _engine_worker(rank, world_size, port, q, wire='fp32'):
     lo, hi = world.shard(n)
     net = um.UNetResNet(34, 2, num_filters=32, dropout_2d=0.0, is_deconv=True, compute_dtype='fp32')
     net.load_state_dict(unet_ref.seeded_state_dict(unet_ref.UNetResNetRef(34)))
-    net._host_interpreter = True
     net.flatten_parameters('cpu')
     net.train()
     prog = net.train_forward(x[lo:hi])
@@ -196,8 +195,7 @@ def _fit_worker(rank, world_size, port, q, tmp):
     from mapping_challenge_amd import models as hip_models
     from mapping_challenge_amd.distributed import World
     from oracle import unet_ref, losses_ref
-    um._Program.run = staticmethod(emu.run)
-    hip_models._HOST_INTERPRETER = True
+    emu.install(models=True)
     World.from_env(backend='gloo')
     ckpt = os.path.join(tmp, 'checkpoints', 'best.torch')
     arch = {'model_params': {'encoder': 'ResNet34', 'compute_dtype': 'fp32'}, 'optimizer_params': {'lr': 5e-4},

@@ -11,7 +11,7 @@ from oracle import unet_ref, losses_ref
 
 @pytest.fixture()
 def interpreted(monkeypatch):
-    monkeypatch.setattr(um._Program, 'run', staticmethod(emu.run))
+    emu.install(monkeypatch.setattr)
 
 
 def build(depth):
@@ -20,7 +20,6 @@ def build(depth):
     ref.load_state_dict(sd)
     net = um.UNetResNet(depth, 2, num_filters=32, dropout_2d=0.0, is_deconv=True, compute_dtype='fp32')
     net.load_state_dict({'module.' + k: v for k, v in sd.items()})      # DataParallel-prefixed, like reference checkpoints
-    net._host_interpreter = True
     net.flatten_parameters('cpu')
     return ref, net
 
@@ -62,7 +61,7 @@ def test_state_dict_roundtrip_and_flat_views(interpreted):
     assert not any(n.startswith('encoder.fc') for n, _ in net._trainable())
 
 
-def test_rejects_unsupported_configurations():
+def test_rejects_unsupported_configurations(monkeypatch):
     with pytest.raises(NotImplementedError):
         um.UNetResNet(50, 2, is_deconv=True, dropout_2d=0.0)
     with pytest.raises(NotImplementedError):
@@ -70,7 +69,7 @@ def test_rejects_unsupported_configurations():
     net = um.UNetResNet(34, 2, is_deconv=True, dropout_2d=0.0)
     with pytest.raises(Exception, match='no CPU path'):
         net(torch.zeros(1, 3, 64, 64))
-    net._host_interpreter = True
+    monkeypatch.setattr(um, '_require_device', lambda x: None)
     with pytest.raises(ValueError, match='divisible by 64'):
         net.eval()(torch.zeros(1, 3, 300, 300))       # 300x300 is not a legal network input
 
