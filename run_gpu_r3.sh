@@ -44,7 +44,7 @@ deconv) timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -k 'transpo
 join) timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_unet.py -q -x -k 'residual_join or batchnorm_backward or train or backward or gradient or graph or every_kernel' > gpurun_out/join.log 2>&1; grep -E 'passed|failed' gpurun_out/join.log | tail -1; grep -E '^FAILED|Error' gpurun_out/join.log | head; for v in 1 0 1 0; do MSC_FUSE_JOIN_BWD=$v timeout 600 python bench.py --steps 100 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); f=d['roofline']['family_ms_per_step']; print('join fuse $v:', round(d['ms_per_step'],3), 'conv', f['msc_conv_igemm'], 'reduce', f['msc_bn_bwd_reduce'])"; done;;
 stem) timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -k 'stem_halo' 2>&1 | tail -3; for nb in 0 256 512 1024; do MSC_STEM_BLOCKS=$nb MSC_TUNE_DB=0 MSC_TUNE_CACHE=/tmp/t_$nb.json timeout 300 python bench.py --workload infer --encoder 101 --steps 30 --no-cpu-baseline --dump-launches gpurun_out/l_$nb.json > /dev/null 2>&1; python -c "import json; d=json.load(open('gpurun_out/l_$nb.json')); print('stem blocks $nb:', [round(x['us'],1) for x in d if x['k']=='conv' and x['KH']==7], round(sum(x['us'] for x in d),1))"; done;;
 c32) timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -k '32_channel or fused_final or relu_backward or every_kernel' 2>&1 | tail -3; for nb in 0 512 1024 2048; do MSC_C32_BLOCKS=$nb timeout 300 python bench.py --workload infer --encoder 101 --steps 30 --no-cpu-baseline --dump-launches gpurun_out/l_$nb.json > /dev/null 2>&1; python -c "import json; d=json.load(open('gpurun_out/l_$nb.json')); print('c32 blocks $nb:', [round(x['us'],1) for x in d if x['k']=='conv' and x['Cin']==32 and x['Cout']==32], round(sum(x['us'] for x in d),1))"; done;;
-stream) timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k 'streaming' 2>&1 | tail -3; for l in 1 0; do for m in fwd eval; do echo LST=$l; MSC_STREAM_LST=$l MODE=$m timeout 300 python tools/conv1x1_probe.py 2>&1 | grep -v amdgpu.ids | tail -12; done; done;;
+stream) timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k 'streaming' 2>&1 | tail -3; for m in fwd eval dgrad; do MODE=$m timeout 300 python tools/conv1x1_probe.py 2>&1 | grep -v amdgpu.ids | tail -12; done;;
 smoke)  timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 gpurun_out/smoke.log;;
 esac
 done
