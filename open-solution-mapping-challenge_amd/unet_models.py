@@ -840,6 +840,28 @@ class _Builder:
             self._tuned_new = True
         d.cfg = cache[key]
 
+    def tune_join(self, d):
+        """the configuration of a data-gradient conv that carries a residual join's reductions (stats_kind 1 with stats_z): its epilogue
+        reads three more tensors than the launch tune_conv timed, which shifts the best tile towards more, smaller blocks"""
+        if not self.net.autotune or self.dev.type != 'cuda' or _os_env.environ.get('MSC_TUNE_JOIN', '1') == '0':
+            return
+        key = repr(('j', self.tune_dt, d.N, d.Hi, d.Wi, d.Cin, d.Cout, d.KH, d.KW, bool(d.res), d.in_ld, d.out_ld))
+        cache, lib = _TUNE_CACHE, self.lib
+        if key not in cache or (cache[key] and not lib.msc_conv_cfg_ok(C.byref(d), int(cache[key]))):
+            best, best_t, keep = 0, 1e30, d.cfg
+            for c in range(1, lib.msc_conv_num_cfgs() + 1):
+                if not lib.msc_conv_cfg_ok(C.byref(d), c):
+                    continue
+                d.cfg = c
+                t = self._time(lib.msc_conv_igemm, C.byref(d))      # (the slots and the gradient buffer it adds into are reset by the step itself)
+                if t is not None and t < best_t:
+                    best, best_t = c, t
+            d.cfg = keep
+            cache[key] = best
+            self._tuned_new = True
+        if cache[key]:
+            d.cfg = cache[key]
+
     def tune_wgrad(self, d):
         if not self.net.autotune or self.dev.type != 'cuda':
             return
@@ -908,6 +930,7 @@ class _Builder:
             wl.stats_kind, wl.stats_y, wl.stats_y_ld = 1, y.ptr, y.ld
             wl.stats_z, wl.stats_z_ld = out.ptr, out.ld
             wl.stats = bslots
+            self.tune_join(wl)
             if wl.cfg and not lib.msc_conv_cfg_ok(C.byref(wl), int(wl.cfg)):
                 wl.cfg = 0
         elif wd is not None:
