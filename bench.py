@@ -478,7 +478,8 @@ def main():
                 traffic = json.load(open(pmc_file)).get('hbm_bytes_per_launch')
             result['roofline'] = {
                 'kernel': ('msc_conv_igemm family: conv3x3_halo_dma_kernel (3x3 stride-1 layers) + conv_igemm_dma_kernel (1x1, strided, transposed) '
-                           '+ the two 32-channel halo kernels%s; conv / dgrad / deconv, %d launches per step, per-layer autotuned configuration'
+                           '+ the 32-channel / stem halo kernels + conv1x1_stream_kernel%s; conv / dgrad / deconv, %d launches per step, per-layer autotuned configuration; '
+                           'the time includes the BatchNorm statistics, residual-join reductions and ReLU-backward / bias sums their epilogues carry'
                            % ((' + bottleneck_fused_kernel (%d eval-mode identity Bottlenecks, one launch each: %.3f ms, %.0f TFLOP/s)'
                                % (round(fused['launches']), fused['ms'], fused['flops'] / (fused['ms'] * 1e-3) / 1e12)) if fused else '',
                               round(conv['launches']))),
