@@ -13,12 +13,14 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------ 1x1, streaming
 // The 1x1 / stride 1 layers of layer1 and layer2 (64 <-> 256 channels on 131 072 pixels, 128 <-> 512 on 32 768; forward and data
-// gradient) are pure streams: 84 MB in + out for 4.3 GFLOP.  The implicit-GEMM kernel runs them at 2.4 TB/s -- one or two k-steps
-// per block, so a block is a prologue (address set-up, first fill from HBM), one MFMA burst and an epilogue, nothing of which
-// overlaps within the block (probes/conv_ablate.hip: 26-30 of 30-34 us remain with the main loop ablated).  Here a block is
-// persistent: the wave's slice of the weight matrix stays in registers as MFMA fragments for the whole launch, the pixel tiles
-// ([TP][Cin], the whole reduction in one stage) stream through two LDS buffers by DMA (tile t+1 in flight while tile t is multiplied
-// and stored), the BatchNorm sums are carried in registers across the tiles and folded once per block.
+// gradient) are pure streams: 84 MB in + out for 4.3 GFLOP.  As tiles of the implicit-GEMM kernel they are one or two k-steps per
+// block -- a prologue (address set-up, first fill from HBM), one MFMA burst and an epilogue, nothing of which overlaps within the
+// block: 2.4 TB/s before the epilogue was rewritten (its 21 VALU instructions per output element were the bound),
+// 3.2 TB/s after.  Here a block is persistent: the wave's slice of the weight matrix stays in registers as MFMA fragments for the
+// whole launch, the pixel tiles ([TP][Cin], the whole reduction in one stage) stream through two LDS buffers by DMA (tile t+1 in
+// flight while tile t is multiplied and stored), the BatchNorm sums are carried in registers across the tiles and folded once per
+// block: 3.8 TB/s on the 64 -> 256 forward layers (22 us against 26.6), where the per-layer timing picks it; the implicit-GEMM tiles
+// stay ahead on the layers with longer reductions (256 -> 64: 17.6 us against 24.7).
 //   waves: WC along the channels (FM fragments of 16 each) x WP along the pixels of the tile
 //   LDS image: a row = a pixel's Cin*2 bytes; 16-byte chunks permuted on the source side (128-byte rows as KB = 128 above, longer rows
 //   within each 256-byte window as KB = 256) so the fragment reads of 16 consecutive pixels hit distinct banks
