@@ -191,11 +191,26 @@ def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, step, gscale, state):
         st = _arr(state, 2)
         step, lr = float(st[0]), float(st[1])
     pp, gg, mm, vv = _arr(p, n), _arr(g, n), _arr(m, n), _arr(v, n)
-    gr = gg * np.float32(gscale) + np.float32(wd) * pp
-    mm[...] = b1 * mm + (1 - b1) * gr
-    vv[...] = b2 * vv + (1 - b2) * gr * gr
+    # same operations and rounding points as the kernel, with two scratch arrays instead of a dozen temporaries (the flat buffers are
+    # 20-80 M elements: the allocations, not the arithmetic, were what this function spent its time on)
+    f = np.float32
+    gr = gg * f(gscale)
+    tmp = pp * f(wd)
+    gr += tmp
+    mm *= f(b1)
+    np.multiply(gr, f(1 - b1), out=tmp)
+    mm += tmp
+    vv *= f(b2)
+    np.multiply(gr, f(1 - b2), out=tmp)
+    tmp *= gr
+    vv += tmp
     bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
-    pp[...] = pp - (lr / bc1) * (mm / (np.sqrt(vv) / np.sqrt(bc2) + eps))
+    np.sqrt(vv, out=tmp)
+    tmp /= f(np.sqrt(bc2))
+    tmp += f(eps)
+    np.divide(mm, tmp, out=gr)
+    gr *= f(lr / bc1)
+    pp -= gr
 
 
 def pack_transpose(src, dst, dtype, A, T, B):
