@@ -58,6 +58,23 @@ def test_conv_descriptor_validation_is_host_side():
     # stem form: 4-element pixels are fine when every addressed pixel start stays 16-byte aligned
     ok = _desc(in_ld=4, Cin=32, KH=7, KW=1, stride=2, pad=0, Hi=22, Wi=24, Ho=8, Wo=8)
     assert lib.msc_conv_stats_slices(C.byref(ok)) > 0
+    assert lib.msc_conv_cfg_ok(C.byref(_desc(in_ld=4, Cin=32, KH=7, KW=1, stride=2, pad=0, Hi=38, Wi=40, Ho=16, Wo=16)), 58)      # the stem's halo kernel
+    assert not lib.msc_conv_cfg_ok(C.byref(ok), 58)                                    # ... needs 8 x 16 output patches
+    # more than 2^24 output pixels (or 2 GiB of input) per call run as image ranges inside msc_conv_igemm: the descriptor is valid;
+    # a single image beyond 2^24 pixels is not
+    big = _desc(N=80, Hi=512, Wi=512, Ho=512, Wo=512, KH=1, KW=1, pad=0)
+    assert lib.msc_conv_stats_slices(C.byref(big)) > 0 and lib.msc_conv_cfg_ok(C.byref(big), 57)      # 1x1 / stride 1: the streaming kernel applies
+    huge = _desc(N=1, Hi=4096, Wi=4100, Ho=4096, Wo=4100, KH=1, KW=1, pad=0)
+    assert lib.msc_conv_stats_slices(C.byref(huge)) == -1
+    # ABI v6: BatchNorm-backward sums of a residual join -- a residual needs stats_z for the mask, stats_z excludes the coefficients
+    import ctypes
+    y = (ctypes.c_char * 65536)()
+    base = ctypes.addressof(y) + (-ctypes.addressof(y)) % 16
+    join = dict(KH=1, KW=1, pad=0, stats=base, stats_kind=1, stats_y=base, stats_y_ld=64)
+    assert lib.msc_conv_stats_slices(C.byref(_desc(res=base, res_ld=64, stats_z=base, stats_z_ld=64, **join))) > 0
+    assert lib.msc_conv_stats_slices(C.byref(_desc(res=base, res_ld=64, **join))) == -1
+    assert lib.msc_conv_stats_slices(C.byref(_desc(stats_z=base, stats_z_ld=64, scale=base, shift=base, **join))) == -1
+    assert not lib.msc_conv_cfg_ok(C.byref(_desc(stats_z=base, stats_z_ld=64, Cout=128, **join)), 30)      # 32-fragment wave tiles do not carry it
 
 
 def test_postprocessing_argument_errors():
