@@ -456,7 +456,7 @@ def main():
         value = batch * world.size * args.steps / dt
         result.update(value=value, ms_per_step=1e3 * dt / args.steps)
         if world.rank == 0 and not args.no_breakdown:
-            launches = list(prog.fwd) + (list(prog.bwd) if args.workload == 'train' else [])
+            launches = list(prog.fwd) + (list(prog.bwd) + list(step.opt.launches()) if args.workload == 'train' else [])
             if args.workload == 'train':
                 net._flat[1].zero_()
             fam = family_times(launches, stream)

@@ -261,15 +261,47 @@ typedef struct msc_loss_cfg {
 int msc_loss_sums(const float* logits, const float* target, int tc, const msc_loss_cfg* cfg, double* sums,
                   int N, int H, int W, void* stream);
 int msc_loss_grad(const float* logits, const float* target, int tc, const msc_loss_cfg* cfg, const double* sums,
-                  double total_pixels, float grad_scale, float* loss, float* dlogits, int N, int H, int W, void* stream);
+                  double total_pixels, float grad_scale, const float* scale_state, float* loss, float* dlogits, int N, int H, int W,
+                  void* stream);
+/* scale_state (device, may be NULL; ABI v7): the optimizer state below -- dlogits are additionally multiplied by its dynamic loss
+ * scale state[MSC_OPT_SCALE] (> 0), read on the device so that a captured hipGraph replays with the current scale. */
+
+/* Optimizer state in device memory, f32[MSC_OPT_STATE] (ABI v7; was {step, lr}): what a captured step must read at REPLAY time.
+ *   STEP      Adam's step count (bias corrections)            LR       learning rate
+ *   OVERFLOW  raised by msc_grad_check when a gradient element is not finite
+ *   SKIP      set by msc_adam_tick for the current step: msc_adam_step / msc_adam_pack leave p, m, v untouched
+ *   SCALE     loss scale: msc_loss_grad multiplies by it, the Adam kernels divide the gradient by it (0: no scaling)
+ *   GOOD / GROWTH  clean steps since the last change of SCALE / clean steps after which SCALE doubles (0: static scale)
+ *   SKIPPED   number of skipped steps so far
+ * msc_adam_tick: OVERFLOW set -> SKIP = 1, SCALE halves (not below 1), STEP unchanged; else SKIP = 0, STEP += 1, GOOD counted.
+ * Replaces the reference's plain optimizer.step() (src/steps/pytorch/models.py:111), which has no 16-bit mode to protect. */
+enum { MSC_OPT_STEP = 0, MSC_OPT_LR = 1, MSC_OPT_OVERFLOW = 2, MSC_OPT_SKIP = 3, MSC_OPT_SCALE = 4, MSC_OPT_GOOD = 5, MSC_OPT_GROWTH = 6,
+       MSC_OPT_SKIPPED = 7, MSC_OPT_STATE = 8 };
 
 /* Adam with L2 folded into the gradient (torch.optim.Adam(weight_decay), src/models.py:57,287-292) over one flat
- * fp32 parameter buffer. */
+ * fp32 parameter buffer.  `state` (device f32[MSC_OPT_STATE], may be NULL): when given it overrides `step` and `lr`, divides
+ * grad_scale by its loss scale and makes a skipped step a no-op. */
 int msc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, float grad_scale, const float* state, void* stream);
-/* `state` (device f32[2] = {step count, learning rate}, may be NULL): when given it overrides `step` and `lr`, so a
- * captured hipGraph replays with the bias corrections of the current iteration; msc_adam_tick does state[0] += 1. */
 int msc_adam_tick(float* state, void* stream);
+/* state[MSC_OPT_OVERFLOW] = 1 if any of g[0..n) is NaN or +-inf (launched between the backward / gradient exchange and
+ * msc_adam_tick in the fp16 mode) */
+int msc_grad_check(const float* g, int64_t n, float* state, void* stream);
+/* The same update over a TABLE of tensors inside the flat buffers that ALSO writes the compute copies of the weights (ABI v7): the
+ * conv weights' 16-bit copy in their own layout (`direct`) and the [B][T][A] transpose of the [A][T][B] master (`trans`; the
+ * data-gradient / ConvTranspose2d operand) leave the kernel that has the updated fp32 values in registers -- msc_pack_multi after
+ * the optimizer re-read every master (602 MB per ResNet101 step).  Block b handles items[block_item[b]], piece block_local[b]:
+ * without `trans` 2048 consecutive elements, with it one 64x32 (A x B) tile of tap t, local index = (t*ceil(A/64) + a_tile)*
+ * ceil(B/32) + b_tile, B % 4 == 0.  `off` (elements, multiple of 4) locates the tensor in p / g / m / v; tables in device memory. */
+typedef struct msc_adam_item {
+    int64_t off, n;
+    void* direct;
+    void* trans;
+    int32_t A, T, B, reserved;
+} msc_adam_item;
+int msc_adam_pack(float* p, const float* g, float* m, float* v, const msc_adam_item* items, const int32_t* block_item,
+                  const int32_t* block_local, int nblocks, int dtype, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, float grad_scale, const float* state, void* stream);
 
 /* ---------------------------------------------------------------- mask post-processing --------
  * Batched over B images; each replaces a per-image Python/scipy/skimage loop of src/postprocessing.py. */

@@ -56,6 +56,9 @@ class BiasSlotsItem(C.Structure):         # == msc_bias_slots_item
 
 BIAS_SLOTS_MAX = 16
 
+# optimizer state in device memory (include/msc.h, ABI v7): f32[OPT_STATE]
+OPT_STEP, OPT_LR, OPT_OVERFLOW, OPT_SKIP, OPT_SCALE, OPT_GOOD, OPT_GROWTH, OPT_SKIPPED, OPT_STATE = range(9)
+
 
 class LossCfg(C.Structure):
     _fields_ = [('w0', C.c_float), ('sigma', C.c_float), ('size_c', C.c_float),
@@ -109,9 +112,11 @@ SIGNATURES = {
     'msc_bias_slots_finalize_multi': (_i, [C.POINTER(BiasSlotsItem), _i, _vp]),
     'msc_final_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'msc_loss_sums': (_i, [_vp, _vp, _i, C.POINTER(LossCfg), _vp, _i, _i, _i, _vp]),
-    'msc_loss_grad': (_i, [_vp, _vp, _i, C.POINTER(LossCfg), _vp, _d, _f, _vp, _vp, _i, _i, _i, _vp]),
+    'msc_loss_grad': (_i, [_vp, _vp, _i, C.POINTER(LossCfg), _vp, _d, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'msc_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
     'msc_adam_tick': (_i, [_vp, _vp]),
+    'msc_grad_check': (_i, [_vp, _i64, _vp, _vp]),
+    'msc_adam_pack': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
     'msc_resize_bilinear': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'msc_crop_center': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'msc_threshold_layers': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),

@@ -458,19 +458,67 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------ Adam (+L2), torch.optim.Adam semantics
-// `state` (device, optional) = [step count, learning rate]: lets a captured hipGraph replay the step with the
-// bias corrections / lr of the CURRENT iteration (msc_adam_tick advances it inside the graph).
-__global__ void adam_tick_kernel(float* state) { state[0] += 1.f; }
+// `state` (device f32[MSC_OPT_STATE], optional; include/msc.h) = step count, learning rate and the dynamic loss scale: lets a
+// captured hipGraph replay the step with the bias corrections / lr / scale of the CURRENT iteration.  msc_adam_tick advances it
+// inside the graph: a step whose gradients msc_grad_check found non-finite is SKIPPED (no parameter, moment or step-count
+// change) and halves the scale; `growth` clean steps in a row double it (torch.cuda.amp.GradScaler's rule).
+__global__ void adam_tick_kernel(float* state) {
+    if (state[MSC_OPT_OVERFLOW] != 0.f) {
+        state[MSC_OPT_OVERFLOW] = 0.f;
+        state[MSC_OPT_SKIP] = 1.f;
+        state[MSC_OPT_SKIPPED] += 1.f;
+        state[MSC_OPT_GOOD] = 0.f;
+        if (state[MSC_OPT_SCALE] > 1.f) state[MSC_OPT_SCALE] *= 0.5f;
+    } else {
+        state[MSC_OPT_SKIP] = 0.f;
+        state[MSC_OPT_STEP] += 1.f;
+        if (state[MSC_OPT_GROWTH] > 0.f && (state[MSC_OPT_GOOD] += 1.f) >= state[MSC_OPT_GROWTH]) {
+            state[MSC_OPT_GOOD] = 0.f;
+            if (state[MSC_OPT_SCALE] > 0.f && state[MSC_OPT_SCALE] < 16777216.f) state[MSC_OPT_SCALE] *= 2.f;
+        }
+    }
+}
+
+// any non-finite gradient element raises the overflow flag (every writer stores the same value: no atomics needed)
+__global__ void grad_check_kernel(const float* __restrict__ g, long n, float* __restrict__ state) {
+    const long n4 = n / 4;
+    bool bad = false;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 G = reinterpret_cast<const float4*>(g)[i];
+        // x - x is 0 for finite x and NaN for +-inf / NaN: one test per vector
+        const float t = (G.x - G.x) + (G.y - G.y) + (G.z - G.z) + (G.w - G.w);
+        bad |= !(t == 0.f);
+    }
+    for (long i = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) bad |= !((g[i] - g[i]) == 0.f);
+    if (bad) state[MSC_OPT_OVERFLOW] = 1.f;
+}
+
+struct AdamC { float lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale; };
+
+// false: this step is skipped (overflow)
+__device__ __forceinline__ bool adam_coeffs(AdamC& c, const float* __restrict__ state) {
+    if (state) {
+        if (state[MSC_OPT_SKIP] != 0.f) return false;
+        const float step = state[MSC_OPT_STEP];
+        c.lr = state[MSC_OPT_LR];
+        c.bc1 = 1.f - powf(c.b1, step);
+        c.bc2_sqrt = sqrtf(1.f - powf(c.b2, step));
+        if (state[MSC_OPT_SCALE] > 0.f) c.gscale /= state[MSC_OPT_SCALE];
+    }
+    return true;
+}
+
+__device__ __forceinline__ void adam_update(const AdamC& c, float& p, float g, float& m, float& v) {
+    const float gr = g * c.gscale + c.wd * p;
+    m = c.b1 * m + (1.f - c.b1) * gr;
+    v = c.b2 * v + (1.f - c.b2) * gr * gr;
+    const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+    p -= (c.lr / c.bc1) * (m / denom);
+}
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
-                            float bc1, float bc2_sqrt, float gscale, const float* __restrict__ state) {
-    if (state) {
-        const float step = state[0];
-        lr = state[1];
-        bc1 = 1.f - powf(b1, step);
-        bc2_sqrt = sqrtf(1.f - powf(b2, step));
-    }
+                            float* __restrict__ v, long n, AdamC c, const float* __restrict__ state) {
+    if (!adam_coeffs(c, state)) return;
     const long n4 = n / 4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 P = reinterpret_cast<float4*>(p)[i];
@@ -480,24 +528,102 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x, G.y, G.z, G.w};
         float mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {V.x, V.y, V.z, V.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float gr = gg[e] * gscale + wd * pp[e];
-            mm[e] = b1 * mm[e] + (1.f - b1) * gr;
-            vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
-            const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
-            pp[e] -= (lr / bc1) * (mm[e] / denom);
-        }
+        for (int e = 0; e < 4; ++e) adam_update(c, pp[e], gg[e], mm[e], vv[e]);
         reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
         reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
         reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
     }
     // tail
     for (long i = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float gr = g[i] * gscale + wd * p[i];
-        const float mm = b1 * m[i] + (1.f - b1) * gr;
-        const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
-        m[i] = mm; v[i] = vv;
-        p[i] -= (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+        float pp = p[i], mm = m[i], vv = v[i];
+        adam_update(c, pp, g[i], mm, vv);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+// Adam over a TABLE of tensors that also writes the 16-bit compute copies the convolutions read (msc_adam_pack): the separate
+// msc_pack_multi pass re-read 602 MB of fp32 masters per step that this kernel has in registers.  Block b works on
+// items[block_item[b]], piece block_local[b]:
+//   item without `trans`: 2048 consecutive elements (8 per thread), optional `direct` copy in the tensor's own layout;
+//   item with `trans`   : one 64 (a) x 32 (b) tile of tap t of the [A][T][B] master (local index as msc_pack_multi: (t*ceil(A/64) +
+//                         a_tile)*ceil(B/32) + b_tile), B % 4 == 0: 128-byte row segments of p / g / m / v, the `direct` copy from
+//                         registers, the [B][T][A] copy through an LDS transpose (128-byte segments along a).
+template <typename T>
+__global__ __launch_bounds__(256) void adam_pack_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, const msc_adam_item* __restrict__ items,
+                                                        const int32_t* __restrict__ block_item, const int32_t* __restrict__ block_local,
+                                                        AdamC c, const float* __restrict__ state) {
+    __shared__ float tile[64][33];
+    if (!adam_coeffs(c, state)) return;
+    const msc_adam_item it = items[block_item[blockIdx.x]];
+    const int lb = block_local[blockIdx.x];
+    T* direct = reinterpret_cast<T*>(it.direct);
+    if (!it.trans) {
+        const long i0 = (long)lb * 2048 + threadIdx.x * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long i = i0 + h * 4;
+            if (i + 4 <= it.n) {
+                const long e0 = it.off + i;
+                float4 P = *reinterpret_cast<float4*>(p + e0);
+                const float4 G = *reinterpret_cast<const float4*>(g + e0);
+                float4 M = *reinterpret_cast<float4*>(m + e0);
+                float4 V = *reinterpret_cast<float4*>(v + e0);
+                adam_update(c, P.x, G.x, M.x, V.x); adam_update(c, P.y, G.y, M.y, V.y);
+                adam_update(c, P.z, G.z, M.z, V.z); adam_update(c, P.w, G.w, M.w, V.w);
+                *reinterpret_cast<float4*>(p + e0) = P;
+                *reinterpret_cast<float4*>(m + e0) = M;
+                *reinterpret_cast<float4*>(v + e0) = V;
+                if (direct) {
+                    ElemIO<T>::store(direct + i, P.x); ElemIO<T>::store(direct + i + 1, P.y);
+                    ElemIO<T>::store(direct + i + 2, P.z); ElemIO<T>::store(direct + i + 3, P.w);
+                }
+            } else {
+                for (long k = i; k < it.n && k < i + 4; ++k) {
+                    const long e = it.off + k;
+                    float pp = p[e], mm = m[e], vv = v[e];
+                    adam_update(c, pp, g[e], mm, vv);
+                    p[e] = pp; m[e] = mm; v[e] = vv;
+                    if (direct) ElemIO<T>::store(direct + k, pp);
+                }
+            }
+        }
+        return;
+    }
+    const int tiles_b = (it.B + 31) / 32, tiles_a = (it.A + 63) / 64;
+    const int t = lb / (tiles_a * tiles_b);
+    const int rem = lb - t * (tiles_a * tiles_b);
+    const int a0 = (rem / tiles_b) * 64, b0 = (rem % tiles_b) * 32;
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = ty + 32 * h;
+        const int a = a0 + r, b = b0 + tx * 4;
+        float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a < it.A && b < it.B) {
+            const long k = ((long)a * it.T + t) * it.B + b, e0 = it.off + k;
+            P = *reinterpret_cast<float4*>(p + e0);
+            const float4 G = *reinterpret_cast<const float4*>(g + e0);
+            float4 M = *reinterpret_cast<float4*>(m + e0);
+            float4 V = *reinterpret_cast<float4*>(v + e0);
+            adam_update(c, P.x, G.x, M.x, V.x); adam_update(c, P.y, G.y, M.y, V.y);
+            adam_update(c, P.z, G.z, M.z, V.z); adam_update(c, P.w, G.w, M.w, V.w);
+            *reinterpret_cast<float4*>(p + e0) = P;
+            *reinterpret_cast<float4*>(m + e0) = M;
+            *reinterpret_cast<float4*>(v + e0) = V;
+            if (direct) {
+                ElemIO<T>::store(direct + k, P.x); ElemIO<T>::store(direct + k + 1, P.y);
+                ElemIO<T>::store(direct + k + 2, P.z); ElemIO<T>::store(direct + k + 3, P.w);
+            }
+        }
+        tile[r][tx * 4] = P.x; tile[r][tx * 4 + 1] = P.y; tile[r][tx * 4 + 2] = P.z; tile[r][tx * 4 + 3] = P.w;
+    }
+    __syncthreads();
+    T* trans = reinterpret_cast<T*>(it.trans);
+    const int sx = threadIdx.x & 63, sy = threadIdx.x >> 6;
+    for (int r = sy; r < 32; r += 4) {
+        const int b = b0 + r, a = a0 + sx;
+        if (a < it.A && b < it.B) ElemIO<T>::store(trans + ((long)b * it.T + t) * it.A + a, tile[sx][r]);
     }
 }
 
@@ -843,14 +969,41 @@ extern "C" int msc_adam_tick(float* state, void* stream) {
     return msc_check_launch("msc_adam_tick");
 }
 
+static AdamC adam_host_coeffs(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale) {
+    const float bc1 = 1.f - powf(beta1, (float)(step < 1 ? 1 : step));
+    const float bc2 = 1.f - powf(beta2, (float)(step < 1 ? 1 : step));
+    return AdamC{lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale};
+}
+
 extern "C" int msc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                              float eps, float weight_decay, int step, float grad_scale, const float* state, void* stream) {
     if (!p || !g || !m || !v || n < 0 || (!state && step < 1)) return msc_fail(MSC_ERR_ARG, "msc_adam_step: bad argument");
     if (n == 0) return MSC_OK;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return msc_fail(MSC_ERR_ARG, "msc_adam_step: buffers must be 16-byte aligned");
-    const float bc1 = 1.f - powf(beta1, (float)(step < 1 ? 1 : step));
-    const float bc2 = 1.f - powf(beta2, (float)(step < 1 ? 1 : step));
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2, eps,
-                       weight_decay, bc1, sqrtf(bc2), grad_scale, state);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream, p, g, m, v, (long)n,
+                       adam_host_coeffs(lr, beta1, beta2, eps, weight_decay, step, grad_scale), state);
     return msc_check_launch("msc_adam_step");
+}
+
+extern "C" int msc_adam_pack(float* p, const float* g, float* m, float* v, const msc_adam_item* items, const int32_t* block_item,
+                             const int32_t* block_local, int nblocks, int dtype, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int step, float grad_scale, const float* state, void* stream) {
+    DT_CHECK("msc_adam_pack", dtype);
+    if (!p || !g || !m || !v || !items || !block_item || !block_local || nblocks < 0 || (!state && step < 1))
+        return msc_fail(MSC_ERR_ARG, "msc_adam_pack: bad argument");
+    if (nblocks == 0) return MSC_OK;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return msc_fail(MSC_ERR_ARG, "msc_adam_pack: buffers must be 16-byte aligned");
+    const AdamC c = adam_host_coeffs(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MSC_F16) hipLaunchKernelGGL(adam_pack_kernel<f16_t>, dim3(nblocks), dim3(256), 0, st, p, g, m, v, items, block_item, block_local, c, state);
+    else if (dtype == MSC_BF16) hipLaunchKernelGGL(adam_pack_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, st, p, g, m, v, items, block_item, block_local, c, state);
+    else hipLaunchKernelGGL(adam_pack_kernel<float>, dim3(nblocks), dim3(256), 0, st, p, g, m, v, items, block_item, block_local, c, state);
+    return msc_check_launch("msc_adam_pack");
+}
+
+extern "C" int msc_grad_check(const float* g, int64_t n, float* state, void* stream) {
+    if (!g || !state || n < 0 || ((uintptr_t)g & 15)) return msc_fail(MSC_ERR_ARG, "msc_grad_check: bad argument");
+    if (n == 0) return MSC_OK;
+    hipLaunchKernelGGL(grad_check_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream, g, (long)n, state);
+    return msc_check_launch("msc_grad_check");
 }

@@ -31,6 +31,7 @@
 // k-step: 0.23-0.25 PFLOP/s, the 64-bit address arithmetic sat in front of the MFMAs of an in-order wave; removed in round 3.
 // Operands beyond the 31-bit offsets of a buffer descriptor are run as image ranges, one launch after the other.)
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <type_traits>
@@ -1087,36 +1088,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgK p) {
 }
 
 // Several weight-gradient problems of one tile shape in a single launch (msc_wgrad_group_*): the layers of a
-// ResNet stage are too small to fill 256 CUs one at a time, together they do.  `starts` are the first block of
-// each problem (multiples of 8, so a problem's XCD-local order is the same as in a launch of its own).
-template <typename T, int TA, int TB, int NST>
-__global__ __launch_bounds__(256) void conv_wgrad_group_kernel(const WgK* __restrict__ tab, const int* __restrict__ starts, int n) {
-    const int b = blockIdx.x;
-    int i = 0;
-    while (i + 1 < n && starts[i + 1] <= b) ++i;
-    WgK p;
+// ResNet stage are too small to fill 256 CUs one at a time, together they do.  `blk` holds one (problem, block of that problem)
+// pair per workgroup -- the host decides which XCD runs what (workgroup b runs on XCD b % 8, msc_wgrad_group_create) -- and
+// problem -1 marks the padding of the shorter XCD queues.
+__device__ __forceinline__ bool wgrad_group_fetch(const WgK* __restrict__ tab, const int2* __restrict__ blk, WgK& p, int& orig) {
+    const int2 e = blk[blockIdx.x];
+    const int i = __builtin_amdgcn_readfirstlane(e.x);
+    orig = __builtin_amdgcn_readfirstlane(e.y);
+    if (i < 0) return false;
     const int* src = reinterpret_cast<const int*>(tab + i);
     int* dst = reinterpret_cast<int*>(&p);
 #pragma unroll
     for (unsigned j = 0; j < sizeof(WgK) / 4; ++j) dst[j] = __builtin_amdgcn_readfirstlane(src[j]);
-    const int orig = b - __builtin_amdgcn_readfirstlane(starts[i]);
-    if (orig >= p.nblocks) return;
+    return orig < p.nblocks;
+}
+
+template <typename T, int TA, int TB, int NST>
+__global__ __launch_bounds__(256) void conv_wgrad_group_kernel(const WgK* __restrict__ tab, const int2* __restrict__ blk) {
+    WgK p;
+    int orig;
+    if (!wgrad_group_fetch(tab, blk, p, orig)) return;
     wgrad_dma_body<T, TA, TB, NST>(p, orig, p.nblocks);
 }
 
 template <typename T, int TA, int TB, int NST, int NWV = 4>
-__global__ __launch_bounds__(NWV * 64) void conv_wgrad3_group_kernel(const WgK* __restrict__ tab, const int* __restrict__ starts, int n) {
+__global__ __launch_bounds__(NWV * 64) void conv_wgrad3_group_kernel(const WgK* __restrict__ tab, const int2* __restrict__ blk) {
     if constexpr (sizeof(T) == 2) {
-        const int b = blockIdx.x;
-        int i = 0;
-        while (i + 1 < n && starts[i + 1] <= b) ++i;
         WgK p;
-        const int* src = reinterpret_cast<const int*>(tab + i);
-        int* dst = reinterpret_cast<int*>(&p);
-#pragma unroll
-        for (unsigned j = 0; j < sizeof(WgK) / 4; ++j) dst[j] = __builtin_amdgcn_readfirstlane(src[j]);
-        const int orig = b - __builtin_amdgcn_readfirstlane(starts[i]);
-        if (orig >= p.nblocks) return;
+        int orig;
+        if (!wgrad_group_fetch(tab, blk, p, orig)) return;
         wgrad3_dma_body<T, TA, TB, NST, NWV>(p, orig, p.nblocks);
     }
 }
@@ -1637,13 +1637,13 @@ struct WgLaunchOne {
 };
 
 struct WgLaunchGroup {
-    const WgK* tab; const int* starts; int n, blocks; hipStream_t st; bool kw3;
+    const WgK* tab; const int2* blk; int blocks; hipStream_t st; bool kw3;
     template <typename T, int TA, int TB> void operator()() const {
         if (kw3) {
-            if constexpr (TA == 128) hipLaunchKernelGGL((conv_wgrad3_group_kernel<T, TA, TB, 4, 8>), dim3(blocks), dim3(512), 0, st, tab, starts, n);
-            else hipLaunchKernelGGL((conv_wgrad3_group_kernel<T, TA, TB, 4>), dim3(blocks), dim3(256), 0, st, tab, starts, n);
+            if constexpr (TA == 128) hipLaunchKernelGGL((conv_wgrad3_group_kernel<T, TA, TB, 4, 8>), dim3(blocks), dim3(512), 0, st, tab, blk);
+            else hipLaunchKernelGGL((conv_wgrad3_group_kernel<T, TA, TB, 4>), dim3(blocks), dim3(256), 0, st, tab, blk);
         }
-        else hipLaunchKernelGGL((conv_wgrad_group_kernel<T, TA, TB, 4>), dim3(blocks), dim3(256), 0, st, tab, starts, n);
+        else hipLaunchKernelGGL((conv_wgrad_group_kernel<T, TA, TB, 4>), dim3(blocks), dim3(256), 0, st, tab, blk);
     }
 };
 
@@ -1687,10 +1687,80 @@ extern "C" int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream) {
 
 // ---- grouped weight gradients ---------------------------------------------------------------------
 struct msc_wgrad_group {
-    struct Bucket { int dtype, ta, tb, n, blocks; WgK* tab; int* starts; bool kw3; };
+    struct Bucket { int dtype, ta, tb, n, blocks; WgK* tab; int2* blk; bool kw3; };
     std::vector<Bucket> buckets;      // problems by (dtype, tile): one launch each
     void* dev = nullptr;              // one allocation behind every table
 };
+
+namespace {
+
+// Which workgroup of a grouped launch runs which block.  Workgroup b runs on XCD b % 8 (observed dispatch order; only speed
+// depends on it) and the eight L2s do not share: the blocks that read one pixel range of a problem -- its (A tiles x B tiles x
+// taps) blocks of one split -- re-read the same P / Q rows, so they should sit on ONE XCD, close in time.  A problem's own XCD-local
+// order (wgrad_block) only achieves that when it has many splits; ResNet101's layer3 / layer4 / decoder-bottom problems have one
+// or two (8192 pixels = 2 splits of 128 k-steps x 16-48 blocks), were spread four blocks per XCD and fetched every slab once PER
+// XCD: 7.4 GB of HBM traffic for 2.6 GB of operands in the step's two 128x128 launches (profiles/r3_run47_pmc_summary_train.txt).
+// Placement: unit = (problem, split); problems with >= 8 splits give every XCD a contiguous run of splits, the units of the
+// others go whole to the XCD with the shortest queue; queues are kept in the order longest blocks first and interleaved
+// b = 8 * position + xcd, shorter queues padded with problem -1.  MSC_WGRAD_PLACE=0 keeps the per-problem order.
+void wgrad_place(const std::vector<WgPlan>& plans, const std::vector<int>& members, int kp, std::vector<int2>& blk) {
+    static const bool place_on = [] { const char* e = getenv("MSC_WGRAD_PLACE"); return !(e && e[0] == '0'); }();
+    blk.clear();
+    if (!place_on || !xcd_order_enabled()) {
+        for (size_t j = 0; j < members.size(); ++j) {
+            const WgK& k = plans[members[j]].k;
+            const int nb8 = (k.nblocks + 7) & ~7;
+            for (int o = 0; o < nb8; ++o) {
+                int wgid = o;
+                if (xcd_order_enabled() && o < k.nblocks) {
+                    const int xcd = o & 7, wq = k.nblocks >> 3, wr = k.nblocks & 7;
+                    wgid = (xcd < wr ? xcd * (wq + 1) : wr * (wq + 1) + (xcd - wr) * wq) + (o >> 3);
+                }
+                blk.push_back(o < k.nblocks ? make_int2((int)j, wgid) : make_int2(-1, 0));
+            }
+        }
+        return;
+    }
+    // Workgroups are dispatched in index order, round-robin over the XCDs: a queue whose blocks run longer than the others' at the
+    // same position holds the whole dispatch back (first version of this placement: +11 % on the step's grouped launches).  So the
+    // queues are filled class by class -- a class = the problems of one block length (mchunk; members are sorted by it) -- with
+    // the units of a class dealt to the queue holding the fewest blocks, and every queue padded to the class's longest before the
+    // next class starts: at any position the eight XCDs run blocks of the same length.
+    std::vector<int2> queue[8];
+    int rot = 0;
+    size_t j = 0;
+    while (j < members.size()) {
+        const int cls = plans[members[j]].k.mchunk;
+        for (; j < members.size() && plans[members[j]].k.mchunk == cls; ++j) {
+            const WgK& k = plans[members[j]].k;
+            const int per = k.ntiles * k.ntaps, splits = k.nblocks / per;
+            if (splits >= 8) {
+                for (int x = 0; x < 8; ++x) {
+                    const int s0 = (int)((long)splits * x / 8), s1 = (int)((long)splits * (x + 1) / 8);
+                    auto& q = queue[(x + rot) & 7];
+                    for (int o = s0 * per; o < s1 * per; ++o) q.push_back(make_int2((int)j, o));
+                }
+                rot = (rot + 3) & 7;                    // the one-split remainders do not always land on the same queues
+            } else {
+                for (int sp = 0; sp < splits; ++sp) {
+                    int qi = 0;
+                    for (int x = 1; x < 8; ++x) if (queue[x].size() < queue[qi].size()) qi = x;
+                    for (int o = sp * per; o < (sp + 1) * per; ++o) queue[qi].push_back(make_int2((int)j, o));
+                }
+            }
+        }
+        size_t len = 0;
+        for (int x = 0; x < 8; ++x) len = std::max(len, queue[x].size());
+        for (int x = 0; x < 8; ++x) queue[x].resize(len, make_int2(-1, 0));
+    }
+    const size_t len = queue[0].size();
+    blk.assign(len * 8, make_int2(-1, 0));
+    for (int x = 0; x < 8; ++x)
+        for (size_t pos = 0; pos < len; ++pos) blk[pos * 8 + x] = queue[x][pos];
+    (void)kp;
+}
+
+}  // namespace
 
 extern "C" int msc_wgrad_group_create(const msc_wgrad_desc* descs, int n, int steps_per_block, int tile_cap, msc_wgrad_group** out) {
     if (!descs || n <= 0 || !out) return msc_fail(MSC_ERR_ARG, "msc_wgrad_group_create: bad argument");
@@ -1703,6 +1773,7 @@ extern "C" int msc_wgrad_group_create(const msc_wgrad_desc* descs, int n, int st
             WgPlan pl;
             int rc = wgrad_plan(&part, steps_per_block, tile_cap > 0 ? tile_cap : 128, &pl);
             if (rc != MSC_OK) return rc;
+            pl.k.xcd_order = 0;        // the block table below carries the placement: a block's index within its problem is used as it is
             plans.push_back(pl);
         }
     }
@@ -1719,8 +1790,12 @@ extern "C" int msc_wgrad_group_create(const msc_wgrad_desc* descs, int n, int st
         if (b == g->buckets.size()) { g->buckets.push_back({p.dtype, p.ta, p.tb, 0, 0, nullptr, nullptr, p.kw3}); members.emplace_back(); }
         members[b].push_back(i);
     }
+    std::vector<std::vector<int2>> tables(g->buckets.size());
     size_t bytes = 0;
-    for (size_t b = 0; b < g->buckets.size(); ++b) bytes += members[b].size() * (sizeof(WgK) + 16) + 256;
+    for (size_t b = 0; b < g->buckets.size(); ++b) {
+        wgrad_place(plans, members[b], 64 / msc_dtype_size(g->buckets[b].dtype), tables[b]);
+        bytes += ((members[b].size() * sizeof(WgK) + 255) & ~(size_t)255) + ((tables[b].size() * sizeof(int2) + 255) & ~(size_t)255);
+    }
     if (bytes) {
         if (hipMalloc(&g->dev, bytes) != hipSuccess) { delete g; return msc_fail(MSC_ERR_HIP, "msc_wgrad_group_create: hipMalloc(%zu)", bytes); }
         std::vector<char> host(bytes, 0);
@@ -1730,17 +1805,12 @@ extern "C" int msc_wgrad_group_create(const msc_wgrad_desc* descs, int n, int st
             bk.n = (int)members[b].size();
             bk.tab = reinterpret_cast<WgK*>((char*)g->dev + off);
             WgK* ht = reinterpret_cast<WgK*>(host.data() + off);
-            off += (size_t)bk.n * sizeof(WgK);
-            bk.starts = reinterpret_cast<int*>((char*)g->dev + off);
-            int* hs = reinterpret_cast<int*>(host.data() + off);
-            off = (off + (size_t)bk.n * sizeof(int) + 255) & ~(size_t)255;
-            int start = 0;
-            for (int j = 0; j < bk.n; ++j) {
-                ht[j] = plans[members[b][j]].k;
-                hs[j] = start;
-                start += (ht[j].nblocks + 7) & ~7;
-            }
-            bk.blocks = start;
+            for (int j = 0; j < bk.n; ++j) ht[j] = plans[members[b][j]].k;
+            off += ((size_t)bk.n * sizeof(WgK) + 255) & ~(size_t)255;
+            bk.blk = reinterpret_cast<int2*>((char*)g->dev + off);
+            memcpy(host.data() + off, tables[b].data(), tables[b].size() * sizeof(int2));
+            off += (tables[b].size() * sizeof(int2) + 255) & ~(size_t)255;
+            bk.blocks = (int)tables[b].size();
         }
         if (hipMemcpy(g->dev, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipFree(g->dev); delete g;
@@ -1755,7 +1825,7 @@ extern "C" int msc_wgrad_group_run(const msc_wgrad_group* g, void* stream) {
     if (!g) return msc_fail(MSC_ERR_ARG, "msc_wgrad_group_run: null group");
     hipStream_t st = (hipStream_t)stream;
     for (const auto& bk : g->buckets)
-        wgrad_tile_dispatch(bk.dtype, bk.ta, bk.tb, WgLaunchGroup{bk.tab, bk.starts, bk.n, bk.blocks, st, bk.kw3});
+        if (bk.blocks > 0) wgrad_tile_dispatch(bk.dtype, bk.ta, bk.tb, WgLaunchGroup{bk.tab, bk.blk, bk.blocks, st, bk.kw3});
     return msc_check_launch("wgrad_group");
 }
 

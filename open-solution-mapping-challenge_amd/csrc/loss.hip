@@ -66,7 +66,8 @@ __global__ void loss_sums_kernel(const float* __restrict__ logits, const float* 
 
 __global__ void loss_grad_kernel(const float* __restrict__ logits, const float* __restrict__ target, int tc,
                                  msc_loss_cfg cfg, const double* __restrict__ sums, double total_pixels, float gscale,
-                                 float* loss, float* __restrict__ dlogits, int N, long HW) {
+                                 const float* __restrict__ scale_state, float* loss, float* __restrict__ dlogits, int N, long HW) {
+    if (scale_state && scale_state[MSC_OPT_SCALE] > 0.f) gscale *= scale_state[MSC_OPT_SCALE];      // dynamic loss scale (fp16 training)
     const double A = 2.0 * sums[1] + cfg.smooth;
     const double B = sums[2] + sums[3] + cfg.smooth + cfg.eps;
     if (blockIdx.x == 0 && threadIdx.x == 0 && loss)
@@ -110,7 +111,8 @@ extern "C" int msc_loss_sums(const float* logits, const float* target, int tc, c
 }
 
 extern "C" int msc_loss_grad(const float* logits, const float* target, int tc, const msc_loss_cfg* cfg, const double* sums,
-                             double total_pixels, float grad_scale, float* loss, float* dlogits, int N, int H, int W, void* stream) {
+                             double total_pixels, float grad_scale, const float* scale_state, float* loss, float* dlogits, int N, int H, int W,
+                             void* stream) {
     int rc = loss_check("msc_loss_grad", logits, target, tc, cfg, N, H, W);
     if (rc) return rc;
     if (!sums || !dlogits || total_pixels <= 0) return msc_fail(MSC_ERR_ARG, "msc_loss_grad: bad argument");
@@ -118,6 +120,6 @@ extern "C" int msc_loss_grad(const float* logits, const float* target, int tc, c
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(loss_grad_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, logits, target, tc, *cfg, sums,
-                       total_pixels, grad_scale, loss, dlogits, N, (long)H * W);
+                       total_pixels, grad_scale, scale_state, loss, dlogits, N, (long)H * W);
     return msc_check_launch("msc_loss_grad");
 }

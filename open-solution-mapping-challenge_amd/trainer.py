@@ -76,15 +76,17 @@ def loss_sums(logits, target, spec, sums):
          logits.device)
 
 
-def loss_grad(logits, target, spec, dlogits, loss_out, sums, total_pixels, grad_scale=1.0):
-    """phase 2: loss value and dlogits from the (all-reduced) sums; total_pixels = pixels of the GLOBAL batch"""
+def loss_grad(logits, target, spec, dlogits, loss_out, sums, total_pixels, grad_scale=1.0, scale_state=None):
+    """phase 2: loss value and dlogits from the (all-reduced) sums; total_pixels = pixels of the GLOBAL batch.  `scale_state`: the
+    optimizer's device state -- dlogits are additionally multiplied by its (dynamic) loss scale, read on the device"""
     import ctypes as C
     N, _, H, W = logits.shape
     _run(_lib.load().msc_loss_grad, (logits.data_ptr(), target.data_ptr(), target.shape[1], C.byref(spec.cfg), sums.data_ptr(),
-                                     float(total_pixels), float(grad_scale), loss_out.data_ptr(), dlogits.data_ptr(), N, H, W), logits.device)
+                                     float(total_pixels), float(grad_scale), None if scale_state is None else scale_state.data_ptr(),
+                                     loss_out.data_ptr(), dlogits.data_ptr(), N, H, W), logits.device)
 
 
-def loss_forward_backward(logits, target, spec, dlogits, loss_out, sums, world=None, grad_scale=1.0):
+def loss_forward_backward(logits, target, spec, dlogits, loss_out, sums, world=None, grad_scale=1.0, scale_state=None):
     """Fused loss: fills `dlogits` (f32 NCHW) and `loss_out` (f32[1]); `sums` f64[4] scratch.
     With `world` (a torch.distributed process group wrapper) the sums are all-reduced first."""
     N, _, H, W = logits.shape
@@ -93,7 +95,7 @@ def loss_forward_backward(logits, target, spec, dlogits, loss_out, sums, world=N
     if world is not None and world.size > 1:
         world.all_reduce(sums)
         total *= world.size
-    loss_grad(logits, target, spec, dlogits, loss_out, sums, total, grad_scale)
+    loss_grad(logits, target, spec, dlogits, loss_out, sums, total, grad_scale, scale_state)
 
 
 class _LossFunction(torch.autograd.Function):
@@ -139,13 +141,49 @@ class HipAdam(torch.optim.Optimizer):
     """torch.optim.Adam(params, lr, weight_decay) semantics over the model's flat parameter buffer.  It IS a
     torch.optim.Optimizer (one param group holding the model's trainable parameters), so the reference's
     `ExponentialLR(self.optimizer, gamma)` scheduler callback (src/steps/pytorch/callbacks.py:222) drives it unchanged:
-    the learning rate is read from `param_groups[0]['lr']` at every step."""
+    the learning rate is read from `param_groups[0]['lr']` at every step.
+
+    One update = msc_adam_tick + msc_adam_pack: the Adam kernel also writes the 16-bit compute copies of the conv weights (own
+    layout + the transpose the data gradient reads), so no separate packing pass re-reads the masters.  Step count, learning
+    rate and the loss scale live in device memory (`dev_state`, include/msc.h MSC_OPT_*): a captured hipGraph replays with the
+    current values.  fp16 training (`set_loss_scale(..., dynamic=True)`): msc_grad_check raises a flag when a gradient is not
+    finite, the step is then skipped on the device (parameters, moments and step count untouched) and the scale halves; it
+    doubles again after `growth_interval` clean steps."""
 
     def __init__(self, net, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__([p for _, p in net._trainable()], dict(lr=float(lr), betas=betas, eps=float(eps), weight_decay=float(weight_decay)))
         self.net, self.lr, self.betas, self.eps, self.weight_decay = net, float(lr), betas, float(eps), float(weight_decay)
         self.m = self.v = self.dev_state = None
-        self.steps = 0
+        self._steps = 0
+        self.loss_scale, self.dynamic_scale, self.growth_interval = 1.0, False, 2000
+        self._pending = None          # a state_dict loaded before the flat buffers exist
+        self._table = None            # (key, keep-alive tensors, msc_adam_pack table arguments)
+        self.on_hyper_change = None   # TrainStep: drop captured graphs (betas / eps / weight_decay are launch arguments)
+
+    # the step count lives on the device once training runs: a skipped (overflowed) step does not advance it
+    @property
+    def steps(self):
+        if self.dev_state is not None:
+            self._steps = int(round(float(self.dev_state[_lib.OPT_STEP].item())))
+        return self._steps
+
+    @steps.setter
+    def steps(self, value):
+        self._steps = int(value)
+
+    @property
+    def skipped_steps(self):
+        return 0 if self.dev_state is None else int(round(float(self.dev_state[_lib.OPT_SKIPPED].item())))
+
+    def current_loss_scale(self):
+        return self.loss_scale if self.dev_state is None else float(self.dev_state[_lib.OPT_SCALE].item())
+
+    def set_loss_scale(self, scale, dynamic=False, growth_interval=2000):
+        self.loss_scale, self.dynamic_scale, self.growth_interval = float(scale), bool(dynamic), int(growth_interval)
+        if self.dev_state is not None:
+            self.dev_state[_lib.OPT_SCALE] = self.loss_scale
+            self.dev_state[_lib.OPT_GROWTH] = float(self.growth_interval if self.dynamic_scale else 0)
+            self.dev_state[_lib.OPT_GOOD] = 0.0
 
     def _ensure(self):
         p = self.net.flat_params
@@ -153,14 +191,21 @@ class HipAdam(torch.optim.Optimizer):
             raise _lib.MscError('HipAdam: model parameters are not flattened yet (run a forward pass first)')
         if self.m is None or self.m.shape != p.shape or self.m.device != p.device:
             self.m, self.v = torch.zeros_like(p), torch.zeros_like(p)
-            self.dev_state = torch.tensor([float(self.steps), self.lr], dtype=torch.float32, device=p.device)
+            st = [0.0] * _lib.OPT_STATE
+            st[_lib.OPT_STEP], st[_lib.OPT_LR], st[_lib.OPT_SCALE] = float(self._steps), self.lr, self.loss_scale
+            st[_lib.OPT_GROWTH] = float(self.growth_interval if self.dynamic_scale else 0)
+            self.dev_state = torch.tensor(st, dtype=torch.float32, device=p.device)
+            self._table = None
+            if self._pending is not None:
+                state, self._pending = self._pending, None
+                self._apply_state(state)
         return p
 
     def set_lr(self, lr):
         self.lr = float(lr)
         self.param_groups[0]['lr'] = self.lr
         if self.dev_state is not None:
-            self.dev_state[1] = self.lr
+            self.dev_state[_lib.OPT_LR] = self.lr
 
     def sync_lr(self):
         """pick up a learning rate a scheduler wrote into param_groups (also before a hipGraph replay: the captured
@@ -172,31 +217,107 @@ class HipAdam(torch.optim.Optimizer):
         if self.net.flat_grads is not None:
             self.net.flat_grads.zero_()
 
+    def _pack_table(self):
+        """device tables of msc_adam_pack: one item per trainable tensor (conv weights with their compute copies), blocks of 2048
+        elements / 64x32 tiles"""
+        import numpy as np
+        net = self.net
+        dev = net.flat_params.device
+        if net._pack is None:
+            net._pack = net._build_pack()
+            net._programs = {}
+            net._packed_version = -1
+        key = (id(net._pack), net.flat_params.data_ptr())
+        if self._table is not None and self._table[0] == key:
+            return self._table[2]
+        copies = {}
+        for name, mod, kind in net._conv_list():
+            if kind == 'stem':
+                continue
+            w, wt = net._pack['w'][name], net._pack['wt'][name]
+            direct, trans = (w, wt) if kind == 'conv' else (wt, w)
+            copies[id(mod.weight)] = (None if direct.data_ptr() == mod.weight.data_ptr() else direct, trans)
+        base = net.flat_params.data_ptr()
+        rec = np.zeros(len(net._trainable()), dtype=np.dtype({'names': ['off', 'n', 'direct', 'trans', 'A', 'T', 'B', 'r'],
+                                                              'formats': ['<i8', '<i8', '<u8', '<u8', '<i4', '<i4', '<i4', '<i4'],
+                                                              'offsets': [0, 8, 16, 24, 32, 36, 40, 44], 'itemsize': 48}))
+        blk_item, blk_local = [], []
+        for i, (name, prm) in enumerate(net._trainable()):
+            off = (prm.data_ptr() - base) // 4
+            n = prm.numel()
+            cp = copies.get(id(prm))
+            if cp is not None:
+                a, b, kh, kw = prm.shape                   # torch-logical [a, b, kh, kw] over the physical [a][kh][kw][b]
+                if b % 4:
+                    raise _lib.MscError('HipAdam: conv weight %s has %d input channels (multiple of 4 needed)' % (name, b))
+                rec[i] = (off, n, cp[0].data_ptr() if cp[0] is not None else 0, cp[1].data_ptr(), a, kh * kw, b, 0)
+                nb = kh * kw * ((a + 63) // 64) * ((b + 31) // 32)
+            else:
+                rec[i] = (off, n, 0, 0, 0, 0, 0, 0)
+                nb = (n + 2047) // 2048
+            blk_item.append(np.full(nb, i, np.int32))
+            blk_local.append(np.arange(nb, dtype=np.int32))
+        t_items = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+        t_bi = torch.from_numpy(np.concatenate(blk_item)).to(dev)
+        t_bl = torch.from_numpy(np.concatenate(blk_local)).to(dev)
+        args = (t_items.data_ptr(), t_bi.data_ptr(), t_bl.data_ptr(), int(t_bi.numel()), net._dt)
+        self._table = (key, (t_items, t_bi, t_bl), args)
+        return args
+
     def launches(self, grad_scale=1.0):
-        """the two launches of one update (step counter tick + fused Adam) as (fn, args) pairs"""
+        """the launches of one update as (fn, args) pairs: (overflow check in the dynamic-scale mode,) step counter tick, fused
+        Adam + weight packing, the stem's own compute layout"""
         p = self._ensure()
         lib = _lib.load()
         g = self.net.flat_grads
-        return [(lib.msc_adam_tick, (self.dev_state.data_ptr(),)),
-                (lib.msc_adam_step, (p.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), p.numel(), self.lr, self.betas[0],
-                                     self.betas[1], self.eps, self.weight_decay, 0, float(grad_scale), self.dev_state.data_ptr()))]
+        items, bi, bl, nb, dt = self._pack_table()
+        out = []
+        if self.dynamic_scale:
+            out.append((lib.msc_grad_check, (g.data_ptr(), g.numel(), self.dev_state.data_ptr())))
+        out.append((lib.msc_adam_tick, (self.dev_state.data_ptr(),)))
+        out.append((lib.msc_adam_pack, (p.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), items, bi, bl, nb, dt, self.lr,
+                                        self.betas[0], self.betas[1], self.eps, self.weight_decay, 0, float(grad_scale), self.dev_state.data_ptr())))
+        out += [op for op in self.net._pack['ops'] if op[0].__name__ == 'msc_stem_pack']
+        return out
 
     def step(self, closure=None, grad_scale=1.0):
         p = self._ensure()
         self.sync_lr()
         from .unet_models import _Program, _stream_of
-        self.steps += 1
         _Program.run(self.launches(grad_scale), _stream_of(p.device))
         self.net.weights_changed()
+        self.net._packed_version = self.net._version        # the update wrote the compute copies itself
 
     def state_dict(self):
-        return {'m': self.m, 'v': self.v, 'steps': self.steps, 'lr': self.lr,
+        return {'m': self.m, 'v': self.v, 'steps': self.steps, 'lr': self.lr, 'loss_scale': self.current_loss_scale(),
                 'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
 
     def load_state_dict(self, state):
         """restore what state_dict() returned: both moment buffers (flat, in the model's parameter order), the step count the
-        bias correction uses and the learning rate -- also into the device-resident state a captured graph reads"""
-        p = self._ensure()
+        bias correction uses and the learning rate -- also into the device-resident state a captured graph reads.  Works
+        before the first forward pass too (the usual resume order: build model and optimizer, load both, train): the state is
+        kept and applied when the flat buffers appear."""
+        if self.net.flat_params is None:
+            self._pending = state
+            self._apply_hyper(state)
+            return
+        self._ensure()
+        self._apply_state(state)
+
+    def _apply_hyper(self, state):
+        old = (tuple(self.betas), self.eps, self.weight_decay)
+        for g, saved in zip(self.param_groups, state.get('param_groups', [])):
+            g.update({k: v for k, v in saved.items() if k != 'params'})
+        g0 = self.param_groups[0]
+        self.betas, self.eps, self.weight_decay = tuple(g0['betas']), float(g0['eps']), float(g0['weight_decay'])
+        self._steps = int(state['steps'])
+        self.lr = float(state['lr'])
+        self.param_groups[0]['lr'] = self.lr
+        if (tuple(self.betas), self.eps, self.weight_decay) != old and self.on_hyper_change is not None:
+            self.on_hyper_change()       # betas / eps / weight_decay are arguments of already captured launches
+
+    def _apply_state(self, state):
+        p = self.net.flat_params
         for key in ('m', 'v'):
             src = state[key]
             if src is None:
@@ -205,13 +326,11 @@ class HipAdam(torch.optim.Optimizer):
                 if src.numel() != p.numel():
                     raise ValueError('HipAdam.load_state_dict: %s has %d elements, the model has %d' % (key, src.numel(), p.numel()))
                 getattr(self, key).copy_(src.to(p.device, torch.float32).reshape(p.shape))
-        self.steps = int(state['steps'])
-        for g, saved in zip(self.param_groups, state.get('param_groups', [])):
-            g.update({k: v for k, v in saved.items() if k != 'params'})
-        g0 = self.param_groups[0]
-        self.betas, self.eps, self.weight_decay = tuple(g0['betas']), float(g0['eps']), float(g0['weight_decay'])
-        self.set_lr(float(state['lr']))
-        self.dev_state[0] = float(self.steps)
+        self._apply_hyper(state)
+        self.set_lr(self.lr)
+        self.dev_state[_lib.OPT_STEP] = float(self._steps)
+        if state.get('loss_scale') and self.dynamic_scale:
+            self.dev_state[_lib.OPT_SCALE] = float(state['loss_scale'])
 
 
 DDP_FRACTIONS = (0.40, 0.65, 0.85)      # share of the gradient bytes that must be final before the first three exchanges
@@ -294,7 +413,12 @@ class TrainStep:
         # fp16 activations cannot hold the gradients of a mean over millions of pixels (dlogits ~ 1e-7 per pixel, below
         # the smallest fp16 subnormal): a static loss scale multiplies dlogits and is divided out again inside the
         # Adam kernel, on the fp32 weight gradients.  bf16 / fp32 share fp32's exponent range and need none.
-        self.loss_scale = float(loss_scale) if loss_scale is not None else (4096.0 if getattr(net, 'compute_dtype', '') == 'fp16' else 1.0)
+        # fp16: the scale is DYNAMIC (device-resident, HipAdam.set_loss_scale): a step whose gradients overflowed is skipped and halves
+        # it; an explicit loss_scale argument pins a static one.
+        fp16 = getattr(net, 'compute_dtype', '') == 'fp16'
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (4096.0 if fp16 else 1.0)
+        optimizer.set_loss_scale(self.loss_scale, dynamic=(fp16 and loss_scale is None))
+        optimizer.on_hyper_change = self._drop_graphs
         self.dist = world is not None and (world.size > 1 or force_collectives)     # force: exercise RCCL with one rank
         self.use_graph = use_graph
         self.shapes = {}
@@ -307,6 +431,11 @@ class TrainStep:
     prog = property(lambda self: self.cur.prog if self.cur else None)
     graph = property(lambda self: self.cur.graph if self.cur else None)
     pieces = property(lambda self: self.cur.pieces if self.cur else None)
+
+    def _drop_graphs(self):
+        """captured launches carry betas / eps / weight_decay as arguments: re-capture after they changed"""
+        for st in self.shapes.values():
+            st.graph = st.pieces = None
 
     def _setup(self, x, target):
         key = (tuple(x.shape), tuple(target.shape), x.device)
@@ -323,12 +452,13 @@ class TrainStep:
         net, st = self.net, self.cur
         prog = net.train_forward(st.x)
         st.prog = prog
-        loss_forward_backward(prog.logits, st.t, self.spec, prog.dlogits, self.loss, self.sums, self.world, self.loss_scale)
+        self.opt._ensure()
+        loss_forward_backward(prog.logits, st.t, self.spec, prog.dlogits, self.loss, self.sums, self.world, 1.0, self.opt.dev_state)
         if self.dist:
             self._backward_overlapped(prog)
         else:
             net.train_backward(prog)
-        self.opt.step(grad_scale=1.0 / self.loss_scale)
+        self.opt.step()
 
     def _backward_overlapped(self, prog):
         """backward in pieces; each piece's finished gradient range goes to RCCL (async, its own stream) while the
@@ -382,10 +512,9 @@ class TrainStep:
             self._replay_pieces()
         else:
             st.graph.replay()
-        self.opt.steps += 1
         self.opt._opt_called = True       # torch's LR schedulers check that optimizer.step() ran before scheduler.step(): the replay was that step
-        self.net._packed_version = -1     # the replay changed the master weights; packed copies are refreshed inside every replay
-        self.net._version += 1
+        self.net._version += 1            # the replay changed the master weights -- and wrote their compute copies (msc_adam_pack)
+        self.net._packed_version = self.net._version
         return self.loss
 
     # ---- piecewise capture: graphs around the collectives ----------------------------------------------
@@ -410,7 +539,6 @@ class TrainStep:
             return g
 
         def forward(stream):
-            _Program.run(net._pack['ops'], stream)
             _copy(prog.x_in, st.x, stream)
             _Program.run(prog.fwd, stream)
             loss_sums(prog.logits, st.t, self.spec, self.sums)
@@ -418,21 +546,20 @@ class TrainStep:
         def piece(beg, end, first):
             def fn(stream):
                 if first:
-                    loss_grad(prog.logits, st.t, self.spec, prog.dlogits, self.loss, self.sums, total, self.loss_scale)
+                    loss_grad(prog.logits, st.t, self.spec, prog.dlogits, self.loss, self.sums, total, 1.0, self.opt.dev_state)
                     _zero(flat_g, stream)
                     _zero(prog.stem_dw, stream)
                 _Program.run_backward(prog.bwd[beg:end], dev)
             return fn
 
         def adam(stream):
-            _Program.run(self.opt.launches(1.0 / self.loss_scale), stream)
+            _Program.run(self.opt.launches(), stream)
 
         pieces, beg = [], 0
         for end, lo, hi in prog._ddp_plan:
             pieces.append((capture(piece(beg, end, beg == 0)), lo, hi))
             beg = end
         st.pieces = (capture(forward), pieces, capture(adam))
-        net._packed_version = -1
 
     def _replay_pieces(self):
         fwd, pieces, adam = self.cur.pieces
@@ -449,17 +576,15 @@ class TrainStep:
         adam.replay()
 
     def _body_captured(self):
-        # same as _body, but the weight repack after Adam is part of the graph so replays stay consistent
+        # same as _body; the compute copies of the weights are written by the Adam launch at the end of every replay
         net, st = self.net, self.cur
         from .unet_models import _Program, _stream_of
         stream = _stream_of(st.x.device)
-        _Program.run(net._pack['ops'], stream)
         prog = st.prog
         _copy(prog.x_in, st.x, stream)
         _Program.run(prog.fwd, stream)
-        loss_forward_backward(prog.logits, st.t, self.spec, prog.dlogits, self.loss, self.sums, None, self.loss_scale)
+        loss_forward_backward(prog.logits, st.t, self.spec, prog.dlogits, self.loss, self.sums, None, 1.0, self.opt.dev_state)
         _zero(net._flat[1], stream)
         _zero(prog.stem_dw, stream)
         _Program.run_backward(prog.bwd, st.x.device)
-        _Program.run(self.opt.launches(1.0 / self.loss_scale), stream)
-        net._packed_version = -1      # host bookkeeping: packed copies refreshed at the head of every replay
+        _Program.run(self.opt.launches(), stream)

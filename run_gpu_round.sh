@@ -57,13 +57,14 @@ pmcsq) # SQ / LDS / L2 counters of the train step, one rocprofv3 pass per counte
          timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmcsq_$i" -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-breakdown > "$GRAFT_REPO_ROOT/gpurun_out/pmcsq_$i.log" 2>&1; echo "pmcsq $i rc=$?"
        done
        cd "$GRAFT_REPO_ROOT"; python tools/pmc_sq_summary.py gpurun_out/pmcsq_1 gpurun_out/pmcsq_2 gpurun_out/pmcsq_3 > gpurun_out/pmcsq_summary.txt 2>&1; head -30 gpurun_out/pmcsq_summary.txt | cut -c1-260;;
+b32)   timeout 900 python -m pytest tests/test_gpu_parity_timed.py tests/test_gpu_fullsize.py -m gpu -q -rf --tb=short -p no:cacheprovider -k "batch32" --durations=5 > gpurun_out/pytest_b32.log 2>&1; echo "pytest rc=$?"; tail -15 gpurun_out/pytest_b32.log; cat gpurun_out/parity_timed.json | head -60;;
 ktests) timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_unet.py -m gpu -q -rf --tb=short -p no:cacheprovider > gpurun_out/pytest_k.log 2>&1; echo "pytest rc=$?"; tail -15 gpurun_out/pytest_k.log;;
 ab)    # A/B of environment switches on the train step: AB="NAME=VAL,NAME2=VAL2 NAME=VAL ..." (one run per word)
        python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
        for cfg in $AB; do
          tag=$(echo "$cfg" | tr ',=' '__')
          ( IFS=,; for kv in $cfg; do export "$kv"; done; unset IFS; timeout 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline $ABFLAGS > "gpurun_out/ab_$tag.log" 2>&1 )
-         echo "$cfg: $(grep -o '"ms_per_step": [0-9.]*' "gpurun_out/ab_$tag.log" | head -1) $(grep -o '"wgrad": {[^}]*}' "gpurun_out/ab_$tag.log" | head -1)"
+         echo "$cfg: $(grep -o '"ms_per_step": [0-9.]*' "gpurun_out/ab_$tag.log" | head -1) $(grep -o '"wgrad": {[^}]*}' "gpurun_out/ab_$tag.log" | head -1) $(grep -o '"msc_adam_pack": [0-9.]*' "gpurun_out/ab_$tag.log" | head -1)"
        done;;
 esac
 done

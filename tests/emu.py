@@ -171,7 +171,12 @@ def loss_sums(logits, target, tc, cfg, sums, N, H, W):
     _arr(sums, 4, np.float64)[...] = [(w * ce).sum(), (p1 * t1).sum(), p1.sum(), t1.sum()]
 
 
-def loss_grad(logits, target, tc, cfg, sums, total_pixels, grad_scale, loss, dlogits, N, H, W):
+OPT_STEP, OPT_LR, OPT_OVERFLOW, OPT_SKIP, OPT_SCALE, OPT_GOOD, OPT_GROWTH, OPT_SKIPPED, OPT_STATE = range(9)      # include/msc.h MSC_OPT_*
+
+
+def loss_grad(logits, target, tc, cfg, sums, total_pixels, grad_scale, scale_state, loss, dlogits, N, H, W):
+    if scale_state and _arr(scale_state, OPT_STATE)[OPT_SCALE] > 0:
+        grad_scale = grad_scale * float(_arr(scale_state, OPT_STATE)[OPT_SCALE])
     ce, w, p0, p1, t1 = _loss_terms(logits, target, tc, cfg, N, H, W)
     s = _arr(sums, 4, np.float64)
     A, B = 2.0 * s[1] + cfg.smooth, s[2] + s[3] + cfg.smooth + cfg.eps
@@ -183,13 +188,56 @@ def loss_grad(logits, target, tc, cfg, sums, total_pixels, grad_scale, loss, dlo
 
 
 def adam_tick(state):
-    _arr(state, 2)[0] += 1.0
+    st = _arr(state, OPT_STATE)
+    if st[OPT_OVERFLOW] != 0:
+        st[OPT_OVERFLOW], st[OPT_SKIP], st[OPT_GOOD] = 0.0, 1.0, 0.0
+        st[OPT_SKIPPED] += 1.0
+        if st[OPT_SCALE] > 1.0:
+            st[OPT_SCALE] *= 0.5
+    else:
+        st[OPT_SKIP] = 0.0
+        st[OPT_STEP] += 1.0
+        if st[OPT_GROWTH] > 0:
+            st[OPT_GOOD] += 1.0
+            if st[OPT_GOOD] >= st[OPT_GROWTH]:
+                st[OPT_GOOD] = 0.0
+                if 0 < st[OPT_SCALE] < 16777216.0:
+                    st[OPT_SCALE] *= 2.0
+
+
+def grad_check(g, n, state):
+    if not np.isfinite(_arr(g, n)).all():
+        _arr(state, OPT_STATE)[OPT_OVERFLOW] = 1.0
+
+
+def adam_pack(p, g, m, v, items, block_item, block_local, nblocks, dtype, lr, b1, b2, eps, wd, step, gscale, state):
+    """msc_adam_pack: the Adam update of every table item (here: one pass over the flat range the items span -- the padding between
+    tensors carries zero gradients) and the compute copies of the conv weights"""
+    bi = _arr(block_item, nblocks, np.int32)
+    raw = np.ctypeslib.as_array((C.c_uint8 * (48 * (int(bi.max()) + 1))).from_address(int(items)))
+    rec = raw.view(np.dtype({'names': ['off', 'n', 'direct', 'trans', 'A', 'T', 'B', 'r'],
+                             'formats': ['<i8', '<i8', '<u8', '<u8', '<i4', '<i4', '<i4', '<i4'], 'offsets': [0, 8, 16, 24, 32, 36, 40, 44],
+                             'itemsize': 48}))
+    if state and _arr(state, OPT_STATE)[OPT_SKIP] != 0:
+        return
+    lo, hi = int(min(rec['off'])), int(max(rec['off'] + rec['n']))
+    adam_step(p + 4 * lo, g + 4 * lo, m + 4 * lo, v + 4 * lo, hi - lo, lr, b1, b2, eps, wd, step, gscale, state)
+    for it in rec:
+        src = p + 4 * int(it['off'])
+        if it['direct']:
+            pack_cast(src, int(it['direct']), dtype, int(it['n']))
+        if it['trans']:
+            pack_transpose(src, int(it['trans']), dtype, int(it['A']), int(it['T']), int(it['B']))
 
 
 def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, step, gscale, state):
     if state:
-        st = _arr(state, 2)
-        step, lr = float(st[0]), float(st[1])
+        st = _arr(state, OPT_STATE)
+        if st[OPT_SKIP] != 0:
+            return
+        step, lr = float(st[OPT_STEP]), float(st[OPT_LR])
+        if st[OPT_SCALE] > 0:
+            gscale = gscale / float(st[OPT_SCALE])
     pp, gg, mm, vv = _arr(p, n), _arr(g, n), _arr(m, n), _arr(v, n)
     # same operations and rounding points as the kernel, with two scratch arrays instead of a dozen temporaries (the flat buffers are
     # 20-80 M elements: the allocations, not the arithmetic, were what this function spent its time on)
@@ -414,7 +462,8 @@ TABLE = {'msc_conv_igemm': conv_igemm, 'msc_conv_wgrad': conv_wgrad, 'msc_pack_c
          'msc_stem_prepare': stem_prepare, 'msc_maxpool2_fwd': maxpool2_fwd, 'msc_maxpool2_bwd': maxpool2_bwd,
          'msc_memset_zero': memset_zero, 'msc_copy': copy, 'msc_bn_fold': bn_fold, 'msc_bn_apply': bn_apply,
          'msc_bn_bwd_reduce': bn_bwd_reduce, 'msc_bn_bwd_apply': bn_bwd_apply,
-         'msc_loss_sums': loss_sums, 'msc_loss_grad': loss_grad, 'msc_adam_tick': adam_tick, 'msc_adam_step': adam_step,
+         'msc_loss_sums': loss_sums, 'msc_loss_grad': loss_grad, 'msc_adam_tick': adam_tick, 'msc_adam_step': adam_step, 'msc_adam_pack': adam_pack,
+         'msc_grad_check': grad_check,
          'msc_grad_reduce': grad_reduce, 'msc_grad_unpack': grad_unpack,
          'msc_relu_bwd': relu_bwd, 'msc_bias_grad': bias_grad, 'msc_relu_bias_grad': relu_bias_grad, 'msc_final_fwd': final_fwd, 'msc_final_bwd': final_bwd,
          'msc_bias_slots_finalize': bias_slots_finalize, 'msc_bias_slots_finalize_multi': bias_slots_finalize_multi}

@@ -1,6 +1,7 @@
 """CPU: host logic of the HIP engine (program construction, buffer wiring, concat slices, gradient
 accumulation flags, weight layouts) checked by executing its launch lists with tests/emu.py -- a numpy
 interpreter of the documented C-ABI semantics -- against the torch-CPU oracle."""
+import numpy as np
 import pytest
 import torch
 
@@ -149,6 +150,76 @@ def test_hipadam_state_dict_roundtrip_restores_moments_step_and_lr(interpreted):
     assert torch.equal(after, net.flat_params)
     with pytest.raises(ValueError):
         opt2.load_state_dict(dict(state, m=torch.zeros(3)))
+
+
+def test_hipadam_resumes_before_the_first_forward_and_keeps_the_compute_copies_fresh(interpreted):
+    """the usual resume order -- build model and optimizer, load both state dicts, THEN train -- works: a state loaded before the flat
+    buffers exist is applied when they appear (round-3 advisory); and the fused update leaves the packed weight copies current (no
+    re-pack at the next forward), equal to what a fresh pack of the new masters gives"""
+    from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
+    ref, net = build(34)
+    net.train()
+    opt = HipAdam(net, lr=1e-3, weight_decay=1e-4)
+    step = TrainStep(net, LossSpec.plain_ce(), opt)
+    x = unet_ref.synthetic_batch(1, 64, 64)
+    t = losses_ref.synthetic_target(1, 64, 64)[:, :1].contiguous()
+    step(x, t); step(x, t)
+    assert net._packed_version == net._version                       # the Adam launch wrote the copies
+    name = 'encoder.layer1.0.conv1'
+    w, wt = net._pack['w'][name].clone(), net._pack['wt'][name].clone()
+    net._packed_version = -1
+    net._refresh_weights(0)                                           # what msc_pack_multi makes of the same masters
+    assert torch.equal(w, net._pack['w'][name]) and torch.equal(wt, net._pack['wt'][name])
+    state = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state_dict().items()}
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    step(x, t)
+    after = net.flat_params.clone()
+    ref2, net2 = build(34)
+    net2.load_state_dict(sd)
+    net2.train()
+    opt2 = HipAdam(net2, lr=9.0)
+    opt2.load_state_dict(state)                                       # no forward has run: nothing is flattened yet
+    assert opt2.steps == 2 and opt2.lr == 1e-3
+    TrainStep(net2, LossSpec.plain_ce(), opt2)(x, t)
+    assert opt2.steps == 3 and torch.equal(after, net2.flat_params)
+
+
+def test_dynamic_loss_scale_skips_an_overflowed_step(interpreted):
+    """fp16 `fit()` safety (the device-side protocol, run here on the interpreter in fp32 arithmetic): with a dynamic scale an
+    overflowing gradient leaves parameters, moments and the step count untouched and halves the scale; the next clean step trains"""
+    from mapping_challenge_amd import _lib
+    from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
+    ref, net = build(34)
+    net.train()
+    opt = HipAdam(net, lr=1e-3)
+    step = TrainStep(net, LossSpec.plain_ce(), opt)
+    opt.set_loss_scale(1024.0, dynamic=True, growth_interval=2)
+    x = unet_ref.synthetic_batch(1, 64, 64)
+    t = losses_ref.synthetic_target(1, 64, 64)[:, :1].contiguous()
+    l0 = step(x, t).item()
+    assert opt.steps == 1 and opt.current_loss_scale() == 1024.0
+    assert any(fn.__name__ == 'msc_grad_check' for fn, _ in opt.launches())
+    before = net.flat_params.clone()
+    bad = x.clone()
+    bad[0, 0, 0, 0] = float('inf')
+    step(bad, t)
+    assert torch.equal(before, net.flat_params) and opt.steps == 1 and opt.skipped_steps == 1 and opt.current_loss_scale() == 512.0
+    step(x, t); step(x, t)
+    assert opt.steps == 3 and opt.current_loss_scale() == 1024.0       # two clean steps: doubled again
+    assert not torch.equal(before, net.flat_params) and np.isfinite(l0)
+    # the same gradients at any scale: scaled dlogits, divided out inside the Adam kernel
+    ref2, net2 = build(34)
+    net2.train()
+    opt3 = HipAdam(net2, lr=1e-3)
+    s3 = TrainStep(net2, LossSpec.plain_ce(), opt3)
+    s3(x, t)
+    ref3, net3 = build(34)
+    net3.train()
+    opt4 = HipAdam(net3, lr=1e-3)
+    s4 = TrainStep(net3, LossSpec.plain_ce(), opt4)
+    opt4.set_loss_scale(64.0)
+    s4(x, t)
+    assert torch.allclose(net2.flat_params, net3.flat_params, atol=1e-6)
 
 
 def test_residual_join_reduces_ride_on_the_last_writer(interpreted, monkeypatch):

@@ -35,9 +35,19 @@ def test_config2_resnet34_bf16_batch32_256_inference_properties():
     diff = (alone[0] - p1[5]).abs()
     assert diff.max().item() < 4e-2 and diff.mean().item() < 1e-3, (diff.max().item(), diff.mean().item())
     # bf16 mode against the exact-fp32 mode of the same engine (which the small-size tests hold to 1e-4 of the reference)
+    # Band (derived as in tests/test_gpu_parity_timed.py): every stored activation is rounded once to bf16 (u = 2^-8), d stored
+    # tensors on the longest path => logits within u*sqrt(d) relative L2; the softmax has slope <= 1/4, so the probabilities differ
+    # by band = u*sqrt(d)/4 on average.  A mask pixel can only flip where the fp32 probability is closer to 0.5 than the local
+    # error: pixels further than 4 bands from 0.5 must agree (the seeded random weights put most pixels NEAR 0.5, which is why a
+    # plain agreement ratio says nothing here).
     pf = fp.predict_proba(x)
-    assert (pf - p1).abs().max().item() < 0.2
-    assert ((pf[:, 1] > 0.5) == (p1[:, 1] > 0.5)).float().mean().item() > 0.97
+    band = 2.0 ** -8 * (226 ** 0.5) / 4
+    dp = (pf - p1).abs()
+    assert dp.mean().item() < band, (dp.mean().item(), band)
+    sure = (pf[:, 1] - 0.5).abs() > 4 * band
+    flips = ((pf[:, 1] > 0.5) != (p1[:, 1] > 0.5)) & sure
+    assert sure.float().mean().item() > 0.05                              # the statement is about a real share of the pixels
+    assert flips.float().sum().item() <= 1e-4 * sure.float().sum().item(), (flips.sum().item(), sure.sum().item())
 
 
 def test_config3_resnet101_bf16_batch32_train_step_properties():

@@ -225,6 +225,85 @@ def test_adam_matches_torch_optim():
         assert torch.allclose(p[:10007].cpu(), pr.data, atol=1e-6)
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
+def test_adam_pack_updates_like_torch_and_writes_the_compute_copies(dtype):
+    """msc_adam_pack (ABI v7): one launch over a table of tensors = torch.optim.Adam on each of them (src/models.py:57,287-292), plus
+    the conv weights' compute copies: `direct` = the updated master rounded to the compute dtype, `trans` = its [B][T][A] transpose;
+    ragged channel counts (a tile's edge) and a plain tensor whose length is not a multiple of 4 (a bias).  A step whose gradients
+    hold an inf is skipped on the device: parameters, moments, step count untouched, loss scale halved (msc_grad_check + msc_adam_tick)."""
+    from mapping_challenge_amd import _lib
+    lib = _lib.load()
+    dt = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}[dtype]
+    torch.manual_seed(3)
+    shapes = [(96, 9, 40), None, (32, 16, 128), None]           # [A][T][B] conv weights and plain tensors
+    plain_n = [1003, 2]
+    sizes, offs, total = [], [], 0
+    pi = iter(plain_n)
+    for sh in shapes:
+        n = sh[0] * sh[1] * sh[2] if sh else next(pi)
+        sizes.append(n); offs.append(total); total += (n + 3) // 4 * 4
+    p0 = torch.randn(total)
+    refs = [torch.nn.Parameter(p0[o:o + n].clone()) for o, n in zip(offs, sizes)]
+    opt = torch.optim.Adam(refs, lr=5e-4, weight_decay=1e-4)
+    p = p0.cuda()
+    m, v, g = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
+    direct = [torch.zeros(n, dtype=dtype, device='cuda') if sh else None for sh, n in zip(shapes, sizes)]
+    trans = [torch.zeros(n, dtype=dtype, device='cuda') if sh else None for sh, n in zip(shapes, sizes)]
+    rec = np.zeros(len(shapes), dtype=np.dtype({'names': ['off', 'n', 'direct', 'trans', 'A', 'T', 'B', 'r'],
+                                                'formats': ['<i8', '<i8', '<u8', '<u8', '<i4', '<i4', '<i4', '<i4'],
+                                                'offsets': [0, 8, 16, 24, 32, 36, 40, 44], 'itemsize': 48}))
+    bi, bl = [], []
+    for i, (sh, n, o) in enumerate(zip(shapes, sizes, offs)):
+        if sh:
+            use_direct = dtype != torch.float32 or i == 0          # fp32 mode: the master is its own direct copy (exercise both)
+            rec[i] = (o, n, direct[i].data_ptr() if use_direct else 0, trans[i].data_ptr(), sh[0], sh[1], sh[2], 0)
+            nb = sh[1] * ((sh[0] + 63) // 64) * ((sh[2] + 31) // 32)
+        else:
+            rec[i] = (o, n, 0, 0, 0, 0, 0, 0)
+            nb = (n + 2047) // 2048
+        bi.append(np.full(nb, i, np.int32)); bl.append(np.arange(nb, dtype=np.int32))
+    t_items = torch.from_numpy(rec.view(np.uint8).copy()).cuda()
+    t_bi, t_bl = torch.from_numpy(np.concatenate(bi)).cuda(), torch.from_numpy(np.concatenate(bl)).cuda()
+    state = torch.zeros(_lib.OPT_STATE, device='cuda')
+    state[_lib.OPT_LR], state[_lib.OPT_SCALE], state[_lib.OPT_GROWTH] = 5e-4, 8.0, 3.0
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def update():
+        _lib.check(lib.msc_grad_check(g.data_ptr(), g.numel(), state.data_ptr(), stream), 'check')
+        _lib.check(lib.msc_adam_tick(state.data_ptr(), stream), 'tick')
+        _lib.check(lib.msc_adam_pack(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), t_items.data_ptr(), t_bi.data_ptr(), t_bl.data_ptr(),
+                                     int(t_bi.numel()), dt, 9.0, 0.9, 0.999, 1e-8, 1e-4, 0, 1.0, state.data_ptr(), stream), 'adam_pack')
+
+    for step in range(1, 4):
+        scale = float(state[_lib.OPT_SCALE])
+        for r, o, n in zip(refs, offs, sizes):
+            gr = torch.randn(n)
+            r.grad = gr.clone()
+            g[o:o + n] = (gr * scale).cuda()                       # the backward ran on scaled dlogits
+        opt.step()
+        update()
+        for i, (r, o, n, sh) in enumerate(zip(refs, offs, sizes, shapes)):
+            assert torch.allclose(p[o:o + n].cpu(), r.data, atol=2e-6), (step, i)
+            if sh:
+                want = p[o:o + n].view(sh)
+                if rec[i]['direct']:
+                    assert torch.equal(direct[i].view(sh), want.to(dtype)), (step, i)
+                assert torch.equal(trans[i].view(sh[2], sh[1], sh[0]), want.permute(2, 1, 0).to(dtype)), (step, i)
+    assert float(state[_lib.OPT_STEP]) == 3.0 and float(state[_lib.OPT_SCALE]) == 16.0       # 3 clean steps: the scale doubled
+    # an overflowed gradient: nothing moves, the scale halves, the next clean step continues with step count 4
+    keep = (p.clone(), m.clone(), v.clone())
+    g[offs[2] + 17] = float('inf')
+    update()
+    assert torch.equal(p, keep[0]) and torch.equal(m, keep[1]) and torch.equal(v, keep[2])
+    assert float(state[_lib.OPT_STEP]) == 3.0 and float(state[_lib.OPT_SCALE]) == 8.0 and float(state[_lib.OPT_SKIPPED]) == 1.0
+    g[offs[2] + 17] = float('nan')
+    update()
+    assert torch.equal(p, keep[0]) and float(state[_lib.OPT_SCALE]) == 4.0
+    g[offs[2] + 17] = 0.0
+    update()
+    assert float(state[_lib.OPT_STEP]) == 4.0 and float(state[_lib.OPT_SKIP]) == 0.0 and not torch.equal(p, keep[0])
+
+
 def test_loss_kernels_match_oracle_and_golden(golden_dir):
     import os
     from mapping_challenge_amd.trainer import LossSpec, loss_forward_backward

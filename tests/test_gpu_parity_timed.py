@@ -155,6 +155,48 @@ def test_16bit_train_step_resnet101_256_vs_oracle(dtype):
         assert e_hip[q] <= 1.2 * e_emu[q] + 0.02, (q, e_hip, e_emu)
 
 
+def test_batch32_timed_shape_resnet101_256_vs_oracle():
+    """the EXACT shape bench.py times -- ResNet101, 256x256, batch 32 (the tile configurations the tuner picks depend on the batch
+    size: tune/gfx950.json is keyed by N) -- against the fp32 oracle (src/steps/pytorch/models.py:76-113: forward, loss, backward):
+    fp32 mode: eval logits within the north star's 1e-4;  bf16 mode: eval logits within u*sqrt(d), and one training step's
+    train-mode logits, loss and dlogits within the same band; every parameter gradient as close to the fp32 oracle's as the
+    reference arithmetic with bf16 storage is (the band of test_16bit_train_step_resnet101_256_vs_oracle, at batch 32)"""
+    N = 32
+    x = unet_ref.synthetic_batch(N, 256, 256, seed=41)
+    tgt = losses_ref.synthetic_target(4, 256, 256, seed=41).repeat(N // 4, 1, 1, 1)
+    ref, fp = build(101, 'fp32')
+    ref.eval(); fp.eval()
+    with torch.no_grad():
+        yr = ref(x)
+    yf = fp(x.cuda()).cpu()
+    err32 = (yr - yf).abs().max().item()
+    del fp
+    _, net = build(101, 'bf16')
+    net.eval()
+    yb = net(x.cuda()).cpu()
+    u = UNIT['bf16']
+    tol = K * u * math.sqrt(D_FWD)
+    e_eval = rel_l2(yb, yr)
+    # training step: fp32 oracle as the truth (its own distance to the float64 gradient, 5e-3, is far inside the 16-bit band)
+    to, tl, td, tg = oracle_step(101, x, tgt, torch.float32)
+    eo, el, ed, eg = oracle_step(101, x, tgt, torch.float32, 'bf16')
+    ho, hl, hd, hg = hip_step(net, x, tgt)
+    e_logits, e_dlogits = rel_l2(ho, to), rel_l2(hd, td)
+    e_hip = stats({n: rel_l2(hg[n], tg[n]) for n in hg if n in tg})
+    e_emu = stats({n: rel_l2(eg[n], tg[n]) for n in hg if n in eg})
+    record('batch32_r101_256', {'fp32_eval_logits_maxabs': err32, 'bf16_eval_logits_rel_l2': e_eval, 'bf16_train_logits_rel_l2': e_logits,
+                                'bf16_dlogits_rel_l2': e_dlogits, 'loss': [hl, tl, el], 'tol_fwd': tol,
+                                'grad_rel_l2_vs_fp32_oracle': {'engine': e_hip, 'same_storage_oracle': e_emu}})
+    assert err32 < 1e-4, err32
+    assert e_eval < tol, (e_eval, tol)
+    assert torch.isfinite(ho).all() and all(torch.isfinite(g).all() for g in hg.values())
+    assert e_logits < tol and e_dlogits < tol, (e_logits, e_dlogits, tol)
+    assert abs(hl - tl) < tol * max(1.0, abs(tl)), (hl, tl)
+    assert len(hg) > 300
+    for q in ('median', 'p90', 'max'):
+        assert e_hip[q] <= 1.2 * e_emu[q] + 0.02, (q, e_hip, e_emu)
+
+
 def _trained_state(depth=101, steps=40):
     """a few dozen optimizer steps on inputs that carry the target (noise + mask), so that the eval masks are building-like
     blobs instead of the near-0.5 noise of random weights; returns (state_dict on the host, inputs)"""
