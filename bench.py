@@ -271,11 +271,35 @@ def bench_e2e(args, world, dev, stream, timed):
     out['images_per_tail_call'] = batch * TB
     dt_list = timed(lambda: tail(probs0, as_list=True))
     out['plain_as_python_dicts_post_only_img_s'] = imgs / dt_list      # the same tail building one dict per instance in Python
+    from mapping_challenge_amd.pipelines import OverlappedAnnotator
+
+    def overlapped(n_groups, kw):
+        """n_groups complete steps through pipelines.OverlappedAnnotator: the network batches of step g+1 are enqueued on their own stream
+        before the host drives the tail of step g on another (pipeline fill and drain are inside the timed region)"""
+        ann_ = OverlappedAnnotator(net, cat_ids, layers, (300, 300), 0, 2, watershed_selem_size=kw['ws'])
+        docs = list(ann_.annotate((ids, [x] * TB, rgb_t if kw['crf'] else None) for _ in range(n_groups)))
+        return docs
+
+    def timed_overlapped(kw):
+        overlapped(max(args.warmup, 1), kw)
+        world.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        docs = overlapped(args.steps, kw)
+        torch.cuda.synchronize()
+        world.barrier()
+        assert len(docs) == args.steps
+        return time.perf_counter() - t0
+    assert overlapped(2, variants['plain'])[1] == tail(probs0)          # the two-stream pipeline returns the one-stream document
+    sequential = os.environ.get('MSC_E2E_SEQUENTIAL') == '1'          # A/B: network and tail alternating on one stream (round 3)
     for name, kw in variants.items():
         dt_tail = timed(lambda: tail(probs0, **kw))                                  # the post-processing + annotation part alone
-        dt_all = timed(lambda: tail(forward_all(), **kw))                            # TB network batches + one tail call, on one stream
+        dt_seq = timed(lambda: tail(forward_all(), **kw))                            # TB network batches + one tail call, on one stream
+        dt_all = dt_seq if sequential else timed_overlapped(kw)
         out[name] = {'post_only_img_s': imgs / dt_tail, 'post_only_ms_per_img': 1e3 * dt_tail / (batch * TB * args.steps),
                      'end_to_end_img_s': imgs / dt_all, 'end_to_end_ms_per_step': 1e3 * dt_all / args.steps,
+                     'end_to_end_one_stream_img_s': imgs / dt_seq,
+                     'end_to_end_vs_slower_half': (imgs / dt_all) / min(imgs / dt_tail, out['inference_only_img_s'] * 1.0),
                      'post_not_slower_than_network': imgs / dt_tail >= out['inference_only_img_s']}
     # dense CRF alone: HIP events around the launches of one call on the launch stream
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -301,7 +325,7 @@ def bench_e2e(args, world, dev, stream, timed):
            'config': {'workload': 'ResNet%d-U-Net eval forward (batch %d/GPU, %s, %s) -> dense CRF (5 iterations, sxy 1, srgb 50) -> resize 256->300, threshold, '
                                   'erosion-marker watershed (extension, k=5), 2x2 label dilation, scoring -> COCO RLE + bbox annotations; weights '
                                   'trained 40 steps on synthetic blobs (foreground %.2f, %d annotations per tail call of %d images in the plain variant); '
-                                  'one step = %d network batches + one tail call'
+                                  'one step = %d network batches + one tail call; network (step g+1) and tail (step g) on two streams (pipelines.OverlappedAnnotator)'
                                   % (enc, batch, tile_text(hw), args.dtype, fg, len(ann), batch * TB, TB),
                       'global_batch': batch * world.size, 'parallelism': 'dp%d' % world.size, 'images_per_step': batch * TB, 'variants': out},
            'roofline': {'kernel': 'conv family of the forward (dominant: %.2f of %.2f ms per step are the network)' % (1e3 * TB * dt_net / args.steps, full['end_to_end_ms_per_step']),
@@ -402,9 +426,9 @@ def main():
         net.load_state_dict(unet_ref.seeded_state_dict(net))
         net.flatten_parameters(dev)
         world.sync_model(net)
-        if args.dtype != 'fp32':
-            from mapping_challenge_amd.distributed import wire_for
-            world.grad_wire = os.environ.get('MSC_GRAD_WIRE', wire_for(args.dtype))      # 16-bit gradient exchange (bf16: fp16's range cannot hold loss-scaled gradients)
+        # gradient exchange: fp32 ring all-reduce, the reference's reduce-add precision (nn.DataParallel, src/models.py:65); the 16-bit
+        # all-to-all wire (half the bytes, each rank's partial rounded before the sum) is opt-in: MSC_GRAD_WIRE=bf16
+        world.grad_wire = os.environ.get('MSC_GRAD_WIRE', 'fp32')
         x = unet_ref.synthetic_batch(batch, hw, hw, seed=1234 + world.rank).to(dev)
         fwd_gf = None
         if args.workload == 'train':

@@ -270,13 +270,15 @@ int msc_loss_grad(const float* logits, const float* target, int tc, const msc_lo
  *   STEP      Adam's step count (bias corrections)            LR       learning rate
  *   OVERFLOW  raised by msc_grad_check when a gradient element is not finite
  *   SKIP      set by msc_adam_tick for the current step: msc_adam_step / msc_adam_pack leave p, m, v untouched
- *   SCALE     loss scale: msc_loss_grad multiplies by it, the Adam kernels divide the gradient by it (0: no scaling)
+ *   SCALE     loss scale: msc_loss_grad multiplies dlogits by it (0: no scaling)
  *   GOOD / GROWTH  clean steps since the last change of SCALE / clean steps after which SCALE doubles (0: static scale)
  *   SKIPPED   number of skipped steps so far
+ *   UNSCALE   1 / SCALE as it was when this step's loss gradient was scaled (written by msc_adam_tick BEFORE it changes SCALE): the
+ *             factor the Adam kernels apply to the gradient (0: none -- a state nobody ticked yet)
  * msc_adam_tick: OVERFLOW set -> SKIP = 1, SCALE halves (not below 1), STEP unchanged; else SKIP = 0, STEP += 1, GOOD counted.
  * Replaces the reference's plain optimizer.step() (src/steps/pytorch/models.py:111), which has no 16-bit mode to protect. */
 enum { MSC_OPT_STEP = 0, MSC_OPT_LR = 1, MSC_OPT_OVERFLOW = 2, MSC_OPT_SKIP = 3, MSC_OPT_SCALE = 4, MSC_OPT_GOOD = 5, MSC_OPT_GROWTH = 6,
-       MSC_OPT_SKIPPED = 7, MSC_OPT_STATE = 8 };
+       MSC_OPT_SKIPPED = 7, MSC_OPT_UNSCALE = 8, MSC_OPT_STATE = 12 };
 
 /* Adam with L2 folded into the gradient (torch.optim.Adam(weight_decay), src/models.py:57,287-292) over one flat
  * fp32 parameter buffer.  `state` (device f32[MSC_OPT_STATE], may be NULL): when given it overrides `step` and `lr`, divides

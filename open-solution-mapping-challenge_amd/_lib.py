@@ -57,7 +57,8 @@ class BiasSlotsItem(C.Structure):         # == msc_bias_slots_item
 BIAS_SLOTS_MAX = 16
 
 # optimizer state in device memory (include/msc.h, ABI v7): f32[OPT_STATE]
-OPT_STEP, OPT_LR, OPT_OVERFLOW, OPT_SKIP, OPT_SCALE, OPT_GOOD, OPT_GROWTH, OPT_SKIPPED, OPT_STATE = range(9)
+OPT_STEP, OPT_LR, OPT_OVERFLOW, OPT_SKIP, OPT_SCALE, OPT_GOOD, OPT_GROWTH, OPT_SKIPPED, OPT_UNSCALE = range(9)
+OPT_STATE = 12
 
 
 class LossCfg(C.Structure):

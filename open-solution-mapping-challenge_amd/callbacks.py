@@ -88,7 +88,13 @@ class Callback:
             # decisions taken from the value (best checkpoint, early stopping) must be the same on every rank or a rank
             # that stops alone leaves the others in the next gradient all-reduce -> mean over ranks
             if self.world is not None and self.world.size > 1:
-                score = {k: self.world.all_reduce(v.detach().clone().float()) / self.world.size for k, v in score.items()}
+                # the collective runs on the backend's device: RCCL cannot reduce the CPU zeros score_model returns for a rank whose
+                # validation shard is empty
+                import torch.distributed as dist
+                on_gpu = dist.is_initialized() and dist.get_backend(self.world.group) == 'nccl'
+                dev = next(self.model.parameters()).device if on_gpu else None
+                score = {k: self.world.all_reduce(v.detach().to(dev if on_gpu else v.device, torch.float32).clone()) / self.world.size
+                         for k, v in score.items()}
             self.validation_loss[self.epoch_id] = score
         return self.validation_loss[self.epoch_id]
 

@@ -300,10 +300,12 @@ extern "C" int msc_rle_encode(const void* seg_ws, int layers, int H, int W, int 
 namespace {
 struct JsonOut {
     char* p; char* end; int64_t need;
-    void raw(const char* s, size_t n) { need += (int64_t)n; if (p + n <= end) { memcpy(p, s, n); p += n; } else p = end; }
+    void raw(const char* s, size_t n) { need += (int64_t)n; if (p && n <= (size_t)(end - p)) { memcpy(p, s, n); p += n; } else p = end; }
     void lit(const char* s) { raw(s, strlen(s)); }
     void i64(long long v) { char b[24]; auto r = std::to_chars(b, b + sizeof(b), v); raw(b, (size_t)(r.ptr - b)); }
     void f64(double v) {                   // shortest text that reads back as the same double (what Python's repr gives json.dumps)
+        if (v != v) { lit("NaN"); return; }                              // json.dumps' spellings of the non-finite values (they round-trip
+        if (v - v != 0.0) { lit(v > 0 ? "Infinity" : "-Infinity"); return; }   // through json.loads; std::to_chars' "nan" / "inf" do not)
         char b[40];
         auto r = std::to_chars(b, b + sizeof(b), v);
         size_t n = (size_t)(r.ptr - b);

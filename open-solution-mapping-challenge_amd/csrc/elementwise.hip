@@ -463,6 +463,8 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
 // inside the graph: a step whose gradients msc_grad_check found non-finite is SKIPPED (no parameter, moment or step-count
 // change) and halves the scale; `growth` clean steps in a row double it (torch.cuda.amp.GradScaler's rule).
 __global__ void adam_tick_kernel(float* state) {
+    // the gradients of THIS step carry the scale the loss kernel read: the Adam kernels divide by that one, whatever happens to the scale below
+    state[MSC_OPT_UNSCALE] = state[MSC_OPT_SCALE] > 0.f ? 1.f / state[MSC_OPT_SCALE] : 1.f;
     if (state[MSC_OPT_OVERFLOW] != 0.f) {
         state[MSC_OPT_OVERFLOW] = 0.f;
         state[MSC_OPT_SKIP] = 1.f;
@@ -503,7 +505,7 @@ __device__ __forceinline__ bool adam_coeffs(AdamC& c, const float* __restrict__ 
         c.lr = state[MSC_OPT_LR];
         c.bc1 = 1.f - powf(c.b1, step);
         c.bc2_sqrt = sqrtf(1.f - powf(c.b2, step));
-        if (state[MSC_OPT_SCALE] > 0.f) c.gscale /= state[MSC_OPT_SCALE];
+        if (state[MSC_OPT_UNSCALE] > 0.f) c.gscale *= state[MSC_OPT_UNSCALE];
     }
     return true;
 }

@@ -330,6 +330,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
         // lane's NV channels are consecutive); splitk_finish_kernel adds the planes in slice order -- deterministic -- and applies the
         // epilogue.  (fp32 atomics into one plane were 2x SLOWER than the unsplit launch: 16 slices hammering the same lines.)
         if (MODE == 0) {
+            // no channel bound on the store: msc_conv_cfg_ok admits a configuration only when Cout % TC == 0 (every lane's NV channels exist)
             const int cb = c0 + wc * WTC + g * NV;
 #pragma unroll
             for (int b = 0; b < FN; ++b) {
@@ -1089,8 +1090,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgK p) {
 
 // Several weight-gradient problems of one tile shape in a single launch (msc_wgrad_group_*): the layers of a
 // ResNet stage are too small to fill 256 CUs one at a time, together they do.  `blk` holds one (problem, block of that problem)
-// pair per workgroup -- the host decides which XCD runs what (workgroup b runs on XCD b % 8, msc_wgrad_group_create) -- and
-// problem -1 marks the padding of the shorter XCD queues.
+// pair per workgroup (msc_wgrad_group_create / wgrad_place); problem -1 marks padding.
 __device__ __forceinline__ bool wgrad_group_fetch(const WgK* __restrict__ tab, const int2* __restrict__ blk, WgK& p, int& orig) {
     const int2 e = blk[blockIdx.x];
     const int i = __builtin_amdgcn_readfirstlane(e.x);
@@ -1694,70 +1694,30 @@ struct msc_wgrad_group {
 
 namespace {
 
-// Which workgroup of a grouped launch runs which block.  Workgroup b runs on XCD b % 8 (observed dispatch order; only speed
-// depends on it) and the eight L2s do not share: the blocks that read one pixel range of a problem -- its (A tiles x B tiles x
-// taps) blocks of one split -- re-read the same P / Q rows, so they should sit on ONE XCD, close in time.  A problem's own XCD-local
-// order (wgrad_block) only achieves that when it has many splits; ResNet101's layer3 / layer4 / decoder-bottom problems have one
-// or two (8192 pixels = 2 splits of 128 k-steps x 16-48 blocks), were spread four blocks per XCD and fetched every slab once PER
-// XCD: 7.4 GB of HBM traffic for 2.6 GB of operands in the step's two 128x128 launches (profiles/r3_run47_pmc_summary_train.txt).
-// Placement: unit = (problem, split); problems with >= 8 splits give every XCD a contiguous run of splits, the units of the
-// others go whole to the XCD with the shortest queue; queues are kept in the order longest blocks first and interleaved
-// b = 8 * position + xcd, shorter queues padded with problem -1.  MSC_WGRAD_PLACE=0 keeps the per-problem order.
-void wgrad_place(const std::vector<WgPlan>& plans, const std::vector<int>& members, int kp, std::vector<int2>& blk) {
-    static const bool place_on = [] { const char* e = getenv("MSC_WGRAD_PLACE"); return !(e && e[0] == '0'); }();
+// Which workgroup of a grouped launch runs which block: problem after problem (longest blocks first), each padded to a multiple
+// of 8 workgroups so that its XCD-local order (wgrad_block: workgroup b runs on XCD b % 8, every XCD gets a contiguous run of the
+// problem's split-major block order) is the one a launch of its own would have.
+// Measured and NOT kept (round 4, profiles/r4_run1_wgrad_place_ab.txt): placing all blocks that read one pixel range of a problem on
+// ONE XCD (whole small problems per XCD instead of four blocks on each of the eight).  The PMC traffic of these launches is 2.8x
+// their operands (7.4 GB for 2.6 GB) because every XCD's L2 fetches the slabs its four blocks need, and the placement removes
+// exactly those re-fetches -- the grouped launches got SLOWER, 2.06 -> 2.28 ms (queues balanced by cost) and 2.47 ms (queues
+// position-balanced by block length): the re-fetches are served by the 256 MB Infinity Cache at a rate that is not the bound, while
+// sixteen to forty-eight blocks hammering the same lines of ONE L2 are.  FETCH_SIZE counts fabric requests, not DRAM reads.
+void wgrad_place(const std::vector<WgPlan>& plans, const std::vector<int>& members, std::vector<int2>& blk) {
     blk.clear();
-    if (!place_on || !xcd_order_enabled()) {
-        for (size_t j = 0; j < members.size(); ++j) {
-            const WgK& k = plans[members[j]].k;
-            const int nb8 = (k.nblocks + 7) & ~7;
-            for (int o = 0; o < nb8; ++o) {
-                int wgid = o;
-                if (xcd_order_enabled() && o < k.nblocks) {
-                    const int xcd = o & 7, wq = k.nblocks >> 3, wr = k.nblocks & 7;
-                    wgid = (xcd < wr ? xcd * (wq + 1) : wr * (wq + 1) + (xcd - wr) * wq) + (o >> 3);
-                }
-                blk.push_back(o < k.nblocks ? make_int2((int)j, wgid) : make_int2(-1, 0));
+    const bool xo = xcd_order_enabled();
+    for (size_t j = 0; j < members.size(); ++j) {
+        const WgK& k = plans[members[j]].k;
+        const int nb8 = (k.nblocks + 7) & ~7;
+        for (int o = 0; o < nb8; ++o) {
+            int wgid = o;
+            if (xo && o < k.nblocks) {
+                const int xcd = o & 7, wq = k.nblocks >> 3, wr = k.nblocks & 7;
+                wgid = (xcd < wr ? xcd * (wq + 1) : wr * (wq + 1) + (xcd - wr) * wq) + (o >> 3);
             }
+            blk.push_back(o < k.nblocks ? make_int2((int)j, wgid) : make_int2(-1, 0));
         }
-        return;
     }
-    // Workgroups are dispatched in index order, round-robin over the XCDs: a queue whose blocks run longer than the others' at the
-    // same position holds the whole dispatch back (first version of this placement: +11 % on the step's grouped launches).  So the
-    // queues are filled class by class -- a class = the problems of one block length (mchunk; members are sorted by it) -- with
-    // the units of a class dealt to the queue holding the fewest blocks, and every queue padded to the class's longest before the
-    // next class starts: at any position the eight XCDs run blocks of the same length.
-    std::vector<int2> queue[8];
-    int rot = 0;
-    size_t j = 0;
-    while (j < members.size()) {
-        const int cls = plans[members[j]].k.mchunk;
-        for (; j < members.size() && plans[members[j]].k.mchunk == cls; ++j) {
-            const WgK& k = plans[members[j]].k;
-            const int per = k.ntiles * k.ntaps, splits = k.nblocks / per;
-            if (splits >= 8) {
-                for (int x = 0; x < 8; ++x) {
-                    const int s0 = (int)((long)splits * x / 8), s1 = (int)((long)splits * (x + 1) / 8);
-                    auto& q = queue[(x + rot) & 7];
-                    for (int o = s0 * per; o < s1 * per; ++o) q.push_back(make_int2((int)j, o));
-                }
-                rot = (rot + 3) & 7;                    // the one-split remainders do not always land on the same queues
-            } else {
-                for (int sp = 0; sp < splits; ++sp) {
-                    int qi = 0;
-                    for (int x = 1; x < 8; ++x) if (queue[x].size() < queue[qi].size()) qi = x;
-                    for (int o = sp * per; o < (sp + 1) * per; ++o) queue[qi].push_back(make_int2((int)j, o));
-                }
-            }
-        }
-        size_t len = 0;
-        for (int x = 0; x < 8; ++x) len = std::max(len, queue[x].size());
-        for (int x = 0; x < 8; ++x) queue[x].resize(len, make_int2(-1, 0));
-    }
-    const size_t len = queue[0].size();
-    blk.assign(len * 8, make_int2(-1, 0));
-    for (int x = 0; x < 8; ++x)
-        for (size_t pos = 0; pos < len; ++pos) blk[pos * 8 + x] = queue[x][pos];
-    (void)kp;
 }
 
 }  // namespace
@@ -1793,7 +1753,7 @@ extern "C" int msc_wgrad_group_create(const msc_wgrad_desc* descs, int n, int st
     std::vector<std::vector<int2>> tables(g->buckets.size());
     size_t bytes = 0;
     for (size_t b = 0; b < g->buckets.size(); ++b) {
-        wgrad_place(plans, members[b], 64 / msc_dtype_size(g->buckets[b].dtype), tables[b]);
+        wgrad_place(plans, members[b], tables[b]);
         bytes += ((members[b].size() * sizeof(WgK) + 255) & ~(size_t)255) + ((tables[b].size() * sizeof(int2) + 255) & ~(size_t)255);
     }
     if (bytes) {

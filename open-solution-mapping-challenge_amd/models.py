@@ -97,10 +97,12 @@ class BasePyTorchUNet(BaseTransformer):
         self.optimizer = HipAdam(self.model, lr=opt.get('lr', 1e-3), weight_decay=wd)
         self.loss_spec = None
         self.loss_function = None                    # [(name, callable(output, target) -> loss, weight)] set by subclasses
-        # gradients travel in 16 bits when the network computes in 16 bits (distributed.World.all_reduce_grad_range) -- always
-        # as bf16: under fp16 compute the gradients still carry the static loss scale (divided out inside Adam), and an
-        # fp16 wire would overflow at |g| > 65504 / scale; bf16 has fp32's exponent range
-        self.world = World(grad_wire=wire_for(self.model.compute_dtype))
+        # gradient exchange over ranks: fp32 ring all-reduce by default -- the precision of the reference's reduce-add (nn.DataParallel,
+        # src/models.py:65).  training_config['grad_wire'] = 'bf16' (or MSC_GRAD_WIRE) opts into the 16-bit all-to-all wire: half the
+        # bytes, every rank's partial rounded once before the sum (distributed.World.all_reduce_grad_range; always bf16 -- under fp16
+        # compute the gradients still carry the loss scale, an fp16 wire would overflow at |g| > 65504 / scale)
+        wire = (training_config or {}).get('grad_wire', 'fp32')
+        self.world = World(grad_wire='fp32' if wire == 'fp32' else wire_for(self.model.compute_dtype))
         self.callbacks = callbacks_unet(self.callbacks_config)     # replaceable by the reference's own CallbackList
         self.epoch_losses = []
 

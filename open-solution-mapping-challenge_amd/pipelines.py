@@ -243,6 +243,70 @@ def unet_padded(config, loader=None, fused_postprocessing=False):
                 adapter={'y_pred': ([(post_step.name, 'images_with_scores')])}, cache_dirpath=cache)
 
 
+class OverlappedAnnotator:
+    """Inference -> post-processing -> annotations with the two halves on two HIP streams (BASELINE.json configs[3] end to end).
+
+    The tail of the reference's inference pipeline (mask_postprocessing, src/pipelines.py:248-304, then create_annotations,
+    src/utils.py:76-115) is latency-bound on the device -- ~60 small launches and four host synchronisations per call -- while the
+    network keeps every CU busy and needs no host attention once enqueued.  On one stream the two alternate (round 3: 5.9 k img/s end
+    to end from a 12.8 k img/s network and a 12.7 k img/s tail).  Here the network batches of group g+1 are ENQUEUED first, on their
+    own stream, into the other half of a double-buffered probability buffer; then the host drives the tail of group g on the tail
+    stream (whose synchronisations wait for that stream only) while the GPU works through the queued forward passes.  An event
+    hands each filled buffer over; a buffer is written again only after the tail that read it has returned (the tail ends with its
+    results on the host).
+
+    annotate(groups): `groups` yields (image_ids, [x batches: cuda f32 [N,3,H,W]], rgb or None) -- rgb cuda u8 [sum N,H,W,3] switches the
+    dense CRF on; yields one JSON document (bytes; `as_list=True`: the list of annotation dicts) per group, in order."""
+
+    def __init__(self, net, category_ids, category_layers, target_size=None, erode_selem_size=0, dilate_selem_size=0,
+                 watershed_selem_size=0, crf_params=None, as_list=False):
+        self.net = net
+        self.kw = dict(category_ids=category_ids, category_layers=category_layers, target_size=target_size, erode_selem_size=erode_selem_size,
+                       dilate_selem_size=dilate_selem_size, watershed_selem_size=watershed_selem_size, crf_params=crf_params)
+        self.as_list = as_list
+        self._bufs, self._streams = {}, None
+
+    def _buf(self, slot, n, h, w, dev):
+        key = (slot, n, h, w)
+        if key not in self._bufs:
+            self._bufs[key] = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev)
+        return self._bufs[key]
+
+    def _tail(self, ids, probs, rgb):
+        from . import utils
+        fn = utils.annotations_from_probabilities if self.as_list else utils.annotations_json_from_probabilities
+        return fn(ids, probs, crf_images=rgb, **self.kw)
+
+    def annotate(self, groups):
+        pending = None                    # (image ids, probability buffer, rgb, event: buffer filled)
+        for slot, (ids, batches, rgb) in enumerate(groups):
+            dev = batches[0].device
+            if self._streams is None:
+                self._streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            s_net, s_tail = self._streams
+            n = sum(int(b.shape[0]) for b in batches)
+            buf = self._buf(slot & 1, n, batches[0].shape[2], batches[0].shape[3], dev)
+            s_net.wait_stream(torch.cuda.current_stream(dev))          # the caller produced the inputs on its stream
+            with torch.cuda.stream(s_net):
+                at = 0
+                for x in batches:
+                    buf[at:at + x.shape[0]].copy_(self.net.predict_proba(x))
+                    at += x.shape[0]
+                filled = torch.cuda.Event()
+                filled.record(s_net)
+            if pending is not None:
+                yield self._run_tail(pending, s_tail)
+            pending = (ids, buf, rgb, filled)
+        if pending is not None:
+            yield self._run_tail(pending, self._streams[1])
+
+    def _run_tail(self, pending, s_tail):
+        ids, buf, rgb, filled = pending
+        with torch.cuda.stream(s_tail):
+            s_tail.wait_event(filled)
+            return self._tail(ids, buf, rgb)
+
+
 # the scoring-model pipelines (src/pipelines.py:307-392: LightGBM/random-forest second level) are outside the hot path
 PIPELINES = {'unet': {'train': partial(unet, train_mode=True), 'inference': partial(unet, train_mode=False)},
              'unet_weighted': {'train': partial(unet_weighted, train_mode=True),

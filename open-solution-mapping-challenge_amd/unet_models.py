@@ -747,7 +747,8 @@ class _Builder:
             # 18432 = 32 tiles of 128x128 for 256 CUs): the reduction runs in slices, a finishing pass applies the epilogue
             pixels, ksteps = self.N * d.Ho * d.Wo, d.Cin * KH * KW * self.es // 128
             tiles = ((pixels + 127) // 128) * ((d.Cout + 127) // 128)
-            split = min(16, 256 // max(tiles, 1), ksteps // 16)
+            cus = torch.cuda.get_device_properties(self.dev).multi_processor_count if self.dev.type == 'cuda' else 256
+            split = min(16, cus // max(tiles, 1), ksteps // 16)
             if tiles <= 64 and split >= 2 and d.Cout % 8 == 0:
                 d.splitk = split
                 ws = self.vec(split * pixels * d.Cout)
@@ -845,17 +846,28 @@ class _Builder:
         reads three more tensors than the launch tune_conv timed, which shifts the best tile towards more, smaller blocks"""
         if not self.net.autotune or self.dev.type != 'cuda' or _os_env.environ.get('MSC_TUNE_JOIN', '1') == '0':
             return
-        key = repr(('j', self.tune_dt, d.N, d.Hi, d.Wi, d.Cin, d.Cout, d.KH, d.KW, bool(d.res), d.in_ld, d.out_ld))
+        key = repr(('j', self.tune_dt, d.N, d.Hi, d.Wi, d.Cin, d.Cout, d.KH, d.KW, bool(d.res), d.in_ld, d.out_ld) +
+                   ((d.flip, d.pad) if (d.flip, d.pad) != (1, 0) else ()))      # (the shipped db holds the 1x1 data-gradient keys without the pair)
         cache, lib = _TUNE_CACHE, self.lib
         if key not in cache or (cache[key] and not lib.msc_conv_cfg_ok(C.byref(d), int(cache[key]))):
             best, best_t, keep = 0, 1e30, d.cfg
+            # the launch accumulates in place (res == out): timed on a scratch copy of its output / addend so that the 1 + 5 repetitions per
+            # configuration neither grow the values of a live gradient buffer to Inf nor time the kernel on degenerate data (the slots
+            # it adds into are reset by the step itself)
+            res0, out0 = d.res, d.out
+            scratch = torch.zeros(((d.N * d.Ho * d.Wo - 1) * max(d.out_ld, d.res_ld) + d.Cout,), dtype=self.tdtype, device=self.dev)
+            if res0 and res0 == out0:
+                d.res = d.out = scratch.data_ptr()
             for c in range(1, lib.msc_conv_num_cfgs() + 1):
                 if not lib.msc_conv_cfg_ok(C.byref(d), c):
                     continue
                 d.cfg = c
-                t = self._time(lib.msc_conv_igemm, C.byref(d))      # (the slots and the gradient buffer it adds into are reset by the step itself)
+                scratch.zero_()
+                t = self._time(lib.msc_conv_igemm, C.byref(d), reps=3)
                 if t is not None and t < best_t:
                     best, best_t = c, t
+            d.res, d.out = res0, out0
+            del scratch
             d.cfg = keep
             cache[key] = best
             self._tuned_new = True
@@ -939,6 +951,8 @@ class _Builder:
             wd.stats_kind, wd.stats_y, wd.stats_y_ld = 1, y.ptr, y.ld
             wd.scale, wd.shift = (scale.data_ptr(), shift.data_ptr()) if mask == 2 else (None, None)
             wd.stats = bslots
+            if wd.cfg and not lib.msc_conv_cfg_ok(C.byref(wd), int(wd.cfg)):
+                wd.cfg = 0                                   # the tuned configuration cannot carry the statistics: heuristic one
         else:
             self.emit(bwd, lib.msc_bn_bwd_reduce, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, mask, scale.data_ptr(),
                       shift.data_ptr(), bslots, self.dt, count, cout)

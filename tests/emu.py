@@ -171,7 +171,8 @@ def loss_sums(logits, target, tc, cfg, sums, N, H, W):
     _arr(sums, 4, np.float64)[...] = [(w * ce).sum(), (p1 * t1).sum(), p1.sum(), t1.sum()]
 
 
-OPT_STEP, OPT_LR, OPT_OVERFLOW, OPT_SKIP, OPT_SCALE, OPT_GOOD, OPT_GROWTH, OPT_SKIPPED, OPT_STATE = range(9)      # include/msc.h MSC_OPT_*
+OPT_STEP, OPT_LR, OPT_OVERFLOW, OPT_SKIP, OPT_SCALE, OPT_GOOD, OPT_GROWTH, OPT_SKIPPED, OPT_UNSCALE = range(9)      # include/msc.h MSC_OPT_*
+OPT_STATE = 12
 
 
 def loss_grad(logits, target, tc, cfg, sums, total_pixels, grad_scale, scale_state, loss, dlogits, N, H, W):
@@ -189,6 +190,7 @@ def loss_grad(logits, target, tc, cfg, sums, total_pixels, grad_scale, scale_sta
 
 def adam_tick(state):
     st = _arr(state, OPT_STATE)
+    st[OPT_UNSCALE] = 1.0 / st[OPT_SCALE] if st[OPT_SCALE] > 0 else 1.0
     if st[OPT_OVERFLOW] != 0:
         st[OPT_OVERFLOW], st[OPT_SKIP], st[OPT_GOOD] = 0.0, 1.0, 0.0
         st[OPT_SKIPPED] += 1.0
@@ -236,8 +238,8 @@ def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, step, gscale, state):
         if st[OPT_SKIP] != 0:
             return
         step, lr = float(st[OPT_STEP]), float(st[OPT_LR])
-        if st[OPT_SCALE] > 0:
-            gscale = gscale / float(st[OPT_SCALE])
+        if st[OPT_UNSCALE] > 0:
+            gscale = gscale * float(st[OPT_UNSCALE])
     pp, gg, mm, vv = _arr(p, n), _arr(g, n), _arr(m, n), _arr(v, n)
     # same operations and rounding points as the kernel, with two scratch arrays instead of a dozen temporaries (the flat buffers are
     # 20-80 M elements: the allocations, not the arithmetic, were what this function spent its time on)

@@ -30,7 +30,8 @@ def test_reexec_line_really_starts_n_ranks_with_the_torchrun_environment(tmp_pat
         'import torch\n'
         'from mapping_challenge_amd.distributed import World, wire_for\n'
         'w = World.from_env(backend="gloo")\n'
-        'w.grad_wire = os.environ.get("MSC_GRAD_WIRE", wire_for("fp16"))\n'      # as bench.py: chosen after construction
+        'assert w.grad_wire == "fp32"\n'                                           # the default: the reference's fp32 reduce-add
+        'w.grad_wire = os.environ.get("MSC_GRAD_WIRE", wire_for("fp16"))\n'      # the opt-in 16-bit wire, chosen after construction
         't = torch.tensor([float(w.rank + 1)])\n'
         'w.all_reduce(t)\n'
         'w.barrier()\n'

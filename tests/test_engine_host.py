@@ -217,8 +217,9 @@ def test_dynamic_loss_scale_skips_an_overflowed_step(interpreted):
     net3.train()
     opt4 = HipAdam(net3, lr=1e-3)
     s4 = TrainStep(net3, LossSpec.plain_ce(), opt4)
-    opt4.set_loss_scale(64.0)
-    s4(x, t)
+    opt4.set_loss_scale(64.0, dynamic=True, growth_interval=1)      # the scale doubles at EVERY tick: the update must still divide by
+    s4(x, t)                                                        # the scale the loss gradient was multiplied with
+    assert opt4.current_loss_scale() == 128.0
     assert torch.allclose(net2.flat_params, net3.flat_params, atol=1e-6)
 
 

@@ -171,3 +171,36 @@ def test_fit_runs_the_callback_protocol_on_the_device(tmp_path, use_graph):
         assert all(s.graph is not None for s in tr._step.shapes.values())
     ck = torch.load(cfg['callbacks_config']['model_checkpoint']['filepath'])
     assert set(ck) == {'module.' + k for k in sd}
+
+
+def test_overlapped_annotator_equals_the_one_stream_tail():
+    """pipelines.OverlappedAnnotator (network of group g+1 on one stream while the host drives the tail of group g on another,
+    double-buffered probabilities): every group's document equals the one the same network + tail give on ONE stream -- also with
+    the watershed extension and the dense CRF in the chain, groups of different size, and more groups than buffers"""
+    import json
+    from mapping_challenge_amd import postprocessing as post, utils
+    from mapping_challenge_amd.pipelines import OverlappedAnnotator
+    from mapping_challenge_amd.unet_models import UNetResNet
+    net = UNetResNet(34, 2, num_filters=32, dropout_2d=0.0, is_deconv=True, compute_dtype='bf16')
+    net.load_state_dict(unet_ref.seeded_state_dict(net))
+    net.eval()
+    groups = []
+    for g in range(5):
+        nb = 1 + g % 2
+        xs = [(unet_ref.synthetic_batch(2, 64, 64, seed=50 + 7 * g + k) * (1.0 + 0.5 * g)).cuda() for k in range(nb)]
+        n = 2 * nb
+        rgb = torch.randint(0, 256, (n, 64, 64, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(g)).cuda()
+        groups.append((list(range(100 * g, 100 * g + n)), xs, rgb))
+    cat_ids, layers = [None, 100], [1, 1]
+    for ws, crf in ((0, False), (3, True)):
+        ann = OverlappedAnnotator(net, cat_ids, layers, (75, 75), 0, 2, watershed_selem_size=ws)
+        docs = list(ann.annotate((ids, xs, rgb if crf else None) for ids, xs, rgb in groups))
+        assert len(docs) == len(groups)
+        total = 0
+        for (ids, xs, rgb), doc in zip(groups, docs):
+            probs = torch.cat([net.predict_proba(x).clone() for x in xs])
+            want = utils.annotations_json_from_probabilities(ids, probs, cat_ids, layers, (75, 75), 0, 2, watershed_selem_size=ws,
+                                                             crf_images=rgb if crf else None)
+            assert doc == want
+            total += len(json.loads(doc))
+        assert total > 0
