@@ -298,6 +298,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[FM][F
 }
 
 
+bool xcd_order_enabled();              // igemm.hip: MSC_XCD_ORDER != 0 (XCD-aware block order; 0 for A/B measurements)
+
 // conv1x1.hip: the streaming kernel of the 1x1 / stride 1 layers (configuration 57 of msc_conv_igemm)
 constexpr int CFG_STREAM = 57;        // conv1x1_stream_kernel (pixel tiles through LDS by DMA, weights in registers)
 bool conv1x1_cfg_ok(const ConvK& k, int es);
