@@ -487,6 +487,17 @@ def main():
             if args.dump_launches:
                 dump_launches(launches, stream, args.dump_launches)
             conv = {k: fam.get('msc_conv_igemm', {}).get(k, 0.0) + fam.get('msc_bottleneck_fused', {}).get(k, 0.0) for k in ('ms', 'launches', 'flops')}
+            # the same family enqueued back to back between ONE pair of events (the per-launch events above put a host round trip
+            # between two kernels; this is the figure that matches the rocprofv3 kernel-time sum of the family)
+            conv_only = [(fn, a) for fn, a in launches if fn.__name__ in ('msc_conv_igemm', 'msc_bottleneck_fused')]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for fn, a in conv_only:
+                assert fn(*a, stream) == 0
+            e1.record()
+            torch.cuda.synchronize()
+            conv_b2b_ms = e0.elapsed_time(e1)
             fused = fam.get('msc_bottleneck_fused')
             wg = {'ms': 0.0, 'launches': 0.0, 'flops': 0.0}
             for name in ('msc_conv_wgrad', 'msc_wgrad_group_run'):
@@ -496,10 +507,18 @@ def main():
             dom = max(fam.items(), key=lambda kv: kv[1]['ms'])
             peak = PEAK_F32 if args.dtype == 'fp32' else PEAK_BF16        # bf16 and fp16 MFMA share the dense peak
             ach = conv['flops'] / (conv['ms'] * 1e-3) if conv['ms'] else 0.0
-            traffic = None
+            # HBM bytes per launch from separate rocprofv3 --pmc passes (run_gpu_round.sh pmc -> tools/pmc_summary.py).  The file is
+            # stamped with a hash of the kernel sources it was measured on: a number measured on other kernels is not reported
+            traffic, traffic_note = None, 'no PMC pass on file'
             pmc_file = os.path.join(ROOT, 'profiles', 'pmc_traffic_%s_r%d.json' % (args.workload, enc))
-            if os.path.exists(pmc_file):      # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_summary.py)
-                traffic = json.load(open(pmc_file)).get('hbm_bytes_per_launch')
+            if os.path.exists(pmc_file):
+                sys.path.insert(0, os.path.join(ROOT, 'tools'))
+                from pmc_summary import csrc_stamp
+                pmc = json.load(open(pmc_file))
+                if pmc.get('csrc_sha16') == csrc_stamp():
+                    traffic, traffic_note = pmc.get('hbm_bytes_per_launch'), 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch, measured on these kernel sources (csrc sha %s)' % pmc['csrc_sha16']
+                else:
+                    traffic_note = 'stale: %s was measured on kernel sources %s, the run uses %s' % (os.path.basename(pmc_file), pmc.get('csrc_sha16', 'unstamped'), csrc_stamp())
             result['roofline'] = {
                 'kernel': ('msc_conv_igemm family: conv3x3_halo_dma_kernel (3x3 stride-1 layers) + conv_igemm_dma_kernel (1x1, strided, transposed) '
                            '+ the 32-channel / stem halo kernels + conv1x1_stream_kernel%s; conv / dgrad / deconv, %d launches per step, per-layer autotuned configuration; '
@@ -508,6 +527,8 @@ def main():
                                % (round(fused['launches']), fused['ms'], fused['flops'] / (fused['ms'] * 1e-3) / 1e12)) if fused else '',
                               round(conv['launches']))),
                 'bound': 'mfma', 'achieved': ach / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
+                'traffic_note': traffic_note,
+                'back_to_back': {'ms_per_step': conv_b2b_ms, 'achieved': conv['flops'] / (conv_b2b_ms * 1e-3) / 1e12, 'frac': conv['flops'] / (conv_b2b_ms * 1e-3) / peak},
                 'avg_launch_us': 1e3 * conv['ms'] / max(conv['launches'], 1),
                 'algorithmic_gflop_per_step': conv['flops'] / 1e9,
                 'wgrad': {'achieved': (wg['flops'] / (wg['ms'] * 1e-3) / 1e12) if wg['ms'] else None, 'ms_per_step': wg['ms'],

@@ -75,20 +75,23 @@ typedef short v4i16_t __attribute__((ext_vector_type(4)));
 
 // ABL (probes/wgrad_ablate.hip only; 0 in the product): bit 0 = no MFMA, bit 1 = no DMA after the prologue, bit 2 = no fragment
 // reads and no MFMA, bit 5 = no atomics (the epilogue keeps the accumulators alive only)
-template <typename T, int TA, int TB, int NST, int ABL = 0>
+template <typename T, int TA, int TB, int NST, int ABL = 0, int NWV = 4>
 __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, const int nwg) {
     constexpr int ES = sizeof(T);
     constexpr int KP = 64 / ES;                  // pixels per k-step (32 bf16 / 16 f32)
     constexpr int RBA = TA * ES, RBB = TB * ES;  // bytes per pixel row of each tile
     constexpr int UA = RBA / 16, UB = RBB / 16;  // 16-byte units per row
     constexpr int NIA = KP * RBA / 1024, NIB = KP * RBB / 1024;   // DMA wave-instructions per tile
-    constexpr int IA = (NIA + 3) / 4, IB = (NIB + 3) / 4;         // ... per wave
+    constexpr int IA = (NIA + NWV - 1) / NWV, IB = (NIB + NWV - 1) / NWV;   // ... per wave
     constexpr int RPA = 1024 / RBA, RPB = 1024 / RBB;            // pixel rows per wave-instruction
     constexpr int STAGE = KP * (RBA + RBB);
     constexpr int LPW = IA + IB;
-    constexpr int WTA = TA / 2, WTB = TB / 2;
+    constexpr int NWA = NWV / 2;                                 // waves along A x 2 along B
+    constexpr int WTA = TA / NWA, WTB = TB / 2;
     constexpr int FM = WTA / 16, FN = WTB / 16;
     static_assert(NIA >= 2 && NIB >= 2, "tile too small");
+    static_assert(NWV == 4 || (NIA >= NWV && NIB >= NWV), "8-wave form: every wave fetches");
+    static_assert(NST * STAGE <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
 
     const int tid = threadIdx.x;
@@ -115,13 +118,13 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
     unsigned pcol[IA], qcol[IB];
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-        const int j = NIA >= 4 ? i * 4 + wid : (wid & (NIA - 1));
+        const int j = NIA >= NWV ? i * NWV + wid : (wid & (NIA - 1));
         prow[i] = j * RPA + lane / UA;
         pcol[i] = (unsigned)a0 * ES + (unsigned)wg_swz<T>(lane % UA, prow[i], UA) * 16u;
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-        const int j = NIB >= 4 ? i * 4 + wid : (wid & (NIB - 1));
+        const int j = NIB >= NWV ? i * NWV + wid : (wid & (NIB - 1));
         qrow[i] = j * RPB + lane / UB;
         qcol[i] = (unsigned)b0 * ES + (unsigned)wg_swz<T>(lane % UB, qrow[i], UB) * 16u;
     }
@@ -151,12 +154,12 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
             const int ii = i < IA ? i : 0;
             const int m = mb + prow[ii];
             const unsigned off = m < mend ? (unsigned)m * ppix + pcol[ii] : OOB_OFF;
-            dma16(rp, sp + (NIA >= 4 ? ii * 4 + wid : (wid & (NIA - 1))) * 1024, off, 0);
+            dma16(rp, sp + (NIA >= NWV ? ii * NWV + wid : (wid & (NIA - 1))) * 1024, off, 0);
         } else if (direct) {          // 1x1 / stride 1: the Q pixel IS the P pixel -- no decode, no bounds beyond the pixel range
             const int ii = i >= IA ? i - IA : 0;
             const int m = mb + qrow[ii];
             const unsigned off = m < mend ? (unsigned)m * qpix + qcol[ii] : OOB_OFF;
-            dma16(rq, sq + (NIB >= 4 ? ii * 4 + wid : (wid & (NIB - 1))) * 1024, off, 0);
+            dma16(rq, sq + (NIB >= NWV ? ii * NWV + wid : (wid & (NIB - 1))) * 1024, off, 0);
         } else {
             const int ii = i >= IA ? i - IA : 0;
             const int m = mb + qrow[ii];
@@ -174,7 +177,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
             const int iy = y * p.stride - p.pad + kh, ix = x * p.stride - p.pad + kw + qsp;
             if (m < mend && (unsigned)iy < (unsigned)p.Hq && (unsigned)ix < (unsigned)p.Wq)
                 off = (unsigned)((n * p.Hq + iy) * p.Wq + ix - qsp) * qpix + qcol[ii];
-            dma16(rq, sq + (NIB >= 4 ? ii * 4 + wid : (wid & (NIB - 1))) * 1024, off, 0);
+            dma16(rq, sq + (NIB >= NWV ? ii * NWV + wid : (wid & (NIB - 1))) * 1024, off, 0);
             // advance this piece's pixel by one k-step
             x += dxs;
             if (x >= p.Wp) { x -= p.Wp; ++y; }
@@ -537,12 +540,14 @@ __device__ __forceinline__ bool wgrad_group_fetch(const WgK* __restrict__ tab, c
     return orig < p.nblocks;
 }
 
-template <typename T, int TA, int TB, int NST>
-__global__ __launch_bounds__(256) void conv_wgrad_group_kernel(const WgK* __restrict__ tab, const int2* __restrict__ blk) {
-    WgK p;
-    int orig;
-    if (!wgrad_group_fetch(tab, blk, p, orig)) return;
-    wgrad_dma_body<T, TA, TB, NST>(p, orig, p.nblocks);
+template <typename T, int TA, int TB, int NST, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void conv_wgrad_group_kernel(const WgK* __restrict__ tab, const int2* __restrict__ blk) {
+    if constexpr (TA <= 128 || sizeof(T) == 2) {      // the 256x256 tile exists for the 16-bit types
+        WgK p;
+        int orig;
+        if (!wgrad_group_fetch(tab, blk, p, orig)) return;
+        wgrad_dma_body<T, TA, TB, NST, 0, NWV>(p, orig, p.nblocks);
+    }
 }
 
 template <typename T, int TA, int TB, int NST, int NWV = 4>
@@ -620,11 +625,18 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
     k.kw3 = kw3 ? 1 : 0;
     k.sw = d->Wp < 32 ? d->Wp : 32;
     bool big = (d->A % 128 == 0) && (d->B % 128 == 0);
+    // 256x256 tiles (grouped launches, 16-bit, single-tap problems whose channel counts allow it -- ResNet101's layer3 / layer4 1x1
+    // convolutions, the 512 -> 256 ConvTranspose2d layers): half the operand bytes per MFMA of the 128x128 tile, which runs at a
+    // quarter of the matrix peak while moving 9 TB/s through the L2 -> LDS fill and 5 TB/s past the L2 (round 4).  Eight waves, 128
+    // accumulator registers each, one block per CU; half the k-steps per block so that a layer still gives the chip enough blocks.
+    static const bool t256_on = [] { const char* e = getenv("MSC_WGRAD_T256"); return !(e && e[0] == '0'); }();
+    bool huge = false;
     int tsel = 0, splits;
     if (steps_per_block > 0) {
         if (tile_cap < 128) big = false;
         if (tile_cap < 64) tsel = 2;
-        splits = ceil_div(ksteps, steps_per_block);
+        huge = t256_on && big && fits && es == 2 && !kw3 && d->A % 256 == 0 && d->B % 256 == 0;
+        splits = ceil_div(ksteps, huge ? (steps_per_block + 1) / 2 : steps_per_block);
     } else {
         // Tile and split-K choice.  Every split adds one fp32-atomic pass over dW and a pipeline fill, so a block
         // should run >= 24 k-steps; within that, prefer the largest tile that still gives >= 384 blocks.
@@ -647,7 +659,7 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
         splits = ceil_div(target, (d->A / ta0) * (d->B / tb0) * ntaps);
         if (splits > max_splits) splits = max_splits;
     }
-    const int ta = big ? 128 : (d->A % 64 == 0 && tsel != 2 ? 64 : 32), tbs = big ? 128 : (d->B % 64 == 0 ? 64 : 32);
+    const int ta = huge ? 256 : big ? 128 : (d->A % 64 == 0 && tsel != 2 ? 64 : 32), tbs = huge ? 256 : big ? 128 : (d->B % 64 == 0 ? 64 : 32);
     if (splits < 1) splits = 1;
     int mchunk = ceil_div(k.M, splits);
     mchunk = ceil_div(mchunk, kp) * kp;
@@ -676,7 +688,8 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
 template <typename F>
 void wgrad_tile_dispatch(int dtype, int ta, int tb, F&& f) {
 #define MSC_WG_CASE(T) \
-    if (ta == 128) f.template operator()<T, 128, 128>(); \
+    if (ta == 256) f.template operator()<T, 256, 256>(); \
+    else if (ta == 128) f.template operator()<T, 128, 128>(); \
     else if (ta == 64 && tb == 64) f.template operator()<T, 64, 64>(); \
     else if (ta == 64) f.template operator()<T, 64, 32>(); \
     else if (tb == 64) f.template operator()<T, 32, 64>(); \
@@ -688,11 +701,13 @@ void wgrad_tile_dispatch(int dtype, int ta, int tb, F&& f) {
 struct WgLaunchOne {
     const WgK& k; hipStream_t st;
     template <typename T, int TA, int TB> void operator()() const {
-        if (k.kw3) {
-            if constexpr (TA == 128) hipLaunchKernelGGL((conv_wgrad3_dma_kernel<T, TA, TB, 4, 8>), dim3(k.nblocks), dim3(512), 0, st, k);
-            else hipLaunchKernelGGL((conv_wgrad3_dma_kernel<T, TA, TB, 4>), dim3(k.nblocks), dim3(256), 0, st, k);
+        if constexpr (TA <= 128) {      // (256x256 tiles are planned for grouped launches only)
+            if (k.kw3) {
+                if constexpr (TA == 128) hipLaunchKernelGGL((conv_wgrad3_dma_kernel<T, TA, TB, 4, 8>), dim3(k.nblocks), dim3(512), 0, st, k);
+                else hipLaunchKernelGGL((conv_wgrad3_dma_kernel<T, TA, TB, 4>), dim3(k.nblocks), dim3(256), 0, st, k);
+            }
+            else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, TA, TB, 4>), dim3(k.nblocks), dim3(256), 0, st, k);
         }
-        else hipLaunchKernelGGL((conv_wgrad_dma_kernel<T, TA, TB, 4>), dim3(k.nblocks), dim3(256), 0, st, k);
     }
 };
 
@@ -701,8 +716,9 @@ struct WgLaunchGroup {
     template <typename T, int TA, int TB> void operator()() const {
         if (kw3) {
             if constexpr (TA == 128) hipLaunchKernelGGL((conv_wgrad3_group_kernel<T, TA, TB, 4, 8>), dim3(blocks), dim3(512), 0, st, tab, blk);
-            else hipLaunchKernelGGL((conv_wgrad3_group_kernel<T, TA, TB, 4>), dim3(blocks), dim3(256), 0, st, tab, blk);
+            else if constexpr (TA < 128) hipLaunchKernelGGL((conv_wgrad3_group_kernel<T, TA, TB, 4>), dim3(blocks), dim3(256), 0, st, tab, blk);
         }
+        else if constexpr (TA == 256) hipLaunchKernelGGL((conv_wgrad_group_kernel<T, TA, TB, 4, 8>), dim3(blocks), dim3(512), 0, st, tab, blk);
         else hipLaunchKernelGGL((conv_wgrad_group_kernel<T, TA, TB, 4>), dim3(blocks), dim3(256), 0, st, tab, blk);
     }
 };

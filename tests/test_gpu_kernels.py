@@ -373,7 +373,8 @@ def test_grouped_weight_gradients_equal_separate_ones(dtype, steps, cap):
     launch per bucket; each gradient equals torch's, also when the group is run twice into the same buffers (+=)"""
     import hip_ops as ops
     shapes = [(128, 128, 3, 1, 20, 3), (64, 256, 1, 1, 16, 4), (32, 32, 3, 1, 24, 2), (64, 64, 3, 2, 18, 2), (256, 128, 1, 1, 9, 3),
-              (128, 256, 3, 1, 7, 1), (32, 96, 1, 2, 10, 2)]
+              (128, 256, 3, 1, 7, 1), (32, 96, 1, 2, 10, 2),
+              (512, 256, 1, 1, 11, 2), (256, 256, 1, 2, 12, 2)]      # channel counts that take the 256x256 tile (16-bit, grouped; ragged pixels)
     problems, refs = [], []
     for i, (cin, cout, k, stride, hw, n) in enumerate(shapes):
         pad = k // 2
@@ -386,7 +387,7 @@ def test_grouped_weight_gradients_equal_separate_ones(dtype, steps, cap):
         dw = torch.zeros((cout, k, k, cin), dtype=torch.float32, device='cuda')
         problems.append((nhwc(dy, dtype), nhwc(x, dtype), dw, k, k, stride, pad))
     launches = ops.conv_wgrad_group(problems, steps, cap, runs=2)
-    assert 1 <= launches <= 5
+    assert 1 <= launches <= 6
     for pr, gref in zip(problems, refs):
         err = (pr[2].cpu() / 2 - gref).abs().max().item() / gref.abs().max().item()
         assert err < (2e-5 if dtype == torch.float32 else 1e-2), (pr[2].shape, err)

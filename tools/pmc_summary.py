@@ -13,6 +13,19 @@ import sys
 from collections import defaultdict
 
 
+def csrc_stamp():
+    """sha256 (first 16 hex digits) over the kernel sources the counters were measured on: bench.py reports the traffic only while
+    the sources it runs are the ones stamped here (the GPU box has no .git to ask)"""
+    import hashlib
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'open-solution-mapping-challenge_amd', 'csrc')
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(here)):
+        if f.endswith(('.hip', '.h')):
+            h.update(f.encode())
+            h.update(open(os.path.join(here, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def main():
     root = sys.argv[1]
     acc = defaultdict(lambda: defaultdict(float))
@@ -35,7 +48,7 @@ def main():
               'stem7_halo_kernel', 'splitk_finish_kernel')      # = msc_conv_igemm
     fam = [r for r in rows if r['kernel'].startswith(FAMILY)]
     tot_l = sum(r['launches'] for r in fam)
-    summary = {'family': 'msc_conv_igemm (conv_igemm_dma_kernel + halo-tile kernels)', 'launches': tot_l,
+    summary = {'family': 'msc_conv_igemm (conv_igemm_dma_kernel + halo-tile kernels)', 'launches': tot_l, 'csrc_sha16': csrc_stamp(),
                'hbm_bytes_per_launch': sum(r['hbm_bytes_per_launch'] * r['launches'] for r in fam) / max(tot_l, 1),
                'note': 'FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes, averaged over all launches of the family',
                'kernels': rows[:40]}
