@@ -42,6 +42,8 @@ prof)  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > g
        prof_stats infer_r101 --workload infer --encoder 101 --steps 20 --warmup 2
        prof_stats post --workload post --steps 20 --warmup 2
        prof_stats e2e --workload e2e --steps 5 --warmup 2;;
+proft) python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
+       prof_stats train --steps 20 --warmup 2;;
 pmc)   python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
        cd /tmp; export TMPDIR=/tmp
        for c in FETCH_SIZE WRITE_SIZE; do
