@@ -626,10 +626,13 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
     k.sw = d->Wp < 32 ? d->Wp : 32;
     bool big = (d->A % 128 == 0) && (d->B % 128 == 0);
     // 256x256 tiles (grouped launches, 16-bit, single-tap problems whose channel counts allow it -- ResNet101's layer3 / layer4 1x1
-    // convolutions, the 512 -> 256 ConvTranspose2d layers): half the operand bytes per MFMA of the 128x128 tile, which runs at a
-    // quarter of the matrix peak while moving 9 TB/s through the L2 -> LDS fill and 5 TB/s past the L2 (round 4).  Eight waves, 128
-    // accumulator registers each, one block per CU; half the k-steps per block so that a layer still gives the chip enough blocks.
-    static const bool t256_on = [] { const char* e = getenv("MSC_WGRAD_T256"); return !(e && e[0] == '0'); }();
+    // convolutions, the 512 -> 256 ConvTranspose2d layers): half the operand bytes per MFMA of the 128x128 tile; eight waves, 128
+    // accumulator registers each, one block per CU, half the k-steps per block.  MEASURED NEUTRAL (round 4, profiles/
+    // r4_run4_wgrad_t256_ab.txt): the 284 GFLOP that move into this bucket take 499 us against ~470 us in the 128x128 one -- the
+    // single-tap kernels are bound by what they fetch from BEYOND the L2 (5 TB/s of fabric reads, 2.7 us of queueing latency against
+    // 48 KB in flight per block), and with 4 tiles x 2-4 splits a problem has one block per XCD: every slab is still fetched once per
+    // block.  Opt-in: MSC_WGRAD_T256=1.
+    static const bool t256_on = [] { const char* e = getenv("MSC_WGRAD_T256"); return e && e[0] == '1'; }();
     bool huge = false;
     int tsel = 0, splits;
     if (steps_per_block > 0) {
