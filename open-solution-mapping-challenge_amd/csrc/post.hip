@@ -664,6 +664,128 @@ __global__ __launch_bounds__(256) void crf_iter_tiled_kernel(const float* __rest
     }
 }
 
+// ---- round 4: the same tiled iteration for window radii <= 5 (the reference's sxy = 1 for both kernels) with the inner loops laid out
+// for the machine.  The first tiled form keeps 32 bytes per halo pixel and the two spatial tables in LDS (74 KB per block: two blocks =
+// two waves per SIMD) and reads the tables with two broadcast ds_read_b32 per (tap, pixel) inside a loop the compiler cannot unroll
+// (runtime radius): every k-iteration is a dependent LDS read -> exp -> FMA chain that nothing else covers -- 857 us per iteration
+// for 128 images against ~260 us of VALU issue.  Here: radius as template parameter (the 11 columns of a halo row are straight-line
+// code: all their LDS reads are in flight together); colours packed to one dword per halo pixel (20 bytes per pixel, 35 KB per
+// block: four blocks per CU); the spatial weights are SEPARABLE -- exp(-(dx^2+dy^2)c) = gx[dx]*gy[dy], and for the bilateral kernel the
+// exponent is bx[dx] + by[dy] -- so the column factors sit in registers and the row factors cost one v_exp_f32 per (halo row, pixel).
+template <int R>
+struct CrfHaloR {
+    static constexpr int HW_ = CRF_T + 2 * R;
+    float4 a[HW_ * HW_];        // (q0*ng, q1*ng, q0*nb, q1*nb); zeros outside the image
+    uint32_t c[HW_ * HW_];      // r | g << 8 | b << 16 | inside << 24
+};
+
+// NORM: the normalisers (sum of the kernel weights over the window clipped to the image) instead of one iteration
+template <int R> struct CrfCols { float gx[2 * R + 1], bx[2 * R + 1]; };      // column factors, computed on the host: kernel arguments = SGPR operands
+
+template <int R, bool NORM>
+__global__ __launch_bounds__(256, 4) void crf_r_kernel(const float* __restrict__ probs, const uint8_t* __restrict__ rgb, float* __restrict__ ng,
+                                                    float* __restrict__ nb, const float* __restrict__ qin, float* __restrict__ qout, CrfP c,
+                                                    CrfCols<R> cols) {
+    __shared__ CrfHaloR<R> s;
+    constexpr int hw = CRF_T + 2 * R;
+    const long HW = (long)c.H * c.W, b = blockIdx.z;
+    const int x0 = blockIdx.x * CRF_T, y0 = blockIdx.y * CRF_T;
+    const float* q0 = NORM ? nullptr : qin + (b * 2) * HW;
+    const float* q1 = NORM ? nullptr : q0 + HW;
+    for (int i = threadIdx.x; i < hw * hw; i += blockDim.x) {
+        const int yy = y0 - R + i / hw, xx = x0 - R + i % hw;
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t vc = 0;
+        if ((unsigned)yy < (unsigned)c.H && (unsigned)xx < (unsigned)c.W) {
+            const long j = (long)yy * c.W + xx;
+            const uint8_t* px = rgb + (b * HW + j) * 3;
+            vc = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | (1u << 24);
+            if (!NORM) {
+                const float a0 = q0[j], a1 = q1[j], n_g = ng[b * HW + j], n_b = nb[b * HW + j];
+                va = make_float4(a0 * n_g, a1 * n_g, a0 * n_b, a1 * n_b);
+            }
+        }
+        if (!NORM) s.a[i] = va;
+        s.c[i] = vc;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = (threadIdx.x >> 5) * CRF_PV;
+    const int x = x0 + tx;
+    if (x >= c.W || y0 + ty >= c.H) return;
+    // column factors of the two kernels come as kernel arguments (scalar registers: the dx loop below is unrolled, so cols.gx[i] is a
+    // fixed SGPR); a kernel whose own radius is smaller has zeros / -1e30 there
+    const float kg2 = c.inv2g * 1.44269504f, kb2 = c.inv2b * 1.44269504f, krgb = c.inv2rgb * 1.44269504f;
+    float mr[CRF_PV], mg[CRF_PV], mb[CRF_PV];
+#pragma unroll
+    for (int k = 0; k < CRF_PV; ++k) {
+        const uint32_t m = s.c[(ty + k + R) * hw + tx + R];
+        mr[k] = (float)(m & 255u); mg[k] = (float)((m >> 8) & 255u); mb[k] = (float)((m >> 16) & 255u);
+    }
+    float g0[CRF_PV], g1[CRF_PV], b0[CRF_PV], b1[CRF_PV];
+#pragma unroll
+    for (int k = 0; k < CRF_PV; ++k) { g0[k] = 0.f; g1[k] = 0.f; b0[k] = 0.f; b1[k] = 0.f; }
+    for (int hy = 0; hy < CRF_PV + 2 * R; ++hy) {
+        // row factors for the (up to four) pixels this halo row is in the window of; dy is the same for every lane
+        // row factors for the (up to four) pixels this halo row is in the window of; dy is the same for every lane.  Rows outside a pixel's
+        // window are skipped with a wave-uniform branch -- measured against the branch-free form (factors 0 / -1e30 for those rows, the
+        // four pixels' chains interleaved by the scheduler): that one needs 182-254 registers (two or three waves per SIMD) or spills at
+        // 128, and ran 1.18-1.25 ms per 32 images against 0.90 ms for this one at four waves per SIMD (profiles/r4_run7_crf_variants.txt)
+        float gy[CRF_PV], by[CRF_PV];
+        bool on[CRF_PV];
+#pragma unroll
+        for (int k = 0; k < CRF_PV; ++k) {
+            const int dy = hy - k - R, ad = dy < 0 ? -dy : dy;
+            on[k] = ad <= R;
+            gy[k] = ad <= c.rg ? __builtin_amdgcn_exp2f(-(float)(dy * dy) * kg2) : 0.f;
+            by[k] = ad <= c.rb ? -(float)(dy * dy) * kb2 : -1e30f;
+        }
+        const int h0 = (ty + hy) * hw + tx;
+        uint32_t oc[2 * R + 1];
+        float4 qv[2 * R + 1];
+#pragma unroll
+        for (int i = 0; i <= 2 * R; ++i) {
+            oc[i] = s.c[h0 + i];
+            if (!NORM) qv[i] = s.a[h0 + i];
+        }
+#pragma unroll
+        for (int i = 0; i <= 2 * R; ++i) {
+            const float orr = (float)(oc[i] & 255u), og = (float)((oc[i] >> 8) & 255u), ob = (float)((oc[i] >> 16) & 255u);
+            const float ins = (float)(oc[i] >> 24);
+#pragma unroll
+            for (int k = 0; k < CRF_PV; ++k) {
+                if (!on[k]) continue;                                        // wave-uniform
+                const float d0 = orr - mr[k], d1 = og - mg[k], d2 = ob - mb[k];
+                const float kg = cols.gx[i] * gy[k];
+                const float kb = __builtin_amdgcn_exp2f((cols.bx[i] + by[k]) - (d0 * d0 + d1 * d1 + d2 * d2) * krgb);      // argument <= 0
+                if (NORM) {
+                    g0[k] += kg * ins;
+                    b0[k] += kb * ins;
+                } else {
+                    g0[k] += kg * qv[i].x; g1[k] += kg * qv[i].y;            // out-of-image neighbours carry Q = 0
+                    b0[k] += kb * qv[i].z; b1[k] += kb * qv[i].w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CRF_PV; ++k) {
+        const int y = y0 + ty + k;
+        if (y >= c.H) break;
+        const long p = (long)y * c.W + x;
+        if (NORM) {
+            ng[b * HW + p] = 1.f / sqrtf(g0[k] + 1e-20f);
+            nb[b * HW + p] = 1.f / sqrtf(b0[k] + 1e-20f);
+        } else {
+            const float u0 = -logf(fminf(fmaxf(probs[(b * 2) * HW + p], 1e-5f), 1.f));
+            const float u1 = -logf(fminf(fmaxf(probs[(b * 2 + 1) * HW + p], 1e-5f), 1.f));
+            const float n_g = ng[b * HW + p], n_b = nb[b * HW + p];
+            const float t0 = -u0 + c.compat_g * g0[k] * n_g + c.compat_b * b0[k] * n_b;
+            const float t1 = -u1 + c.compat_g * g1[k] * n_g + c.compat_b * b1[k] * n_b;
+            softmax2(t0, t1, &qout[(b * 2) * HW + p], &qout[(b * 2 + 1) * HW + p]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ test-time augmentation (src/loaders.py:401-517)
 // spec bits: 0 = ud flip, 1 = lr flip (the reference's elif chain: ud wins), 2-3 = rotation / 90 (counter-clockwise,
 // as skimage.rotate / np.rot90).  transformed = rot90^k(flip(image)).
@@ -905,13 +1027,23 @@ extern "C" int msc_dense_crf(const float* probs, const uint8_t* rgb, float* out,
     static const bool naive = [] { const char* e = getenv("MSC_CRF_NAIVE"); return e && e[0] == '1'; }();      // A/B: the global-memory kernels
     const bool tiled = r <= CRF_RMAX && !naive;
     const dim3 gt(ceil_div(W, CRF_T), ceil_div(H, CRF_T), B);
-    if (tiled) hipLaunchKernelGGL(crf_norm_tiled_kernel, gt, dim3(256), 0, st, rgb, ng, nb, c, r);
+    static const bool r5_off = [] { const char* e = getenv("MSC_CRF_R5"); return e && e[0] == '0'; }();                // A/B: the first tiled form
+    const bool fast = tiled && r <= 5 && !r5_off;
+    CrfCols<5> cols;
+    for (int i = 0; i <= 10; ++i) {
+        const int dx = i - 5, ad = dx < 0 ? -dx : dx;
+        cols.gx[i] = ad <= c.rg ? exp2f(-(float)(dx * dx) * c.inv2g * 1.44269504f) : 0.f;
+        cols.bx[i] = ad <= c.rb ? -(float)(dx * dx) * c.inv2b * 1.44269504f : -1e30f;
+    }
+    if (fast) hipLaunchKernelGGL((crf_r_kernel<5, true>), gt, dim3(256), 0, st, (const float*)nullptr, rgb, ng, nb, (const float*)nullptr, (float*)nullptr, c, cols);
+    else if (tiled) hipLaunchKernelGGL(crf_norm_tiled_kernel, gt, dim3(256), 0, st, rgb, ng, nb, c, r);
     else hipLaunchKernelGGL(crf_norm_kernel, g, dim3(256), 0, st, rgb, ng, nb, c);
     hipLaunchKernelGGL(crf_init_kernel, g, dim3(256), 0, st, probs, iterations == 0 ? out : qa, HW);
     float* cur = qa;
     for (int it = 0; it < iterations; ++it) {
         float* dst = (it == iterations - 1) ? out : (cur == qa ? qb : qa);
-        if (tiled) hipLaunchKernelGGL(crf_iter_tiled_kernel, gt, dim3(256), 0, st, probs, rgb, ng, nb, cur, dst, c, r);
+        if (fast) hipLaunchKernelGGL((crf_r_kernel<5, false>), gt, dim3(256), 0, st, probs, rgb, ng, nb, (const float*)cur, dst, c, cols);
+        else if (tiled) hipLaunchKernelGGL(crf_iter_tiled_kernel, gt, dim3(256), 0, st, probs, rgb, ng, nb, cur, dst, c, r);
         else hipLaunchKernelGGL(crf_iter_kernel, g, dim3(256), 0, st, probs, rgb, ng, nb, cur, dst, c);
         cur = dst;
     }
