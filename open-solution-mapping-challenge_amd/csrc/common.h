@@ -81,6 +81,31 @@ template <> struct ElemIO<bf16_t> {
     static __device__ __forceinline__ bf16_t from(float v) { return f32_to_bf16(v); }
 };
 
+// One 16-byte global store per lane, the form every tensor-producing kernel writes its output with.  MSC_STORE_WT selects the cache
+// policy (MI355X_MICROARCH.md, "stores of each flavour"): 0 = plain (default), 1 = sc1 (write-through, line dropped from the L2), 2 =
+// sc0 sc1, 3 = nt.  Measured (round 4, profiles/r4_run8_store_policy_ab.txt): write-through avoids the write-back burst at the kernel
+// boundary but LOSES -- train step 11.09 -> 11.40 ms, forward 2.29 -> 2.45 ms: the boundary's write-back leaves the lines clean in the
+// producing XCD's L2, where the XCD-aware tile order lets the next kernel's blocks find them; sc1 drops them.
+#ifndef MSC_STORE_WT
+#define MSC_STORE_WT 0
+#endif
+typedef unsigned msc_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16(void* p, uint4 v) {
+#if MSC_STORE_WT == 0
+    *reinterpret_cast<uint4*>(p) = v;
+#else
+    msc_u32x4 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+#if MSC_STORE_WT == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+#elif MSC_STORE_WT == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(t) : "memory");
+#endif
+#endif
+}
+
 // 16-byte vector of T as floats: 4 x f32 or 8 x bf16
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
@@ -95,9 +120,7 @@ template <> struct Vec16<float> {
     static __device__ __forceinline__ uint4 pack(const float* v) {
         return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
     }
-    static __device__ __forceinline__ void store(float* p, const float* v) {
-        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    }
+    static __device__ __forceinline__ void store(float* p, const float* v) { store16(p, pack(v)); }
 };
 template <> struct Vec16<bf16_t> {
     static constexpr int N = 8;
@@ -116,7 +139,7 @@ template <> struct Vec16<bf16_t> {
         t.z = pack_bf16x2(v[4], v[5]); t.w = pack_bf16x2(v[6], v[7]);
         return t;
     }
-    static __device__ __forceinline__ void store(bf16_t* p, const float* v) { *reinterpret_cast<uint4*>(p) = pack(v); }
+    static __device__ __forceinline__ void store(bf16_t* p, const float* v) { store16(p, pack(v)); }
 };
 
 template <> struct Vec16<f16_t> {
@@ -137,7 +160,7 @@ template <> struct Vec16<f16_t> {
         t.z = pack_f16x2(v[4], v[5]); t.w = pack_f16x2(v[6], v[7]);
         return t;
     }
-    static __device__ __forceinline__ void store(f16_t* p, const float* v) { *reinterpret_cast<uint4*>(p) = pack(v); }
+    static __device__ __forceinline__ void store(f16_t* p, const float* v) { store16(p, pack(v)); }
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
