@@ -172,6 +172,25 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
 // arithmetic, as the former finalize kernels did) and park them in LDS -- 208 dependent 6-8 us finalize launches per
 // ResNet101 train step are gone.  The blocks of the first pixel range also publish what later kernels need (scale / shift /
 // mean / invstd, running statistics; dgamma / dbeta).
+// Block -> (pixel block, channel tile) of the channel-tiled BatchNorm kernels (1-D grid of npb * nct blocks).  XCD-aware (round 4): workgroup
+// b runs on XCD b % 8; every XCD gets a CONTIGUOUS run of pixel blocks, channel tile fastest -- the same pixel ranges the convolution
+// kernels give it (conv_igemm_dma_kernel's tile order).  The write-back at a kernel boundary leaves a producer's lines clean in ITS XCD's
+// L2 (profiles/r4_run8_store_policy_ab.txt: dropping them costs 3 %); with pixel blocks dealt round-robin over the XCDs, as before, seven
+// eighths of what a BatchNorm pass reads had been written through another XCD's L2 and came from the fabric.
+__device__ __forceinline__ void bn_block(int nct, int xcd_order, int& pb, int& ct) {
+    int wgid = (int)blockIdx.x;
+    if (xcd_order) {
+        const int nwg = (int)gridDim.x, xcd = wgid & 7, wq = nwg >> 3, wr = nwg & 7;
+        wgid = (xcd < wr ? xcd * (wq + 1) : wr * (wq + 1) + (xcd - wr) * wq) + (wgid >> 3);
+    } else {                      // the former 2-D grid: pixel block fastest
+        const int npb = (int)gridDim.x / nct;
+        pb = wgid % npb; ct = wgid / npb;
+        return;
+    }
+    pb = wgid / nct;
+    ct = wgid - pb * nct;
+}
+
 struct BnFwdFin {
     const double* slots; double count; const float* gamma; const float* beta; float eps, momentum;
     float* running_mean; float* running_var; float* scale; float* shift; float* save_mean; float* save_invstd;
@@ -179,10 +198,13 @@ struct BnFwdFin {
 
 template <typename T, int CT>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, long y_ld, const T* __restrict__ res, long res_ld,
-                                                       T* __restrict__ out, long out_ld, BnFwdFin f, int relu, long pixels, int C, long ppb) {
+                                                       T* __restrict__ out, long out_ld, BnFwdFin f, int relu, long pixels, int C, long ppb,
+                                                       int xcd_order) {
     constexpr int CE = Vec16<T>::N, VC = CT / CE, R = 256 / VC;
     __shared__ float s_sc[CT], s_sh[CT];
-    const int tid = threadIdx.x, c0 = blockIdx.y * CT;
+    int pb, ct;
+    bn_block(C / CT, xcd_order, pb, ct);
+    const int tid = threadIdx.x, c0 = ct * CT;
     if (tid < CT) {
         const int c = c0 + tid;
         float sc, sh;
@@ -200,7 +222,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
             const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
             sc = g * invstd;
             sh = b - (float)mean * sc;
-            if (blockIdx.x == 0) {
+            if (pb == 0) {
                 f.scale[c] = sc;
                 f.shift[c] = sh;
                 if (f.save_mean) f.save_mean[c] = (float)mean;
@@ -222,8 +244,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
     float sc[CE], sh[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) { sc[e] = s_sc[col * CE + e]; sh[e] = s_sh[col * CE + e]; }
-    const long p1 = min(pixels, ((long)blockIdx.x + 1) * ppb);
-    for (long pix = (long)blockIdx.x * ppb + r; pix < p1; pix += R) {
+    const long p1 = min(pixels, ((long)pb + 1) * ppb);
+    for (long pix = (long)pb * ppb + r; pix < p1; pix += R) {
         float v[CE], rr[CE];
         Vec16<T>::load(y + pix * y_ld + c, v);
 #pragma unroll
@@ -250,10 +272,13 @@ template <typename T, int CT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, long dout_ld, const T* __restrict__ out, long out_ld,
                                                            const T* __restrict__ y, long y_ld, int relu, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, BnBwdFin f, T* __restrict__ dy, long dy_ld,
-                                                           T* __restrict__ dres, long dres_ld, int dres_acc, long pixels, int C, long ppb) {
+                                                           T* __restrict__ dres, long dres_ld, int dres_acc, long pixels, int C, long ppb,
+                                                           int xcd_order) {
     constexpr int CE = Vec16<T>::N, VC = CT / CE, R = 256 / VC;
     __shared__ float s_a[CT], s_b[CT], s_k[CT], s_sc[CT], s_sh[CT];
-    const int tid = threadIdx.x, c0 = blockIdx.y * CT;
+    int pb, ct;
+    bn_block(C / CT, xcd_order, pb, ct);
+    const int tid = threadIdx.x, c0 = ct * CT;
     if (tid < CT) {
         const int c = c0 + tid;
         double s1 = 0.0, s2 = 0.0;
@@ -272,7 +297,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         s_a[tid] = (float)a; s_b[tid] = (float)b; s_k[tid] = (float)k0;
         s_sc[tid] = relu == 2 ? scale[c] : 0.f;
         s_sh[tid] = relu == 2 ? shift[c] : 0.f;
-        if (blockIdx.x == 0) {
+        if (pb == 0) {
             if (f.dgamma) f.dgamma[c] += (float)dga;
             if (f.dbeta) f.dbeta[c] += (float)dbe;
         }
@@ -286,8 +311,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         ca[e] = s_a[col * CE + e]; cb[e] = s_b[col * CE + e]; ck[e] = s_k[col * CE + e];
         sc[e] = s_sc[col * CE + e]; sh[e] = s_sh[col * CE + e];
     }
-    const long p1 = min(pixels, ((long)blockIdx.x + 1) * ppb);
-    for (long pix = (long)blockIdx.x * ppb + r; pix < p1; pix += R) {
+    const long p1 = min(pixels, ((long)pb + 1) * ppb);
+    for (long pix = (long)pb * ppb + r; pix < p1; pix += R) {
         float d[CE], o[CE], yy[CE], rr[CE];
         Vec16<T>::load(dout + pix * dout_ld + c, d);
         Vec16<T>::load(y + pix * y_ld + c, yy);
@@ -829,6 +854,7 @@ extern "C" int msc_bn_fold(const float* gamma, const float* beta, const float* r
 }
 
 namespace {
+static int bn_xcd_order() { static const int v = [] { const char* e = getenv("MSC_BN_XCD"); return (e && e[0] == '0') ? 0 : 1; }(); return v; }
 // grid of the channel-tiled BatchNorm kernels: CT channels x `ppb` pixels per block, about 2048 blocks in all
 template <int R>
 long bn_ppb(long pixels, int ctiles) {
@@ -843,8 +869,8 @@ void launch_bn_apply(const void* y, long y_ld, const void* res, long res_ld, voi
                      hipStream_t st) {
     constexpr int R = 256 / (CT / Vec16<T>::N);
     const long ppb = bn_ppb<R>(pixels, C / CT);
-    hipLaunchKernelGGL((bn_apply_kernel<T, CT>), dim3(ceil_div(pixels, ppb), C / CT), dim3(256), 0, st, (const T*)y, y_ld, (const T*)res, res_ld, (T*)out,
-                       out_ld, f, relu, pixels, C, ppb);
+    hipLaunchKernelGGL((bn_apply_kernel<T, CT>), dim3(ceil_div(pixels, ppb) * (C / CT)), dim3(256), 0, st, (const T*)y, y_ld, (const T*)res, res_ld, (T*)out,
+                       out_ld, f, relu, pixels, C, ppb, bn_xcd_order());
 }
 template <typename T, int CT>
 void launch_bn_bwd_apply(const void* dout, long dout_ld, const void* out, long out_ld, const void* y, long y_ld, int relu, const float* scale,
@@ -852,8 +878,8 @@ void launch_bn_bwd_apply(const void* dout, long dout_ld, const void* out, long o
                          hipStream_t st) {
     constexpr int R = 256 / (CT / Vec16<T>::N);
     const long ppb = bn_ppb<R>(pixels, C / CT);
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, CT>), dim3(ceil_div(pixels, ppb), C / CT), dim3(256), 0, st, (const T*)dout, dout_ld, (const T*)out, out_ld,
-                       (const T*)y, y_ld, relu, scale, shift, f, (T*)dy, dy_ld, (T*)dres, dres_ld, dres_acc, pixels, C, ppb);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, CT>), dim3(ceil_div(pixels, ppb) * (C / CT)), dim3(256), 0, st, (const T*)dout, dout_ld, (const T*)out, out_ld,
+                       (const T*)y, y_ld, relu, scale, shift, f, (T*)dy, dy_ld, (T*)dres, dres_ld, dres_acc, pixels, C, ppb, bn_xcd_order());
 }
 }  // namespace
 

@@ -19,14 +19,24 @@ template <typename T, int K>
 __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ dout, long dout_ld, const T* __restrict__ out, long out_ld,
                                                         const T* __restrict__ y, long y_ld, int relu, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, void* __restrict__ partials_,
-                                                        long pixels, int C, int cols, int S, int ppb, T* __restrict__ dx, long dx_ld) {
+                                                        long pixels, int C, int cols, int S, int ppb, T* __restrict__ dx, long dx_ld, int chunks, int xcd_order) {
     constexpr int CE = Vec16<T>::N;
     __shared__ float red[256 * K * CE];
     float* partials = reinterpret_cast<float*>(partials_);          // K = 1: [C][S] f32 workspace; K = 2: double slots, below
     const int tid = threadIdx.x;
     const int col = tid % cols, r = tid / cols, R = 256 / cols;
-    const int vc = blockIdx.y * cols + col;
-    const long p0 = (long)blockIdx.x * ppb;
+    // 1-D grid of S * chunks blocks; XCD-aware (round 4, as the BatchNorm apply kernels): workgroup b runs on XCD b % 8, every XCD gets a
+    // contiguous run of pixel slices (channel chunk fastest) -- the pixel range the data-gradient conv that wrote `dout` gave it
+    int wgid = (int)blockIdx.x, ps, cy;
+    if (xcd_order) {
+        const int nwg = (int)gridDim.x, xcd = wgid & 7, wq = nwg >> 3, wr = nwg & 7;
+        wgid = (xcd < wr ? xcd * (wq + 1) : wr * (wq + 1) + (xcd - wr) * wq) + (wgid >> 3);
+        ps = wgid / chunks; cy = wgid - ps * chunks;
+    } else {
+        ps = wgid % S; cy = wgid / S;
+    }
+    const int vc = cy * cols + col;
+    const long p0 = (long)ps * ppb;
     const long p1 = min(pixels, p0 + ppb);
     float s1[CE], s2[CE];
 #pragma unroll
@@ -83,14 +93,14 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ do
             for (int e = 0; e < CE; ++e) *reinterpret_cast<float2*>(red + (col * CE + e) * 2) = make_float2(s1[e], s2[e]);
         } else {
 #pragma unroll
-            for (int e = 0; e < CE; ++e) partials[(long)(vc * CE + e) * S + blockIdx.x] = s1[e];
+            for (int e = 0; e < CE; ++e) partials[(long)(vc * CE + e) * S + ps] = s1[e];
         }
     }
     if (K == 2) {
         // one slot per XCD ([MSC_BN_SLOTS][C][2], common.h); consecutive lanes -> consecutive floats: an atomic costs the L2 per
         // touched line, so one instruction covers whole lines
         __syncthreads();
-        const int cbase = blockIdx.y * cols * CE;
+        const int cbase = cy * cols * CE;
         const int nval = min(cols * CE, C - cbase) * 2;
         double* slot = reinterpret_cast<double*>(partials_) + ((long)msc_xcc_id() * C + cbase) * 2;      // double: see conv_epilogue (igemm.hip)
         for (int f = tid; f < nval; f += 256) atomicAdd(slot + f, (double)red[f]);
@@ -167,9 +177,9 @@ int launch_colreduce(const void* dout, long dout_ld, const void* out, long out_l
                      void* dx = nullptr, long dx_ld = 0) {
     RedGeom g;
     if (!red_geom(pixels, C, Vec16<T>::N, &g)) return msc_fail(MSC_ERR_UNSUPPORTED, "column reduce: C=%d not supported", C);
-    dim3 grid(g.S, g.chunks);
-    hipLaunchKernelGGL((colreduce_kernel<T, K>), grid, dim3(256), 0, st, (const T*)dout, dout_ld, (const T*)out, out_ld, (const T*)y, y_ld,
-                       relu, scale, shift, partials, pixels, C, g.cols, g.S, g.ppb, (T*)dx, dx_ld);
+    static const int xo = [] { const char* e = getenv("MSC_BN_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+    hipLaunchKernelGGL((colreduce_kernel<T, K>), dim3(g.S * g.chunks), dim3(256), 0, st, (const T*)dout, dout_ld, (const T*)out, out_ld, (const T*)y, y_ld,
+                       relu, scale, shift, partials, pixels, C, g.cols, g.S, g.ppb, (T*)dx, dx_ld, g.chunks, xo);
     return msc_check_launch("colreduce");
 }
 
