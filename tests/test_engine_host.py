@@ -125,37 +125,11 @@ def test_backward_twice_for_one_forward_is_refused_and_backward_sums_start_clean
     assert prog.bwd[0][0].__name__ == 'msc_memset_zero' and prog.bwd[0][1][1] > 0
 
 
-def test_hipadam_state_dict_roundtrip_restores_moments_step_and_lr(interpreted):
-    from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
-    ref, net = build(34)
-    net.train()
-    opt = HipAdam(net, lr=1e-3, weight_decay=1e-4)
-    step = TrainStep(net, LossSpec.plain_ce(), opt)
-    x = unet_ref.synthetic_batch(1, 64, 64)
-    t = losses_ref.synthetic_target(1, 64, 64)[:, :1].contiguous()
-    step(x, t); step(x, t)
-    opt.set_lr(2.5e-4)
-    state = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state_dict().items()}
-    params = net.flat_params.clone()
-    step(x, t)
-    after = net.flat_params.clone()
-    # a fresh optimizer restored from the state continues identically from the same parameters
-    net.flat_params.copy_(params)
-    net.weights_changed()
-    opt2 = HipAdam(net, lr=9.0)
-    opt2.load_state_dict(state)
-    assert opt2.steps == 2 and opt2.lr == 2.5e-4 and opt2.param_groups[0]['lr'] == 2.5e-4
-    assert float(opt2.dev_state[0]) == 2.0 and abs(float(opt2.dev_state[1]) - 2.5e-4) < 1e-10
-    TrainStep(net, LossSpec.plain_ce(), opt2)(x, t)
-    assert torch.equal(after, net.flat_params)
-    with pytest.raises(ValueError):
-        opt2.load_state_dict(dict(state, m=torch.zeros(3)))
-
-
-def test_hipadam_resumes_before_the_first_forward_and_keeps_the_compute_copies_fresh(interpreted):
-    """the usual resume order -- build model and optimizer, load both state dicts, THEN train -- works: a state loaded before the flat
-    buffers exist is applied when they appear (round-3 advisory); and the fused update leaves the packed weight copies current (no
-    re-pack at the next forward), equal to what a fresh pack of the new masters gives"""
+def test_hipadam_state_dict_roundtrip_resume_order_and_fresh_compute_copies(interpreted):
+    """HipAdam.state_dict / load_state_dict: moments, step count and learning rate (also the device-resident state a captured graph
+    reads) come back, a restored optimizer continues identically -- also in the usual resume order (build model and optimizer, load
+    both state dicts, THEN train: the state is applied when the flat buffers appear; round-3 advisory) -- and the fused update leaves
+    the packed weight copies current: no re-pack at the next forward, equal to what a fresh pack of the new masters gives"""
     from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
     ref, net = build(34)
     net.train()
@@ -170,18 +144,32 @@ def test_hipadam_resumes_before_the_first_forward_and_keeps_the_compute_copies_f
     net._packed_version = -1
     net._refresh_weights(0)                                           # what msc_pack_multi makes of the same masters
     assert torch.equal(w, net._pack['w'][name]) and torch.equal(wt, net._pack['wt'][name])
+    opt.set_lr(2.5e-4)
     state = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state_dict().items()}
     sd = {k: v.clone() for k, v in net.state_dict().items()}
+    params = net.flat_params.clone()
     step(x, t)
     after = net.flat_params.clone()
-    ref2, net2 = build(34)
-    net2.load_state_dict(sd)
-    net2.train()
-    opt2 = HipAdam(net2, lr=9.0)
-    opt2.load_state_dict(state)                                       # no forward has run: nothing is flattened yet
-    assert opt2.steps == 2 and opt2.lr == 1e-3
-    TrainStep(net2, LossSpec.plain_ce(), opt2)(x, t)
-    assert opt2.steps == 3 and torch.equal(after, net2.flat_params)
+    # (a) a fresh optimizer on the SAME (already flattened) model, restored from the state, continues identically
+    net.flat_params.copy_(params)
+    net.weights_changed()
+    opt2 = HipAdam(net, lr=9.0)
+    opt2.load_state_dict(state)
+    assert opt2.steps == 2 and opt2.lr == 2.5e-4 and opt2.param_groups[0]['lr'] == 2.5e-4
+    assert float(opt2.dev_state[0]) == 2.0 and abs(float(opt2.dev_state[1]) - 2.5e-4) < 1e-10
+    TrainStep(net, LossSpec.plain_ce(), opt2)(x, t)
+    assert torch.equal(after, net.flat_params)
+    with pytest.raises(ValueError):
+        opt2.load_state_dict(dict(state, m=torch.zeros(3)))
+    # (b) resume order: nothing is flattened yet when the state is loaded
+    ref3, net3 = build(34)
+    net3.load_state_dict(sd)
+    net3.train()
+    opt3 = HipAdam(net3, lr=9.0)
+    opt3.load_state_dict(state)
+    assert opt3.steps == 2 and opt3.lr == 2.5e-4
+    TrainStep(net3, LossSpec.plain_ce(), opt3)(x, t)
+    assert opt3.steps == 3 and torch.equal(after, net3.flat_params)
 
 
 def test_dynamic_loss_scale_skips_an_overflowed_step(interpreted):
