@@ -35,7 +35,7 @@ struct WgK {
     int nblocks;                     // ntiles*ntaps*splits
     unsigned p_bytes, q_bytes;
     float rcp_hw, rcp_w;
-    int kw3, sw;                     // kw3: a block covers the three taps of a kernel row (wgrad3_dma_body; ntaps = KH); sw = min(Wp, 32)
+    int kw3, sw;                     // kw3: taps of a kernel row a block covers (wgrad3_dma_body; ntaps = KH): 0 one, 3 (3x3 / stride 1), 4 (4x4 / stride 2: ConvTranspose2d); sw = min(Wp, 32)
     int span_bytes;                  // > 0: a Q row of B*ES bytes spans several consecutive pixels of span_bytes each (KW taps merged, wgrad_plan)
     int no_direct;                   // 1: keep the general pixel decode also for 1x1 / stride 1 (A/B measurements, MSC_WGRAD_DIRECT=0)
 };
@@ -320,7 +320,12 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
 // 3 x (32 + 32) rows feeding them one by one (2.9x fewer bytes through the L2 -> LDS fill that bounds the single-tap kernel,
 // and the P fragments are read from LDS once for the three).  A block accumulates 3 tiles; the kernel rows (kh) stay separate
 // blocks.  Geometry: Wp a multiple of 32, or 16, or 8 (a k-step is 32 consecutive pixels = one segment, 2 or 4 image rows).
-template <typename T, int TA, int TB, int NST, int NWV = 4>
+// Round 4, the same for ConvTranspose2d(k4, s2, p1) (NT = 4, QS = 2): P is the coarse input, Q the fine output gradient, tap (kh, kw) of
+// coarse pixel (y, x) reads fine pixel (2y - 1 + kh, 2x - 1 + kw) -- the four kw taps of a run of sw coarse pixels read ONE fine row
+// segment of 2 sw + 2 pixels at rows 2 j + kw.  Staged once it feeds four products: 32 P rows + 66-72 Q rows per k-step instead of 4 x
+// (32 + 32), and the single-tap form these layers ran in is bound by exactly those bytes (fabric reads, section 3 of DESIGN.md).
+//   general: NT taps, Q row stride QS; a segment holds QS (sw - 1) + NT rows; LDS row of (pixel r, tap kw) = seg SEGROWS + QS (r % sw) + kw
+template <typename T, int TA, int TB, int NST, int NWV = 4, int NT = 3, int QS = 1>
 __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, const int nwg) {
     static_assert(sizeof(T) == 2, "16-bit types");
     constexpr int ES = 2, KP = 32;
@@ -330,7 +335,7 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
     constexpr int NIA = KP * RBA / 1024;
     constexpr int NWA = NWV / 2;                                    // waves along the A (output-gradient channel) dimension x 2 along B
     constexpr int IA = (NIA + NWV - 1) / NWV;
-    constexpr int QRMAX = KP + 8;                                  // sw = 8: four segments with two halo rows each
+    constexpr int QRMAX = (KP / 8) * (QS * 7 + NT);                // sw = 8: four segments of QS (sw - 1) + NT rows
     constexpr int IB = ((QRMAX + RPB - 1) / RPB + NWV - 1) / NWV;  // Q wave-instructions per wave (uniform; rows past the image: out of range)
     constexpr int QROWS = IB * NWV * RPB;                          // rows the Q part of a stage holds
     constexpr int STAGE = KP * RBA + QROWS * RBB;
@@ -353,8 +358,8 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
     const int mbeg = split * p.mchunk;
     const int mend = min(p.M, mbeg + p.mchunk);
     const int nsteps = mend > mbeg ? (mend - mbeg + KP - 1) / KP : 0;
-    const int sw = p.sw, seg_rows = sw + 2;
-    const int qr_used = KP + 2 * (KP / sw);
+    const int sw = p.sw, seg_rows = QS * (sw - 1) + NT;
+    const int qr_used = (KP / sw) * seg_rows;
 
     const u32x4_t rp = make_srd(p.p, p.p_bytes);
     const u32x4_t rq = make_srd(p.q, p.q_bytes);
@@ -401,7 +406,7 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
             const int ii = i >= IA ? i - IA : 0;
             int n = qn_[ii], y = qy_[ii], x = qx_[ii];
             unsigned off = OOB_OFF;
-            const int iy = y - 1 + kh, ix = x + qxi[ii];
+            const int iy = QS * y - 1 + kh, ix = QS * x + qxi[ii];
             if (qlive[ii] && mb < mend && (unsigned)iy < (unsigned)p.Hq && (unsigned)ix < (unsigned)p.Wq)
                 off = (unsigned)((n * p.Hq + iy) * p.Wq + ix) * qpix + qcol[ii];
             dma16(rq, sq + (ii * NWV + wid) * 1024, off, 0);
@@ -419,7 +424,7 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
 
     // fragment read offsets (bytes within a stage): lane t=pl of a 16-lane group addresses pixel row 8g + (pl>>2) (+4 for the
     // second half), channels 4*(pl&3)..+3; Q rows additionally shifted by the tap and the halo rows of the segments before
-    int aoff[FM][2], boff[3][FN][2];
+    int aoff[FM][2], boff[NT][FN][2];
 #pragma unroll
     for (int a = 0; a < FM; ++a) {
         const int c = wa * WTA + a * 16 + 4 * (pl & 3);
@@ -430,14 +435,14 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
         }
     }
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw)
+    for (int kw = 0; kw < NT; ++kw)
 #pragma unroll
         for (int b = 0; b < FN; ++b) {
             const int c = wb * WTB + b * 16 + 4 * (pl & 3);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int r = 8 * g + (pl >> 2) + 4 * h;
-                const int q = r + kw + 2 * (r / sw);
+                const int q = (r / sw) * seg_rows + QS * (r % sw) + kw;
                 boff[kw][b][h] = KP * RBA + q * RBB + wg_swz<T>(c >> 3, q, UB) * 16 + (c & 7) * 2;
             }
         }
@@ -449,9 +454,9 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
         return make_uint4(l.x, l.y, h.x, h.y);
     };
 
-    f32x4 acc[3][FM][FN];
+    f32x4 acc[NT][FM][FN];
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw)
+    for (int kw = 0; kw < NT; ++kw)
 #pragma unroll
         for (int a = 0; a < FM; ++a)
 #pragma unroll
@@ -461,7 +466,7 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
 #pragma unroll
         for (int st = 0; st < NST - 1; ++st)
             if (st < nsteps) issue(st, st);
-        constexpr int NM = 3 * FM * FN;
+        constexpr int NM = NT * FM * FN;
         auto kstep = [&](auto issue_tag, int s) {
             constexpr bool ISSUE = decltype(issue_tag)::value;
             const char* sb = smem + (s & (NST - 1)) * STAGE;
@@ -469,7 +474,7 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
 #pragma unroll
             for (int a = 0; a < FM; ++a) af[a] = frag(sb, aoff[a]);
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
+            for (int kw = 0; kw < NT; ++kw) {
                 uint4 bf[FN];
 #pragma unroll
                 for (int b = 0; b < FN; ++b) bf[b] = frag(sb, boff[kw][b]);
@@ -500,7 +505,7 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
             kstep(std::false_type{}, s);
         }
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
+        for (int kw = 0; kw < NT; ++kw)
 #pragma unroll
             for (int a = 0; a < FM; ++a)
 #pragma unroll
@@ -509,15 +514,15 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
 #pragma unroll
                     for (int b = 0; b < FN; ++b) {
                         const int ib = b0 + wb * WTB + b * 16 + pl;
-                        if (ia < p.A && ib < p.B) atomicAdd(p.dw + (ia * 9L + kh * 3 + kw) * p.B + ib, acc[kw][a][b][r]);
+                        if (ia < p.A && ib < p.B) atomicAdd(p.dw + (ia * (long)(p.KH * NT) + kh * NT + kw) * p.B + ib, acc[kw][a][b][r]);
                     }
                 }
     }
 }
 
-template <typename T, int TA, int TB, int NST, int NWV = 4>
+template <typename T, int TA, int TB, int NST, int NWV = 4, int NT = 3, int QS = 1>
 __global__ __launch_bounds__(NWV * 64) void conv_wgrad3_dma_kernel(WgK p) {
-    if constexpr (sizeof(T) == 2) wgrad3_dma_body<T, TA, TB, NST, NWV>(p, blockIdx.x, gridDim.x);
+    if constexpr (sizeof(T) == 2) wgrad3_dma_body<T, TA, TB, NST, NWV, NT, QS>(p, blockIdx.x, gridDim.x);
 }
 
 template <typename T, int TA, int TB, int NST, int ABL = 0>
@@ -550,13 +555,13 @@ __global__ __launch_bounds__(NWV * 64) void conv_wgrad_group_kernel(const WgK* _
     }
 }
 
-template <typename T, int TA, int TB, int NST, int NWV = 4>
+template <typename T, int TA, int TB, int NST, int NWV = 4, int NT = 3, int QS = 1>
 __global__ __launch_bounds__(NWV * 64) void conv_wgrad3_group_kernel(const WgK* __restrict__ tab, const int2* __restrict__ blk) {
     if constexpr (sizeof(T) == 2) {
         WgK p;
         int orig;
         if (!wgrad_group_fetch(tab, blk, p, orig)) return;
-        wgrad3_dma_body<T, TA, TB, NST, NWV>(p, orig, p.nblocks);
+        wgrad3_dma_body<T, TA, TB, NST, NWV, NT, QS>(p, orig, p.nblocks);
     }
 }
 
@@ -566,7 +571,7 @@ extern "C" int msc_conv_wgrad_num_cfgs(void) { return WGRAD_NCFG; }
 
 namespace {
 
-struct WgPlan { WgK k; int dtype, ta, tb; bool kw3; };
+struct WgPlan { WgK k; int dtype, ta, tb; int kw3; };
 
 // Validates a descriptor and fixes tile shape and split-K.  steps_per_block > 0 (grouped launches: other problems
 // fill the chip, so a block just runs that many k-steps) overrides the per-launch policy selected by d->cfg.
@@ -621,8 +626,12 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
     static const bool kw3_on = [] { const char* e = getenv("MSC_WGRAD_KW3"); return !(e && e[0] == '0'); }();
     const bool kw3 = kw3_on && fits && es == 2 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Hq == d->Hp &&
                      d->Wq == d->Wp && (d->Wp % 32 == 0 || d->Wp == 16 || d->Wp == 8) && d->Hp >= 8 && k.M % 32 == 0;
-    const int ntaps = kw3 ? d->KH : d->KH * d->KW;
-    k.kw3 = kw3 ? 1 : 0;
+    // ... and the four kw taps of a ConvTranspose2d(k4, s2, p1) kernel row (round 4; MSC_WGRAD_KW4=0: single-tap blocks)
+    static const bool kw4_on = [] { const char* e = getenv("MSC_WGRAD_KW4"); return !(e && e[0] == '0'); }();
+    const bool kw4 = kw4_on && fits && es == 2 && !span_bytes && d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1 && d->Hq == 2 * d->Hp &&
+                     d->Wq == 2 * d->Wp && (d->Wp % 32 == 0 || d->Wp == 16 || d->Wp == 8) && d->Hp >= 8 && k.M % 32 == 0;
+    const int ntaps = (kw3 || kw4) ? d->KH : d->KH * d->KW;
+    k.kw3 = kw3 ? 3 : kw4 ? 4 : 0;
     k.sw = d->Wp < 32 ? d->Wp : 32;
     bool big = (d->A % 128 == 0) && (d->B % 128 == 0);
     // 256x256 tiles (grouped launches, 16-bit, single-tap problems whose channel counts allow it -- ResNet101's layer3 / layer4 1x1
@@ -638,7 +647,7 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
     if (steps_per_block > 0) {
         if (tile_cap < 128) big = false;
         if (tile_cap < 64) tsel = 2;
-        huge = t256_on && big && fits && es == 2 && !kw3 && d->A % 256 == 0 && d->B % 256 == 0;
+        huge = t256_on && big && fits && es == 2 && !kw3 && !kw4 && d->A % 256 == 0 && d->B % 256 == 0;
         splits = ceil_div(ksteps, huge ? (steps_per_block + 1) / 2 : steps_per_block);
     } else {
         // Tile and split-K choice.  Every split adds one fp32-atomic pass over dW and a pipeline fill, so a block
@@ -671,7 +680,7 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
     k.ntiles = (d->A / ta) * (d->B / tbs); k.ntaps = ntaps; k.xcd_order = xcd_order_enabled() ? 1 : 0;
     k.nblocks = k.ntiles * k.ntaps * splits;
     out->dtype = d->dtype; out->ta = ta; out->tb = tbs;
-    out->kw3 = kw3;
+    out->kw3 = k.kw3;
     // 128x128 tiles: with 4 waves three accumulator sets leave one wave per SIMD and one block per CU -- measured 15 % slower
     // than the single-tap blocks at two blocks per CU (859 vs 745 us for the 3x3 layers of the ResNet101 step); the 8-wave form
     // (two waves per SIMD, 96 accumulator registers) was neutral in round 2 and is 4 % ahead since the epilogue / prologue work of
@@ -679,7 +688,7 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
     // 128x128 tiles single-tap.
     static const bool kw3_big = [] { const char* e = getenv("MSC_WGRAD_KW3"); return !(e && e[0] == '1'); }();
     if (kw3 && ta == 128 && !kw3_big) {
-        out->kw3 = false;
+        out->kw3 = 0;
         k.kw3 = 0;
         k.ntaps = d->KH * d->KW;
         k.nblocks = k.ntiles * k.ntaps * splits;
@@ -705,7 +714,10 @@ struct WgLaunchOne {
     const WgK& k; hipStream_t st;
     template <typename T, int TA, int TB> void operator()() const {
         if constexpr (TA <= 128) {      // (256x256 tiles are planned for grouped launches only)
-            if (k.kw3) {
+            if (k.kw3 == 4) {
+                if constexpr (TA == 128) hipLaunchKernelGGL((conv_wgrad3_dma_kernel<T, TA, TB, 4, 8, 4, 2>), dim3(k.nblocks), dim3(512), 0, st, k);
+                else hipLaunchKernelGGL((conv_wgrad3_dma_kernel<T, TA, TB, 4, 4, 4, 2>), dim3(k.nblocks), dim3(256), 0, st, k);
+            } else if (k.kw3) {
                 if constexpr (TA == 128) hipLaunchKernelGGL((conv_wgrad3_dma_kernel<T, TA, TB, 4, 8>), dim3(k.nblocks), dim3(512), 0, st, k);
                 else hipLaunchKernelGGL((conv_wgrad3_dma_kernel<T, TA, TB, 4>), dim3(k.nblocks), dim3(256), 0, st, k);
             }
@@ -715,9 +727,12 @@ struct WgLaunchOne {
 };
 
 struct WgLaunchGroup {
-    const WgK* tab; const int2* blk; int blocks; hipStream_t st; bool kw3;
+    const WgK* tab; const int2* blk; int blocks; hipStream_t st; int kw3;
     template <typename T, int TA, int TB> void operator()() const {
-        if (kw3) {
+        if (kw3 == 4) {
+            if constexpr (TA == 128) hipLaunchKernelGGL((conv_wgrad3_group_kernel<T, TA, TB, 4, 8, 4, 2>), dim3(blocks), dim3(512), 0, st, tab, blk);
+            else if constexpr (TA < 128) hipLaunchKernelGGL((conv_wgrad3_group_kernel<T, TA, TB, 4, 4, 4, 2>), dim3(blocks), dim3(256), 0, st, tab, blk);
+        } else if (kw3) {
             if constexpr (TA == 128) hipLaunchKernelGGL((conv_wgrad3_group_kernel<T, TA, TB, 4, 8>), dim3(blocks), dim3(512), 0, st, tab, blk);
             else if constexpr (TA < 128) hipLaunchKernelGGL((conv_wgrad3_group_kernel<T, TA, TB, 4>), dim3(blocks), dim3(256), 0, st, tab, blk);
         }
@@ -766,7 +781,7 @@ extern "C" int msc_conv_wgrad(const msc_wgrad_desc* d, void* stream) {
 
 // ---- grouped weight gradients ---------------------------------------------------------------------
 struct msc_wgrad_group {
-    struct Bucket { int dtype, ta, tb, n, blocks; WgK* tab; int2* blk; bool kw3; };
+    struct Bucket { int dtype, ta, tb, n, blocks; WgK* tab; int2* blk; int kw3; };
     std::vector<Bucket> buckets;      // problems by (dtype, tile): one launch each
     void* dev = nullptr;              // one allocation behind every table
 };

@@ -134,7 +134,10 @@ def test_data_gradient(dtype, cin, cout, k, stride, hw):
 
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('cin,cout,k,stride,hw,n', [(64, 64, 3, 1, 12, 2), (64, 128, 1, 1, 9, 3), (128, 64, 3, 2, 16, 2),
-                                                    (32, 32, 3, 1, 24, 2), (256, 128, 3, 1, 8, 4), (64, 32, 4, 2, 10, 2), (128, 32, 4, 2, 24, 3)])
+                                                    (32, 32, 3, 1, 24, 2), (256, 128, 3, 1, 8, 4), (64, 32, 4, 2, 10, 2), (128, 32, 4, 2, 24, 3),
+                                                    # ConvTranspose2d shapes whose four kw taps share one staged fine-row segment (wgrad3_dma_body<NT=4, QS=2>):
+                                                    # map widths 16 / 8 / 32 / 64, the 128x128 and the 64x64 tile
+                                                    (128, 128, 4, 2, 16, 2), (64, 64, 4, 2, 8, 2), (256, 64, 4, 2, 32, 1), (128, 128, 4, 2, 64, 1)])
 def test_weight_gradient(dtype, cin, cout, k, stride, hw, n):
     import hip_ops as ops
     if k == 4:           # ConvTranspose2d: dW[cin][kh][kw][cout]
@@ -386,8 +389,18 @@ def test_grouped_weight_gradients_equal_separate_ones(dtype, steps, cap):
         refs.append(wv.grad.permute(0, 2, 3, 1))
         dw = torch.zeros((cout, k, k, cin), dtype=torch.float32, device='cuda')
         problems.append((nhwc(dy, dtype), nhwc(x, dtype), dw, k, k, stride, pad))
+    # ... and two ConvTranspose2d(k4, s2, p1) layers (four-tap blocks; P = the coarse input, Q = the fine output gradient)
+    for i, (cin, cout, hw, n) in enumerate([(128, 128, 16, 2), (64, 64, 32, 1)]):
+        x = rnd((n, cin, hw, hw), dtype, 70 + i)
+        wt = rnd((cin, cout, 4, 4), dtype, 80 + i, 0.05).requires_grad_(True)
+        y = F.conv_transpose2d(x, wt, stride=2, padding=1)
+        dy = rnd(tuple(y.shape), dtype, 90 + i)
+        y.backward(dy)
+        refs.append(wt.grad.permute(0, 2, 3, 1))
+        dw = torch.zeros((cin, 4, 4, cout), dtype=torch.float32, device='cuda')
+        problems.append((nhwc(x, dtype), nhwc(dy, dtype), dw, 4, 4, 2, 1))
     launches = ops.conv_wgrad_group(problems, steps, cap, runs=2)
-    assert 1 <= launches <= 6
+    assert 1 <= launches <= 8
     for pr, gref in zip(problems, refs):
         err = (pr[2].cpu() / 2 - gref).abs().max().item() / gref.abs().max().item()
         assert err < (2e-5 if dtype == torch.float32 else 1e-2), (pr[2].shape, err)
