@@ -212,6 +212,23 @@ int msc_bn_bwd_apply(const void* dout, int64_t dout_ld, const void* out, int64_t
                      const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* dy, int64_t dy_ld,
                      void* dres, int64_t dres_ld, int dres_acc, int dtype, int64_t pixels, int C, void* stream);
 
+/* The stem's BatchNorm2d (training) + ReLU + MaxPool2d(2,2) (self.conv1 = Sequential(encoder.conv1, encoder.bn1, encoder.relu, self.pool),
+ * src/unet_models.py:360-363) without materialising the full-resolution activation (ABI v7): nothing but the pool reads it.
+ *   msc_bn_apply_pool:      y [N, 2Ho, 2Wo, C] (raw conv output, statistics in `slots` as for msc_bn_apply) -> out [N, Ho, Wo, C] =
+ *                           max over the 2x2 window of relu(scale*y + shift); publishes scale / shift / mean / invstd / running statistics
+ *   msc_bn_pool_bwd_reduce: slots += (sum dh, sum dh*y), dh = the pooled gradient at the window's FIRST maximum of relu(scale*y + shift)
+ *                           (torch's tie rule) if that maximum is positive, zero elsewhere -- MaxPool backward + ReLU backward + the sums
+ *                           of msc_bn_bwd_reduce from (dpool, y) alone
+ *   msc_bn_pool_bwd_apply:  y <- dy = g*invstd*(dh - mean(dh) - xhat*mean(dh*xhat)) in place; dgamma / dbeta += as msc_bn_bwd_apply */
+int msc_bn_apply_pool(const void* y, int64_t y_ld, void* out, int64_t out_ld, const double* slots, int64_t count, const float* gamma,
+                      const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                      float* save_mean, float* save_invstd, int dtype, int N, int Ho, int Wo, int C, void* stream);
+int msc_bn_pool_bwd_reduce(const void* dpool, int64_t dpool_ld, const void* y, int64_t y_ld, const float* scale, const float* shift,
+                           double* slots, int dtype, int N, int Ho, int Wo, int C, void* stream);
+int msc_bn_pool_bwd_apply(const void* dpool, int64_t dpool_ld, void* y, int64_t y_ld, const float* scale, const float* shift,
+                          const double* slots, int64_t count, const float* gamma, const float* save_mean, const float* save_invstd,
+                          float* dgamma, float* dbeta, int dtype, int N, int Ho, int Wo, int C, void* stream);
+
 /* ReLU backward for the decoder (ConvRelu / deconv+ReLU): dx = dy*[y>0], optionally dx += */
 int msc_relu_bwd(const void* dy, int64_t dy_ld, const void* y, int64_t y_ld, void* dx, int64_t dx_ld,
                  int accumulate, int dtype, int64_t pixels, int C, void* stream);

@@ -340,6 +340,180 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// ---- round 4: the stem's BatchNorm + ReLU + MaxPool2d(2,2) (src/unet_models.py:360-363) without the full-resolution activation.
+// relu(bn(y)) of the 7x7 conv is read by nothing but the pool (the stem's weight gradient reads the image, the BatchNorm backward takes
+// its ReLU mask from y): forward = one pass y -> pooled (67 MB read + 17 MB written instead of 268 + 17); backward = the pool's gradient
+// routing, the ReLU mask and the BatchNorm backward from (pooled gradient, y) in two passes (sums, apply) instead of three kernels over
+// five full-resolution tensors.  The window's maximum is taken over the fp32 activations (first maximum wins, as torch; the stored
+// pooled value is the rounded maximum = the maximum of the rounded values), and the backward recomputes the same comparison.
+template <typename T, int CT>
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const T* __restrict__ y, long y_ld, T* __restrict__ out, long out_ld, BnFwdFin f,
+                                                            int N, int Ho, int Wo, int C, long ppb, int xcd_order) {
+    constexpr int CE = Vec16<T>::N, VC = CT / CE, R = 256 / VC;
+    __shared__ float s_sc[CT], s_sh[CT];
+    int pb, ct;
+    bn_block(C / CT, xcd_order, pb, ct);
+    const int tid = threadIdx.x, c0 = ct * CT;
+    if (tid < CT) {
+        const int c = c0 + tid;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int x = 0; x < MSC_BN_SLOTS; ++x) {
+            const double2 v = *reinterpret_cast<const double2*>(f.slots + ((long)x * C + c) * 2);
+            s1 += v.x; s2 += v.y;
+        }
+        const double mean = s1 / f.count;
+        double var = s2 / f.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+        const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+        const float sc = g * invstd, sh = b - (float)mean * sc;
+        if (pb == 0) {
+            f.scale[c] = sc;
+            f.shift[c] = sh;
+            if (f.save_mean) f.save_mean[c] = (float)mean;
+            if (f.save_invstd) f.save_invstd[c] = invstd;
+            if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
+            if (f.running_var) {
+                const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+                f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
+            }
+        }
+        s_sc[tid] = sc; s_sh[tid] = sh;
+    }
+    __syncthreads();
+    const int col = tid % VC, r = tid / VC;
+    const int c = c0 + col * CE;
+    float sc[CE], sh[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { sc[e] = s_sc[col * CE + e]; sh[e] = s_sh[col * CE + e]; }
+    const long total = (long)N * Ho * Wo, p1 = min(total, ((long)pb + 1) * ppb);
+    const int Wi = 2 * Wo;
+    for (long q = (long)pb * ppb + r; q < p1; q += R) {
+        const long n = q / ((long)Ho * Wo), rem = q - n * ((long)Ho * Wo);
+        const int py = (int)(rem / Wo), px = (int)(rem - (long)py * Wo);
+        const long base = ((n * 2 * Ho + 2 * py) * Wi + 2 * px);
+        float best[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) best[e] = 0.f;                 // relu: the maximum of the four max(v, 0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v[CE];
+            Vec16<T>::load(y + (base + (k >> 1) * Wi + (k & 1)) * y_ld + c, v);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) best[e] = fmaxf(best[e], fmaf(v[e], sc[e], sh[e]));
+        }
+        Vec16<T>::store(out + q * out_ld + c, best);
+    }
+}
+
+// PASS 0: (sum dh, sum dh*y) into the per-XCD slots; PASS 1: dy = a*dh + b*y + k written over y.  dh = the pooled gradient at the window's
+// first maximum of relu(scale*y + shift), if that maximum is positive; zero elsewhere.
+template <typename T, int CT, int PASS>
+__global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ dpool, long dpool_ld, T* __restrict__ y, long y_ld,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift, double* __restrict__ slots,
+                                                          BnBwdFin f, int N, int Ho, int Wo, int C, long ppb, int xcd_order) {
+    constexpr int CE = Vec16<T>::N, VC = CT / CE, R = 256 / VC;
+    __shared__ float s_a[CT], s_b[CT], s_k[CT], s_sc[CT], s_sh[CT];
+    __shared__ float red[PASS == 0 ? 256 * 2 * CE : 1];
+    int pb, ct;
+    bn_block(C / CT, xcd_order, pb, ct);
+    const int tid = threadIdx.x, c0 = ct * CT;
+    if (tid < CT) {
+        const int c = c0 + tid;
+        s_sc[tid] = scale[c]; s_sh[tid] = shift[c];
+        if (PASS == 1) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int x = 0; x < MSC_BN_SLOTS; ++x) {
+                const double2 v = *reinterpret_cast<const double2*>(f.slots + ((long)x * C + c) * 2);
+                s1 += v.x; s2 += v.y;
+            }
+            const double mu = f.save_mean[c], is = f.save_invstd[c], g = f.gamma ? f.gamma[c] : 1.0;
+            const double dbe = s1, dga = is * (s2 - mu * s1);
+            const double a = g * is, b = -g * is * is * dga / f.count, k0 = -g * is * dbe / f.count - b * mu;
+            s_a[tid] = (float)a; s_b[tid] = (float)b; s_k[tid] = (float)k0;
+            if (pb == 0) {
+                if (f.dgamma) f.dgamma[c] += (float)dga;
+                if (f.dbeta) f.dbeta[c] += (float)dbe;
+            }
+        }
+    }
+    __syncthreads();
+    const int col = tid % VC, r = tid / VC;
+    const int c = c0 + col * CE;
+    float sc[CE], sh[CE], ca[CE], cb[CE], ck[CE], s1[CE], s2[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+        sc[e] = s_sc[col * CE + e]; sh[e] = s_sh[col * CE + e];
+        ca[e] = PASS ? s_a[col * CE + e] : 0.f; cb[e] = PASS ? s_b[col * CE + e] : 0.f; ck[e] = PASS ? s_k[col * CE + e] : 0.f;
+        s1[e] = 0.f; s2[e] = 0.f;
+    }
+    const long total = (long)N * Ho * Wo, p1 = min(total, ((long)pb + 1) * ppb);
+    const int Wi = 2 * Wo;
+    for (long q = (long)pb * ppb + r; q < p1; q += R) {
+        const long n = q / ((long)Ho * Wo), rem = q - n * ((long)Ho * Wo);
+        const int py = (int)(rem / Wo), px = (int)(rem - (long)py * Wo);
+        const long base = ((n * 2 * Ho + 2 * py) * Wi + 2 * px);
+        float g[CE], yy[4][CE];
+        Vec16<T>::load(dpool + q * dpool_ld + c, g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Vec16<T>::load(y + (base + (k >> 1) * Wi + (k & 1)) * y_ld + c, yy[k]);
+        int arg[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+            float best = 0.f;
+            arg[e] = -1;                                            // no positive activation in the window: the gradient stops at the ReLU
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v = fmaf(yy[k][e], sc[e], sh[e]);
+                if (v > best) { best = v; arg[e] = k; }             // strict: the first maximum wins
+            }
+        }
+        if (PASS == 0) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                float ys = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ys = arg[e] == k ? yy[k][e] : ys;
+                const float dh = arg[e] >= 0 ? g[e] : 0.f;
+                s1[e] += dh;
+                s2[e] = fmaf(dh, ys, s2[e]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float o[CE];
+#pragma unroll
+                for (int e = 0; e < CE; ++e) o[e] = ca[e] * (arg[e] == k ? g[e] : 0.f) + cb[e] * yy[k][e] + ck[e];
+                Vec16<T>::store(y + (base + (k >> 1) * Wi + (k & 1)) * y_ld + c, o);
+            }
+        }
+    }
+    if (PASS == 0) {
+        // fold the block's partial sums through LDS, one coalesced double atomic per (channel, sum) into this XCD's slot (as colreduce_kernel)
+        float* mine = red + tid * 2 * CE;
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { mine[e] = s1[e]; mine[CE + e] = s2[e]; }
+        __syncthreads();
+        if (r == 0) {
+            for (int k = 1; k < R; ++k) {
+                const float* o = red + (k * VC + col) * 2 * CE;
+#pragma unroll
+                for (int e = 0; e < CE; ++e) { s1[e] += o[e]; s2[e] += o[CE + e]; }
+            }
+        }
+        __syncthreads();
+        if (r == 0) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) *reinterpret_cast<float2*>(red + (col * CE + e) * 2) = make_float2(s1[e], s2[e]);
+        }
+        __syncthreads();
+        double* slot = slots + ((long)msc_xcc_id() * C + c0) * 2;
+        for (int i = tid; i < CT * 2; i += 256) atomicAdd(slot + i, (double)red[i]);
+    }
+}
+
 template <typename T>
 __global__ void relu_bwd_kernel(const T* __restrict__ dy, long dy_ld, const T* __restrict__ y, long y_ld,
                                 T* __restrict__ dx, long dx_ld, int accumulate, long pixels, int C) {
@@ -917,6 +1091,58 @@ extern "C" int msc_bn_bwd_apply(const void* dout, int64_t dout_ld, const void* o
     MSC_BN_DISPATCH(launch_bn_bwd_apply, dout, (long)dout_ld, out, (long)out_ld, y, (long)y_ld, relu, scale, shift, f, dy, (long)dy_ld, dres, (long)dres_ld,
                     dres_acc, (long)pixels, C, (hipStream_t)stream);
     return msc_check_launch("msc_bn_bwd_apply");
+}
+
+namespace {
+template <typename T, int CT>
+void launch_bn_apply_pool(const void* y, long y_ld, void* out, long out_ld, const BnFwdFin& f, int N, int Ho, int Wo, int C, hipStream_t st) {
+    constexpr int R = 256 / (CT / Vec16<T>::N);
+    const long pixels = (long)N * Ho * Wo, ppb = bn_ppb<R>(pixels, C / CT);
+    hipLaunchKernelGGL((bn_apply_pool_kernel<T, CT>), dim3(ceil_div(pixels, ppb) * (C / CT)), dim3(256), 0, st, (const T*)y, y_ld, (T*)out, out_ld, f, N, Ho,
+                       Wo, C, ppb, bn_xcd_order());
+}
+template <typename T, int CT>
+void launch_bn_pool_bwd(int pass, const void* dpool, long dpool_ld, void* y, long y_ld, const float* scale, const float* shift, double* slots,
+                        const BnBwdFin& f, int N, int Ho, int Wo, int C, hipStream_t st) {
+    constexpr int R = 256 / (CT / Vec16<T>::N);
+    const long pixels = (long)N * Ho * Wo, ppb = bn_ppb<R>(pixels, C / CT);
+    const dim3 grid(ceil_div(pixels, ppb) * (C / CT));
+    if (pass == 0) hipLaunchKernelGGL((bn_pool_bwd_kernel<T, CT, 0>), grid, dim3(256), 0, st, (const T*)dpool, dpool_ld, (T*)y, y_ld, scale, shift, slots, f, N, Ho, Wo, C, ppb, bn_xcd_order());
+    else hipLaunchKernelGGL((bn_pool_bwd_kernel<T, CT, 1>), grid, dim3(256), 0, st, (const T*)dpool, dpool_ld, (T*)y, y_ld, scale, shift, slots, f, N, Ho, Wo, C, ppb, bn_xcd_order());
+}
+}  // namespace
+
+extern "C" int msc_bn_apply_pool(const void* y, int64_t y_ld, void* out, int64_t out_ld, const double* slots, int64_t count, const float* gamma,
+                                 const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                                 float* save_mean, float* save_invstd, int dtype, int N, int Ho, int Wo, int C, void* stream) {
+    DT_CHECK("msc_bn_apply_pool", dtype);
+    if (C % 32) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bn_apply_pool: C=%d must be a multiple of 32", C);
+    if (!y || !out || !slots || !scale || !shift || count <= 0 || N <= 0 || Ho <= 0 || Wo <= 0) return msc_fail(MSC_ERR_ARG, "msc_bn_apply_pool: bad argument");
+    const BnFwdFin f = {slots, (double)count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd};
+    MSC_BN_DISPATCH(launch_bn_apply_pool, y, (long)y_ld, out, (long)out_ld, f, N, Ho, Wo, C, (hipStream_t)stream);
+    return msc_check_launch("msc_bn_apply_pool");
+}
+
+extern "C" int msc_bn_pool_bwd_reduce(const void* dpool, int64_t dpool_ld, const void* y, int64_t y_ld, const float* scale, const float* shift,
+                                      double* slots, int dtype, int N, int Ho, int Wo, int C, void* stream) {
+    DT_CHECK("msc_bn_pool_bwd_reduce", dtype);
+    if (C % 32) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bn_pool_bwd_reduce: C=%d must be a multiple of 32", C);
+    if (!dpool || !y || !scale || !shift || !slots || N <= 0 || Ho <= 0 || Wo <= 0) return msc_fail(MSC_ERR_ARG, "msc_bn_pool_bwd_reduce: bad argument");
+    const BnBwdFin f = {slots, 1.0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    MSC_BN_DISPATCH(launch_bn_pool_bwd, 0, dpool, (long)dpool_ld, const_cast<void*>(y), (long)y_ld, scale, shift, slots, f, N, Ho, Wo, C, (hipStream_t)stream);
+    return msc_check_launch("msc_bn_pool_bwd_reduce");
+}
+
+extern "C" int msc_bn_pool_bwd_apply(const void* dpool, int64_t dpool_ld, void* y, int64_t y_ld, const float* scale, const float* shift,
+                                     const double* slots, int64_t count, const float* gamma, const float* save_mean, const float* save_invstd,
+                                     float* dgamma, float* dbeta, int dtype, int N, int Ho, int Wo, int C, void* stream) {
+    DT_CHECK("msc_bn_pool_bwd_apply", dtype);
+    if (C % 32) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bn_pool_bwd_apply: C=%d must be a multiple of 32", C);
+    if (!dpool || !y || !scale || !shift || !slots || !save_mean || !save_invstd || count <= 0 || N <= 0 || Ho <= 0 || Wo <= 0)
+        return msc_fail(MSC_ERR_ARG, "msc_bn_pool_bwd_apply: bad argument");
+    const BnBwdFin f = {slots, (double)count, gamma, save_mean, save_invstd, dgamma, dbeta};
+    MSC_BN_DISPATCH(launch_bn_pool_bwd, 1, dpool, (long)dpool_ld, y, (long)y_ld, scale, shift, const_cast<double*>(slots), f, N, Ho, Wo, C, (hipStream_t)stream);
+    return msc_check_launch("msc_bn_pool_bwd_apply");
 }
 
 extern "C" int msc_copy(void* dst, const void* src, int64_t bytes, void* stream) {

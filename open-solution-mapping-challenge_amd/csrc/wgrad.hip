@@ -63,8 +63,12 @@ __device__ __forceinline__ void wgrad_block(const WgK& p, int orig, int nwg, int
 //   f32 : 64-byte granule index ^= (r>>2)&1
 // applied on the DMA source side and on the read side alike.
 
-template <typename T> __device__ __forceinline__ int wg_swz(int unit, int row, int upr) {
+// QS = 2 (the four-tap ConvTranspose2d form reads every other row of its Q stage: rows 2 j + kw): keyed on row >> 1, so that the four
+// rows a lane group reads still fall into four different unit pairs (keyed on the row itself they alternate between two: 2-way conflicts
+// on 32 of the 36 transposing reads of a k-step)
+template <typename T, int QS = 1> __device__ __forceinline__ int wg_swz(int unit, int row, int upr) {
     if (sizeof(T) == 2) {
+        if (QS == 2) row >>= 1;
         const int key = ((row & 3) | (((row >> 3) & 1) << 2)) & (upr / 2 - 1);
         return (((unit >> 1) ^ key) << 1) | (unit & 1);
     }
@@ -386,7 +390,7 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
         const int sg = q / seg_rows;
         qlive[i] = q < qr_used;
         qxi[i] = q - sg * seg_rows - 1;
-        qcol[i] = (unsigned)b0 * ES + (unsigned)wg_swz<T>(lane % UB, q, UB) * 16u;
+        qcol[i] = (unsigned)b0 * ES + (unsigned)wg_swz<T, QS>(lane % UB, q, UB) * 16u;
         const unsigned m = (unsigned)(mbeg + (qlive[i] ? sg * sw : 0));
         const unsigned n = udiv_rcp(m, hw, p.rcp_hw);
         const unsigned rem = m - n * hw;
@@ -443,7 +447,7 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
             for (int h = 0; h < 2; ++h) {
                 const int r = 8 * g + (pl >> 2) + 4 * h;
                 const int q = (r / sw) * seg_rows + QS * (r % sw) + kw;
-                boff[kw][b][h] = KP * RBA + q * RBB + wg_swz<T>(c >> 3, q, UB) * 16 + (c & 7) * 2;
+                boff[kw][b][h] = KP * RBA + q * RBB + wg_swz<T, QS>(c >> 3, q, UB) * 16 + (c & 7) * 2;
             }
         }
     auto frag = [&](const char* sb, const int* off) -> uint4 {
@@ -626,8 +630,10 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
     static const bool kw3_on = [] { const char* e = getenv("MSC_WGRAD_KW3"); return !(e && e[0] == '0'); }();
     const bool kw3 = kw3_on && fits && es == 2 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Hq == d->Hp &&
                      d->Wq == d->Wp && (d->Wp % 32 == 0 || d->Wp == 16 || d->Wp == 8) && d->Hp >= 8 && k.M % 32 == 0;
-    // ... and the four kw taps of a ConvTranspose2d(k4, s2, p1) kernel row (round 4; MSC_WGRAD_KW4=0: single-tap blocks)
-    static const bool kw4_on = [] { const char* e = getenv("MSC_WGRAD_KW4"); return !(e && e[0] == '0'); }();
+    // ... and the four kw taps of a ConvTranspose2d(k4, s2, p1) kernel row (round 4).  MEASURED SLOWER and therefore opt-in (MSC_WGRAD_KW4=1;
+    // profiles/r4_run12_wgrad_kw4_ab.txt): grouped launches 2.04-2.08 -> 2.12-2.16 ms, also with the stride-2 swizzle key -- at 128x128
+    // four accumulator sets leave one block of 228 registers and 128 KB of LDS per CU, where the single-tap form runs two blocks.
+    static const bool kw4_on = [] { const char* e = getenv("MSC_WGRAD_KW4"); return e && e[0] == '1'; }();
     const bool kw4 = kw4_on && fits && es == 2 && !span_bytes && d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1 && d->Hq == 2 * d->Hp &&
                      d->Wq == 2 * d->Wp && (d->Wp % 32 == 0 || d->Wp == 16 || d->Wp == 8) && d->Hp >= 8 && k.M % 32 == 0;
     const int ntaps = (kw3 || kw4) ? d->KH : d->KH * d->KW;

@@ -985,6 +985,34 @@ class _Builder:
         else:
             self.conv(bwd, dy, wt, gx, KH=k, KW=k, stride=2, pad=geo['pad'], mode=1, res=gx if acc else None)
 
+    def stem_bn_pool(self, name, x, conv, bn, pooled, stem):
+        """encoder.conv1 (7-tap x 32-wide implicit GEMM on the prepared image) + BatchNorm2d (batch statistics) + ReLU + MaxPool2d(2,2)
+        -> pooled (src/unet_models.py:360-363)"""
+        net, lib, P, fwd = self.net, self.lib, self.prog, self.prog.fwd
+        cout = conv.out_channels
+        y = self.act(pooled.H * 2, pooled.W * 2, cout)
+        d = self.conv_desc(x, net._pack['w'][name], y, want_stats=True, KH=7, KW=1, stride=2, pad=0, in_hw=stem, in_ld=4, cin=32)
+        d.stats = self.slots(cout)
+        self.emit(fwd, lib.msc_conv_igemm, C.byref(d))
+        scale, shift, mean, invstd = self.vec(cout), self.vec(cout), self.vec(cout), self.vec(cout)
+        count = self.N * y.H * y.W
+        self.emit(fwd, lib.msc_bn_apply_pool, y.ptr, y.ld, pooled.ptr, pooled.ld, d.stats, count, bn.weight.data_ptr(), bn.bias.data_ptr(), BN_EPS,
+                  BN_MOMENTUM, bn.running_mean.data_ptr(), bn.running_var.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                  invstd.data_ptr(), self.dt, self.N, pooled.H, pooled.W, cout)
+
+        def bwd():
+            dpool = self.grad_of(pooled)
+            bslots = self.slots(cout)
+            self.emit(P.bwd, lib.msc_bn_pool_bwd_reduce, dpool.ptr, dpool.ld, y.ptr, y.ld, scale.data_ptr(), shift.data_ptr(), bslots, self.dt,
+                      self.N, pooled.H, pooled.W, cout)
+            gw, gb = self.g(bn.weight), self.g(bn.bias)
+            self.emit(P.bwd, lib.msc_bn_pool_bwd_apply, dpool.ptr, dpool.ld, y.ptr, y.ld, scale.data_ptr(), shift.data_ptr(), bslots, count,
+                      bn.weight.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gw, gb, self.dt, self.N, pooled.H, pooled.W, cout)
+            self.wgrad(P.bwd, y, x, P.stem_dw.data_ptr(), 7, 1, 2, 0, q_hw=stem, q_ld=4, B=32)      # dy overwrote y in place
+            self.flush_wgrads()
+            self.emit(P.bwd, lib.msc_stem_unpack_grad, P.stem_dw.data_ptr(), self.g(conv.weight), 64)
+        self.ops.append(bwd)
+
     def bottleneck_fused(self, base, x, blk, out):
         """Eval mode, 16-bit compute: the identity Bottleneck `blk` (conv1x1-bn-relu, conv3x3-bn-relu, conv1x1-bn, + x, relu) as ONE
         launch (msc_bottleneck_fused; csrc/bottleneck.hip) when the kernel takes the shape -- the intermediates never leave
@@ -1165,10 +1193,16 @@ class _Builder:
         xp = torch.zeros((N, H + 6, W + 8, 4), dtype=self.tdtype, device=self.dev)
         P.bytes += xp.numel() * xp.element_size()
         self.emit(P.fwd, lib.msc_stem_prepare, P.x_in.data_ptr(), xp.data_ptr(), self.dt, N, H, W)
-        s1 = self.act(H // 2, W // 2, 64)
-        self.conv_bn('encoder.conv1', Act(xp), enc.conv1, enc.bn1, 2, True, s1, stem=(H + 6, W + 8))
         cur = self.act(H // 4, W // 4, 64)
-        self.maxpool(s1, cur)
+        if self.training and _os_env.environ.get('MSC_FUSE_STEM_POOL', '1') != '0':
+            # training: BatchNorm + ReLU + MaxPool in one pass over the raw conv output (msc_bn_apply_pool, ABI v7): the full-resolution
+            # activation is read by nothing but the pool, so it is not stored; the backward routes the pooled gradient from y alone
+            s1 = None
+            self.stem_bn_pool('encoder.conv1', Act(xp), enc.conv1, enc.bn1, cur, stem=(H + 6, W + 8))
+        else:
+            s1 = self.act(H // 2, W // 2, 64)
+            self.conv_bn('encoder.conv1', Act(xp), enc.conv1, enc.bn1, 2, True, s1, stem=(H + 6, W + 8))
+            self.maxpool(s1, cur)
 
         # encoder.layer1-4 (torchvision BasicBlock / Bottleneck)
         for li in range(1, 5):

@@ -405,6 +405,57 @@ def bn_bwd_apply(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, slots,
     _rows(dy, pixels, Cc, dy_ld)[...] = ca * d + cb * yy + ck
 
 
+def _pool_routing(y, y_ld, scale, shift, N, Ho, Wo, Cc):
+    """windows of relu(scale*y + shift) in the order (0,0),(0,1),(1,0),(1,1): values [N,Ho,Wo,4,C], first maximum per (window, channel),
+    and whether that maximum is positive"""
+    v = np.maximum(_rows(y, N * Ho * 2 * Wo * 2, Cc, y_ld) * _arr(scale, Cc) + _arr(shift, Cc), 0)
+    cand = v.reshape(N, Ho, 2, Wo, 2, Cc).transpose(0, 1, 3, 2, 4, 5).reshape(N, Ho, Wo, 4, Cc)
+    best = cand.argmax(3)
+    return cand, best, np.take_along_axis(cand, best[:, :, :, None, :], 3)[:, :, :, 0, :] > 0
+
+
+def bn_apply_pool(y, y_ld, out, out_ld, slots, count, gamma, beta, eps, momentum, rm, rv, scale, shift, smean, sinv, dtype, N, Ho, Wo, Cc):
+    _bn_finalize(slots, Cc, count, gamma, beta, eps, momentum, rm, rv, scale, shift, smean, sinv)
+    cand, _, _ = _pool_routing(y, y_ld, scale, shift, N, Ho, Wo, Cc)
+    _rows(out, N * Ho * Wo, Cc, out_ld)[...] = cand.max(3).reshape(-1, Cc)
+
+
+def _pool_dh(dpool, dpool_ld, y, y_ld, scale, shift, N, Ho, Wo, Cc):
+    """dh [N*2Ho*2Wo, C]: the pooled gradient at each window's first positive maximum, zero elsewhere"""
+    cand, best, pos = _pool_routing(y, y_ld, scale, shift, N, Ho, Wo, Cc)
+    g = _rows(dpool, N * Ho * Wo, Cc, dpool_ld).reshape(N, Ho, Wo, Cc) * pos
+    o = np.zeros_like(cand)
+    np.put_along_axis(o, best[:, :, :, None, :], g[:, :, :, None, :], axis=3)
+    return o.reshape(N, Ho, Wo, 2, 2, Cc).transpose(0, 1, 3, 2, 4, 5).reshape(-1, Cc)
+
+
+def bn_pool_bwd_reduce(dpool, dpool_ld, y, y_ld, scale, shift, slots, dtype, N, Ho, Wo, Cc):
+    d = _pool_dh(dpool, dpool_ld, y, y_ld, scale, shift, N, Ho, Wo, Cc).astype(np.float64)
+    yy = _rows(y, N * Ho * 2 * Wo * 2, Cc, y_ld).astype(np.float64)
+    p = _arr(slots, SLOTS * Cc * 2, np.float64).reshape(SLOTS, Cc, 2)
+    p[0, :, 0] += d.sum(0)
+    p[0, :, 1] += (d * yy).sum(0)
+
+
+def bn_pool_bwd_apply(dpool, dpool_ld, y, y_ld, scale, shift, slots, count, gamma, mean, invstd, dgamma, dbeta, dtype, N, Ho, Wo, Cc):
+    pixels = N * Ho * 2 * Wo * 2
+    d = _pool_dh(dpool, dpool_ld, y, y_ld, scale, shift, N, Ho, Wo, Cc)
+    p = _arr(slots, SLOTS * Cc * 2, np.float64).reshape(SLOTS, Cc, 2).sum(0)
+    mu, inv = _arr(mean, Cc).astype(np.float64), _arr(invstd, Cc).astype(np.float64)
+    g = _arr(gamma, Cc).astype(np.float64) if gamma else 1.0
+    dbe = p[:, 0]
+    dga = inv * (p[:, 1] - mu * p[:, 0])
+    if dgamma:
+        _arr(dgamma, Cc)[...] += dga
+    if dbeta:
+        _arr(dbeta, Cc)[...] += dbe
+    ca = g * inv
+    cb = -g * inv * inv * dga / count
+    ck = -g * inv * dbe / count - cb * mu
+    yy = _rows(y, pixels, Cc, y_ld)
+    yy[...] = ca * d + cb * yy.copy() + ck
+
+
 def relu_bwd(dy, dy_ld, y, y_ld, dx, dx_ld, accumulate, dtype, pixels, Cc):
     d = _rows(dy, pixels, Cc, dy_ld) * (_rows(y, pixels, Cc, y_ld) > 0)
     dst = _rows(dx, pixels, Cc, dx_ld)
@@ -464,6 +515,7 @@ TABLE = {'msc_conv_igemm': conv_igemm, 'msc_conv_wgrad': conv_wgrad, 'msc_pack_c
          'msc_stem_prepare': stem_prepare, 'msc_maxpool2_fwd': maxpool2_fwd, 'msc_maxpool2_bwd': maxpool2_bwd,
          'msc_memset_zero': memset_zero, 'msc_copy': copy, 'msc_bn_fold': bn_fold, 'msc_bn_apply': bn_apply,
          'msc_bn_bwd_reduce': bn_bwd_reduce, 'msc_bn_bwd_apply': bn_bwd_apply,
+         'msc_bn_apply_pool': bn_apply_pool, 'msc_bn_pool_bwd_reduce': bn_pool_bwd_reduce, 'msc_bn_pool_bwd_apply': bn_pool_bwd_apply,
          'msc_loss_sums': loss_sums, 'msc_loss_grad': loss_grad, 'msc_adam_tick': adam_tick, 'msc_adam_step': adam_step, 'msc_adam_pack': adam_pack,
          'msc_grad_check': grad_check,
          'msc_grad_reduce': grad_reduce, 'msc_grad_unpack': grad_unpack,

@@ -757,6 +757,64 @@ def test_batchnorm_training_forward_and_backward_with_prologue_finalize(dtype, c
         assert (~torch.isclose(to_nchw(dresd), rr.grad, **t)).float().mean().item() <= (0.0 if dtype == torch.float32 else 2e-3)
 
 
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('c,hw,n', [(64, 12, 3), (32, 6, 2), (128, 10, 1)])
+def test_stem_batchnorm_relu_maxpool_fused_forward_and_backward(dtype, c, hw, n):
+    """msc_bn_apply_pool / msc_bn_pool_bwd_reduce / msc_bn_pool_bwd_apply (ABI v7): BatchNorm2d (training) + ReLU + MaxPool2d(2,2) of the stem
+    (src/unet_models.py:360-363) against torch autograd -- pooled output, running statistics, the gradient w.r.t. the conv output
+    (MaxPool routing to the first maximum + ReLU mask + BatchNorm backward), dgamma, dbeta; windows that are entirely non-positive and
+    windows with ties are in the data"""
+    from mapping_challenge_amd import _lib
+    lib = _lib.load()
+    dt = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}[dtype]
+    st = torch.cuda.current_stream().cuda_stream
+    y = rnd((n, c, hw, hw), dtype, 1, 1.5) + 0.1
+    y[:, :, 0:2, 0:2] = -3.0                      # a window the ReLU zeroes completely: its gradient stops
+    y[:, :, 2:4, 2:4] = y[:, :, 2:3, 2:3]         # a window of four equal values: the first one gets the gradient
+    y = y.to(dtype).float()
+    gamma, beta = torch.rand(c) + 0.5, torch.randn(c) * 0.2
+    bn = torch.nn.BatchNorm2d(c)
+    bn.weight.data, bn.bias.data = gamma.clone(), beta.clone()
+    bn.train()
+    yr = y.clone().requires_grad_(True)
+    o = F.max_pool2d(torch.relu(bn(yr)), 2, 2)
+    dout = rnd(tuple(o.shape), dtype, 3)
+    o.backward(dout)
+    pixels, ho = n * hw * hw, hw // 2
+    yd, outd = nhwc(y, dtype), torch.empty((n, ho, ho, c), dtype=dtype, device='cuda')
+    flat = y.permute(0, 2, 3, 1).reshape(-1, c).double()
+    slots = torch.zeros((_lib.BN_SLOTS, c, 2), dtype=torch.float64, device='cuda')
+    for x_ in range(_lib.BN_SLOTS):
+        part = flat[x_::_lib.BN_SLOTS]
+        slots[x_, :, 0] = part.sum(0).cuda()
+        slots[x_, :, 1] = (part * part).sum(0).cuda()
+    g_d, b_d = gamma.cuda(), beta.cuda()
+    rm, rv = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+    scale, shift, mean, invstd = (torch.empty(c, device='cuda') for _ in range(4))
+    _lib.check(lib.msc_bn_apply_pool(yd.data_ptr(), c, outd.data_ptr(), c, slots.data_ptr(), pixels, g_d.data_ptr(), b_d.data_ptr(), 1e-5, 0.1,
+                                     rm.data_ptr(), rv.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dt, n, ho, ho,
+                                     c, st), 'msc_bn_apply_pool')
+    assert torch.allclose(to_nchw(outd), o.detach(), **tol(dtype))
+    assert torch.allclose(rm.cpu(), bn.running_mean, atol=1e-5) and torch.allclose(rv.cpu(), bn.running_var, rtol=1e-5, atol=1e-6)
+    doutd = nhwc(dout, dtype)
+    bslots = torch.zeros((_lib.BN_SLOTS, c, 2), dtype=torch.float64, device='cuda')
+    _lib.check(lib.msc_bn_pool_bwd_reduce(doutd.data_ptr(), c, yd.data_ptr(), c, scale.data_ptr(), shift.data_ptr(), bslots.data_ptr(), dt, n, ho, ho, c,
+                                          st), 'msc_bn_pool_bwd_reduce')
+    dgamma, dbeta = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda')
+    _lib.check(lib.msc_bn_pool_bwd_apply(doutd.data_ptr(), c, yd.data_ptr(), c, scale.data_ptr(), shift.data_ptr(), bslots.data_ptr(), pixels,
+                                         g_d.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dt, n, ho, ho, c, st),
+               'msc_bn_pool_bwd_apply')
+    t = tol(dtype)
+    # the device takes the maximum over fp32 activations computed from ITS coefficients: a near-tie inside a window may route the gradient
+    # to the other element than torch's fp32 chain does (16-bit inputs make near-ties common) -- allowed for a handful of elements
+    bad = (~torch.isclose(to_nchw(yd), yr.grad, **t)).float().mean().item()
+    assert bad <= (1e-4 if dtype == torch.float32 else 4e-3), bad
+    assert (dgamma.cpu() - bn.weight.grad).abs().max().item() < (2e-4 if dtype == torch.float32 else 5e-2) * max(1.0, bn.weight.grad.abs().max().item())
+    assert (dbeta.cpu() - bn.bias.grad).abs().max().item() < (2e-4 if dtype == torch.float32 else 5e-2) * max(1.0, bn.bias.grad.abs().max().item())
+    # the all-negative window passes no gradient through the pool; the BatchNorm backward's mean terms still reach it
+    assert yr.grad[:, :, 0:2, 0:2].abs().max().item() < 1.0
+
+
 def test_conv_and_wgrad_beyond_2gib_run_as_image_ranges():
     """the kernels address their operands with 31-bit byte offsets (buffer descriptors): a 2.4 GB input (9 images of
     512 x 512 x 512 channels in bf16) is run as consecutive image ranges -- conv with a statistics epilogue (accumulated
