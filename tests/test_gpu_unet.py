@@ -217,6 +217,36 @@ def test_bf16_train_step_runs_and_reduces_loss():
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
 
 
+def test_fp16_training_with_the_dynamic_loss_scale_inside_the_captured_graph():
+    """fp16 `fit()` safety on the device (ABI v7): TrainStep in fp16 uses a DYNAMIC loss scale kept in device memory -- the captured
+    hipGraph holds msc_grad_check / msc_adam_tick / msc_adam_pack and replays with the current scale.  Clean steps train; a scale
+    that overflows the fp16 activations' gradients makes the step a no-op (parameters, step count) and halves the scale until
+    training resumes -- without re-capturing."""
+    from mapping_challenge_amd import _lib
+    from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
+    arch = {'weighted_cross_entropy': {'w0': 50, 'sigma': 10, 'imsize': (256, 256)},
+            'loss_weights': {'dice_mask': 0.2, 'bce_mask': 1.0}, 'dice': {'smooth': 1, 'dice_activation': 'softmax'}}
+    _, net = build(34, 'fp16')
+    net.train()
+    opt = HipAdam(net, lr=5e-4, weight_decay=1e-4)
+    step = TrainStep(net, LossSpec.mixed(arch), opt, use_graph=True)
+    assert opt.dynamic_scale and opt.current_loss_scale() == 4096.0
+    x = unet_ref.synthetic_batch(2, 64, 64).cuda()
+    t = losses_ref.synthetic_target(2, 64, 64).cuda()
+    losses = [step(x, t).item() for _ in range(4)]          # first call eager + capture, then replays
+    assert step.graph is not None and np.isfinite(losses).all() and losses[-1] < losses[0]
+    assert opt.steps == 4 and opt.skipped_steps == 0
+    before = net.flat_params.clone()
+    opt.dev_state[_lib.OPT_SCALE] = 2.0 ** 40                 # dlogits * 2^40 overflows fp16 in the first backward layer
+    step(x, t)
+    assert torch.equal(before, net.flat_params) and opt.steps == 4 and opt.skipped_steps == 1
+    assert opt.current_loss_scale() == 2.0 ** 39
+    opt.dev_state[_lib.OPT_SCALE] = 4096.0
+    l5 = step(x, t).item()
+    assert opt.steps == 5 and not torch.equal(before, net.flat_params) and np.isfinite(l5)
+    assert torch.isfinite(net.flat_params).all()
+
+
 def test_rccl_world1_overlapped_backward_equals_plain():
     """RCCL smoke (one GPU is all gpurun exposes): process group of size 1 on backend nccl; the piecewise backward
     with asynchronous per-piece all-reduce must give the gradients of the plain backward"""
