@@ -859,7 +859,8 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
     k->span_bytes = 0;
     if (d->mode == 1) {
         if (d->stride != 2 || (d->Ho & 1) || (d->Wo & 1)) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: transposed mode needs stride 2 and even output size");
-        if (d->stats) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: stats not available in transposed mode");
+        // statistics in transposed mode (round 4): the epilogue is the same code in both modes (side tensors are addressed by the OUTPUT
+        // pixel); every output pixel belongs to exactly one parity phase, so the phases' blocks add disjoint contributions to the slots
         k->Hq = d->Ho / 2; k->Wq = d->Wo / 2;
     } else if (d->mode == 0) {
         if (d->flip && d->stride != 1) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: flip needs stride 1");

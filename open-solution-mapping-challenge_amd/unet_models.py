@@ -847,7 +847,7 @@ class _Builder:
         if not self.net.autotune or self.dev.type != 'cuda' or _os_env.environ.get('MSC_TUNE_JOIN', '1') == '0':
             return
         key = repr(('j', self.tune_dt, d.N, d.Hi, d.Wi, d.Cin, d.Cout, d.KH, d.KW, bool(d.res), d.in_ld, d.out_ld) +
-                   ((d.flip, d.pad) if (d.flip, d.pad) != (1, 0) else ()))      # (the shipped db holds the 1x1 data-gradient keys without the pair)
+                   ((d.flip, d.pad) if (d.flip, d.pad) != (1, 0) else ()) + (('t', d.stride) if d.mode else ()))      # (the shipped db holds the 1x1 data-gradient keys without the pair)
         cache, lib = _TUNE_CACHE, self.lib
         if key not in cache or (cache[key] and not lib.msc_conv_cfg_ok(C.byref(d), int(cache[key]))):
             best, best_t, keep = 0, 1e30, d.cfg
@@ -983,7 +983,13 @@ class _Builder:
                 self.gwriter[(id(x.buf), x.c0, x.C)] = d
             self.glast[(id(x.buf), x.c0, x.C)] = d
         else:
-            self.conv(bwd, dy, wt, gx, KH=k, KW=k, stride=2, pad=geo['pad'], mode=1, res=gx if acc else None)
+            d = self.conv(bwd, dy, wt, gx, KH=k, KW=k, stride=2, pad=geo['pad'], mode=1, res=gx if acc else None)
+            # round 4: a transposed-mode data gradient (the stride-2 3x3 of a stage's first block) that is the only writer of its output
+            # can carry the BatchNorm-backward sums of the layer before it as well (the epilogue is the same code in both modes)
+            if _os_env.environ.get('MSC_FUSE_BN_BWD_T', '1') != '0':
+                if not acc:
+                    self.gwriter[(id(x.buf), x.c0, x.C)] = d
+                self.glast[(id(x.buf), x.c0, x.C)] = d      # ... or, as the LAST writer of a stage's output gradient (the downsample branch), a join's
 
     def stem_bn_pool(self, name, x, conv, bn, pooled, stem):
         """encoder.conv1 (7-tap x 32-wide implicit GEMM on the prepared image) + BatchNorm2d (batch statistics) + ReLU + MaxPool2d(2,2)

@@ -815,6 +815,69 @@ def test_stem_batchnorm_relu_maxpool_fused_forward_and_backward(dtype, c, hw, n)
     assert yr.grad[:, :, 0:2, 0:2].abs().max().item() < 1.0
 
 
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('cin,cout,k,hw,n,join', [(128, 64, 3, 8, 2, False), (256, 128, 1, 6, 3, True), (64, 64, 3, 10, 1, True)])
+def test_transposed_mode_epilogue_carries_the_batchnorm_backward_sums(dtype, cin, cout, k, hw, n, join):
+    """round 4: stats_kind 1 in TRANSPOSED mode (the stride-2 data gradients of a stage's first block: 3x3 and the 1x1 downsample) -- the
+    plain form (mask from scale*y + shift) and the residual-join form (out = acc + res in place, mask from stats_z), every valid
+    configuration, against the stride-2 conv's data gradient computed by torch"""
+    import ctypes as C
+    from mapping_challenge_amd import _lib
+    import hip_ops as ops
+    lib = _lib.load()
+    pad = k // 2
+    # forward conv: fine [n, cout_f = `cout`... here the data gradient maps dy [n, cin, hw, hw] (coarse) -> dx [n, cout, 2hw, 2hw] (fine)
+    xf = rnd((n, cout, 2 * hw, 2 * hw), dtype, 1).requires_grad_(True)
+    w = rnd((cin, cout, k, k), dtype, 2, 0.05)                              # forward weight [Cout_fwd = cin][Cin_fwd = cout][k][k]
+    yf = F.conv2d(xf, w, stride=2, padding=pad)
+    assert yf.shape[2] == hw
+    dy = rnd(tuple(yf.shape), dtype, 3)
+    yf.backward(dy)
+    ref = xf.grad                                                           # [n, cout, 2hw, 2hw]
+    master = w.permute(0, 2, 3, 1).contiguous()                             # [cin][kh][kw][cout]
+    wk = ops.pack_transpose(master.view(cin, k * k, cout).cuda(), dtype).view(cout, k, k, cin)
+    ysave = rnd((n, cout, 2 * hw, 2 * hw), dtype, 4)
+    scale, shift = rnd((cout,), torch.float32, 5), rnd((cout,), torch.float32, 6) * 0.3
+    z = torch.relu(rnd((n, cout, 2 * hw, 2 * hw), dtype, 7))
+    g0 = rnd((n, cout, 2 * hw, 2 * hw), dtype, 8)
+    if join:
+        tot = ref + g0
+        m = (z > 0).float()
+    else:
+        tot = ref
+        m = ((ysave * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) > 0).float()
+    e1, e2 = (tot * m).sum((0, 2, 3)), (tot * m * ysave).sum((0, 2, 3))
+    dyd, yd, zd = nhwc(dy, dtype), nhwc(ysave, dtype), nhwc(z, dtype)
+    out = torch.empty((n, 2 * hw, 2 * hw, cout), dtype=dtype, device='cuda')
+    sc, sh = scale.cuda(), shift.cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    tried = 0
+    for c in [0] + ops.conv_valid_cfgs(dyd, wk, out, 2, pad, mode=1):
+        d = ops.ConvDesc()
+        d.in_, d.wt, d.out = dyd.data_ptr(), wk.data_ptr(), out.data_ptr()
+        d.in_ld, d.out_ld, d.dtype, d.mode = cin, cout, ops._dt(dyd), 1
+        d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.cfg = n, hw, hw, cin, 2 * hw, 2 * hw, cout, k, k, 2, pad, c
+        d.stats_kind, d.stats_y, d.stats_y_ld = 1, yd.data_ptr(), cout
+        if join:
+            d.stats_z, d.stats_z_ld = zd.data_ptr(), cout
+            out.copy_(nhwc(g0, dtype))
+            d.res, d.res_ld = out.data_ptr(), cout
+        else:
+            d.scale, d.shift = sc.data_ptr(), sh.data_ptr()
+            out.zero_()
+        stats = torch.zeros((_lib.BN_SLOTS, cout, 2), dtype=torch.float64, device='cuda')
+        d.stats = stats.data_ptr()
+        if c and not lib.msc_conv_cfg_ok(C.byref(d), c):
+            continue
+        _lib.check(lib.msc_conv_igemm(C.byref(d), stream), 'conv')
+        tried += 1
+        assert torch.allclose(to_nchw(out), tot.detach(), **tol(dtype)), c
+        s_ = stats.sum(0).float().cpu()
+        t = dict(rtol=2e-3, atol=5e-2) if dtype == torch.float32 else dict(rtol=2e-2, atol=0.5)
+        assert torch.allclose(s_[:, 0], e1.detach(), **t) and torch.allclose(s_[:, 1], e2.detach(), **t), c
+    assert tried >= 1
+
+
 def test_conv_and_wgrad_beyond_2gib_run_as_image_ranges():
     """the kernels address their operands with 31-bit byte offsets (buffer descriptors): a 2.4 GB input (9 images of
     512 x 512 x 512 channels in bf16) is run as consecutive image ranges -- conv with a statistics epilogue (accumulated
