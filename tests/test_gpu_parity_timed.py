@@ -211,8 +211,9 @@ def _trained_state(depth=101, steps=40):
     return {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, x, tgt
 
 
-def _instances_iou(la, lb, min_area=16):
-    """for every instance of label image la with >= min_area pixels: IoU with its best-overlapping instance of lb"""
+def _instances_iou(la, lb, min_area=16, with_diff=False):
+    """for every instance of label image la with >= min_area pixels: IoU with its best-overlapping instance of lb (with_diff: also the
+    number of pixels the two differ in)"""
     out = []
     for i in range(1, int(la.max()) + 1):
         ma = la == i
@@ -220,11 +221,13 @@ def _instances_iou(la, lb, min_area=16):
             continue
         cand = np.unique(lb[ma])
         cand = cand[cand > 0]
-        best = 0.0
+        best, diff = 0.0, int(ma.sum())
         for j in cand:
             mb = lb == j
-            best = max(best, (ma & mb).sum() / float((ma | mb).sum()))
-        out.append(best)
+            iou = (ma & mb).sum() / float((ma | mb).sum())
+            if iou > best:
+                best, diff = iou, int((ma ^ mb).sum())
+        out.append((best, diff) if with_diff else best)
     return out
 
 
@@ -246,12 +249,13 @@ def test_16bit_masks_agree_with_fp32_path_after_postprocessing(dtype):
     dp = (pf - pl).abs()
     lab_f = post.postprocess_batch(pf, (300, 300), 0, 2)
     lab_l = post.postprocess_batch(pl, (300, 300), 0, 2)
-    agree, fg_iou, inst = [], [], []
+    agree, fg_iou, inst_d = [], [], []
     for (a, _), (b, _) in zip(lab_f, lab_l):
         ma, mb = a[1] > 0, b[1] > 0
         agree.append((ma == mb).mean())
         fg_iou.append((ma & mb).sum() / max(1.0, float((ma | mb).sum())))
-        inst += _instances_iou(a[1], b[1])
+        inst_d += _instances_iou(a[1], b[1], with_diff=True)
+    inst = [i for i, _ in inst_d]
     frac_fg = float(np.mean([(a[1] > 0).mean() for a, _ in lab_f]))
     stats = {'prob_maxabs': dp.max().item(), 'prob_mean_abs': dp.mean().item(), 'pixel_agreement': float(np.mean(agree)),
              'foreground_iou': float(np.mean(fg_iou)), 'instances': len(inst), 'instance_iou_mean': float(np.mean(inst)) if inst else None,
@@ -262,4 +266,8 @@ def test_16bit_masks_agree_with_fp32_path_after_postprocessing(dtype):
     assert dp.mean().item() < K * u * math.sqrt(D_FWD) / 4, stats      # probabilities: softmax slope <= 1/4
     # measured (gpurun_out/parity_timed.json): bf16 pixel agreement 0.9998, foreground IoU 0.9993, instance IoU mean 0.9993 / min 0.986
     assert np.mean(agree) > 0.999 and np.mean(fg_iou) > 0.995, stats
-    assert np.mean(inst) > 0.99 and np.min(inst) > 0.9, stats
+    # per instance: IoU > 0.9 -- or, for the smallest ones (16-40 pixels, where every boundary pixel is 3-6 % of the area), at most three
+    # pixels of difference: a 17-pixel instance that differs in two boundary pixels has IoU 0.88 and is the same building
+    worst = min(inst_d, key=lambda t: t[0])
+    record('%s_r101_256_masks_worst_instance' % dtype, {'iou': worst[0], 'pixels_differing': worst[1]})
+    assert np.mean(inst) > 0.99 and all(i > 0.9 or d <= 3 for i, d in inst_d), (stats, worst)

@@ -9,12 +9,12 @@ import sys
 
 FAMILIES = [('conv_igemm / halo (conv, dgrad, deconv)', r'conv_igemm|halo_kernel|conv3x3_|deconv4_'),
             ('conv_wgrad', r'conv_wgrad'),
-            ('BatchNorm elementwise (bn_apply, bn_bwd_apply)', r'bn_apply_kernel|bn_bwd_apply_kernel'),
+            ('BatchNorm elementwise (bn_apply, bn_bwd_apply, stem bn + pool)', r'bn_apply_kernel|bn_bwd_apply_kernel|bn_apply_pool_kernel|bn_pool_bwd_kernel'),
             ('column reductions (BN backward sums, bias grads)', r'colreduce'),
             ('BatchNorm finalize kernels', r'bn_finalize|bn_bwd_finalize|bias_finalize'),
             ('post-processing (resize, threshold, ccl, dilate, score)', r'resize_|threshold_|ccl_|rect_filter|score_|dropped_|crop_|argmax_'),
             ('annotation encoding', r'seg_|transpose_cm|rocprim|DeviceRadix|device_scan|lookback'),
-            ('optimizer + weight packing', r'adam|pack_multi|stem_pack'),
+            ('optimizer + weight packing', r'adam|pack_multi|stem_pack|grad_check'),
             ('loss + final 1x1', r'loss_|final_')]
 
 
