@@ -64,5 +64,9 @@ def predict_tta(model, x, specs, method='gmean'):
     """probabilities of `model` (UNetResNet) for batch x aggregated over the TTA variants: cuda f32 [N,2,H,W]"""
     N = x.shape[0]
     xt = transform_batch(x, specs)
-    probs = torch.cat([model.predict_proba(xt[v * N:(v + 1) * N]).clone() for v in range(len(specs))])
+    # V forward passes of the batch size the program is tuned for; each variant's probabilities go straight into their slice of ONE
+    # buffer (the program's own output buffer is overwritten by the next pass): one copy per variant, no list / cat of clones
+    probs = torch.empty((len(specs) * N, 2) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    for v in range(len(specs)):
+        probs[v * N:(v + 1) * N].copy_(model.predict_proba(xt[v * N:(v + 1) * N]))
     return aggregate_batch(probs, specs, method)
