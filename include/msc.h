@@ -210,7 +210,11 @@ int msc_bn_bwd_reduce(const void* dout, int64_t dout_ld, const void* out, int64_
 int msc_bn_bwd_apply(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
                      int relu, const float* scale, const float* shift, const double* slots, int64_t count, const float* gamma,
                      const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* dy, int64_t dy_ld,
-                     void* dres, int64_t dres_ld, int dres_acc, int dtype, int64_t pixels, int C, void* stream);
+                     void* dres, int64_t dres_ld, int dres_acc, const void* res_y, int64_t res_y_ld, double* res_slots, int dtype,
+                     int64_t pixels, int C, void* stream);
+/* res_y / res_slots (ABI v7, may be NULL): the launch also adds (sum dh, sum dh*res_y) to res_slots -- the BatchNorm-backward sums of the
+ * layer that produced the residual (the downsample branch of a stage's first block, whose output gradient is the dh written to dres and
+ * whose pre-BN tensor is res_y): no msc_bn_bwd_reduce launch for that layer. */
 
 /* The stem's BatchNorm2d (training) + ReLU + MaxPool2d(2,2) (self.conv1 = Sequential(encoder.conv1, encoder.bn1, encoder.relu, self.pool),
  * src/unet_models.py:360-363) without materialising the full-resolution activation (ABI v7): nothing but the pool reads it.

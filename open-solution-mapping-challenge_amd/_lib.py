@@ -103,7 +103,7 @@ SIGNATURES = {
     'msc_copy': (_i, [_vp, _vp, _i64, _vp]),
     'msc_bn_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp]),
     'msc_bn_bwd_reduce': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i, _i64, _i, _vp]),
-    'msc_bn_bwd_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i64, _i, _vp]),
+    'msc_bn_bwd_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i64, _vp, _i, _i64, _i, _vp]),
     'msc_bn_apply_pool': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'msc_bn_pool_bwd_reduce': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'msc_bn_pool_bwd_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -273,14 +273,21 @@ struct BnBwdFin {
     float* dgamma; float* dbeta;
 };
 
-template <typename T, int CT>
+// RSUM (round 4): the launch also reduces (sum dh, sum dh*ry) into `rslots` -- the BatchNorm-backward sums of the layer that produced the
+// RESIDUAL (the downsample branch of a stage's first block: its output gradient IS the dh this kernel writes to `dres`, its pre-BN tensor
+// is ry), which a separate msc_bn_bwd_reduce launch would read back
+template <typename T, int CT, bool RSUM>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, long dout_ld, const T* __restrict__ out, long out_ld,
                                                            const T* __restrict__ y, long y_ld, int relu, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, BnBwdFin f, T* __restrict__ dy, long dy_ld,
                                                            T* __restrict__ dres, long dres_ld, int dres_acc, long pixels, int C, long ppb,
-                                                           int xcd_order) {
+                                                           int xcd_order, const T* __restrict__ ry, long ry_ld, double* __restrict__ rslots) {
     constexpr int CE = Vec16<T>::N, VC = CT / CE, R = 256 / VC;
     __shared__ float s_a[CT], s_b[CT], s_k[CT], s_sc[CT], s_sh[CT];
+    __shared__ float rred[RSUM ? 256 * 2 * CE : 1];
+    float t1[CE], t2[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
     int pb, ct;
     bn_block(C / CT, xcd_order, pb, ct);
     const int tid = threadIdx.x, c0 = ct * CT;
@@ -339,9 +346,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                 Vec16<T>::store(dres + pix * dres_ld + c, d);
             }
         }
+        if (RSUM) {
+            float rv[CE];
+            Vec16<T>::load(ry + pix * ry_ld + c, rv);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { t1[e] += d[e]; t2[e] = fmaf(d[e], rv[e], t2[e]); }
+        }
 #pragma unroll
         for (int e = 0; e < CE; ++e) yy[e] = ca[e] * d[e] + cb[e] * yy[e] + ck[e];
         Vec16<T>::store(dy + pix * dy_ld + c, yy);
+    }
+    if (RSUM) {
+        float* mine = rred + tid * 2 * CE;
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { mine[e] = t1[e]; mine[CE + e] = t2[e]; }
+        __syncthreads();
+        if (r == 0) {
+            for (int k = 1; k < R; ++k) {
+                const float* o = rred + (k * VC + col) * 2 * CE;
+#pragma unroll
+                for (int e = 0; e < CE; ++e) { t1[e] += o[e]; t2[e] += o[CE + e]; }
+            }
+        }
+        __syncthreads();
+        if (r == 0) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) *reinterpret_cast<float2*>(rred + (col * CE + e) * 2) = make_float2(t1[e], t2[e]);
+        }
+        __syncthreads();
+        double* slot = rslots + ((long)msc_xcc_id() * C + c0) * 2;
+        for (int i = tid; i < CT * 2; i += 256) atomicAdd(slot + i, (double)rred[i]);
     }
 }
 
@@ -1054,11 +1088,14 @@ void launch_bn_apply(const void* y, long y_ld, const void* res, long res_ld, voi
 template <typename T, int CT>
 void launch_bn_bwd_apply(const void* dout, long dout_ld, const void* out, long out_ld, const void* y, long y_ld, int relu, const float* scale,
                          const float* shift, const BnBwdFin& f, void* dy, long dy_ld, void* dres, long dres_ld, int dres_acc, long pixels, int C,
-                         hipStream_t st) {
+                         const void* ry, long ry_ld, double* rslots, hipStream_t st) {
     constexpr int R = 256 / (CT / Vec16<T>::N);
     const long ppb = bn_ppb<R>(pixels, C / CT);
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, CT>), dim3(ceil_div(pixels, ppb) * (C / CT)), dim3(256), 0, st, (const T*)dout, dout_ld, (const T*)out, out_ld,
-                       (const T*)y, y_ld, relu, scale, shift, f, (T*)dy, dy_ld, (T*)dres, dres_ld, dres_acc, pixels, C, ppb, bn_xcd_order());
+    const dim3 grid(ceil_div(pixels, ppb) * (C / CT));
+    if (ry) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, CT, true>), grid, dim3(256), 0, st, (const T*)dout, dout_ld, (const T*)out, out_ld, (const T*)y, y_ld, relu,
+                               scale, shift, f, (T*)dy, dy_ld, (T*)dres, dres_ld, dres_acc, pixels, C, ppb, bn_xcd_order(), (const T*)ry, ry_ld, rslots);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, CT, false>), grid, dim3(256), 0, st, (const T*)dout, dout_ld, (const T*)out, out_ld, (const T*)y, y_ld, relu,
+                            scale, shift, f, (T*)dy, dy_ld, (T*)dres, dres_ld, dres_acc, pixels, C, ppb, bn_xcd_order(), (const T*)nullptr, 0L, (double*)nullptr);
 }
 }  // namespace
 
@@ -1086,15 +1123,17 @@ extern "C" int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_
 extern "C" int msc_bn_bwd_apply(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
                                 int relu, const float* scale, const float* shift, const double* slots, int64_t count, const float* gamma,
                                 const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* dy, int64_t dy_ld,
-                                void* dres, int64_t dres_ld, int dres_acc, int dtype, int64_t pixels, int C, void* stream) {
+                                void* dres, int64_t dres_ld, int dres_acc, const void* res_y, int64_t res_y_ld, double* res_slots, int dtype,
+                                int64_t pixels, int C, void* stream) {
     DT_CHECK("msc_bn_bwd_apply", dtype);
+    if (res_y && (!res_slots || !dres)) return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_apply: res_y needs res_slots and dres");
     if (C % 32) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bn_bwd_apply: C=%d must be a multiple of 32", C);
     if (!dout || !y || !slots || !save_mean || !save_invstd || !dy || count <= 0 || pixels <= 0 || relu < 0 || relu > 2 || (relu == 1 && !out) ||
         (relu == 2 && (!scale || !shift)))
         return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_apply: bad argument");
     const BnBwdFin f = {slots, (double)count, gamma, save_mean, save_invstd, dgamma, dbeta};
     MSC_BN_DISPATCH(launch_bn_bwd_apply, dout, (long)dout_ld, out, (long)out_ld, y, (long)y_ld, relu, scale, shift, f, dy, (long)dy_ld, dres, (long)dres_ld,
-                    dres_acc, (long)pixels, C, (hipStream_t)stream);
+                    dres_acc, (long)pixels, C, res_y, (long)res_y_ld, res_slots, (hipStream_t)stream);
     return msc_check_launch("msc_bn_bwd_apply");
 }
 

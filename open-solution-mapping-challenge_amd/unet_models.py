@@ -643,6 +643,7 @@ class _Builder:
         # join's BatchNorm backward (stats_kind 1 with stats_z, ABI v6) -- no msc_bn_bwd_reduce pass over three tensors
         self.fuse_join_bwd = _os_env.environ.get('MSC_FUSE_JOIN_BWD', '1') != '0'
         self.glast = {}               # gradient slice -> ConvDesc of its most recent writer, while that is a mode-0 / stride-1 data-gradient conv
+        self.bn_writer = {}           # gradient slice -> index (in prog.bwd) of the msc_bn_bwd_apply launch that wrote it as its dres
         # decoder: the data-gradient conv that writes the gradient of a bias+ReLU layer's activation first also applies that
         # layer's ReLU mask and sums its bias gradient (stats_kind 2) -- no msc_relu_bias_grad pass over the tensor
         self.fuse_relu_bwd = _os_env.environ.get('MSC_FUSE_RELU_BWD', '1') != '0'
@@ -953,6 +954,12 @@ class _Builder:
             wd.stats = bslots
             if wd.cfg and not lib.msc_conv_cfg_ok(C.byref(wd), int(wd.cfg)):
                 wd.cfg = 0                                   # the tuned configuration cannot carry the statistics: heuristic one
+        elif (mask == 0 and gkey in self.bn_writer and self.gcount.get(gkey, 0) == 1 and self.fuse_bn_bwd and self.dev.type != 'meta'
+              and _os_env.environ.get('MSC_FUSE_BN_BWD_RES', '1') != '0'):
+            # dout was written by ONE launch, the msc_bn_bwd_apply of the block's bn3 (as its dres): that launch also reduces this layer's sums
+            i = self.bn_writer[gkey]
+            fn, a = bwd[i]
+            bwd[i] = (fn, a[:21] + (y.ptr, y.ld, bslots) + a[24:])
         else:
             self.emit(bwd, lib.msc_bn_bwd_reduce, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, mask, scale.data_ptr(),
                       shift.data_ptr(), bslots, self.dt, count, cout)
@@ -963,9 +970,13 @@ class _Builder:
             dres_ptr, dres_ld = gres.ptr, gres.ld
         # dy overwrites y in place (each element is read, then written, by the same lane); the prologue also adds dgamma / dbeta
         gw, gb = self.g(bn.weight), self.g(bn.bias)
+        if res is not None and not dres_acc:
+            # first writer of the residual's gradient: if the residual is a BatchNorm output (the downsample branch), that layer's backward can
+            # have its sums from this launch (msc_bn_bwd_apply res_y / res_slots) -- remembered here, patched in by that layer's backward below
+            self.bn_writer[(id(res.buf), res.c0, res.C)] = len(bwd)
         self.emit(bwd, lib.msc_bn_bwd_apply, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, mask, scale.data_ptr(),
                   shift.data_ptr(), bslots, count, bn.weight.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gw, gb,
-                  y.ptr, y.ld, dres_ptr, dres_ld, dres_acc, self.dt, count, cout)
+                  y.ptr, y.ld, dres_ptr, dres_ld, dres_acc, None, 0, None, self.dt, count, cout)
         dy = y
         if stem is not None:
             self.wgrad(bwd, dy, x, P.stem_dw.data_ptr(), 7, 1, 2, 0, q_hw=stem, q_ld=4, B=32)

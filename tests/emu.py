@@ -382,7 +382,7 @@ def bn_bwd_reduce(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, slots
 
 
 def bn_bwd_apply(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, slots, count, gamma, mean, invstd, dgamma, dbeta, dy, dy_ld, dres, dres_ld,
-                 dres_acc, dtype, pixels, Cc):
+                 dres_acc, res_y, res_y_ld, res_slots, dtype, pixels, Cc):
     p = _arr(slots, SLOTS * Cc * 2, np.float64).reshape(SLOTS, Cc, 2).sum(0)
     mu, inv = _arr(mean, Cc).astype(np.float64), _arr(invstd, Cc).astype(np.float64)
     g = _arr(gamma, Cc).astype(np.float64) if gamma else 1.0
@@ -402,6 +402,11 @@ def bn_bwd_apply(dout, dout_ld, out, out_ld, y, y_ld, relu, scale, shift, slots,
     if dres:
         r = _rows(dres, pixels, Cc, dres_ld)
         r[...] = r + d if dres_acc else d
+    if res_y:                 # the BatchNorm-backward sums of the layer that produced the residual
+        q = _arr(res_slots, SLOTS * Cc * 2, np.float64).reshape(SLOTS, Cc, 2)
+        d64 = d.astype(np.float64)
+        q[0, :, 0] += d64.sum(0)
+        q[0, :, 1] += (d64 * _rows(res_y, pixels, Cc, res_y_ld).astype(np.float64)).sum(0)
     _rows(dy, pixels, Cc, dy_ld)[...] = ca * d + cb * yy + ck
 
 

@@ -231,7 +231,7 @@ def test_residual_join_reduces_ride_on_the_last_writer(interpreted, monkeypatch)
         joins = sum(1 for f, a in prog.bwd if getattr(f, '__name__', '') == 'msc_conv_igemm' and a[0]._obj.stats_z)
         counts.append((names.count('msc_bn_bwd_reduce'), joins))
         grads.append({n: p.grad.clone() for n, p in net._trainable()})
-    assert counts == [(4, 15), (19, 0)]      # round 4: the stem's sums come from msc_bn_pool_bwd_reduce; the three stage ends ride on the downsample branch's transposed-mode data gradient
+    assert counts == [(1, 15), (16, 0)]      # round 4: stem (fused pool backward), three stage ends (transposed-mode data gradient of the downsample branch), three downsample BatchNorms (bn3's msc_bn_bwd_apply); left: the layer4 end
     for n, g in grads[0].items():
         scale = grads[1][n].abs().max().item() + 1e-12
         assert (g - grads[1][n]).abs().max().item() / scale < 1e-5, n

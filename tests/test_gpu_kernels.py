@@ -742,9 +742,13 @@ def test_batchnorm_training_forward_and_backward_with_prologue_finalize(dtype, c
     dgamma, dbeta = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda')
     dyd = torch.empty_like(yd)
     dresd = torch.empty_like(yd) if with_res else None
+    # with a residual: also the BatchNorm-backward sums of the layer that produced it (res_y / res_slots), against a tensor ry
+    ry = rnd((n, c, hw, hw), dtype, 9)
+    ryd, rslots = nhwc(ry, dtype), torch.zeros((_lib.BN_SLOTS, c, 2), dtype=torch.float64, device='cuda')
     _lib.check(lib.msc_bn_bwd_apply(doutd.data_ptr(), c, outd.data_ptr(), c, yd.data_ptr(), c, mask, scale.data_ptr(), shift.data_ptr(), bslots.data_ptr(),
                                     pixels, g_d.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dyd.data_ptr(), c,
-                                    dresd.data_ptr() if with_res else None, c if with_res else 0, 0, dt, pixels, c, st), 'msc_bn_bwd_apply')
+                                    dresd.data_ptr() if with_res else None, c if with_res else 0, 0, ryd.data_ptr() if with_res else None, c if with_res else 0,
+                                    rslots.data_ptr() if with_res else None, dt, pixels, c, st), 'msc_bn_bwd_apply')
     t = tol(dtype)
     # the stored `out` is rounded to the dtype: a 16-bit out of exactly 0 vs a tiny positive reference value may flip a mask
     # element; gradients are compared with that allowance (a handful of elements) in the 16-bit modes
@@ -755,6 +759,10 @@ def test_batchnorm_training_forward_and_backward_with_prologue_finalize(dtype, c
     assert (dbeta.cpu() - bn.bias.grad).abs().max().item() < (2e-4 if dtype == torch.float32 else 5e-2) * max(1.0, bn.bias.grad.abs().max().item())
     if with_res:
         assert (~torch.isclose(to_nchw(dresd), rr.grad, **t)).float().mean().item() <= (0.0 if dtype == torch.float32 else 2e-3)
+        dh = to_nchw(dresd).double()
+        rs = rslots.sum(0).cpu()
+        e1, e2 = dh.sum((0, 2, 3)), (dh * ry.double()).sum((0, 2, 3))
+        assert torch.allclose(rs[:, 0], e1, rtol=1e-3, atol=1e-2) and torch.allclose(rs[:, 1], e2, rtol=1e-3, atol=1e-2)
 
 
 @pytest.mark.parametrize('dtype', DT)
