@@ -161,6 +161,17 @@ def test_hipadam_state_dict_roundtrip_resume_order_and_fresh_compute_copies(inte
     assert torch.equal(after, net.flat_params)
     with pytest.raises(ValueError):
         opt2.load_state_dict(dict(state, m=torch.zeros(3)))
+    # (c) betas / eps / weight_decay are ARGUMENTS of already captured launches: loading a state that changes them drops the captured graphs
+    # of every TrainStep bound to the optimizer (round-3 advisory); the same hyper-parameters keep them
+    ts = TrainStep(net, LossSpec.plain_ce(), opt2)
+    ts(x, t)
+    ts.cur.graph = 'captured'                                          # stands in for a CUDAGraph (none on the CPU interpreter)
+    opt2.load_state_dict(opt2.state_dict())
+    assert ts.cur.graph == 'captured'
+    changed = opt2.state_dict()
+    changed['param_groups'] = [dict(changed['param_groups'][0], betas=(0.8, 0.99))]
+    opt2.load_state_dict(changed)
+    assert ts.cur.graph is None and opt2.betas == (0.8, 0.99)
     # (b) resume order: nothing is flattened yet when the state is loaded
     ref3, net3 = build(34)
     net3.load_state_dict(sd)
