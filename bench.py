@@ -121,12 +121,12 @@ def _es(dtype):
 # algorithmic HBM bytes of the BatchNorm elementwise launches: tensors of pixels*C elements read or written
 # (argument positions: include/msc.h)
 BN_TENSORS = {
-    'msc_bn_apply': lambda a: a[20] * a[21] * _es(a[19]) * (2 + (1 if a[2] else 0)),
+    'msc_bn_apply': lambda a: a[22] * a[23] * _es(a[21]) * (2 + (1 if a[2] else 0)),
     'msc_bn_bwd_reduce': lambda a: a[11] * a[12] * _es(a[10]) * (2 + (1 if a[6] == 1 else 0)),
     'msc_bn_apply_pool': lambda a: a[17] * a[18] * a[19] * a[20] * _es(a[16]) * 5,
     'msc_bn_pool_bwd_reduce': lambda a: a[8] * a[9] * a[10] * a[11] * _es(a[7]) * 5,
     'msc_bn_pool_bwd_apply': lambda a: a[14] * a[15] * a[16] * a[17] * _es(a[13]) * 9,
-    'msc_bn_bwd_apply': lambda a: a[25] * a[26] * _es(a[24]) * (3 + (1 if a[6] == 1 else 0) + ((1 + (1 if a[20] else 0)) if a[18] else 0) + (1 if a[21] else 0)),
+    'msc_bn_bwd_apply': lambda a: a[25] * a[26] * _es(a[24]) * (3 + (1 if a[6] == 1 else (1.0 / 16 if a[6] == 3 else 0)) + ((1 + (1 if a[20] else 0)) if a[18] else 0) + (1 if a[21] else 0)),
 }
 
 

@@ -88,6 +88,10 @@ typedef struct msc_conv_desc {
     /* ABI v6: stats_kind 1 with the ReLU mask taken from a stored activation (see above); same shape as out, stats_z_ld elements per pixel */
     const void* stats_z;
     int64_t stats_z_ld;
+    /* ABI v7: 1 = stats_z is the ReLU byte mask msc_bn_apply wrote (relu_mask: bit e of byte k = channel (16 / sizeof(dtype)) * k + e is
+     * positive), stats_z_ld BYTES per pixel -- the join's gradient is masked without re-reading the 16-bit activation */
+    int32_t stats_z_bits;
+    int32_t reserved0;
 } msc_conv_desc;
 int msc_conv_igemm(const msc_conv_desc* d, void* stream);
 int msc_conv_stats_slices(const msc_conv_desc* d);   /* depends on d->cfg */
@@ -173,7 +177,7 @@ int msc_copy(void* dst, const void* src, int64_t bytes, void* stream);
 int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_t res_ld, void* out, int64_t out_ld,
                  const double* slots, int64_t count, const float* gamma, const float* beta, float eps, float momentum,
                  float* running_mean, float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
-                 int relu, int dtype, int64_t pixels, int C, void* stream);
+                 uint8_t* relu_mask, int64_t relu_mask_ld, int relu, int dtype, int64_t pixels, int C, void* stream);
 /* eval mode (model.eval(), src/steps/pytorch/models.py:116): scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
 int msc_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                 float eps, float* scale, float* shift, int C, void* stream);
@@ -207,6 +211,9 @@ int msc_bottleneck_fused(const msc_bneck_desc* d, void* stream);
 int msc_bn_bwd_reduce(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
                       int relu, const float* scale, const float* shift, double* slots, int dtype, int64_t pixels, int C,
                       void* stream);
+/* msc_bn_apply relu_mask (ABI v7, may be NULL; needs relu): one byte per 16-byte channel vector and pixel, relu_mask_ld bytes per pixel, bit e
+ * = [out channel (16 / sizeof(dtype)) * k + e > 0].  msc_bn_bwd_apply relu 3: `out` points at such a mask (out_ld bytes per pixel) instead
+ * of the activation -- the residual joins' backward reads 1/16 of the bytes for its ReLU mask. */
 int msc_bn_bwd_apply(const void* dout, int64_t dout_ld, const void* out, int64_t out_ld, const void* y, int64_t y_ld,
                      int relu, const float* scale, const float* shift, const double* slots, int64_t count, const float* gamma,
                      const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* dy, int64_t dy_ld,

@@ -31,7 +31,8 @@ class ConvDesc(C.Structure):
                 ('stats_kind', C.c_int32), ('stats_y', C.c_void_p), ('stats_y_ld', C.c_int64),
                 ('final_w', C.c_void_p), ('final_b', C.c_void_p), ('final_logits', C.c_void_p), ('final_probs', C.c_void_p),
                 ('final_skip_store', C.c_int32), ('splitk', C.c_int32), ('splitk_ws', C.c_void_p),
-                ('stats_z', C.c_void_p), ('stats_z_ld', C.c_int64)]        # ABI v6: stats_kind 1 masked by a stored activation, residual allowed
+                ('stats_z', C.c_void_p), ('stats_z_ld', C.c_int64),        # ABI v6: stats_kind 1 masked by a stored activation, residual allowed
+                ('stats_z_bits', C.c_int32), ('reserved0', C.c_int32)]     # ABI v7: stats_z is msc_bn_apply's ReLU byte mask
 
 
 class WgradDesc(C.Structure):
@@ -101,7 +102,7 @@ SIGNATURES = {
     'msc_annotations_json': (_i64, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64]),
     'msc_memset_zero': (_i, [_vp, _i64, _vp]),
     'msc_copy': (_i, [_vp, _vp, _i64, _vp]),
-    'msc_bn_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp]),
+    'msc_bn_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i64, _i, _vp]),
     'msc_bn_bwd_reduce': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i, _i64, _i, _vp]),
     'msc_bn_bwd_apply': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i64, _vp, _i, _i64, _i, _vp]),
     'msc_bn_apply_pool': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

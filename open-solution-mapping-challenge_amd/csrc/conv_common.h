@@ -9,6 +9,7 @@ struct ConvK {
     const char* in; const char* wt; char* out; const char* res;
     const float* scale; const float* shift; double* stats;
     const char* sz; long sz_ld;                     // stats_kind 1: the activation the ReLU mask is taken from (0: from scale*sy + shift, or none)
+    int sz_bits;                                    // 1: sz is the byte mask msc_bn_apply wrote (one byte per 16-byte channel vector, sz_ld bytes per pixel)
     const char* sy; long sy_ld; int stats_kind;     // stats_kind 1: BatchNorm-backward sums against the tensor sy;
                                                     // 2: ReLU backward (mask [sy > 0] applied to the output) + bias-gradient sums
     long in_ld, out_ld, res_ld;
@@ -118,7 +119,14 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvK& p, f32x4 (&acc)[
     constexpr bool JOIN = KIND == 1 && FM * FN <= 16;      // the residual-join form (sz / res) is compiled for wave tiles of up to 16 fragments (msc_conv_cfg_ok)
     constexpr bool PRE2 = JOIN && PRE;
     uint4 prez[PRE2 ? FN : 1][PRE2 ? NV / CE : 1], prer[PRE2 ? FN : 1][PRE2 ? NV / CE : 1];
-    if (PRE2 && p.sz) {
+    unsigned zbits[JOIN ? FN : 1][JOIN ? NV / CE : 1];      // sz_bits: the mask bytes of this lane's channel vectors (one byte where the activation is 16)
+    if (JOIN && p.sz && p.sz_bits) {
+        const uint8_t* zb = reinterpret_cast<const uint8_t*>(p.sz);
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+            for (int j = 0; j < NV; j += CE) zbits[JOIN ? b : 0][JOIN ? j / CE : 0] = zb[opixs[b] * p.sz_ld + (cb + j) / CE];
+    } else if (PRE2 && p.sz) {
         const T* sz = reinterpret_cast<const T*>(p.sz);
 #pragma unroll
         for (int b = 0; b < FN; ++b)
@@ -168,6 +176,18 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvK& p, f32x4 (&acc)[
                 for (int j = 0; j < NV; ++j) {
                     v[j] = yv[j] > 0.f ? v[j] : 0.f;
                     s1[j] += v[j];
+                }
+            } else if (JOIN && p.sz && p.sz_bits) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < NV; j += CE) {
+                    const unsigned mb = zbits[JOIN ? b : 0][JOIN ? j / CE : 0];
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) {
+                        const float dh = ((mb >> e) & 1u) ? v[j + e] : 0.f;
+                        s1[j + e] += dh;
+                        s2[j + e] = fmaf(dh, yv[j + e], s2[j + e]);
+                    }
                 }
             } else if (JOIN && p.sz) {
                 asm volatile("" ::: "memory");

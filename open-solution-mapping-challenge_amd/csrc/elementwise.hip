@@ -204,7 +204,7 @@ struct BnFwdFin {
 template <typename T, int CT>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, long y_ld, const T* __restrict__ res, long res_ld,
                                                        T* __restrict__ out, long out_ld, BnFwdFin f, int relu, long pixels, int C, long ppb,
-                                                       int xcd_order) {
+                                                       int xcd_order, uint8_t* __restrict__ mask, long mask_ld) {
     constexpr int CE = Vec16<T>::N, VC = CT / CE, R = 256 / VC;
     __shared__ float s_sc[CT], s_sh[CT];
     int pb, ct;
@@ -265,6 +265,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
             for (int e = 0; e < CE; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         Vec16<T>::store(out + pix * out_ld + c, v);
+        if (mask) {                  // ReLU mask of this lane's CE channels as one byte (bit e = channel c + e): what the backward reads instead of `out`
+            unsigned m = 0;
+#pragma unroll
+            for (int e = 0; e < CE; ++e) m |= (v[e] > 0.f ? 1u : 0u) << e;
+            mask[pix * mask_ld + c / CE] = (uint8_t)m;
+        }
     }
 }
 
@@ -332,6 +338,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             Vec16<T>::load(out + pix * out_ld + c, o);
 #pragma unroll
             for (int e = 0; e < CE; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+        } else if (relu == 3) {      // `out` is the byte mask msc_bn_apply wrote (one byte per CE channels, out_ld bytes per pixel)
+            const unsigned m = reinterpret_cast<const uint8_t*>(out)[pix * out_ld + c / CE];
+#pragma unroll
+            for (int e = 0; e < CE; ++e) d[e] = ((m >> e) & 1u) ? d[e] : 0.f;
         } else if (relu == 2) {
 #pragma unroll
             for (int e = 0; e < CE; ++e) d[e] = fmaf(yy[e], sc[e], sh[e]) > 0.f ? d[e] : 0.f;
@@ -1079,11 +1089,11 @@ long bn_ppb(long pixels, int ctiles) {
 }
 template <typename T, int CT>
 void launch_bn_apply(const void* y, long y_ld, const void* res, long res_ld, void* out, long out_ld, const BnFwdFin& f, int relu, long pixels, int C,
-                     hipStream_t st) {
+                     uint8_t* mask, long mask_ld, hipStream_t st) {
     constexpr int R = 256 / (CT / Vec16<T>::N);
     const long ppb = bn_ppb<R>(pixels, C / CT);
     hipLaunchKernelGGL((bn_apply_kernel<T, CT>), dim3(ceil_div(pixels, ppb) * (C / CT)), dim3(256), 0, st, (const T*)y, y_ld, (const T*)res, res_ld, (T*)out,
-                       out_ld, f, relu, pixels, C, ppb, bn_xcd_order());
+                       out_ld, f, relu, pixels, C, ppb, bn_xcd_order(), mask, mask_ld);
 }
 template <typename T, int CT>
 void launch_bn_bwd_apply(const void* dout, long dout_ld, const void* out, long out_ld, const void* y, long y_ld, int relu, const float* scale,
@@ -1111,12 +1121,13 @@ void launch_bn_bwd_apply(const void* dout, long dout_ld, const void* out, long o
 extern "C" int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_t res_ld, void* out, int64_t out_ld,
                             const double* slots, int64_t count, const float* gamma, const float* beta, float eps, float momentum,
                             float* running_mean, float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
-                            int relu, int dtype, int64_t pixels, int C, void* stream) {
+                            uint8_t* relu_mask, int64_t relu_mask_ld, int relu, int dtype, int64_t pixels, int C, void* stream) {
     DT_CHECK("msc_bn_apply", dtype);
+    if (relu_mask && (!relu || relu_mask_ld * msc_dtype_vec(dtype) < C)) return msc_fail(MSC_ERR_ARG, "msc_bn_apply: relu_mask needs relu and C / %d bytes per pixel", msc_dtype_vec(dtype));
     if (C % 32) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bn_apply: C=%d must be a multiple of 32", C);
     if (!y || !out || !scale || !shift || pixels <= 0 || (slots && count <= 0)) return msc_fail(MSC_ERR_ARG, "msc_bn_apply: bad argument");
     const BnFwdFin f = {slots, (double)count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd};
-    MSC_BN_DISPATCH(launch_bn_apply, y, (long)y_ld, res, (long)res_ld, out, (long)out_ld, f, relu, (long)pixels, C, (hipStream_t)stream);
+    MSC_BN_DISPATCH(launch_bn_apply, y, (long)y_ld, res, (long)res_ld, out, (long)out_ld, f, relu, (long)pixels, C, relu_mask, (long)relu_mask_ld, (hipStream_t)stream);
     return msc_check_launch("msc_bn_apply");
 }
 
@@ -1128,7 +1139,7 @@ extern "C" int msc_bn_bwd_apply(const void* dout, int64_t dout_ld, const void* o
     DT_CHECK("msc_bn_bwd_apply", dtype);
     if (res_y && (!res_slots || !dres)) return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_apply: res_y needs res_slots and dres");
     if (C % 32) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_bn_bwd_apply: C=%d must be a multiple of 32", C);
-    if (!dout || !y || !slots || !save_mean || !save_invstd || !dy || count <= 0 || pixels <= 0 || relu < 0 || relu > 2 || (relu == 1 && !out) ||
+    if (!dout || !y || !slots || !save_mean || !save_invstd || !dy || count <= 0 || pixels <= 0 || relu < 0 || relu > 3 || ((relu == 1 || relu == 3) && !out) ||
         (relu == 2 && (!scale || !shift)))
         return msc_fail(MSC_ERR_ARG, "msc_bn_bwd_apply: bad argument");
     const BnBwdFin f = {slots, (double)count, gamma, save_mean, save_invstd, dgamma, dbeta};

@@ -840,8 +840,11 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
     if (k->stats_kind == 2 && (!d->stats_y || d->res || d->relu || d->scale || d->shift || (d->stats_y_ld * es) % 16 || ((uintptr_t)d->stats_y & 15)))
         return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: ReLU-backward statistics need stats_y (16-byte aligned), no residual, no ReLU, no scale/shift");
     k->sz = k->stats_kind == 1 ? (const char*)d->stats_z : nullptr; k->sz_ld = d->stats_z_ld;
+    k->sz_bits = (k->sz && d->stats_z_bits) ? 1 : 0;      // the byte mask of msc_bn_apply instead of the activation (byte stride, no alignment)
+    if (k->sz_bits && d->stats_z_ld * (16 / es) < d->Cout) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: stats_z_bits needs Cout / %d mask bytes per pixel", 16 / es);
     if (k->stats_kind == 1 && (!d->stats_y || d->relu || (d->stats_y_ld * es) % 16 || ((uintptr_t)d->stats_y & 15) || !d->scale != !d->shift ||
-                               (d->res && !d->stats_z) || (d->stats_z && (d->scale || (d->stats_z_ld * es) % 16 || ((uintptr_t)d->stats_z & 15)))))
+                               (d->res && !d->stats_z) ||
+                               (d->stats_z && (d->scale || (!d->stats_z_bits && ((d->stats_z_ld * es) % 16 || ((uintptr_t)d->stats_z & 15)))))))
         return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: BatchNorm-backward statistics need stats_y (16-byte aligned), no ReLU, and either the forward coefficients "
                                      "(no residual) or stats_z (no coefficients) for the mask");
     k->in_ld = d->in_ld; k->out_ld = d->out_ld; k->res_ld = d->res_ld;
@@ -925,7 +928,7 @@ static msc_conv_desc conv_image_range(const msc_conv_desc* d, int n0, int n) {
     c.out = (char*)d->out + (long)n0 * d->Ho * d->Wo * d->out_ld * es;
     if (d->res) c.res = (const char*)d->res + (long)n0 * d->Ho * d->Wo * d->res_ld * es;
     if (d->stats_y) c.stats_y = (const char*)d->stats_y + (long)n0 * d->Ho * d->Wo * d->stats_y_ld * es;
-    if (d->stats_z) c.stats_z = (const char*)d->stats_z + (long)n0 * d->Ho * d->Wo * d->stats_z_ld * es;
+    if (d->stats_z) c.stats_z = (const char*)d->stats_z + (long)n0 * d->Ho * d->Wo * d->stats_z_ld * (d->stats_z_bits ? 1 : es);
     if (d->final_logits) c.final_logits = d->final_logits + (long)n0 * 2 * d->Ho * d->Wo;
     if (d->final_probs) c.final_probs = d->final_probs + (long)n0 * 2 * d->Ho * d->Wo;
     return c;

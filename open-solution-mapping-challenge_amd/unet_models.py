@@ -920,13 +920,22 @@ class _Builder:
         self.emit(fwd, lib.msc_conv_igemm, C.byref(d))
         mean, invstd = self.vec(cout), self.vec(cout)
         count = self.N * out.H * out.W
+        # residual joins: the ReLU sits after the add, so the backward needs [out > 0] -- twice (the BatchNorm backward and the epilogue of
+        # the data-gradient conv that carries the join's sums).  msc_bn_apply leaves it as one byte per 16-byte channel vector: 1/16 of the
+        # activation's bytes on both reads (round 4; MSC_RELU_BITS=0: the backward reads the activation)
+        rmask = None
+        if res is not None and relu and _os_env.environ.get('MSC_RELU_BITS', '1') != '0':
+            rmask = torch.empty((self.N, out.H, out.W, cout * self.es // 16), dtype=torch.uint8, device=self.dev)
+            self.prog.bytes += rmask.numel()
+            self.prog.keep.append(rmask)
         self.emit(fwd, lib.msc_bn_apply, y.ptr, y.ld, res.ptr if res is not None else None, res.ld if res is not None else 0,
                   out.ptr, out.ld, d.stats, count, bn.weight.data_ptr(), bn.bias.data_ptr(), BN_EPS, BN_MOMENTUM,
                   bn.running_mean.data_ptr(), bn.running_var.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
-                  invstd.data_ptr(), int(relu), self.dt, count, cout)
-        self.ops.append(lambda: self._conv_bn_bwd(name, x, conv, bn, geo, relu, out, res, y, mean, invstd, count, stem, scale, shift))
+                  invstd.data_ptr(), rmask.data_ptr() if rmask is not None else None, rmask.shape[3] if rmask is not None else 0, int(relu), self.dt,
+                  count, cout)
+        self.ops.append(lambda: self._conv_bn_bwd(name, x, conv, bn, geo, relu, out, res, y, mean, invstd, count, stem, scale, shift, rmask))
 
-    def _conv_bn_bwd(self, name, x, conv, bn, geo, relu, out, res, y, mean, invstd, count, stem, scale, shift):
+    def _conv_bn_bwd(self, name, x, conv, bn, geo, relu, out, res, y, mean, invstd, count, stem, scale, shift, rmask=None):
         net, lib, P, bwd = self.net, self.lib, self.prog, self.prog.bwd
         cout = conv.out_channels
         dout = self.grad_of(out)
@@ -941,7 +950,10 @@ class _Builder:
             # residual join: the last writer of dout accumulated onto the other addend(s) (out = acc + res); its epilogue reduces
             # dh = out * [block output > 0] against y -- the block output is the ReLU output that follows the add
             wl.stats_kind, wl.stats_y, wl.stats_y_ld = 1, y.ptr, y.ld
-            wl.stats_z, wl.stats_z_ld = out.ptr, out.ld
+            if rmask is not None:
+                wl.stats_z, wl.stats_z_ld, wl.stats_z_bits = rmask.data_ptr(), rmask.shape[3], 1
+            else:
+                wl.stats_z, wl.stats_z_ld = out.ptr, out.ld
             wl.stats = bslots
             self.tune_join(wl)
             if wl.cfg and not lib.msc_conv_cfg_ok(C.byref(wl), int(wl.cfg)):
@@ -974,7 +986,8 @@ class _Builder:
             # first writer of the residual's gradient: if the residual is a BatchNorm output (the downsample branch), that layer's backward can
             # have its sums from this launch (msc_bn_bwd_apply res_y / res_slots) -- remembered here, patched in by that layer's backward below
             self.bn_writer[(id(res.buf), res.c0, res.C)] = len(bwd)
-        self.emit(bwd, lib.msc_bn_bwd_apply, dout.ptr, dout.ld, out.ptr, out.ld, y.ptr, y.ld, mask, scale.data_ptr(),
+        mptr, mld, mmode = (rmask.data_ptr(), rmask.shape[3], 3) if (rmask is not None and mask == 1) else (out.ptr, out.ld, mask)
+        self.emit(bwd, lib.msc_bn_bwd_apply, dout.ptr, dout.ld, mptr, mld, y.ptr, y.ld, mmode, scale.data_ptr(),
                   shift.data_ptr(), bslots, count, bn.weight.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gw, gb,
                   y.ptr, y.ld, dres_ptr, dres_ld, dres_acc, None, 0, None, self.dt, count, cout)
         dy = y

@@ -74,7 +74,9 @@ def conv_igemm(dref):
             assert d.stats_z and not d.scale
             acc = acc + res
             res = None
-        if d.stats_z:
+        if d.stats_z and d.stats_z_bits:
+            dh = acc * _mask_unpack(d.stats_z, N * Ho * Wo, Cout, d.stats_z_ld)
+        elif d.stats_z:
             dh = acc * (_rows(d.stats_z, N * Ho * Wo, Cout, d.stats_z_ld) > 0)
         else:
             dh = acc * (yy * _arr(d.scale, Cout) + _arr(d.shift, Cout) > 0) if d.scale else acc
@@ -354,7 +356,20 @@ def bn_fold(gamma, beta, rm, rv, eps, scale, shift, Cc):
     _arr(shift, Cc)[...] = b - _arr(rm, Cc) * sc
 
 
-def bn_apply(y, y_ld, res, res_ld, out, out_ld, slots, count, gamma, beta, eps, momentum, rm, rv, scale, shift, smean, sinv, relu, dtype, pixels, Cc):
+def _mask_bytes(ptr, pixels, nbytes, ld):
+    """view [pixels, nbytes] of a ReLU byte mask with `ld` bytes per pixel"""
+    raw = np.ctypeslib.as_array((C.c_uint8 * int((pixels - 1) * ld + nbytes)).from_address(int(ptr)))
+    return np.lib.stride_tricks.as_strided(raw, shape=(pixels, nbytes), strides=(ld, 1))
+
+
+def _mask_unpack(ptr, pixels, Cc, ld, ce=4):
+    """bool [pixels, C] from the byte mask (fp32 interpreter: 4 channels per byte, bit e = channel 4k + e)"""
+    b = _mask_bytes(ptr, pixels, Cc // ce, ld)
+    return ((b[:, :, None] >> np.arange(ce)[None, None, :]) & 1).reshape(pixels, Cc).astype(bool)
+
+
+def bn_apply(y, y_ld, res, res_ld, out, out_ld, slots, count, gamma, beta, eps, momentum, rm, rv, scale, shift, smean, sinv, relu_mask, relu_mask_ld, relu,
+             dtype, pixels, Cc):
     if slots:
         _bn_finalize(slots, Cc, count, gamma, beta, eps, momentum, rm, rv, scale, shift, smean, sinv)
     v = _rows(y, pixels, Cc, y_ld) * _arr(scale, Cc) + _arr(shift, Cc)
@@ -363,11 +378,16 @@ def bn_apply(y, y_ld, res, res_ld, out, out_ld, slots, count, gamma, beta, eps, 
     if relu:
         v = np.maximum(v, 0)
     _rows(out, pixels, Cc, out_ld)[...] = v
+    if relu_mask:
+        bits = (v > 0).reshape(pixels, Cc // 4, 4).astype(np.uint8)
+        _mask_bytes(relu_mask, pixels, Cc // 4, relu_mask_ld)[...] = (bits << np.arange(4, dtype=np.uint8)[None, None, :]).sum(2).astype(np.uint8)
 
 
 def _relu_mask(relu, out, out_ld, y, y_ld, scale, shift, pixels, Cc):
     if relu == 1:
         return _rows(out, pixels, Cc, out_ld) > 0
+    if relu == 3:                      # the byte mask msc_bn_apply wrote
+        return _mask_unpack(out, pixels, Cc, out_ld)
     return _rows(y, pixels, Cc, y_ld) * _arr(scale, Cc) + _arr(shift, Cc) > 0      # relu == 2: recomputed pre-activation
 
 

@@ -728,13 +728,19 @@ def test_batchnorm_training_forward_and_backward_with_prologue_finalize(dtype, c
     g_d, b_d = gamma.cuda(), beta.cuda()
     rm, rv = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
     scale, shift, mean, invstd = (torch.empty(c, device='cuda') for _ in range(4))
+    # residual joins: msc_bn_apply also leaves the ReLU mask as bytes (ABI v7), which the backward reads instead of `out` (relu mode 3)
+    use_mask, ce = bool(relu and with_res), 16 // yd.element_size()
+    maskd = torch.zeros((n, hw, hw, c // ce), dtype=torch.uint8, device='cuda')
     _lib.check(lib.msc_bn_apply(yd.data_ptr(), c, resd.data_ptr() if with_res else None, c if with_res else 0, outd.data_ptr(), c, slots.data_ptr(),
                                 pixels, g_d.data_ptr(), b_d.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                mean.data_ptr(), invstd.data_ptr(), int(relu), dt, pixels, c, st), 'msc_bn_apply')
+                                mean.data_ptr(), invstd.data_ptr(), maskd.data_ptr() if use_mask else None, c // ce if use_mask else 0, int(relu), dt, pixels, c, st), 'msc_bn_apply')
     assert torch.allclose(to_nchw(outd), o.detach(), **tol(dtype))
     assert torch.allclose(rm.cpu(), bn.running_mean, atol=1e-5) and torch.allclose(rv.cpu(), bn.running_var, rtol=1e-5, atol=1e-6)
     # backward: reduce -> apply; mask from `out` (relu 1) with a residual, recomputed from y (relu 2) without
     mask = 0 if not relu else (1 if with_res else 2)
+    if use_mask:
+        bits = (outd.float().view(n, hw, hw, c // ce, ce) > 0).to(torch.int32) << torch.arange(ce, device='cuda', dtype=torch.int32)
+        assert torch.equal(maskd.to(torch.int32), bits.sum(-1))
     doutd = nhwc(dout, dtype)
     bslots = torch.zeros((_lib.BN_SLOTS, c, 2), dtype=torch.float64, device='cuda')
     _lib.check(lib.msc_bn_bwd_reduce(doutd.data_ptr(), c, outd.data_ptr(), c, yd.data_ptr(), c, mask, scale.data_ptr(), shift.data_ptr(), bslots.data_ptr(),
@@ -745,7 +751,8 @@ def test_batchnorm_training_forward_and_backward_with_prologue_finalize(dtype, c
     # with a residual: also the BatchNorm-backward sums of the layer that produced it (res_y / res_slots), against a tensor ry
     ry = rnd((n, c, hw, hw), dtype, 9)
     ryd, rslots = nhwc(ry, dtype), torch.zeros((_lib.BN_SLOTS, c, 2), dtype=torch.float64, device='cuda')
-    _lib.check(lib.msc_bn_bwd_apply(doutd.data_ptr(), c, outd.data_ptr(), c, yd.data_ptr(), c, mask, scale.data_ptr(), shift.data_ptr(), bslots.data_ptr(),
+    _lib.check(lib.msc_bn_bwd_apply(doutd.data_ptr(), c, maskd.data_ptr() if use_mask else outd.data_ptr(), c // ce if use_mask else c, yd.data_ptr(), c,
+                                    3 if use_mask else mask, scale.data_ptr(), shift.data_ptr(), bslots.data_ptr(),
                                     pixels, g_d.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dyd.data_ptr(), c,
                                     dresd.data_ptr() if with_res else None, c if with_res else 0, 0, ryd.data_ptr() if with_res else None, c if with_res else 0,
                                     rslots.data_ptr() if with_res else None, dt, pixels, c, st), 'msc_bn_bwd_apply')
@@ -1196,11 +1203,13 @@ def test_stem_halo_kernel(dtype, n, hw):
 
 
 @pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('bits', [False, True])
 @pytest.mark.parametrize('cin,cout,k,hw,n,with_res', [(256, 1024, 1, 16, 4, True), (64, 64, 3, 20, 2, True), (128, 64, 1, 16, 3, False), (64, 256, 1, 32, 2, True)])
-def test_conv_epilogue_batchnorm_backward_sums_of_a_residual_join(dtype, cin, cout, k, hw, n, with_res):
+def test_conv_epilogue_batchnorm_backward_sums_of_a_residual_join(dtype, cin, cout, k, hw, n, with_res, bits):
     """stats_kind 1 with stats_z (ABI v6): the data-gradient conv that accumulates the last addend of a residual join's gradient stores
     out = acc + res and reduces (sum dh, sum dh*y), dh = out * [z > 0] with z the block's (post-add, post-ReLU) output -- what
-    msc_bn_bwd_reduce (mask mode 1) would compute from the stored tensors; in place (res == out), every valid configuration"""
+    msc_bn_bwd_reduce (mask mode 1) would compute from the stored tensors; in place (res == out), every valid configuration.
+    bits (ABI v7): stats_z is the byte mask msc_bn_apply leaves (one byte per 16-byte channel vector) instead of the activation"""
     import ctypes as C
     from mapping_challenge_amd import _lib
     import hip_ops as ops
@@ -1225,6 +1234,10 @@ def test_conv_epilogue_batchnorm_backward_sums_of_a_residual_join(dtype, cin, co
         d.in_ld, d.out_ld, d.dtype, d.mode = cin, cout, ops._dt(xd), 0
         d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.cfg = n, hw, hw, cin, hw, hw, cout, k, k, 1, pad, c
         d.stats_kind, d.stats_y, d.stats_y_ld, d.stats_z, d.stats_z_ld = 1, yd.data_ptr(), cout, zd.data_ptr(), cout
+        if bits:
+            ce = 16 // zd.element_size()
+            zb = ((zd.float().view(n, hw, hw, cout // ce, ce) > 0).to(torch.int32) << torch.arange(ce, device='cuda', dtype=torch.int32)).sum(-1).to(torch.uint8)
+            d.stats_z, d.stats_z_ld, d.stats_z_bits = zb.data_ptr(), cout // ce, 1
         stats = torch.zeros((_lib.BN_SLOTS, cout, 2), dtype=torch.float64, device='cuda')
         d.stats = stats.data_ptr()
         if c and not lib.msc_conv_cfg_ok(C.byref(d), c):
