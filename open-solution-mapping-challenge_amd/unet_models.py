@@ -1287,11 +1287,11 @@ class _Builder:
         fin = net.final
         dd = self.conv_desc(x, net._pack['w']['dec0.conv'], d0, KH=3, KW=3, stride=1, pad=1, relu=1, shift=net.dec0.conv.bias)
         fused_final = False
-        fuse_train = self.training and _os_env.environ.get('MSC_FUSE_FINAL_TRAIN', '1') != '0'
+        fuse_train = self.training and _os_env.environ.get('MSC_FUSE_FINAL_TRAIN', '0') == '1'      # measured neutral (10.64 / 10.71 vs 10.65 / 10.68 ms): opt-in
         if (not self.training or fuse_train) and self.dev.type == 'cuda' and nf == 32 and _os_env.environ.get('MSC_FUSE_FINAL', '1') != '0':
             # eval: dec0's 3x3 conv + ReLU, the final 1x1 conv and the channel softmax in ONE launch (src/unet_models.py:401-403 +
-            # src/models.py:88-92): dec0's 134 MB output is neither written nor read back.  Training (round 4): the same launch with the
-            # output STORED (the backward needs it) and logits only -- the separate final 1x1 pass does not re-read the 134 MB
+            # src/models.py:88-92): dec0's 134 MB output is neither written nor read back.  Training (round 4, MSC_FUSE_FINAL_TRAIN=1): the same
+            # launch with the output STORED (the backward needs it) and logits only -- the separate final 1x1 pass does not re-read the 134 MB
             dd.final_w, dd.final_b = fin.weight.data_ptr(), fin.bias.data_ptr()
             dd.final_logits, dd.final_probs, dd.final_skip_store = P.logits.data_ptr(), (None if self.training else P.probs.data_ptr()), (0 if self.training else 1)
             if lib.msc_conv_cfg_ok(C.byref(dd), _lib.CFG_HALO):
