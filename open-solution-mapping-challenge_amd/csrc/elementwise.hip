@@ -1078,11 +1078,14 @@ extern "C" int msc_bn_fold(const float* gamma, const float* beta, const float* r
 
 namespace {
 static int bn_xcd_order() { static const int v = [] { const char* e = getenv("MSC_BN_XCD"); return e ? atoi(e) : 1; }(); return v; }
-// grid of the channel-tiled BatchNorm kernels: CT channels x `ppb` pixels per block, about 2048 blocks in all
+// grid of the channel-tiled BatchNorm kernels: CT channels x `ppb` pixels per block, about 1024 blocks in all (four per CU).  With the
+// round-robin block order of rounds 1-3 the count did not matter (512 ... 4096: +-0); with the XCD-aware order fewer, longer blocks are
+// ahead -- 256: 11.60, 512: 10.93, 768: 10.76, 1024: 10.62-10.68, 2048: 10.70-10.77, 4096 / 8192: 10.81 ms per ResNet101 train step
+// (profiles/r4_run25_bn_blocks_ab.txt)
 template <int R>
 long bn_ppb(long pixels, int ctiles) {
     static int target = -1;      // MSC_BN_BLOCKS: blocks per launch aimed at (A/B measurements)
-    if (target < 0) { const char* e = getenv("MSC_BN_BLOCKS"); target = e ? atoi(e) : 2048; if (target < 64) target = 64; }
+    if (target < 0) { const char* e = getenv("MSC_BN_BLOCKS"); target = e ? atoi(e) : 1024; if (target < 64) target = 64; }
     long ppb = ceil_div(pixels * ctiles, target);
     ppb = (ppb + R - 1) / R * R;
     return ppb < R ? R : ppb;
