@@ -122,9 +122,15 @@ int msc_conv_wgrad_num_cfgs(void);
  * steps_per_block > 0: every block runs about that many k-steps (32 bf16 / 16 f32 pixels each) and tiles are capped
  * at tile_cap (128/64/32) -- the policy for grouped launches; steps_per_block == 0: each descriptor's own cfg.
  * The descriptors are copied to the device at creation; the group stays valid until destroyed and may be run any
- * number of times (also inside a hipGraph capture). */
+ * number of times (also inside a hipGraph capture).
+ * flags (ABI v8): MSC_WGRAD_ORDERED -- the blocks that share a gradient tile (one per range of pixels) store their partial tile into a
+ * plane of their own (device memory owned by the group: sum over layers of splits * sizeof(dw)) and one more launch adds the planes
+ * in pixel-range order, instead of fp32 atomics in the order the blocks happen to finish: the gradients, and with msc_final_bwd's
+ * ordered_ws a whole training step, are reproducible bit for bit (torch.use_deterministic_algorithms' role for the cuDNN backward the
+ * reference runs, src/steps/pytorch/models.py:110).  One descriptor per gradient buffer. */
+enum { MSC_WGRAD_ORDERED = 1 };
 typedef struct msc_wgrad_group msc_wgrad_group;
-int msc_wgrad_group_create(const msc_wgrad_desc* descs, int n, int steps_per_block, int tile_cap, msc_wgrad_group** out);
+int msc_wgrad_group_create(const msc_wgrad_desc* descs, int n, int steps_per_block, int tile_cap, int flags, msc_wgrad_group** out);
 int msc_wgrad_group_run(const msc_wgrad_group* g, void* stream);
 int msc_wgrad_group_launches(const msc_wgrad_group* g);
 void msc_wgrad_group_destroy(msc_wgrad_group* g);
@@ -270,9 +276,12 @@ int msc_final_fwd(const void* in, int64_t in_ld, const float* w, const float* b,
 /* backward: dlogits f32 NCHW -> din[p][c] = sum_k dlogits[k][p]*w[k][c] (masked by in>0: the ReLU of dec0),
  * dw[k][c] += sum_p dlogits[k][p]*in[p][c], db[k] += sum_p dlogits[k][p];
  * dbias_in (f32[C], may be NULL): dbias_in[c] += sum_p din[p][c] -- the bias gradient of the layer that produced `in`
- * (dec0's conv bias), so no separate msc_bias_grad pass reads din back.  C*sizeof(dtype) must be a multiple of 16, C <= 64. */
+ * (dec0's conv bias), so no separate msc_bias_grad pass reads din back.  C*sizeof(dtype) must be a multiple of 16, C <= 64.
+ * ordered_ws (ABI v8, may be NULL: fp32 atomics, the order of the additions varies from run to run): MSC_FINAL_BWD_WS_ROWS * (3*C + 2)
+ * floats of scratch.  The per-block sums go there and a second launch adds them in block order: bit-for-bit reproducible. */
+#define MSC_FINAL_BWD_WS_ROWS 1024
 int msc_final_bwd(const float* dlogits, const void* in, int64_t in_ld, const float* w, void* din, int64_t din_ld,
-                  float* dw, float* db, float* dbias_in, int dtype, int N, int H, int W, int C, void* stream);
+                  float* dw, float* db, float* dbias_in, float* ordered_ws, int dtype, int N, int H, int W, int C, void* stream);
 
 /* ---------------------------------------------------------------- losses / optimizer ----------
  * mixed distance-weighted cross entropy + soft Dice (src/models.py:310-454, validation.py:8-16) or plain CE

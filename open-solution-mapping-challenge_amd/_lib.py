@@ -60,6 +60,8 @@ BIAS_SLOTS_MAX = 16
 # optimizer state in device memory (include/msc.h, ABI v7): f32[OPT_STATE]
 OPT_STEP, OPT_LR, OPT_OVERFLOW, OPT_SKIP, OPT_SCALE, OPT_GOOD, OPT_GROWTH, OPT_SKIPPED, OPT_UNSCALE = range(9)
 OPT_STATE = 12
+WGRAD_ORDERED = 1            # msc_wgrad_group_create flags
+FINAL_BWD_WS_ROWS = 1024     # msc_final_bwd ordered_ws rows
 
 
 class LossCfg(C.Structure):
@@ -80,7 +82,7 @@ SIGNATURES = {
     'msc_conv_cfg_ok': (_i, [C.POINTER(ConvDesc), _i]),
     'msc_conv_wgrad': (_i, [C.POINTER(WgradDesc), _vp]),
     'msc_conv_wgrad_num_cfgs': (_i, []),
-    'msc_wgrad_group_create': (_i, [C.POINTER(WgradDesc), _i, _i, _i, C.POINTER(_vp)]),
+    'msc_wgrad_group_create': (_i, [C.POINTER(WgradDesc), _i, _i, _i, _i, C.POINTER(_vp)]),
     'msc_wgrad_group_run': (_i, [_vp, _vp]),
     'msc_wgrad_group_launches': (_i, [_vp]),
     'msc_wgrad_group_destroy': (None, [_vp]),
@@ -115,7 +117,7 @@ SIGNATURES = {
     'msc_final_fwd': (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'msc_bias_slots_finalize': (_i, [_vp, _i, _vp, _i, _vp]),
     'msc_bias_slots_finalize_multi': (_i, [C.POINTER(BiasSlotsItem), _i, _vp]),
-    'msc_final_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'msc_final_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'msc_loss_sums': (_i, [_vp, _vp, _i, C.POINTER(LossCfg), _vp, _i, _i, _i, _vp]),
     'msc_loss_grad': (_i, [_vp, _vp, _i, C.POINTER(LossCfg), _vp, _d, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'msc_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),

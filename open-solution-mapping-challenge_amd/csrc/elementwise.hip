@@ -624,15 +624,17 @@ __global__ void final_fwd_kernel(const T* __restrict__ in, long in_ld, const flo
 // pixel rows (coalesced), din needs no cross-lane traffic, and the per-channel sums (dw, the producer's bias gradient) stay in
 // registers until the end of the block -- one lane per pixel with a wave reduction per element and iteration kept the VALU
 // busier than the memory pipe (0.19 ms for 285 MB).  UNR pixels per lane are in flight together.
-template <typename T, int VC>
+// ORD (ordered_ws of msc_final_bwd): the four waves' sums are added in wave order and the block's 3 C + 2 sums go to row blockIdx.x of
+// `ws` instead of the gradients; final_bwd_finish_kernel adds the rows in block order.
+template <typename T, int VC, bool ORD>
 __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict__ dlogits, const T* __restrict__ in, long in_ld,
                                                         const float* __restrict__ w, T* __restrict__ din, long din_ld,
                                                         float* __restrict__ dw, float* __restrict__ db, float* __restrict__ dbin,
-                                                        int N, long HW) {
-    constexpr int CE = Vec16<T>::N, C = VC * CE, PPB = 256 / VC, UNR = 4;
-    __shared__ float acc[3 * C + 2];                 // dw[2][C], dbias_in[C], db[2]
+                                                        float* __restrict__ ws, int N, long HW) {
+    constexpr int CE = Vec16<T>::N, C = VC * CE, PPB = 256 / VC, UNR = 4, NS = 3 * C + 2;
+    __shared__ float acc[(ORD ? 4 : 1) * NS];        // dw[2][C], dbias_in[C], db[2] (ORD: per wave)
     const int tid = threadIdx.x, chunk = tid % VC, sub = tid / VC;
-    for (int i = tid; i < 3 * C + 2; i += 256) acc[i] = 0.f;
+    for (int i = tid; i < (ORD ? 4 : 1) * NS; i += 256) acc[i] = 0.f;
     float w0[CE], w1[CE], a0[CE], a1[CE], ab[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) { w0[e] = w[chunk * CE + e]; w1[e] = w[C + chunk * CE + e]; a0[e] = 0.f; a1[e] = 0.f; ab[e] = 0.f; }
@@ -690,6 +692,21 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
 #pragma unroll
     for (int o = VC; o < 64; o <<= 1) { g0s += __shfl_xor(g0s, o, 64); g1s += __shfl_xor(g1s, o, 64); }
     __syncthreads();
+    if constexpr (ORD) {
+        if ((tid & 63) < VC) {      // lane `chunk` of every wave holds that wave's sums of its channels
+            float* wa = acc + (tid >> 6) * NS;
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                wa[chunk * CE + e] = a0[e];
+                wa[C + chunk * CE + e] = a1[e];
+                wa[2 * C + chunk * CE + e] = ab[e];
+            }
+            if (chunk == 0) { wa[3 * C] = g0s; wa[3 * C + 1] = g1s; }
+        }
+        __syncthreads();
+        for (int i = tid; i < NS; i += 256) ws[(long)blockIdx.x * NS + i] = ((acc[i] + acc[NS + i]) + acc[2 * NS + i]) + acc[3 * NS + i];
+        return;
+    }
     if ((tid & 63) < VC) {
 #pragma unroll
         for (int e = 0; e < CE; ++e) {
@@ -703,6 +720,24 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
     for (int i = tid; i < 2 * C; i += 256) atomicAdd(dw + i, acc[i]);
     if (dbin) for (int i = tid; i < C; i += 256) atomicAdd(dbin + i, acc[2 * C + i]);
     if (tid < 2 && db) atomicAdd(db + tid, acc[3 * C + tid]);
+}
+
+// one block: element i of the gradients += row 0 + row 1 + ... of the per-block sums (eight partial sums per element, combined in a
+// fixed tree, so that the 1024 rows are not one dependent chain)
+__global__ __launch_bounds__(256) void final_bwd_finish_kernel(const float* __restrict__ ws, int rows, int C, float* __restrict__ dw,
+                                                               float* __restrict__ db, float* __restrict__ dbin) {
+    const int NS = 3 * C + 2;
+    for (int i = threadIdx.x; i < NS; i += 256) {
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < rows; r += 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (r + j < rows) s[j] += ws[(long)(r + j) * NS + i];
+        const float t = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+        if (i < 2 * C) dw[i] += t;
+        else if (i < 3 * C) { if (dbin) dbin[i - 2 * C] += t; }
+        else if (db) db[i - 3 * C] += t;
+    }
 }
 
 // ------------------------------------------------------------------ Adam (+L2), torch.optim.Adam semantics
@@ -1245,12 +1280,14 @@ extern "C" int msc_final_fwd(const void* in, int64_t in_ld, const float* w, cons
 
 template <typename T>
 static int final_bwd_launch(const float* dlogits, const void* in, long in_ld, const float* w, void* din, long din_ld, float* dw,
-                            float* db, float* dbin, int N, long hw, int C, hipStream_t st) {
+                            float* db, float* dbin, float* ws, int N, long hw, int C, hipStream_t st) {
     constexpr int CE = Vec16<T>::N;
     const int vc = C / CE;
     long blocks = ceil_div((long)N * hw, (256 / vc) * 4);
-    if (blocks > 1024) blocks = 1024;
-#define MSC_FB(VC) hipLaunchKernelGGL((final_bwd_kernel<T, VC>), dim3((int)blocks), dim3(256), 0, st, dlogits, (const T*)in, in_ld, w, (T*)din, din_ld, dw, db, dbin, N, hw)
+    if (blocks > MSC_FINAL_BWD_WS_ROWS) blocks = MSC_FINAL_BWD_WS_ROWS;
+#define MSC_FB(VC) \
+    if (ws) hipLaunchKernelGGL((final_bwd_kernel<T, VC, true>), dim3((int)blocks), dim3(256), 0, st, dlogits, (const T*)in, in_ld, w, (T*)din, din_ld, dw, db, dbin, ws, N, hw); \
+    else hipLaunchKernelGGL((final_bwd_kernel<T, VC, false>), dim3((int)blocks), dim3(256), 0, st, dlogits, (const T*)in, in_ld, w, (T*)din, din_ld, dw, db, dbin, ws, N, hw)
     switch (vc) {
         case 1: MSC_FB(1); break;
         case 2: MSC_FB(2); break;
@@ -1260,19 +1297,20 @@ static int final_bwd_launch(const float* dlogits, const void* in, long in_ld, co
         default: return msc_fail(MSC_ERR_UNSUPPORTED, "msc_final_bwd: C=%d (supported: C*sizeof(dtype)/16 a power of two up to 16)", C);
     }
 #undef MSC_FB
+    if (ws) hipLaunchKernelGGL(final_bwd_finish_kernel, dim3(1), dim3(256), 0, st, ws, (int)blocks, C, dw, db, dbin);
     return msc_check_launch("msc_final_bwd");
 }
 
 extern "C" int msc_final_bwd(const float* dlogits, const void* in, int64_t in_ld, const float* w, void* din, int64_t din_ld,
-                             float* dw, float* db, float* dbias_in, int dtype, int N, int H, int W, int C, void* stream) {
+                             float* dw, float* db, float* dbias_in, float* ordered_ws, int dtype, int N, int H, int W, int C, void* stream) {
     DT_CHECK("msc_final_bwd", dtype);
     VEC_CHECK("msc_final_bwd", dtype, C);
     if (!dlogits || !in || !w || !din || !dw) return msc_fail(MSC_ERR_ARG, "msc_final_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const long hw = (long)H * W;
-    if (dtype == MSC_F16) return final_bwd_launch<f16_t>(dlogits, in, in_ld, w, din, din_ld, dw, db, dbias_in, N, hw, C, st);
-    if (dtype == MSC_BF16) return final_bwd_launch<bf16_t>(dlogits, in, in_ld, w, din, din_ld, dw, db, dbias_in, N, hw, C, st);
-    return final_bwd_launch<float>(dlogits, in, in_ld, w, din, din_ld, dw, db, dbias_in, N, hw, C, st);
+    if (dtype == MSC_F16) return final_bwd_launch<f16_t>(dlogits, in, in_ld, w, din, din_ld, dw, db, dbias_in, ordered_ws, N, hw, C, st);
+    if (dtype == MSC_BF16) return final_bwd_launch<bf16_t>(dlogits, in, in_ld, w, din, din_ld, dw, db, dbias_in, ordered_ws, N, hw, C, st);
+    return final_bwd_launch<float>(dlogits, in, in_ld, w, din, din_ld, dw, db, dbias_in, ordered_ws, N, hw, C, st);
 }
 
 extern "C" int msc_adam_tick(float* state, void* stream) {

@@ -38,7 +38,19 @@ struct WgK {
     int kw3, sw;                     // kw3: taps of a kernel row a block covers (wgrad3_dma_body; ntaps = KH): 0 one, 3 (3x3 / stride 1), 4 (4x4 / stride 2: ConvTranspose2d); sw = min(Wp, 32)
     int span_bytes;                  // > 0: a Q row of B*ES bytes spans several consecutive pixels of span_bytes each (KW taps merged, wgrad_plan)
     int no_direct;                   // 1: keep the general pixel decode also for 1x1 / stride 1 (A/B measurements, MSC_WGRAD_DIRECT=0)
+    int pad_;
+    float* part;                     // MSC_WGRAD_ORDERED groups: split s of this problem stores its tile into plane s (part + s * plane) instead of
+    long plane;                      //   adding into dw atomically; wgrad_finish_kernel sums the planes in split order.  nullptr: atomics, or
+                                     //   (plane < 0: an ordered layer that is not split -- every element has ONE writer) a plain dw += v
 };
+static_assert(sizeof(WgK) % 8 == 0, "WgK is copied in dwords and holds pointers");
+
+// one accumulator out of a block: an fp32 atomic onto the gradient, or (ordered groups) a plain store into the split's plane
+__device__ __forceinline__ void wgrad_emit(const WgK& p, int split, long idx, float v) {
+    if (p.part) p.part[(long)split * p.plane + idx] = v;
+    else if (p.plane < 0) p.dw[idx] += v;
+    else atomicAdd(p.dw + idx, v);
+}
 
 // Blocks that share a pixel range (one split) share P/Q: give each XCD (block b runs on XCD b % 8) a contiguous
 // run of the split-major order so that range stays in one L2 instead of all eight.
@@ -311,7 +323,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgK& p, const int orig, con
                 for (int b = 0; b < FN; ++b) {
                     const int ib = b0 + wb * WTB + b * 16 + pl;
                     if (ABL & 32) asm volatile("" ::"v"(acc[a][b][r]));
-                    else if (ia < p.A && ib < p.B) atomicAdd(p.dw + (ia * taps + tap) * p.B + ib, acc[a][b][r]);
+                    else if (ia < p.A && ib < p.B) wgrad_emit(p, split, (ia * taps + tap) * p.B + ib, acc[a][b][r]);
                 }
             }
     }
@@ -518,7 +530,7 @@ __device__ __forceinline__ void wgrad3_dma_body(const WgK& p, const int orig, co
 #pragma unroll
                     for (int b = 0; b < FN; ++b) {
                         const int ib = b0 + wb * WTB + b * 16 + pl;
-                        if (ia < p.A && ib < p.B) atomicAdd(p.dw + (ia * (long)(p.KH * NT) + kh * NT + kw) * p.B + ib, acc[kw][a][b][r]);
+                        if (ia < p.A && ib < p.B) wgrad_emit(p, split, (ia * (long)(p.KH * NT) + kh * NT + kw) * p.B + ib, acc[kw][a][b][r]);
                     }
                 }
     }
@@ -569,6 +581,31 @@ __global__ __launch_bounds__(NWV * 64) void conv_wgrad3_group_kernel(const WgK* 
     }
 }
 
+// Ordered groups: dw += plane 0 + plane 1 + ... in that order, one thread per four consecutive gradient elements.  `items` lists the
+// layers, `blk` (item, first element) per workgroup of 1024 elements.  The sum no longer depends on which block finished first:
+// with it (and msc_final_bwd's ordered workspace) a training step is reproducible bit for bit.
+struct WgFin { float* dw; const float* part; long plane; int splits, pad_; };
+
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const WgFin* __restrict__ items, const int2* __restrict__ blk) {
+    const int2 e = blk[blockIdx.x];
+    const WgFin it = items[e.x];
+    const long i = (long)e.y * 1024 + threadIdx.x * 4;
+    if (i >= it.plane) return;
+    float4 s = *reinterpret_cast<const float4*>(it.part + i);
+    for (int k = 1; k < it.splits; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(it.part + (long)k * it.plane + i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float* d = it.dw + i;
+    if (((uintptr_t)it.dw & 15) == 0) {
+        float4 o = *reinterpret_cast<const float4*>(d);
+        o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+        *reinterpret_cast<float4*>(d) = o;
+    } else {      // a gradient range that does not start on 16 bytes
+        d[0] += s.x; d[1] += s.y; d[2] += s.z; d[3] += s.w;
+    }
+}
+
 }  // namespace
 
 extern "C" int msc_conv_wgrad_num_cfgs(void) { return WGRAD_NCFG; }
@@ -607,6 +644,7 @@ int wgrad_plan(const msc_wgrad_desc* d, int steps_per_block, int tile_cap, WgPla
     k.span_bytes = span_bytes;
     static const bool direct_off = [] { const char* e = getenv("MSC_WGRAD_DIRECT"); return e && e[0] == '0'; }();
     k.no_direct = direct_off ? 1 : 0;
+    k.pad_ = 0; k.part = nullptr; k.plane = 0;
     k.p = (const char*)d->p; k.q = (const char*)d->q; k.dw = d->dw; k.p_ld = d->p_ld; k.q_ld = d->q_ld;
     k.N = d->N; k.Hp = d->Hp; k.Wp = d->Wp; k.A = d->A; k.Hq = d->Hq; k.Wq = d->Wq; k.B = d->B;
     k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad;
@@ -790,6 +828,11 @@ struct msc_wgrad_group {
     struct Bucket { int dtype, ta, tb, n, blocks; WgK* tab; int2* blk; int kw3; };
     std::vector<Bucket> buckets;      // problems by (dtype, tile): one launch each
     void* dev = nullptr;              // one allocation behind every table
+    // MSC_WGRAD_ORDERED: the split planes, and the finish launch that sums them into the gradients
+    void* planes = nullptr;
+    const void* fin_items = nullptr;
+    const int2* fin_blk = nullptr;
+    int fin_blocks = 0;
 };
 
 namespace {
@@ -822,23 +865,62 @@ void wgrad_place(const std::vector<WgPlan>& plans, const std::vector<int>& membe
 
 }  // namespace
 
-extern "C" int msc_wgrad_group_create(const msc_wgrad_desc* descs, int n, int steps_per_block, int tile_cap, msc_wgrad_group** out) {
+extern "C" int msc_wgrad_group_create(const msc_wgrad_desc* descs, int n, int steps_per_block, int tile_cap, int flags, msc_wgrad_group** out) {
     if (!descs || n <= 0 || !out) return msc_fail(MSC_ERR_ARG, "msc_wgrad_group_create: bad argument");
+    if (flags & ~MSC_WGRAD_ORDERED) return msc_fail(MSC_ERR_ARG, "msc_wgrad_group_create: flags 0x%x", flags);
+    const bool ordered = (flags & MSC_WGRAD_ORDERED) != 0;
     std::vector<WgPlan> plans;
     plans.reserve(n);
+    std::vector<WgFin> fin;            // ordered: one entry per layer ...
+    std::vector<long> fin_at, plan_at; // ... and where its planes / the planes of every image range start (floats into the allocation made below)
+    long plane_floats = 0;
     for (int i = 0; i < n; ++i) {      // a layer beyond the 31-bit offsets enters the table as several image ranges
         const int chunk = wgrad_image_chunk(&descs[i]);
+        if (ordered) {
+            for (int j = 0; j < i; ++j)
+                if (descs[j].dw == descs[i].dw) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_wgrad_group_create: ordered sums need one descriptor per gradient (%d and %d share one)", j, i);
+            fin.push_back(WgFin{descs[i].dw, nullptr, (long)descs[i].A * descs[i].KH * descs[i].KW * descs[i].B, 0, 0});
+        }
         for (int n0 = 0; n0 < (descs[i].N > 0 ? descs[i].N : 1); n0 += chunk) {
             const msc_wgrad_desc part = wgrad_image_range(&descs[i], n0, descs[i].N - n0 < chunk ? descs[i].N - n0 : chunk);
             WgPlan pl;
             int rc = wgrad_plan(&part, steps_per_block, tile_cap > 0 ? tile_cap : 128, &pl);
             if (rc != MSC_OK) return rc;
             pl.k.xcd_order = 0;        // the block table below carries the placement: a block's index within its problem is used as it is
+            if (ordered) {             // the image ranges of a layer continue its run of planes
+                WgFin& f = fin.back();
+                pl.k.plane = f.plane;
+                plan_at.push_back(plane_floats + (long)f.splits * f.plane);
+                f.splits += pl.k.nblocks / (pl.k.ntiles * pl.k.ntaps);
+            }
             plans.push_back(pl);
+        }
+        if (ordered) {
+            if (fin.back().splits == 1) {      // one block per gradient tile: it adds to dw itself, no plane
+                fin.pop_back();
+                plan_at.back() = -1;
+            } else {
+                fin_at.push_back(plane_floats);
+                plane_floats += (long)fin.back().splits * fin.back().plane;
+            }
         }
     }
     n = (int)plans.size();
     msc_wgrad_group* g = new msc_wgrad_group;
+    if (ordered) {
+        // every split writes its whole plane on every run; the memset only covers a split the plan could leave without pixels
+        const size_t pb = (size_t)(plane_floats > 0 ? plane_floats : 1) * sizeof(float);
+        if (hipMalloc(&g->planes, pb) != hipSuccess || hipMemset(g->planes, 0, pb) != hipSuccess) {
+            if (g->planes) (void)hipFree(g->planes);
+            delete g;
+            return msc_fail(MSC_ERR_HIP, "msc_wgrad_group_create: %ld bytes of split planes", plane_floats * (long)sizeof(float));
+        }
+        for (size_t i = 0; i < plans.size(); ++i) {
+            if (plan_at[i] < 0) plans[i].k.plane = -1;
+            else plans[i].k.part = (float*)g->planes + plan_at[i];
+        }
+        for (size_t i = 0; i < fin.size(); ++i) fin[i].part = (const float*)g->planes + fin_at[i];
+    }
     // the longest-running blocks first: the launch ends when its slowest block does
     std::stable_sort(plans.begin(), plans.end(), [](const WgPlan& a, const WgPlan& b) { return a.k.mchunk > b.k.mchunk; });
     std::vector<std::vector<int>> members;
@@ -856,9 +938,26 @@ extern "C" int msc_wgrad_group_create(const msc_wgrad_desc* descs, int n, int st
         wgrad_place(plans, members[b], tables[b]);
         bytes += ((members[b].size() * sizeof(WgK) + 255) & ~(size_t)255) + ((tables[b].size() * sizeof(int2) + 255) & ~(size_t)255);
     }
+    std::vector<int2> fin_blk;
+    for (size_t i = 0; i < fin.size(); ++i)
+        for (long e = 0; e < fin[i].plane; e += 1024) fin_blk.push_back(make_int2((int)i, (int)(e / 1024)));
+    const size_t fin_off = bytes;
+    bytes += ((fin.size() * sizeof(WgFin) + 255) & ~(size_t)255) + ((fin_blk.size() * sizeof(int2) + 255) & ~(size_t)255);
     if (bytes) {
-        if (hipMalloc(&g->dev, bytes) != hipSuccess) { delete g; return msc_fail(MSC_ERR_HIP, "msc_wgrad_group_create: hipMalloc(%zu)", bytes); }
+        if (hipMalloc(&g->dev, bytes) != hipSuccess) {
+            if (g->planes) (void)hipFree(g->planes);
+            delete g;
+            return msc_fail(MSC_ERR_HIP, "msc_wgrad_group_create: hipMalloc(%zu)", bytes);
+        }
         std::vector<char> host(bytes, 0);
+        if (!fin.empty()) {
+            memcpy(host.data() + fin_off, fin.data(), fin.size() * sizeof(WgFin));
+            const size_t boff = fin_off + ((fin.size() * sizeof(WgFin) + 255) & ~(size_t)255);
+            memcpy(host.data() + boff, fin_blk.data(), fin_blk.size() * sizeof(int2));
+            g->fin_items = (const char*)g->dev + fin_off;
+            g->fin_blk = reinterpret_cast<const int2*>((const char*)g->dev + boff);
+            g->fin_blocks = (int)fin_blk.size();
+        }
         size_t off = 0;
         for (size_t b = 0; b < g->buckets.size(); ++b) {
             auto& bk = g->buckets[b];
@@ -873,7 +972,9 @@ extern "C" int msc_wgrad_group_create(const msc_wgrad_desc* descs, int n, int st
             bk.blocks = (int)tables[b].size();
         }
         if (hipMemcpy(g->dev, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
-            (void)hipFree(g->dev); delete g;
+            (void)hipFree(g->dev);
+            if (g->planes) (void)hipFree(g->planes);
+            delete g;
             return msc_fail(MSC_ERR_HIP, "msc_wgrad_group_create: hipMemcpy");
         }
     }
@@ -886,15 +987,18 @@ extern "C" int msc_wgrad_group_run(const msc_wgrad_group* g, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     for (const auto& bk : g->buckets)
         if (bk.blocks > 0) wgrad_tile_dispatch(bk.dtype, bk.ta, bk.tb, WgLaunchGroup{bk.tab, bk.blk, bk.blocks, st, bk.kw3});
+    if (g->fin_blocks > 0)
+        hipLaunchKernelGGL(wgrad_finish_kernel, dim3(g->fin_blocks), dim3(256), 0, st, reinterpret_cast<const WgFin*>(g->fin_items), g->fin_blk);
     return msc_check_launch("wgrad_group");
 }
 
 extern "C" int msc_wgrad_group_launches(const msc_wgrad_group* g) {
-    return g ? (int)g->buckets.size() : -1;
+    return g ? (int)g->buckets.size() + (g->fin_blocks > 0 ? 1 : 0) : -1;
 }
 
 extern "C" void msc_wgrad_group_destroy(msc_wgrad_group* g) {
     if (!g) return;
     if (g->dev) (void)hipFree(g->dev);
+    if (g->planes) (void)hipFree(g->planes);
     delete g;
 }

@@ -91,6 +91,8 @@ class BasePyTorchUNet(BaseTransformer):
         self.callbacks_config = callbacks_config or {}
         self.validation_loss = {}
         self.set_model()
+        if (training_config or {}).get('deterministic') is not None:      # fixed-order gradient sums (UNetResNet.deterministic); default: MSC_DETERMINISTIC
+            self.model.deterministic = bool(training_config['deterministic'])
         opt = dict(architecture_config.get('optimizer_params', {}))
         reg = architecture_config.get('regularizer_params', {})
         wd = reg.get('weight_decay_conv2d', 0.0) if reg.get('regularize', False) else 0.0   # src/models.py:287-292

@@ -227,11 +227,15 @@ class UNetResNet(nn.Module):
     0.0, the only values any shipped configuration uses (src/models.py:32-46).
     Extra keyword: compute_dtype 'bf16' (throughput mode, default), 'fp16' (BASELINE.json configs[4]; training in it needs
     the static loss scale TrainStep applies, inference does not) or 'fp32' (exact-f32 parity mode).
+    deterministic (or MSC_DETERMINISTIC=1; read when a training program is built): the weight gradients' partial sums are added in a
+    fixed order instead of by fp32 atomics (msc_wgrad_group_create MSC_WGRAD_ORDERED, msc_final_bwd ordered_ws) -- two runs of the same
+    steps from the same state give the same bits, at the price of one more pass over the split planes per step.
     """
 
     def __init__(self, encoder_depth, num_classes, num_filters=32, dropout_2d=0.2, pretrained=False,
-                 is_deconv=False, compute_dtype='bf16', autotune=None):
+                 is_deconv=False, compute_dtype='bf16', autotune=None, deterministic=None):
         super().__init__()
+        self.deterministic = (_os_env.environ.get('MSC_DETERMINISTIC', '0') == '1') if deterministic is None else bool(deterministic)
         if encoder_depth not in _ENC:
             raise NotImplementedError('only 34, 101, 152 version of Resnet are implemented')
         if num_classes != 2:
@@ -635,6 +639,7 @@ class _Builder:
         self.group_max = int(env.get('MSC_WGRAD_GROUP', '24' if multi else '1000')) if (training and device.type == 'cuda') else 0
         self.group_steps = int(env.get('MSC_WGRAD_GROUP_STEPS', '128'))      # k-steps per block: fewer, longer blocks = fewer fp32-atomic passes over dW
         self.group_tile = int(env.get('MSC_WGRAD_GROUP_TILE', '128'))
+        self.ordered = bool(getattr(net, 'deterministic', False)) and self.group_max > 1      # fixed-order sums (MSC_WGRAD_ORDERED); the per-layer launches stay atomic
         self.pending = []             # deferred (WgradDesc, gradient address or None)
         self.gcount = {}              # activation slice -> number of launches that write its gradient
         self.gwriter = {}             # activation slice -> ConvDesc of the (mode 0, no residual) dgrad conv that wrote it first
@@ -792,7 +797,8 @@ class _Builder:
         n = len(self.pending)
         arr = (WgradDesc * n)(*[d for d, _ in self.pending])
         h = _GroupHandle()
-        _lib.check(self.lib.msc_wgrad_group_create(arr, n, self.group_steps, self.group_tile, C.byref(h)), 'msc_wgrad_group_create')
+        _lib.check(self.lib.msc_wgrad_group_create(arr, n, self.group_steps, self.group_tile, _lib.WGRAD_ORDERED if self.ordered else 0, C.byref(h)),
+                   'msc_wgrad_group_create')
         h.descs = [d for d, _ in self.pending]
         self.prog.groups.append(h)
         idx = len(self.prog.bwd)
@@ -1313,8 +1319,10 @@ class _Builder:
             self.grad_acc(d0)
             # final 1x1 backward also applies dec0's ReLU mask, so dec0's backward skips it
             # ... and sums dec0's bias gradient while the masked gradient is in registers
+            fin_ws = self.vec(_lib.FINAL_BWD_WS_ROWS * (3 * nf + 2)) if self.ordered else None
             self.emit(P.bwd, lib.msc_final_bwd, P.dlogits.data_ptr(), d0.ptr, d0.ld, fin.weight.data_ptr(), gd0.ptr, gd0.ld,
-                      self.g(fin.weight), self.g(fin.bias), self.g(net.dec0.conv.bias), self.dt, N, H, W, nf)
+                      self.g(fin.weight), self.g(fin.bias), self.g(net.dec0.conv.bias), fin_ws.data_ptr() if self.ordered else None,
+                      self.dt, N, H, W, nf)
             self._conv_relu_bwd('dec0.conv', x, net.dec0.conv, d0, masked='done')
             for op in reversed(self.ops):
                 op()

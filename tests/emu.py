@@ -519,7 +519,7 @@ def bias_slots_finalize_multi(items, n):
         bias_slots_finalize(items[i].slots, items[i].Cs, items[i].db, items[i].C)
 
 
-def final_bwd(dlogits, inp, in_ld, w, din, din_ld, dw, db, dbin, dtype, N, H, W, Cc):
+def final_bwd(dlogits, inp, in_ld, w, din, din_ld, dw, db, dbin, ordered_ws, dtype, N, H, W, Cc):
     g = _arr(dlogits, N * 2 * H * W).reshape(N, 2, H * W).transpose(0, 2, 1).reshape(-1, 2).astype(np.float64)
     x = _rows(inp, N * H * W, Cc, in_ld).astype(np.float64)
     ww = _arr(w, 2 * Cc).reshape(2, Cc).astype(np.float64)

@@ -96,13 +96,13 @@ def _wgrad_desc(p, q, dw, KH, KW, stride, pad, cfg=0):
     return d
 
 
-def conv_wgrad_group(problems, steps_per_block=64, tile_cap=128, runs=1):
+def conv_wgrad_group(problems, steps_per_block=64, tile_cap=128, runs=1, flags=0):
     """problems: [(p, q, dw, KH, KW, stride, pad)]; all weight gradients in one launch per tile shape.
     Returns the number of kernel launches one run takes."""
     lib = _lib.load()
     arr = (WgradDesc * len(problems))(*[_wgrad_desc(*pr) for pr in problems])
     h = C.c_void_p()
-    _lib.check(lib.msc_wgrad_group_create(arr, len(problems), steps_per_block, tile_cap, C.byref(h)), 'msc_wgrad_group_create')
+    _lib.check(lib.msc_wgrad_group_create(arr, len(problems), steps_per_block, tile_cap, flags, C.byref(h)), 'msc_wgrad_group_create')
     try:
         for _ in range(runs):
             _lib.check(lib.msc_wgrad_group_run(h, _stream(problems[0][0])), 'msc_wgrad_group_run')

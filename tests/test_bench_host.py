@@ -42,7 +42,7 @@ def test_reexec_line_really_starts_n_ranks_with_the_torchrun_environment(tmp_pat
     env = dict(os.environ, OMP_NUM_THREADS='1')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
-    out = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=240)
+    out = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [open(str(tmp_path / ('rank%d.txt' % r))).read() for r in range(2)]      # one file per rank: stdout of the ranks interleaves
     assert lines == ['RANK 0 2 0 127.0.0.1 bf16 3.0', 'RANK 1 2 1 127.0.0.1 bf16 3.0'], (lines, out.stdout)

@@ -63,7 +63,7 @@ def test_two_rank_protocol_matches_full_batch():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(60)
     assert [(r[3], r[4]) for r in res] == [(0, 2), (2, 4)]
@@ -158,7 +158,7 @@ def test_product_backward_in_pieces_with_async_allreduce_matches_full_batch(wire
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(60)
     n, hw = (4 if W == 2 else W), 64

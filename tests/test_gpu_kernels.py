@@ -370,11 +370,14 @@ def test_every_kernel_configuration_is_correct(dtype, cin, cout, k, stride, hw, 
 
 
 @pytest.mark.parametrize('dtype', DT)
-@pytest.mark.parametrize('steps,cap', [(64, 128), (4, 64), (1, 32), (0, 128)])
-def test_grouped_weight_gradients_equal_separate_ones(dtype, steps, cap):
+@pytest.mark.parametrize('steps,cap,ordered', [(64, 128, 0), (4, 64, 0), (1, 32, 0), (0, 128, 0), (4, 64, 1), (1, 128, 1), (64, 128, 1)])
+def test_grouped_weight_gradients_equal_separate_ones(dtype, steps, cap, ordered):
     """msc_wgrad_group_*: layers of different shapes (several tile buckets, 1x1 / 3x3 / strided, ragged pixel counts) in one
-    launch per bucket; each gradient equals torch's, also when the group is run twice into the same buffers (+=)"""
+    launch per bucket; each gradient equals torch's, also when the group is run twice into the same buffers (+=).
+    ordered (MSC_WGRAD_ORDERED): the split planes summed in a fixed order -- the same, and the same BITS from a second group"""
     import hip_ops as ops
+    if ordered and steps == 0:
+        pytest.skip('per-descriptor policy: covered unordered')
     shapes = [(128, 128, 3, 1, 20, 3), (64, 256, 1, 1, 16, 4), (32, 32, 3, 1, 24, 2), (64, 64, 3, 2, 18, 2), (256, 128, 1, 1, 9, 3),
               (128, 256, 3, 1, 7, 1), (32, 96, 1, 2, 10, 2),
               (512, 256, 1, 1, 11, 2), (256, 256, 1, 2, 12, 2)]      # channel counts that take the 256x256 tile (16-bit, grouped; ragged pixels)
@@ -399,11 +402,18 @@ def test_grouped_weight_gradients_equal_separate_ones(dtype, steps, cap):
         refs.append(wt.grad.permute(0, 2, 3, 1))
         dw = torch.zeros((cin, 4, 4, cout), dtype=torch.float32, device='cuda')
         problems.append((nhwc(x, dtype), nhwc(dy, dtype), dw, 4, 4, 2, 1))
-    launches = ops.conv_wgrad_group(problems, steps, cap, runs=2)
-    assert 1 <= launches <= 8
+    launches = ops.conv_wgrad_group(problems, steps, cap, runs=2, flags=ordered)
+    assert 1 <= launches <= 8 + ordered
     for pr, gref in zip(problems, refs):
         err = (pr[2].cpu() / 2 - gref).abs().max().item() / gref.abs().max().item()
         assert err < (2e-5 if dtype == torch.float32 else 1e-2), (pr[2].shape, err)
+    if ordered:      # a second group on fresh buffers: bit for bit what the first run of the first group added
+        again = [pr[:2] + (torch.zeros_like(pr[2]),) + pr[3:] for pr in problems]
+        ops.conv_wgrad_group(again, steps, cap, runs=1, flags=1)
+        third = [pr[:2] + (torch.zeros_like(pr[2]),) + pr[3:] for pr in problems]
+        ops.conv_wgrad_group(third, steps, cap, runs=1, flags=1)
+        for a, b in zip(again, third):
+            assert torch.equal(a[2], b[2])
 
 
 @pytest.mark.parametrize('dtype', DT)
@@ -513,10 +523,12 @@ def test_conv_epilogue_relu_backward_and_bias_sums(dtype, cin, cout, k, stride, 
 
 
 @pytest.mark.parametrize('dtype', DT)
-@pytest.mark.parametrize('n,hw,c,with_bias_in', [(2, 24, 32, True), (3, 17, 32, False), (1, 64, 64, True), (2, 9, 16, True)])
-def test_final_1x1_backward(dtype, n, hw, c, with_bias_in):
+@pytest.mark.parametrize('n,hw,c,with_bias_in,ordered', [(2, 24, 32, True, 0), (3, 17, 32, False, 0), (1, 64, 64, True, 0), (2, 9, 16, True, 0),
+                                                         (2, 24, 32, True, 1), (3, 65, 32, False, 1), (1, 64, 64, True, 1)])
+def test_final_1x1_backward(dtype, n, hw, c, with_bias_in, ordered):
     """msc_final_bwd against torch autograd of ReLU -> Conv2d(C, 2, 1): the input gradient masked by the producer's ReLU, the
-    1x1 weight / bias gradients, and the producer's bias gradient summed from the stored (rounded) input gradient"""
+    1x1 weight / bias gradients, and the producer's bias gradient summed from the stored (rounded) input gradient.
+    ordered: the per-block sums through ordered_ws, added in block order -- the same values, and the same bits twice"""
     from mapping_challenge_amd import _lib
     import hip_ops as ops
     lib = _lib.load()
@@ -538,9 +550,16 @@ def test_final_1x1_backward(dtype, n, hw, c, with_bias_in):
     dbin = torch.ones(c, device='cuda') if with_bias_in else None
     st = torch.cuda.current_stream().cuda_stream
     gd, wd = g.cuda(), w.cuda()          # kept alive: a temporary's memory is recycled by the next allocation
+    ws = torch.full((_lib.FINAL_BWD_WS_ROWS * (3 * c + 2),), float('nan'), device='cuda') if ordered else None
     _lib.check(lib.msc_final_bwd(gd.data_ptr(), ad.data_ptr(), c, wd.data_ptr(), din.data_ptr(), c, dw.data_ptr(), db.data_ptr(),
-                                 dbin.data_ptr() if with_bias_in else None, ops._dt(ad), n, hw, hw, c, st), 'final_bwd')
+                                 dbin.data_ptr() if with_bias_in else None, ws.data_ptr() if ordered else None, ops._dt(ad), n, hw, hw, c, st), 'final_bwd')
     torch.cuda.synchronize()
+    if ordered:
+        dw2, db2 = torch.ones(2, c, device='cuda'), torch.ones(2, device='cuda')
+        _lib.check(lib.msc_final_bwd(gd.data_ptr(), ad.data_ptr(), c, wd.data_ptr(), din.data_ptr(), c, dw2.data_ptr(), db2.data_ptr(),
+                                     None, ws.data_ptr(), ops._dt(ad), n, hw, hw, c, st), 'final_bwd')
+        torch.cuda.synchronize()
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
     assert torch.allclose(to_nchw(din), din_ref, **tol(dtype))
     t = dict(rtol=1e-4, atol=1e-3)
     assert torch.allclose(dw.cpu() - 1, wt.grad, **t)

@@ -206,6 +206,31 @@ def test_hip_train_loop_graph_equals_eager_and_tracks_oracle():
     assert out['eager'][0][-1] < out['eager'][0][0]
 
 
+@pytest.mark.parametrize('dtype,depth', [('bf16', 34), ('fp32', 34), ('bf16', 101)])
+def test_deterministic_mode_repeats_a_training_run_bit_for_bit(dtype, depth):
+    """UNetResNet(deterministic=True): the weight gradients' partial sums are added in a fixed order (MSC_WGRAD_ORDERED,
+    msc_final_bwd ordered_ws) -- two runs of the same four steps end in the same bits, eager and as a replayed graph; the
+    statistics sums go through fp64 atomics of fp32 partials, which are exact at these sizes.  (The per-layer kernel choices are timed
+    once per process and shape, so the three builds run the same kernels.)"""
+    from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
+    arch = {'weighted_cross_entropy': {'w0': 50, 'sigma': 10, 'imsize': (256, 256)},
+            'loss_weights': {'dice_mask': 0.2, 'bce_mask': 1.0}, 'dice': {'smooth': 1, 'dice_activation': 'softmax'}}
+    x = unet_ref.synthetic_batch(4, 64, 64).cuda()
+    tgt = losses_ref.synthetic_target(4, 64, 64).cuda()
+    runs = []
+    for mode in ('graph', 'graph', 'eager'):
+        _, net = build(depth, dtype)
+        net.deterministic = True
+        net.train()
+        step = TrainStep(net, LossSpec.mixed(arch), HipAdam(net, lr=5e-4, weight_decay=1e-4), use_graph=(mode == 'graph'))
+        losses = [step(x, tgt).item() for _ in range(4)]
+        runs.append((losses, net.flat_params.clone()))
+    assert runs[0][0] == runs[1][0] == runs[2][0]
+    assert torch.equal(runs[0][1], runs[1][1])
+    assert torch.equal(runs[0][1], runs[2][1])
+    assert runs[0][0][-1] < runs[0][0][0]
+
+
 def test_bf16_train_step_runs_and_reduces_loss():
     from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
     ref, net = build(34, 'bf16')

@@ -8,7 +8,7 @@ import re
 import sys
 
 FAMILIES = [('conv_igemm / halo (conv, dgrad, deconv)', r'conv_igemm|halo_kernel|conv3x3_|deconv4_'),
-            ('conv_wgrad', r'conv_wgrad'),
+            ('conv_wgrad', r'conv_wgrad|wgrad_finish'),
             ('BatchNorm elementwise (bn_apply, bn_bwd_apply, stem bn + pool)', r'bn_apply_kernel|bn_bwd_apply_kernel|bn_apply_pool_kernel|bn_pool_bwd_kernel'),
             ('column reductions (BN backward sums, bias grads)', r'colreduce'),
             ('BatchNorm finalize kernels', r'bn_finalize|bn_bwd_finalize|bias_finalize'),
