@@ -278,7 +278,7 @@ int msc_final_fwd(const void* in, int64_t in_ld, const float* w, const float* b,
  * dbias_in (f32[C], may be NULL): dbias_in[c] += sum_p din[p][c] -- the bias gradient of the layer that produced `in`
  * (dec0's conv bias), so no separate msc_bias_grad pass reads din back.  C*sizeof(dtype) must be a multiple of 16, C <= 64.
  * ordered_ws (ABI v8, may be NULL: fp32 atomics, the order of the additions varies from run to run): MSC_FINAL_BWD_WS_ROWS * (3*C + 2)
- * floats of scratch.  The per-block sums go there and a second launch adds them in block order: bit-for-bit reproducible. */
+ * floats of scratch.  The per-block sums go there and a second launch adds them up in a fixed order: bit-for-bit reproducible. */
 #define MSC_FINAL_BWD_WS_ROWS 1024
 int msc_final_bwd(const float* dlogits, const void* in, int64_t in_ld, const float* w, void* din, int64_t din_ld,
                   float* dw, float* db, float* dbias_in, float* ordered_ws, int dtype, int N, int H, int W, int C, void* stream);

@@ -624,8 +624,8 @@ __global__ void final_fwd_kernel(const T* __restrict__ in, long in_ld, const flo
 // pixel rows (coalesced), din needs no cross-lane traffic, and the per-channel sums (dw, the producer's bias gradient) stay in
 // registers until the end of the block -- one lane per pixel with a wave reduction per element and iteration kept the VALU
 // busier than the memory pipe (0.19 ms for 285 MB).  UNR pixels per lane are in flight together.
-// ORD (ordered_ws of msc_final_bwd): the four waves' sums are added in wave order and the block's 3 C + 2 sums go to row blockIdx.x of
-// `ws` instead of the gradients; final_bwd_finish_kernel adds the rows in block order.
+// ORD (ordered_ws of msc_final_bwd): the four waves' sums are added in wave order and the block's 3 C + 2 sums go to column blockIdx.x of
+// `ws` ([3 C + 2][MSC_FINAL_BWD_WS_ROWS]) instead of the gradients; final_bwd_finish_kernel adds each row up in a fixed tree.
 template <typename T, int VC, bool ORD>
 __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict__ dlogits, const T* __restrict__ in, long in_ld,
                                                         const float* __restrict__ w, T* __restrict__ din, long din_ld,
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
             if (chunk == 0) { wa[3 * C] = g0s; wa[3 * C + 1] = g1s; }
         }
         __syncthreads();
-        for (int i = tid; i < NS; i += 256) ws[(long)blockIdx.x * NS + i] = ((acc[i] + acc[NS + i]) + acc[2 * NS + i]) + acc[3 * NS + i];
+        for (int i = tid; i < NS; i += 256) ws[(long)i * MSC_FINAL_BWD_WS_ROWS + blockIdx.x] = ((acc[i] + acc[NS + i]) + acc[2 * NS + i]) + acc[3 * NS + i];
         return;
     }
     if ((tid & 63) < VC) {
@@ -722,18 +722,21 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
     if (tid < 2 && db) atomicAdd(db + tid, acc[3 * C + tid]);
 }
 
-// one block: element i of the gradients += row 0 + row 1 + ... of the per-block sums (eight partial sums per element, combined in a
-// fixed tree, so that the 1024 rows are not one dependent chain)
-__global__ __launch_bounds__(256) void final_bwd_finish_kernel(const float* __restrict__ ws, int rows, int C, float* __restrict__ dw,
+// block i: element i of the gradients += the sum of the per-block values of row i -- thread t adds columns t, t + 256, ... in that order,
+// the 256 partial sums combine in a fixed shuffle tree and wave order
+__global__ __launch_bounds__(256) void final_bwd_finish_kernel(const float* __restrict__ ws, int cols, int C, float* __restrict__ dw,
                                                                float* __restrict__ db, float* __restrict__ dbin) {
-    const int NS = 3 * C + 2;
-    for (int i = threadIdx.x; i < NS; i += 256) {
-        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int r = 0; r < rows; r += 8)
+    __shared__ float w4[4];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const float* r = ws + (long)i * MSC_FINAL_BWD_WS_ROWS;
+    float s = 0.f;
+    for (int k = tid; k < cols; k += 256) s += r[k];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (r + j < rows) s[j] += ws[(long)(r + j) * NS + i];
-        const float t = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((tid & 63) == 0) w4[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        const float t = (w4[0] + w4[1]) + (w4[2] + w4[3]);
         if (i < 2 * C) dw[i] += t;
         else if (i < 3 * C) { if (dbin) dbin[i - 2 * C] += t; }
         else if (db) db[i - 3 * C] += t;
@@ -1297,7 +1300,7 @@ static int final_bwd_launch(const float* dlogits, const void* in, long in_ld, co
         default: return msc_fail(MSC_ERR_UNSUPPORTED, "msc_final_bwd: C=%d (supported: C*sizeof(dtype)/16 a power of two up to 16)", C);
     }
 #undef MSC_FB
-    if (ws) hipLaunchKernelGGL(final_bwd_finish_kernel, dim3(1), dim3(256), 0, st, ws, (int)blocks, C, dw, db, dbin);
+    if (ws) hipLaunchKernelGGL(final_bwd_finish_kernel, dim3(3 * C + 2), dim3(256), 0, st, ws, (int)blocks, C, dw, db, dbin);
     return msc_check_launch("msc_final_bwd");
 }
 

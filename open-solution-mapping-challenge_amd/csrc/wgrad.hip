@@ -592,7 +592,15 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const WgFin* __restri
     const long i = (long)e.y * 1024 + threadIdx.x * 4;
     if (i >= it.plane) return;
     float4 s = *reinterpret_cast<const float4*>(it.part + i);
-    for (int k = 1; k < it.splits; ++k) {
+    int k = 1;
+    for (; k + 4 <= it.splits; k += 4) {      // four planes in flight, added in plane order (a 512-split layer is a chain of loads otherwise)
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float4*>(it.part + (long)(k + j) * it.plane + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+    }
+    for (; k < it.splits; ++k) {
         const float4 v = *reinterpret_cast<const float4*>(it.part + (long)k * it.plane + i);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
