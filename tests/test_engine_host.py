@@ -1,6 +1,8 @@
 """CPU: host logic of the HIP engine (program construction, buffer wiring, concat slices, gradient
 accumulation flags, weight layouts) checked by executing its launch lists with tests/emu.py -- a numpy
 interpreter of the documented C-ABI semantics -- against the torch-CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -46,6 +48,20 @@ def test_eval_and_train_match_oracle(interpreted, depth):
     for (n, b), (_, b2) in zip(sorted(ref.named_buffers()), sorted(net.named_buffers())):
         if 'running' in n:
             assert (b - b2).abs().max() < 1e-5, n
+
+
+def test_deterministic_flag_comes_from_the_argument_the_environment_or_the_training_config(monkeypatch):
+    """UNetResNet(deterministic=...) / MSC_DETERMINISTIC / training_config['deterministic'] (fixed-order gradient sums: MSC_WGRAD_ORDERED groups and
+    msc_final_bwd's ordered_ws on the device; the CPU interpreter's per-layer launches have one order anyway)"""
+    mk = lambda **kw: um.UNetResNet(34, 2, num_filters=32, dropout_2d=0.0, is_deconv=True, compute_dtype='fp32', **kw)
+    monkeypatch.delenv('MSC_DETERMINISTIC', raising=False)
+    assert mk().deterministic is False and mk(deterministic=True).deterministic is True
+    monkeypatch.setenv('MSC_DETERMINISTIC', '1')
+    assert mk().deterministic is True and mk(deterministic=False).deterministic is False
+    from mapping_challenge_amd import _lib
+    assert _lib.WGRAD_ORDERED == 1 and _lib.FINAL_BWD_WS_ROWS == 1024
+    hdr = open(os.path.join(os.path.dirname(__file__), '..', 'include', 'msc.h')).read()
+    assert 'MSC_WGRAD_ORDERED = 1' in hdr and '#define MSC_FINAL_BWD_WS_ROWS 1024' in hdr
 
 
 def test_state_dict_roundtrip_and_flat_views(interpreted):
