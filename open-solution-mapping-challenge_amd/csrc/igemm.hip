@@ -73,7 +73,15 @@ template <int KB> __device__ __forceinline__ int swz_frag(int pl) {      // key 
 // ABL (probes/conv_ablate.hip only; 0 in the product): bit 0 = no MFMA (fragments still read), bit 1 = no DMA after the
 // prologue (compute runs on whatever the ring holds), bit 2 = no fragment reads and no MFMA, bit 3 = no barrier,
 // bit 4 = scheduling barriers around every DMA piece (pins its place between the MFMAs)
-template <typename T, int TP, int TC, int WP, int WC, int MODE, int NST, int KB, int ABL = 0>
+// BNL (msc_conv_desc.in_bn, 1x1 / stride 1, 16-bit): the input is the raw output of a training-mode BatchNorm'd conv.  Each wave rewrites the
+// pixel-tile pieces IT fetched with relu(scale * y + shift), in LDS, right after its own counted wait and before the k-step's barrier (its
+// own DMA has landed by then and nobody reads the stage before the barrier: no second barrier).  The coefficients are finalised from the
+// producer's statistics slots into an LDS table behind the prologue's fills (block 0 publishes them and updates the running statistics: what
+// msc_bn_apply's prologue does); the blocks of channel tile 0 store what they transformed -- the activation the weight gradient reads --
+// from the registers of the pass.  Measured before it was built (probes/bn_on_load_probe.hip, profiles/r4_run28_bn_on_load_probe.txt): +1.3-2.5 us
+// per launch on the 256x128 / 128x256 tiles against 3.8-9 us of the msc_bn_apply launch it replaces; same bits.
+constexpr int BNL_CMAX = 512;        // input channels the coefficient table holds (2 x 2 KB of LDS next to the ring)
+template <typename T, int TP, int TC, int WP, int WC, int MODE, int NST, int KB, int ABL = 0, int BNL = 0>
 __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
     constexpr int ES = sizeof(T);
     constexpr int NW = WP * WC;                  // waves per block
@@ -90,7 +98,10 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
     constexpr int LPW = XI + WI;                 // DMA instructions per wave per stage, uniform over waves
     static_assert(NIX % NW == 0 || NIX < NW, "pixel tile / wave count");
     static_assert(NST * STAGE <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + (BNL ? 8 * BNL_CMAX : 0)];
+    float* const bnl_tab = reinterpret_cast<float*>(smem + NST * STAGE);      // BNL: scale[BNL_CMAX], shift[BNL_CMAX] of the input channels, behind the ring
+    static_assert(!BNL || (NST * STAGE + 8 * BNL_CMAX <= 160 * 1024 && NIX >= NW && MODE == 0 && ES == 2),
+                  "BNL: LDS with the table; every pixel-tile piece has ONE fetching wave; gather mode; 16-bit");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -302,17 +313,55 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
         if (ISSUE) advance();
     };
 
+    // BNL: the pieces this wave fetched of the landed stage `cst` (k-step s = input channels s * KE ..), rewritten in place; lane's 16 bytes =
+    // source chunk xkc / 16 of pixel row (i * NW + wid) * RPI + lr
+    auto bnl_fixup = [&](int s, int cst) {
+        if constexpr (BNL != 0) {
+            char* sx = smem + cst * STAGE;
+            const int cb = s * KE;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                char* ptr = sx + (i * NW + wid) * 1024 + lane * 16;
+                uint4 v = *reinterpret_cast<uint4*>(ptr);
+                const int ch = cb + (int)(xkc[i] / ES);
+                float f[8];
+                Vec16<T>::unpack(v, f);
+                const float4 s0 = *reinterpret_cast<const float4*>(&bnl_tab[ch]), s1 = *reinterpret_cast<const float4*>(&bnl_tab[ch + 4]);
+                const float4 h0 = *reinterpret_cast<const float4*>(&bnl_tab[BNL_CMAX + ch]), h1 = *reinterpret_cast<const float4*>(&bnl_tab[BNL_CMAX + ch + 4]);
+                f[0] = fmaxf(fmaf(f[0], s0.x, h0.x), 0.f); f[1] = fmaxf(fmaf(f[1], s0.y, h0.y), 0.f);
+                f[2] = fmaxf(fmaf(f[2], s0.z, h0.z), 0.f); f[3] = fmaxf(fmaf(f[3], s0.w, h0.w), 0.f);
+                f[4] = fmaxf(fmaf(f[4], s1.x, h1.x), 0.f); f[5] = fmaxf(fmaf(f[5], s1.y, h1.y), 0.f);
+                f[6] = fmaxf(fmaf(f[6], s1.z, h1.z), 0.f); f[7] = fmaxf(fmaf(f[7], s1.w, h1.w), 0.f);
+                v = Vec16<T>::pack(f);
+                *reinterpret_cast<uint4*>(ptr) = v;
+                if (ctile == 0 && p.bnl_out && xv[i])      // the activation itself, once per pixel tile: pixel m0 + row, channels ch .. ch + 7
+                    store16(p.bnl_out + ((long)(m0 + (i * NW + wid) * RPI + lr) * p.bnl_out_ld + ch) * ES, v);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the rewritten pieces are in LDS before the barrier lets the others read them
+        }
+    };
     if (nsteps > 0) {
         if (icch != 0) set_tap(itap);            // a slice that starts inside a tap (issue() refreshes the offsets at chunk 0 only)
 #pragma unroll
         for (int st = 0; st < NST - 1; ++st)
             if (st < nsteps) issue();
+        if constexpr (BNL != 0) {
+            // the coefficient table, behind the prologue's fills (the compiler's vmcnt(0) for these loads waits for those as well); the first
+            // block publishes (every block computes the same values)
+            for (int c = tid; c < p.Cin; c += NW * 64) {
+                float sc, sh;
+                bn_fwd_coeffs(p.bnl, p.Cin, c, blockIdx.x == 0, sc, sh);
+                bnl_tab[c] = sc; bnl_tab[BNL_CMAX + c] = sh;
+            }
+            __syncthreads();
+        }
         int cstage = 0;
         const int nmain = nsteps - (NST - 1);    // k-steps that still have a stage to fetch
         int s = 0;
         for (; s < nmain; ++s) {
             // stage s must have landed; stages s+1 .. s+NST-2 may stay in flight
             wait_vmcnt<(NST - 2) * LPW>();
+            bnl_fixup(s, cstage);
             if (!(ABL & 8)) raw_barrier();       // everyone's DMA of stage s is in LDS, everyone is done with stage s-1
             kstep(std::true_type{}, cstage);
             if (++cstage == NST) cstage = 0;
@@ -320,6 +369,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
         for (; s < nsteps; ++s) {
             if (s + NST - 2 <= nsteps - 1) wait_vmcnt<(NST - 2) * LPW>();
             else wait_vmcnt<0>();
+            bnl_fixup(s, cstage);
             if (!(ABL & 8)) raw_barrier();
             kstep(std::false_type{}, cstage);
             if (++cstage == NST) cstage = 0;
@@ -679,13 +729,17 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {128, 64, 4, 2, 64, 2},     // 58: halo-tile kernel for the stem (7x7 / stride 2 on the prepared 4-channel input)
 };
 
-template <typename T, int TP, int TC, int WP, int WC, int KB, int NST, int ABL = 0>
+template <typename T, int TP, int TC, int WP, int WC, int KB, int NST, int ABL = 0, int BNL = 0>
 int launch_dma(const ConvK& k0, int mode, hipStream_t st) {
     ConvK k = k0;
     k.ntc = ceil_div(k.Cout, TC);
     k.xcd_order = xcd_order_enabled() ? 1 : 0;
     dim3 grid(ceil_div(k.M, TP) * k.ntc * k.ksplit, 1, mode ? 4 : 1);
     constexpr int NT = WP * WC * 64;
+    if constexpr (BNL != 0) {      // in_bn: gather mode, 16-bit (conv_cfg_ok)
+        if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, NST, KB, ABL, 1>), grid, dim3(NT), 0, st, k);
+        return msc_check_launch("conv_igemm_dma (in_bn)");
+    }
     if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1, NST, KB, ABL>), grid, dim3(NT), 0, st, k);
     else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, NST, KB, ABL>), grid, dim3(NT), 0, st, k);
     if (k.ksplit > 1) {
@@ -709,8 +763,12 @@ int launch_halo3(const ConvK& k0, hipStream_t st) {
     return msc_check_launch("conv3x3_halo_dma");
 }
 
+// in_bn (BatchNorm + ReLU of the input on load): the implicit-GEMM kernel's 1x1 form on the two tiles it was measured on
+static inline bool cfg_has_bnl(int cfg) { return cfg == 1 || cfg == 33; }
 bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
     if (cfg < 1 || cfg > N_CONV_CFG) return false;
+    if (k.bnl.slots && !(cfg_has_bnl(cfg) && es == 2 && k.mode == 0 && k.KH == 1 && k.KW == 1 && k.stride == 1 && k.pad == 0 && !k.span_bytes &&
+                         k.ksplit == 1 && k.Cin <= BNL_CMAX && k.Cin % 8 == 0)) return false;
     if (k.fin_w && cfg != CFG_HALO) return false;           // the fused final 1x1 lives in the 32-channel halo kernel's epilogue only
     if (k.sz && cfg >= 29 && cfg <= 32) return false;       // the residual-join epilogue (stats_z) is not compiled for the 32-fragment wave tiles
     if (k.ksplit > 1 && (cfg == CFG_HALO || cfg == CFG_HALO_T || cfg == CFG_STREAM || cfg == CFG_STEM || cfg_is_halo3(cfg))) return false;      // split-K: the implicit-GEMM kernel only
@@ -752,12 +810,16 @@ int pick_cfg(const ConvK& k) {
 
 template <typename T>
 int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
-    if (cfg == 0) cfg = k.fin_w ? CFG_HALO : pick_cfg(k);
+    if (cfg == 0) cfg = k.fin_w ? CFG_HALO : k.bnl.slots ? (k.Cout % 256 == 0 ? 33 : 1) : pick_cfg(k);
     if (!conv_cfg_ok(k, (int)sizeof(T), cfg)) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: configuration %d is not valid for this layer", cfg);
     if (cfg == CFG_HALO) return halo32_conv_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     if (cfg == CFG_HALO_T) return halo32_deconv_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     if (cfg == CFG_STEM) return halo32_stem_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     if (cfg == CFG_STREAM) return conv1x1_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
+    if (k.bnl.slots) {
+        if (cfg == 1) return launch_dma<T, 256, 128, 4, 2, 128, 3, 0, 1>(k, mode, st);
+        return launch_dma<T, 128, 256, 2, 4, 128, 3, 0, 1>(k, mode, st);
+    }
     switch (cfg) {
         case 1: return launch_dma<T, 256, 128, 4, 2, 128, 3>(k, mode, st);
         case 2: return launch_dma<T, 256, 128, 4, 2, 64, 4>(k, mode, st);
@@ -859,6 +921,15 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
         return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: split-K needs mode 0, no statistics, a 16-byte aligned fp32 workspace and at most 64 slices");
     if (d->final_w && (d->res || d->stats || (!d->final_logits && !d->final_probs)))
         return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: the fused final 1x1 takes no residual / statistics and needs a logits or probabilities output");
+    k->bnl = BnFwdFin{}; k->bnl_out = nullptr; k->bnl_out_ld = 0;
+    if (d->in_bn) {
+        const msc_bn_input* b = d->in_bn;
+        if (!b->slots || !b->scale || !b->shift || b->count <= 0 || es != 2 || (b->out && ((b->out_ld * es) % 16 || ((uintptr_t)b->out & 15))))
+            return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: in_bn needs slots, scale / shift outputs, a pixel count, a 16-bit dtype and a 16-byte aligned activation");
+        k->bnl = BnFwdFin{b->slots, (double)b->count, b->gamma, b->beta, b->eps, b->momentum, b->running_mean, b->running_var, b->scale, b->shift,
+                          b->save_mean, b->save_invstd};
+        k->bnl_out = (char*)b->out; k->bnl_out_ld = b->out_ld;
+    }
     k->span_bytes = 0;
     if (d->mode == 1) {
         if (d->stride != 2 || (d->Ho & 1) || (d->Wo & 1)) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: transposed mode needs stride 2 and even output size");
@@ -947,6 +1018,7 @@ extern "C" int msc_conv_cfg_ok(const msc_conv_desc* d, int cfg) {
     ConvK k;
     if (!d) return 0;
     const msc_conv_desc first = conv_image_range(d, 0, conv_image_chunk(d));
+    if (d->in_bn && first.N < d->N) return 0;      // in_bn: one image range per launch (msc_conv_igemm)
     if (conv_fill(&first, &k) != MSC_OK) return 0;
     return conv_cfg_ok(k, msc_dtype_size(d->dtype), cfg) ? 1 : 0;
 }
@@ -955,6 +1027,8 @@ extern "C" int msc_conv_igemm(const msc_conv_desc* d, void* stream) {
     if (!d) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: null descriptor");
     hipStream_t st = (hipStream_t)stream;
     const int chunk = conv_image_chunk(d);
+    // in_bn: the first block of the launch publishes the coefficients and moves the running statistics -- once per layer, so one image range
+    if (d->in_bn && chunk < d->N) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: in_bn needs the whole batch in one image range (%d of %d images fit)", chunk, d->N);
     for (int n0 = 0; n0 < (d->N > 0 ? d->N : 1); n0 += chunk) {
         const msc_conv_desc part = conv_image_range(d, n0, d->N - n0 < chunk ? d->N - n0 : chunk);
         ConvK k;
