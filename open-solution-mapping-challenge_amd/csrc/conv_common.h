@@ -27,7 +27,7 @@ struct ConvK {
     // msc_conv_desc.in_bn (ABI v9; appended, so that the layout the other kernels read is untouched): `in` is the RAW output of a training-mode
     // BatchNorm'd conv -- the kernel finalises that layer's coefficients from bnl.slots and applies relu(scale * y + shift) to the operand tile
     // in LDS; the blocks of channel tile 0 also store the activation to bnl_out (bnl_out_ld elements per pixel; may be null)
-    BnFwdFin bnl; char* bnl_out; long bnl_out_ld;
+    BnFwdFin bnl; char* bnl_out; long bnl_out_ld; unsigned bnl_out_bytes;
 };
 
 // floor(m / d) through the float reciprocal, exact for m < 2^24 (one correction step either way)

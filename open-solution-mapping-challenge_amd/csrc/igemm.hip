@@ -315,7 +315,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
 
     // BNL: the pieces this wave fetched of the landed stage `cst` (k-step s = input channels s * KE ..), rewritten in place; lane's 16 bytes =
     // source chunk xkc / 16 of pixel row (i * NW + wid) * RPI + lr
-    auto bnl_fixup = [&](int s, int cst) {
+    auto bnl_fixup = [&](int s, int cst) __attribute__((always_inline)) {
         if constexpr (BNL != 0) {
             char* sx = smem + cst * STAGE;
             const int cb = s * KE;
@@ -453,7 +453,11 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 //   TPS taps per k-step (1 or 3): on the 16x16 maps a k-step of one tap is 257 MFMA cycles per SIMD between two barriers;
 //   a kernel row per k-step (weight stage = 3 slices) has 12 barriers per chunk-loop pass instead of 36.
 //   MINB = blocks per CU the register allocation has to allow (HIP's second launch bound counts waves per SIMD).
-template <typename T, int PH, int TC, int WP, int WC, int NWS, int TPS = 1, int MINB = 1>
+//   BNL (msc_conv_desc.in_bn, see conv_igemm_dma_kernel): the halo of a chunk is rewritten with relu(scale * y + shift) by the waves that
+//   fetched its pieces, at the k-step whose counted wait covers them (NWS - 1 k-steps after they were issued; the last ones at k-step 0 of the
+//   chunk that reads them, before its barrier).  Lanes whose pixel lies outside the image keep the zeros the DMA wrote (the padding is of the
+//   ACTIVATION); the blocks of channel tile 0 store the interior of what they transformed.
+template <typename T, int PH, int TC, int WP, int WC, int NWS, int TPS = 1, int MINB = 1, int BNL = 0>
 __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo_dma_kernel(ConvK p) {
     static_assert(sizeof(T) == 2, "16-bit types");
     static_assert(TPS == 1 || TPS == 3, "taps per k-step");
@@ -476,8 +480,9 @@ __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo
     static_assert(PH % WP == 0 && TC % (WC * 16) == 0, "wave tiling");
     static_assert(NWS - 1 <= SPC, "ring deeper than a chunk");
     static_assert(NIW % NW == 0 || (NIW < NW && TPS == 1), "weight tile / wave count");
-    static_assert(2 * HBUF + NWS * WSTAGE <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(16))) char smem[2 * HBUF + NWS * WSTAGE];
+    static_assert(2 * HBUF + NWS * WSTAGE + (BNL ? 8 * BNL_CMAX : 0) <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) char smem[2 * HBUF + NWS * WSTAGE + (BNL ? 8 * BNL_CMAX : 0)];
+    float* const bnl_tab = reinterpret_cast<float*>(smem + 2 * HBUF + NWS * WSTAGE);      // BNL: scale[BNL_CMAX], shift[BNL_CMAX], behind the rings
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -498,6 +503,10 @@ __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo
 
     const u32x4_t rx = make_srd(p.in, p.in_bytes);
     const u32x4_t rw = make_srd(p.wt, p.wt_bytes);
+    const u32x4_t ro = make_srd(p.bnl_out, p.bnl_out_bytes);      // BNL: where the blocks of channel tile 0 store the activation
+    // (ctile comes out of a float reciprocal, i.e. a vector register: made a scalar explicitly, or the branch on it counts as divergent and the
+    // SRD operand of the store inside it is no longer accepted as wave-uniform)
+    const bool bnl_wb = BNL != 0 && __builtin_amdgcn_readfirstlane((int)(ctile == 0 && p.bnl_out != nullptr)) != 0;
     const int lr = lane >> 3, slot = lane & 7;
     const unsigned pix_bytes = (unsigned)p.in_ld * ES;
     const unsigned tap_bytes = (unsigned)p.Cin * ES;
@@ -547,18 +556,18 @@ __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo
     char* const wbase = smem + 2 * HBUF;
     // ---- issue state: the next weight stage to fetch is (chunk iwc, first tap iwt) into ring slot iws
     int iwc = 0, iwt = 0, iws = 0;
-    auto w_piece = [&](int i) {                      // piece i of the stage: slice i / WI1 (a tap), rows of piece i % WI1
+    auto w_piece = [&](int i) __attribute__((always_inline)) {      // piece i of the stage: slice i / WI1 (a tap), rows of piece i % WI1
         const int ts = i / WI1, ii = i % WI1;
         const bool live = iwc < nchunks;
         const int soff = (iwt + ts) * (int)tap_bytes + iwc * KB;
         dma16(rw, wbase + iws * WSTAGE + ts * WSLICE + (NIW >= NW ? ii * NW + wid : wid % NIW) * 1024, live ? woff[ii] : OOB_OFF, live ? soff : 0);
     };
-    auto w_advance = [&]() {
+    auto w_advance = [&]() __attribute__((always_inline)) {
         iwt += TPS;
         if (iwt == 9) { iwt = 0; ++iwc; }
         if (++iws == NWS) iws = 0;
     };
-    auto h_piece = [&](int i, int chunk) {            // piece i of the halo of `chunk` into buffer chunk & 1
+    auto h_piece = [&](int i, int chunk) __attribute__((always_inline)) {      // piece i of the halo of `chunk` into buffer chunk & 1
         const bool live = chunk < nchunks;
         dma16(rx, hbase + (chunk & 1) * HBUF + (i * NW + wid) * 1024, live ? hoff[i] : OOB_OFF, live ? chunk * KB : 0);
     };
@@ -572,12 +581,59 @@ __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo
         for (int i = 0; i < WI; ++i) w_piece(i);
         w_advance();
     }
+    // BNL: pieces [i0, i1) of the halo of `chunk` (landed: the caller's counted wait covers them), rewritten in place by this wave
+    auto bnl_fixup = [&](int i0, int i1, int chunk) __attribute__((always_inline)) {
+        if constexpr (BNL != 0) {
+            if (chunk < nchunks) {
+#pragma unroll
+                for (int i = 0; i < XH; ++i) {
+                    if (i >= i0 && i < i1) {
+                        const bool ok = hoff[i] != OOB_OFF;        // outside the image (or past the halo): the zeros stay
+                        char* ptr = hbase + (chunk & 1) * HBUF + (i * NW + wid) * 1024 + lane * 16;
+                        const int hp = (i * NW + wid) * 8 + lr;
+                        const int ch = chunk * 64 + ((slot ^ ((hp >> 1) & 7)) << 3);
+                        const uint4 v = *reinterpret_cast<uint4*>(ptr);
+                        float f[8];
+                        Vec16<T>::unpack(v, f);
+                        const float4 s0 = *reinterpret_cast<const float4*>(&bnl_tab[ch]), s1 = *reinterpret_cast<const float4*>(&bnl_tab[ch + 4]);
+                        const float4 h0 = *reinterpret_cast<const float4*>(&bnl_tab[BNL_CMAX + ch]), h1 = *reinterpret_cast<const float4*>(&bnl_tab[BNL_CMAX + ch + 4]);
+                        f[0] = fmaxf(fmaf(f[0], s0.x, h0.x), 0.f); f[1] = fmaxf(fmaf(f[1], s0.y, h0.y), 0.f);
+                        f[2] = fmaxf(fmaf(f[2], s0.z, h0.z), 0.f); f[3] = fmaxf(fmaf(f[3], s0.w, h0.w), 0.f);
+                        f[4] = fmaxf(fmaf(f[4], s1.x, h1.x), 0.f); f[5] = fmaxf(fmaf(f[5], s1.y, h1.y), 0.f);
+                        f[6] = fmaxf(fmaf(f[6], s1.z, h1.z), 0.f); f[7] = fmaxf(fmaf(f[7], s1.w, h1.w), 0.f);
+                        const uint4 t = Vec16<T>::pack(f);
+                        const uint4 o = make_uint4(ok ? t.x : v.x, ok ? t.y : v.y, ok ? t.z : v.z, ok ? t.w : v.w);
+                        *reinterpret_cast<uint4*>(ptr) = o;
+                        // the activation, once per pixel: the interior of the patch, from the blocks of channel tile 0 (the per-lane part of
+                        // the condition goes into the offset: bstore16)
+                        if (bnl_wb) {
+                            const int hy = hp / HCOLS, hx = hp - hy * HCOLS;
+                            const bool st = ok && hy >= 1 && hy <= PH && hx >= 1 && hx <= 16;
+                            bstore16(ro, st ? ((unsigned)((n * p.Hi + y0 - 1 + hy) * p.Wi + x0 - 1 + hx) * (unsigned)p.bnl_out_ld + (unsigned)ch) * ES : OOB_OFF, o);
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+    };
+    if constexpr (BNL != 0) {
+        // the coefficient table, behind the prologue's fills (the compiler's vmcnt(0) for these loads waits for those as well)
+        for (int c = tid; c < p.Cin; c += NW * 64) {
+            float sc, sh;
+            bn_fwd_coeffs(p.bnl, p.Cin, c, blockIdx.x == 0, sc, sh);
+            bnl_tab[c] = sc; bnl_tab[BNL_CMAX + c] = sh;
+        }
+        __syncthreads();
+    }
 
     int cst = 0;                                      // ring slot of the weight stage being consumed
     constexpr int NM = 2 * FM * FN * TPS;             // MFMAs per k-step and wave
     for (int c = 0; c < nchunks; ++c) {
         const char* hb = hbase + (c & 1) * HBUF;
-        auto step = [&](auto jj) {
+        // (always_inline: with the BNL pass the body outgrew the inliner's budget, and a lambda left as a CALL gets its captures through memory --
+        // the LDS-DMA statements inside need their wave-uniform operands in scalar registers)
+        auto step = [&](auto jj) __attribute__((always_inline)) {
             constexpr int j = decltype(jj)::value;
             // halo pieces this k-step issues, and those the NWS-2 k-steps before it issued: the operations younger than the
             // last piece of this k-step's weight stage are the NWS-2 later stages and those halo pieces
@@ -592,6 +648,14 @@ __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo
                 return h;
             }();
             wait_vmcnt<(NWS - 2) * WI + NH>();
+            if constexpr (BNL != 0) {
+                // this wait covers the halo pieces issued NWS - 1 k-steps ago: at k-step 0 the last pieces of THIS chunk's halo (all of them for
+                // the first chunk, which the prologue fetched), from k-step NWS - 1 on pieces of the next chunk's
+                constexpr int jp = (j - (NWS - 1) + SPC) % SPC;
+                constexpr int F0 = jp * HPS < XH ? jp * HPS : XH, F1 = (jp + 1) * HPS < XH ? (jp + 1) * HPS : XH;
+                if (j == 0) bnl_fixup(c == 0 ? 0 : F0, c == 0 ? XH : F1, c);
+                else if (j >= NWS - 1) bnl_fixup(F0, F1, c + 1);
+            }
             raw_barrier();
             const char* wb = wbase + cst * WSTAGE;
 #pragma unroll
@@ -751,24 +815,25 @@ int launch_dma(const ConvK& k0, int mode, hipStream_t st) {
     return msc_check_launch("conv_igemm_dma");
 }
 
-template <typename T, int PH, int TC, int WP, int WC, int NWS, int TPS = 1, int MINB = 1>
+template <typename T, int PH, int TC, int WP, int WC, int NWS, int TPS = 1, int MINB = 1, int BNL = 0>
 int launch_halo3(const ConvK& k0, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         ConvK k = k0;
         k.ntc = k.Cout / TC;
         k.xcd_order = xcd_order_enabled() ? 1 : 0;
         const int blocks = k.N * (k.Ho / PH) * (k.Wo / 16) * k.ntc;
-        hipLaunchKernelGGL((conv3x3_halo_dma_kernel<T, PH, TC, WP, WC, NWS, TPS, MINB>), dim3(blocks), dim3(WP * WC * 64), 0, st, k);
+        hipLaunchKernelGGL((conv3x3_halo_dma_kernel<T, PH, TC, WP, WC, NWS, TPS, MINB, BNL>), dim3(blocks), dim3(WP * WC * 64), 0, st, k);
     }
     return msc_check_launch("conv3x3_halo_dma");
 }
 
-// in_bn (BatchNorm + ReLU of the input on load): the implicit-GEMM kernel's 1x1 form on the two tiles it was measured on
-static inline bool cfg_has_bnl(int cfg) { return cfg == 1 || cfg == 33; }
+// in_bn (BatchNorm + ReLU of the input on load): the implicit-GEMM kernel's 1x1 form on the two tiles it was measured on (1, 33) and three
+// tiles of the 3x3 halo kernel (42, 51, 53)
+static inline bool cfg_has_bnl(int cfg, int kh) { return kh == 1 ? (cfg == 1 || cfg == 33) : (cfg == 42 || cfg == 51 || cfg == 53); }
 bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
     if (cfg < 1 || cfg > N_CONV_CFG) return false;
-    if (k.bnl.slots && !(cfg_has_bnl(cfg) && es == 2 && k.mode == 0 && k.KH == 1 && k.KW == 1 && k.stride == 1 && k.pad == 0 && !k.span_bytes &&
-                         k.ksplit == 1 && k.Cin <= BNL_CMAX && k.Cin % 8 == 0)) return false;
+    if (k.bnl.slots && !(cfg_has_bnl(cfg, k.KH) && es == 2 && k.mode == 0 && k.KH == k.KW && (k.KH == 1 || k.KH == 3) && k.stride == 1 && k.pad == k.KH / 2 &&
+                         !k.flip && !k.span_bytes && k.ksplit == 1 && k.Cin <= BNL_CMAX && k.Cin % 64 == 0)) return false;
     if (k.fin_w && cfg != CFG_HALO) return false;           // the fused final 1x1 lives in the 32-channel halo kernel's epilogue only
     if (k.sz && cfg >= 29 && cfg <= 32) return false;       // the residual-join epilogue (stats_z) is not compiled for the 32-fragment wave tiles
     if (k.ksplit > 1 && (cfg == CFG_HALO || cfg == CFG_HALO_T || cfg == CFG_STREAM || cfg == CFG_STEM || cfg_is_halo3(cfg))) return false;      // split-K: the implicit-GEMM kernel only
@@ -810,7 +875,7 @@ int pick_cfg(const ConvK& k) {
 
 template <typename T>
 int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
-    if (cfg == 0) cfg = k.fin_w ? CFG_HALO : k.bnl.slots ? (k.Cout % 256 == 0 ? 33 : 1) : pick_cfg(k);
+    if (cfg == 0) cfg = k.fin_w ? CFG_HALO : k.bnl.slots ? (k.KH == 3 ? (k.Ho % 16 == 0 && k.Cout % 128 == 0 ? 42 : 51) : k.Cout % 256 == 0 ? 33 : 1) : pick_cfg(k);
     if (!conv_cfg_ok(k, (int)sizeof(T), cfg)) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: configuration %d is not valid for this layer", cfg);
     if (cfg == CFG_HALO) return halo32_conv_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     if (cfg == CFG_HALO_T) return halo32_deconv_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
@@ -818,7 +883,10 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
     if (cfg == CFG_STREAM) return conv1x1_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     if (k.bnl.slots) {
         if (cfg == 1) return launch_dma<T, 256, 128, 4, 2, 128, 3, 0, 1>(k, mode, st);
-        return launch_dma<T, 128, 256, 2, 4, 128, 3, 0, 1>(k, mode, st);
+        if (cfg == 33) return launch_dma<T, 128, 256, 2, 4, 128, 3, 0, 1>(k, mode, st);
+        if (cfg == 42) return launch_halo3<T, 16, 128, 4, 2, 3, 1, 1, 1>(k, st);
+        if (cfg == 51) return launch_halo3<T, 8, 64, 4, 2, 3, 3, 1, 1>(k, st);
+        return launch_halo3<T, 16, 64, 4, 2, 2, 3, 1, 1>(k, st);
     }
     switch (cfg) {
         case 1: return launch_dma<T, 256, 128, 4, 2, 128, 3>(k, mode, st);
@@ -921,7 +989,7 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
         return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: split-K needs mode 0, no statistics, a 16-byte aligned fp32 workspace and at most 64 slices");
     if (d->final_w && (d->res || d->stats || (!d->final_logits && !d->final_probs)))
         return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: the fused final 1x1 takes no residual / statistics and needs a logits or probabilities output");
-    k->bnl = BnFwdFin{}; k->bnl_out = nullptr; k->bnl_out_ld = 0;
+    k->bnl = BnFwdFin{}; k->bnl_out = nullptr; k->bnl_out_ld = 0; k->bnl_out_bytes = 0;
     if (d->in_bn) {
         const msc_bn_input* b = d->in_bn;
         if (!b->slots || !b->scale || !b->shift || b->count <= 0 || es != 2 || (b->out && ((b->out_ld * es) % 16 || ((uintptr_t)b->out & 15))))
@@ -929,6 +997,9 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
         k->bnl = BnFwdFin{b->slots, (double)b->count, b->gamma, b->beta, b->eps, b->momentum, b->running_mean, b->running_var, b->scale, b->shift,
                           b->save_mean, b->save_invstd};
         k->bnl_out = (char*)b->out; k->bnl_out_ld = b->out_ld;
+        const long out_b = (((long)d->N * d->Hi * d->Wi - 1) * b->out_ld + d->Cin) * es;
+        if (b->out && out_b >= 0x7fffffffL) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: in_bn activation beyond 2 GiB (%ld bytes)", out_b);
+        k->bnl_out_bytes = b->out ? (unsigned)out_b : 0;
     }
     k->span_bytes = 0;
     if (d->mode == 1) {

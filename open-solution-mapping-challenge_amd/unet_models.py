@@ -1294,14 +1294,16 @@ class _Builder:
                 elif self.bottleneck_fused(base, cur, blk, out):
                     pass
                 else:
-                    a = self.act(hh, ww, planes)
-                    self.conv_bn(base + '.conv1', cur, blk.conv1, blk.bn1, 1, True, a)
-                    b = self.act(ho, wo, planes)
-                    # bn2 + ReLU applied by conv3 (1x1, stride 1) on load instead of a msc_bn_apply launch (ABI v9; MSC_BN_ON_LOAD=1):
-                    # measured +1.3-2.5 us on conv3 against 3.8-9 us of the launch (profiles/r4_run28_bn_on_load_probe.txt)
+                    # bn1 / bn2 + ReLU applied by the consuming conv on load instead of msc_bn_apply launches (ABI v9; MSC_BN_ON_LOAD=1): conv3 (1x1,
+                    # stride 1) always, conv2 where it is a stride-1 3x3 on a map the halo-tile kernel takes (8 x 16 pixel patches).  Measured for
+                    # conv3: +1.3-2.5 us against 3.8-9 us of the launch (profiles/r4_run28_bn_on_load_probe.txt)
                     on_load = self.bn_on_load and planes <= 512
-                    pend = self.conv_bn(base + '.conv2', a, blk.conv2, blk.bn2, s, True, b, defer=on_load)
-                    self.conv_bn(base + '.conv3', b, blk.conv3, blk.bn3, 1, True, out, res=idt, pend=pend)
+                    a = self.act(hh, ww, planes)
+                    pend1 = self.conv_bn(base + '.conv1', cur, blk.conv1, blk.bn1, 1, True, a,
+                                         defer=on_load and s == 1 and ww % 16 == 0 and hh % 8 == 0 and _os_env.environ.get('MSC_BN_ON_LOAD_3X3', '1') != '0')
+                    b = self.act(ho, wo, planes)
+                    pend2 = self.conv_bn(base + '.conv2', a, blk.conv2, blk.bn2, s, True, b, defer=on_load, pend=pend1)
+                    self.conv_bn(base + '.conv3', b, blk.conv3, blk.bn3, 1, True, out, res=idt, pend=pend2)
                 cur = out
         c5 = cur
 

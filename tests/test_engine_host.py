@@ -49,9 +49,9 @@ def test_eval_and_train_match_oracle(interpreted, depth):
 
 
 def test_bn_on_load_launch_list_matches_oracle_and_drops_the_apply_launches(interpreted, monkeypatch):
-    """MSC_BN_ON_LOAD=1 (ABI v9): bn2 + ReLU of every unfused Bottleneck ride on conv3's operand fetch (msc_conv_desc.in_bn) -- 33 msc_bn_apply
-    launches fewer for ResNet101, the same loss, gradients and running statistics as the oracle (the activation the weight gradient reads is
-    stored by the consuming conv)"""
+    """MSC_BN_ON_LOAD=1 (ABI v9): bn2 + ReLU of every unfused Bottleneck ride on conv3's operand fetch (msc_conv_desc.in_bn), bn1 + ReLU on
+    conv2's where that is a stride-1 3x3 on a 16-pixel-wide map (layer1 at 64x64 input) -- 33 + 3 msc_bn_apply launches fewer for ResNet101, the
+    same loss, gradients and running statistics as the oracle (the activation the weight gradient reads is stored by the consuming conv)"""
     x = unet_ref.synthetic_batch(2, 64, 64)
     tgt = losses_ref.synthetic_target(2, 64, 64)
     counts = {}
@@ -74,8 +74,8 @@ def test_bn_on_load_launch_list_matches_oracle_and_drops_the_apply_launches(inte
         for (n, b), (_, b2) in zip(sorted(ref.named_buffers()), sorted(net.named_buffers())):
             if 'running' in n:
                 assert (b - b2).abs().max() < 1e-5, n
-    assert counts['0'][1] == 0 and counts['1'][1] == 33
-    assert counts['0'][0] - counts['1'][0] == 33
+    assert counts['0'][1] == 0 and counts['1'][1] == 36
+    assert counts['0'][0] - counts['1'][0] == 36
 
 
 def test_state_dict_roundtrip_and_flat_views(interpreted):

@@ -370,25 +370,28 @@ def test_every_kernel_configuration_is_correct(dtype, cin, cout, k, stride, hw, 
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('cin,cout,hw,n,cfg', [(256, 1024, 16, 4, 0), (256, 1024, 16, 4, 1), (256, 1024, 16, 4, 33), (64, 256, 24, 3, 1), (128, 512, 20, 2, 33),
-                                               (512, 2048, 8, 5, 0), (128, 128, 9, 3, 1)])
-def test_conv_applies_batchnorm_and_relu_to_its_input_on_load(dtype, cin, cout, hw, n, cfg):
+@pytest.mark.parametrize('cin,cout,hw,n,cfg,k', [(256, 1024, 16, 4, 0, 1), (256, 1024, 16, 4, 1, 1), (256, 1024, 16, 4, 33, 1), (64, 256, 24, 3, 1, 1),
+                                                 (128, 512, 20, 2, 33, 1), (512, 2048, 8, 5, 0, 1), (128, 128, 9, 3, 1, 1),
+                                                 (256, 256, 16, 3, 0, 3), (256, 256, 16, 3, 51, 3), (256, 256, 16, 3, 53, 3), (64, 128, 32, 2, 42, 3),
+                                                 (128, 128, 32, 2, 51, 3), (64, 128, 48, 1, 53, 3)])
+def test_conv_applies_batchnorm_and_relu_to_its_input_on_load(dtype, cin, cout, hw, n, cfg, k):
     """msc_conv_desc.in_bn (ABI v9): the 1x1 conv reads the RAW output y of a training-mode BatchNorm'd conv, finalises that layer's
     coefficients from its statistics slots and applies relu(scale*y + shift) to the operand in LDS -- against torch batch_norm + relu + conv2d,
     with the coefficients / saved statistics / running statistics msc_bn_apply would publish and the activation stored for the weight gradient;
-    ragged pixel counts, pixel tiles that end inside a block, every tile that has the path"""
+    ragged pixel counts, pixel tiles that end inside a block, every tile that has the path; 3x3 (halo-tile kernel): the zero padding is of
+    the activation, the halo of a patch is transformed once for the nine taps"""
     import ctypes as C
     from mapping_challenge_amd import _lib
     import hip_ops as ops
     lib = _lib.load()
     y = (rnd((n, cin, hw, hw), dtype, 1) * 1.5 + 0.25).to(dtype).float()
-    w = rnd((cout, cin, 1, 1), dtype, 2, (2.0 / cin) ** 0.5)
+    w = rnd((cout, cin, k, k), dtype, 2, (2.0 / (cin * k * k)) ** 0.5)
     gamma, beta = rnd((cin,), torch.float32, 3) * 0.3 + 1.0, rnd((cin,), torch.float32, 4) * 0.2
     rm0, rv0 = rnd((cin,), torch.float32, 5) * 0.1, rnd((cin,), torch.float32, 6).abs() + 0.5
     rm, rv = rm0.clone(), rv0.clone()
     a_ref = torch.relu(F.batch_norm(y, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5))      # updates rm / rv
     a16 = a_ref.to(dtype).float()
-    ref = F.conv2d(a16, w)
+    ref = F.conv2d(a16, w, padding=k // 2)
     yd = nhwc(y, dtype)
     yf = yd.float().double()
     count = n * hw * hw
@@ -406,7 +409,7 @@ def test_conv_applies_batchnorm_and_relu_to_its_input_on_load(dtype, cin, cout, 
     bi.out, bi.out_ld = act.data_ptr(), cin
     wd = w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
     out = torch.zeros((n, hw, hw, cout), dtype=dtype, device='cuda')
-    ops.conv_igemm(yd, wd, out, cfg=cfg, in_bn=bi)
+    ops.conv_igemm(yd, wd, out, pad=k // 2, cfg=cfg, in_bn=bi)
     torch.cuda.synchronize()
     # the coefficients (the 16-bit y the kernel saw defines the statistics)
     mean = yf.mean((0, 1, 2)); var = yf.var((0, 1, 2), unbiased=False)
@@ -423,9 +426,15 @@ def test_conv_applies_batchnorm_and_relu_to_its_input_on_load(dtype, cin, cout, 
     # not for the shapes / options it does not take
     bad = _lib.ConvDesc()
     bad.in_, bad.wt, bad.out, bad.in_ld, bad.out_ld, bad.dtype = yd.data_ptr(), wd.data_ptr(), out.data_ptr(), cin, cout, ops._dt(yd)
-    bad.N, bad.Hi, bad.Wi, bad.Cin, bad.Ho, bad.Wo, bad.Cout, bad.KH, bad.KW, bad.stride = n, hw, hw, cin, hw, hw, cout, 1, 1, 1
+    bad.N, bad.Hi, bad.Wi, bad.Cin, bad.Ho, bad.Wo, bad.Cout, bad.KH, bad.KW, bad.stride, bad.pad = n, hw, hw, cin, hw, hw, cout, k, k, 1, k // 2
     bad.in_bn = C.addressof(bi)
-    assert [c for c in range(1, lib.msc_conv_num_cfgs() + 1) if lib.msc_conv_cfg_ok(C.byref(bad), c)] == ([1] if cout % 256 else [1, 33])
+    valid = [c for c in range(1, lib.msc_conv_num_cfgs() + 1) if lib.msc_conv_cfg_ok(C.byref(bad), c)]
+    if k == 1:
+        assert valid == ([1] if cout % 256 else [1, 33])
+    else:
+        assert valid and set(valid) <= {42, 51, 53} and (cfg == 0 or cfg in valid)
+    bad.stride = 2
+    assert not any(lib.msc_conv_cfg_ok(C.byref(bad), c) for c in range(1, lib.msc_conv_num_cfgs() + 1))
 
 
 @pytest.mark.parametrize('dtype', DT)
