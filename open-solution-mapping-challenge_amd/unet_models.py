@@ -938,6 +938,9 @@ class _Builder:
         y = self.act(out.H, out.W, cout)
         if pend is not None:           # the producer's BatchNorm + ReLU ride on this conv's operand fetch; `x` (its activation) is written on the way
             d = self.conv_desc(Act(pend._y), w, y, want_stats=True, in_bn=pend, **geo)
+            if self.dev.type == 'cuda' and not any(lib.msc_conv_cfg_ok(C.byref(d), c) for c in range(1, lib.msc_conv_num_cfgs() + 1)):
+                raise _lib.MscError('%s: no kernel configuration applies BatchNorm on load for this layer (N=%d, %dx%d, %d -> %d channels); '
+                                    'run with MSC_BN_ON_LOAD=0' % (name, self.N, x.H, x.W, x.C, cout))
         else:
             d = self.conv_desc(x, w, y, want_stats=True, **geo)
         # batch statistics: the conv epilogue adds (sum, sum of squares) into one slot per XCD; bn_apply sums the slots in its
