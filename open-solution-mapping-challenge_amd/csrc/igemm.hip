@@ -332,7 +332,10 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
                 f[2] = fmaxf(fmaf(f[2], s0.z, h0.z), 0.f); f[3] = fmaxf(fmaf(f[3], s0.w, h0.w), 0.f);
                 f[4] = fmaxf(fmaf(f[4], s1.x, h1.x), 0.f); f[5] = fmaxf(fmaf(f[5], s1.y, h1.y), 0.f);
                 f[6] = fmaxf(fmaf(f[6], s1.z, h1.z), 0.f); f[7] = fmaxf(fmaf(f[7], s1.w, h1.w), 0.f);
-                v = Vec16<T>::pack(f);
+                // rows past the last pixel keep the zeros the DMA wrote: the statistics epilogue sums every row of the tile and relies on
+                // their accumulators being zero (conv_epilogue_body, KIND 3)
+                const uint4 t = Vec16<T>::pack(f);
+                v = make_uint4(xv[i] ? t.x : v.x, xv[i] ? t.y : v.y, xv[i] ? t.z : v.z, xv[i] ? t.w : v.w);
                 *reinterpret_cast<uint4*>(ptr) = v;
                 if (ctile == 0 && p.bnl_out && xv[i])      // the activation itself, once per pixel tile: pixel m0 + row, channels ch .. ch + 7
                     store16(p.bnl_out + ((long)(m0 + (i * NW + wid) * RPI + lr) * p.bnl_out_ld + ch) * ES, v);

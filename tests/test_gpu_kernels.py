@@ -409,8 +409,12 @@ def test_conv_applies_batchnorm_and_relu_to_its_input_on_load(dtype, cin, cout, 
     bi.out, bi.out_ld = act.data_ptr(), cin
     wd = w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
     out = torch.zeros((n, hw, hw, cout), dtype=dtype, device='cuda')
-    ops.conv_igemm(yd, wd, out, pad=k // 2, cfg=cfg, in_bn=bi)
+    st = torch.zeros((8, cout, 2), dtype=torch.float64, device='cuda')      # the consumer's own BatchNorm statistics ride in its epilogue as usual
+    ops.conv_igemm(yd, wd, out, pad=k // 2, cfg=cfg, in_bn=bi, stats=st)
     torch.cuda.synchronize()
+    # ... and see only the real pixels (tile rows past the last pixel must stay zero through the on-load pass)
+    assert torch.allclose(st.sum(0)[:, 0].cpu().float(), ref.sum((0, 2, 3)), rtol=2e-2, atol=2e-2 * ref.abs().sum((0, 2, 3)).max().item())
+    assert torch.allclose(st.sum(0)[:, 1].cpu().float(), (ref * ref).sum((0, 2, 3)), rtol=3e-2)
     # the coefficients (the 16-bit y the kernel saw defines the statistics)
     mean = yf.mean((0, 1, 2)); var = yf.var((0, 1, 2), unbiased=False)
     inv = 1.0 / torch.sqrt(var + 1e-5)
