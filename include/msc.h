@@ -92,7 +92,26 @@ typedef struct msc_conv_desc {
      * positive), stats_z_ld BYTES per pixel -- the join's gradient is masked without re-reading the 16-bit activation */
     int32_t stats_z_bits;
     int32_t reserved0;
+    /* ABI v9: `in` is the RAW output y of a training-mode BatchNorm'd conv (see msc_bn_input below); NULL: `in` is used as it is */
+    const struct msc_bn_input* in_bn;
 } msc_conv_desc;
+/* BatchNorm + ReLU applied to a convolution's input ON LOAD (ABI v9; training; torchvision Bottleneck: bn2 + relu in front of conv3,
+ * src/unet_models.py:345-351,365-371): instead of a msc_bn_apply launch that reads y and writes relu(bn(y)) for the next conv to read,
+ * that conv fetches y, finalises the layer's coefficients from its statistics slots (what msc_bn_apply's prologue does, same arithmetic)
+ * and rewrites every landed operand stage in LDS.  The fields are msc_bn_apply's; `out` (may be NULL) receives the activation relu(scale*y +
+ * shift), stored once per pixel by the blocks of the first channel tile -- the weight gradient of the consuming conv reads it.
+ * Supported: mode 0, stride 1, 1x1 (cfg 0 / 1 / 33) or 3x3 with pad 1 (the halo-tile kernel: cfg 0 / 42 / 51 / 53; the zero padding is of the
+ * activation, not of y), 16-bit dtype, Cin % 64 == 0, Cin <= 512, one image range per launch; msc_conv_cfg_ok tells. */
+typedef struct msc_bn_input {
+    const double* slots;      /* [MSC_BN_SLOTS][Cin][2] partial (sum, sum of squares) of y, as msc_conv_igemm's `stats` leaves them */
+    int64_t count;            /* pixels the statistics are over */
+    const float* gamma; const float* beta;
+    float eps, momentum;
+    float* running_mean; float* running_var;            /* updated (unbiased variance), may be NULL */
+    float* scale; float* shift;                         /* f32[Cin] out: the coefficients, for the backward */
+    float* save_mean; float* save_invstd;               /* f32[Cin] out, may be NULL */
+    void* out; int64_t out_ld;                          /* the activation (dtype, NHWC, out_ld elements per pixel), may be NULL */
+} msc_bn_input;
 int msc_conv_igemm(const msc_conv_desc* d, void* stream);
 int msc_conv_stats_slices(const msc_conv_desc* d);   /* depends on d->cfg */
 /* configurations of the conv kernel that are valid for a descriptor (for per-layer timing by the caller) */

@@ -32,7 +32,15 @@ class ConvDesc(C.Structure):
                 ('final_w', C.c_void_p), ('final_b', C.c_void_p), ('final_logits', C.c_void_p), ('final_probs', C.c_void_p),
                 ('final_skip_store', C.c_int32), ('splitk', C.c_int32), ('splitk_ws', C.c_void_p),
                 ('stats_z', C.c_void_p), ('stats_z_ld', C.c_int64),        # ABI v6: stats_kind 1 masked by a stored activation, residual allowed
-                ('stats_z_bits', C.c_int32), ('reserved0', C.c_int32)]     # ABI v7: stats_z is msc_bn_apply's ReLU byte mask
+                ('stats_z_bits', C.c_int32), ('reserved0', C.c_int32),     # ABI v7: stats_z is msc_bn_apply's ReLU byte mask
+                ('in_bn', C.c_void_p)]                                     # ABI v9: BnInput* -- BatchNorm + ReLU of the input applied on load
+
+
+class BnInput(C.Structure):
+    _fields_ = [('slots', C.c_void_p), ('count', C.c_int64), ('gamma', C.c_void_p), ('beta', C.c_void_p),
+                ('eps', C.c_float), ('momentum', C.c_float), ('running_mean', C.c_void_p), ('running_var', C.c_void_p),
+                ('scale', C.c_void_p), ('shift', C.c_void_p), ('save_mean', C.c_void_p), ('save_invstd', C.c_void_p),
+                ('out', C.c_void_p), ('out_ld', C.c_int64)]
 
 
 class WgradDesc(C.Structure):

@@ -106,6 +106,41 @@ __device__ __forceinline__ void store16(void* p, uint4 v) {
 #endif
 }
 
+// Training-mode BatchNorm2d coefficients of one channel from the per-XCD partial sums (double slots[MSC_BN_SLOTS][C][2] = sum, sum of squares):
+// batch mean / biased variance -> scale = gamma * invstd, shift = beta - mean * scale.  `publish` (one block per launch): the coefficients,
+// save_mean / save_invstd for the backward and the running statistics (unbiased variance) go to memory.  Shared by msc_bn_apply and by the
+// convolution that applies a BatchNorm to its INPUT on load (msc_conv_desc.in_bn): the two paths produce the same coefficients.
+struct BnFwdFin {
+    const double* slots; double count; const float* gamma; const float* beta; float eps, momentum;
+    float* running_mean; float* running_var; float* scale; float* shift; float* save_mean; float* save_invstd;
+};
+__device__ __forceinline__ void bn_fwd_coeffs(const BnFwdFin& f, int C, int c, bool publish, float& sc, float& sh) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int x = 0; x < MSC_BN_SLOTS; ++x) {
+        const double2 v = *reinterpret_cast<const double2*>(f.slots + ((long)x * C + c) * 2);
+        s1 += v.x; s2 += v.y;
+    }
+    const double mean = s1 / f.count;
+    double var = s2 / f.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+    sc = g * invstd;
+    sh = b - (float)mean * sc;
+    if (publish) {
+        f.scale[c] = sc;
+        f.shift[c] = sh;
+        if (f.save_mean) f.save_mean[c] = (float)mean;
+        if (f.save_invstd) f.save_invstd[c] = invstd;
+        if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
+        if (f.running_var) {
+            const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+            f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
+        }
+    }
+}
+
 // 16-byte vector of T as floats: 4 x f32 or 8 x bf16
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {

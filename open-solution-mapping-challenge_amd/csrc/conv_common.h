@@ -24,6 +24,10 @@ struct ConvK {
     int mode;                        // 0 gather, 1 transposed
     int xcd_order;                   // 1: XCD-aware tile order, 0: pixel tile fastest (for A/B measurements)
     float rcp_hw, rcp_w;             // 1/(Hq*Wq), 1/Wq for the pixel decode of the DMA kernel (a launch has fewer than 2^24 pixels)
+    // msc_conv_desc.in_bn (ABI v9; appended, so that the layout the other kernels read is untouched): `in` is the RAW output of a training-mode
+    // BatchNorm'd conv -- the kernel finalises that layer's coefficients from bnl.slots and applies relu(scale * y + shift) to the operand tile
+    // in LDS; the blocks of channel tile 0 also store the activation to bnl_out (bnl_out_ld elements per pixel; may be null)
+    BnFwdFin bnl; char* bnl_out; long bnl_out_ld; unsigned bnl_out_bytes;
 };
 
 // floor(m / d) through the float reciprocal, exact for m < 2^24 (one correction step either way)

@@ -54,5 +54,15 @@ __device__ __forceinline__ void dma16(u32x4_t srd, char* lds_wave_base, unsigned
                  : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
                  : "memory");
 }
+// 16 bytes per lane to buffer offset `voff`; a lane with voff = OOB_OFF stores nothing (range-checked raw buffer) -- a per-lane condition
+// without a divergent branch (behind one, hipcc no longer proves the operands of the LDS-DMA statements that follow wave-uniform).  The
+// s_nop covers the hazard of overwriting the data registers of a store wider than 64 bits right after it (the compiler does not see it).
+__device__ __forceinline__ void bstore16(u32x4_t srd, unsigned voff, uint4 v) {
+    u32x4_t t, r;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    r.x = __builtin_amdgcn_readfirstlane(srd.x); r.y = __builtin_amdgcn_readfirstlane(srd.y);      // (uniform already; spelled out for the compiler)
+    r.z = __builtin_amdgcn_readfirstlane(srd.z); r.w = __builtin_amdgcn_readfirstlane(srd.w);
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(t), "v"(voff), "s"(r) : "memory");
+}
 
 }  // namespace

@@ -196,11 +196,6 @@ __device__ __forceinline__ void bn_block(int nct, int xcd_order, int& pb, int& c
     ct = wgid - pb * nct;
 }
 
-struct BnFwdFin {
-    const double* slots; double count; const float* gamma; const float* beta; float eps, momentum;
-    float* running_mean; float* running_var; float* scale; float* shift; float* save_mean; float* save_invstd;
-};
-
 template <typename T, int CT>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, long y_ld, const T* __restrict__ res, long res_ld,
                                                        T* __restrict__ out, long out_ld, BnFwdFin f, int relu, long pixels, int C, long ppb,
@@ -214,30 +209,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
         const int c = c0 + tid;
         float sc, sh;
         if (f.slots) {
-            double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-            for (int x = 0; x < MSC_BN_SLOTS; ++x) {
-                const double2 v = *reinterpret_cast<const double2*>(f.slots + ((long)x * C + c) * 2);
-                s1 += v.x; s2 += v.y;
-            }
-            const double mean = s1 / f.count;
-            double var = s2 / f.count - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
-            const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
-            sc = g * invstd;
-            sh = b - (float)mean * sc;
-            if (pb == 0) {
-                f.scale[c] = sc;
-                f.shift[c] = sh;
-                if (f.save_mean) f.save_mean[c] = (float)mean;
-                if (f.save_invstd) f.save_invstd[c] = invstd;
-                if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
-                if (f.running_var) {
-                    const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
-                    f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
-                }
-            }
+            bn_fwd_coeffs(f, C, c, pb == 0, sc, sh);
         } else {                        // coefficients given (no statistics to finalise)
             sc = f.scale[c]; sh = f.shift[c];
         }

@@ -73,7 +73,15 @@ template <int KB> __device__ __forceinline__ int swz_frag(int pl) {      // key 
 // ABL (probes/conv_ablate.hip only; 0 in the product): bit 0 = no MFMA (fragments still read), bit 1 = no DMA after the
 // prologue (compute runs on whatever the ring holds), bit 2 = no fragment reads and no MFMA, bit 3 = no barrier,
 // bit 4 = scheduling barriers around every DMA piece (pins its place between the MFMAs)
-template <typename T, int TP, int TC, int WP, int WC, int MODE, int NST, int KB, int ABL = 0>
+// BNL (msc_conv_desc.in_bn, 1x1 / stride 1, 16-bit): the input is the raw output of a training-mode BatchNorm'd conv.  Each wave rewrites the
+// pixel-tile pieces IT fetched with relu(scale * y + shift), in LDS, right after its own counted wait and before the k-step's barrier (its
+// own DMA has landed by then and nobody reads the stage before the barrier: no second barrier).  The coefficients are finalised from the
+// producer's statistics slots into an LDS table behind the prologue's fills (block 0 publishes them and updates the running statistics: what
+// msc_bn_apply's prologue does); the blocks of channel tile 0 store what they transformed -- the activation the weight gradient reads --
+// from the registers of the pass.  Measured before it was built (probes/bn_on_load_probe.hip, profiles/r4_run28_bn_on_load_probe.txt): +1.3-2.5 us
+// per launch on the 256x128 / 128x256 tiles against 3.8-9 us of the msc_bn_apply launch it replaces; same bits.
+constexpr int BNL_CMAX = 512;        // input channels the coefficient table holds (2 x 2 KB of LDS next to the ring)
+template <typename T, int TP, int TC, int WP, int WC, int MODE, int NST, int KB, int ABL = 0, int BNL = 0>
 __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
     constexpr int ES = sizeof(T);
     constexpr int NW = WP * WC;                  // waves per block
@@ -90,7 +98,10 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
     constexpr int LPW = XI + WI;                 // DMA instructions per wave per stage, uniform over waves
     static_assert(NIX % NW == 0 || NIX < NW, "pixel tile / wave count");
     static_assert(NST * STAGE <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + (BNL ? 8 * BNL_CMAX : 0)];
+    float* const bnl_tab = reinterpret_cast<float*>(smem + NST * STAGE);      // BNL: scale[BNL_CMAX], shift[BNL_CMAX] of the input channels, behind the ring
+    static_assert(!BNL || (NST * STAGE + 8 * BNL_CMAX <= 160 * 1024 && NIX >= NW && MODE == 0 && ES == 2),
+                  "BNL: LDS with the table; every pixel-tile piece has ONE fetching wave; gather mode; 16-bit");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -302,17 +313,58 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
         if (ISSUE) advance();
     };
 
+    // BNL: the pieces this wave fetched of the landed stage `cst` (k-step s = input channels s * KE ..), rewritten in place; lane's 16 bytes =
+    // source chunk xkc / 16 of pixel row (i * NW + wid) * RPI + lr
+    auto bnl_fixup = [&](int s, int cst) __attribute__((always_inline)) {
+        if constexpr (BNL != 0) {
+            char* sx = smem + cst * STAGE;
+            const int cb = s * KE;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                char* ptr = sx + (i * NW + wid) * 1024 + lane * 16;
+                uint4 v = *reinterpret_cast<uint4*>(ptr);
+                const int ch = cb + (int)(xkc[i] / ES);
+                float f[8];
+                Vec16<T>::unpack(v, f);
+                const float4 s0 = *reinterpret_cast<const float4*>(&bnl_tab[ch]), s1 = *reinterpret_cast<const float4*>(&bnl_tab[ch + 4]);
+                const float4 h0 = *reinterpret_cast<const float4*>(&bnl_tab[BNL_CMAX + ch]), h1 = *reinterpret_cast<const float4*>(&bnl_tab[BNL_CMAX + ch + 4]);
+                f[0] = fmaxf(fmaf(f[0], s0.x, h0.x), 0.f); f[1] = fmaxf(fmaf(f[1], s0.y, h0.y), 0.f);
+                f[2] = fmaxf(fmaf(f[2], s0.z, h0.z), 0.f); f[3] = fmaxf(fmaf(f[3], s0.w, h0.w), 0.f);
+                f[4] = fmaxf(fmaf(f[4], s1.x, h1.x), 0.f); f[5] = fmaxf(fmaf(f[5], s1.y, h1.y), 0.f);
+                f[6] = fmaxf(fmaf(f[6], s1.z, h1.z), 0.f); f[7] = fmaxf(fmaf(f[7], s1.w, h1.w), 0.f);
+                // rows past the last pixel keep the zeros the DMA wrote: the statistics epilogue sums every row of the tile and relies on
+                // their accumulators being zero (conv_epilogue_body, KIND 3)
+                const uint4 t = Vec16<T>::pack(f);
+                v = make_uint4(xv[i] ? t.x : v.x, xv[i] ? t.y : v.y, xv[i] ? t.z : v.z, xv[i] ? t.w : v.w);
+                *reinterpret_cast<uint4*>(ptr) = v;
+                if (ctile == 0 && p.bnl_out && xv[i])      // the activation itself, once per pixel tile: pixel m0 + row, channels ch .. ch + 7
+                    store16(p.bnl_out + ((long)(m0 + (i * NW + wid) * RPI + lr) * p.bnl_out_ld + ch) * ES, v);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the rewritten pieces are in LDS before the barrier lets the others read them
+        }
+    };
     if (nsteps > 0) {
         if (icch != 0) set_tap(itap);            // a slice that starts inside a tap (issue() refreshes the offsets at chunk 0 only)
 #pragma unroll
         for (int st = 0; st < NST - 1; ++st)
             if (st < nsteps) issue();
+        if constexpr (BNL != 0) {
+            // the coefficient table, behind the prologue's fills (the compiler's vmcnt(0) for these loads waits for those as well); the first
+            // block publishes (every block computes the same values)
+            for (int c = tid; c < p.Cin; c += NW * 64) {
+                float sc, sh;
+                bn_fwd_coeffs(p.bnl, p.Cin, c, blockIdx.x == 0, sc, sh);
+                bnl_tab[c] = sc; bnl_tab[BNL_CMAX + c] = sh;
+            }
+            __syncthreads();
+        }
         int cstage = 0;
         const int nmain = nsteps - (NST - 1);    // k-steps that still have a stage to fetch
         int s = 0;
         for (; s < nmain; ++s) {
             // stage s must have landed; stages s+1 .. s+NST-2 may stay in flight
             wait_vmcnt<(NST - 2) * LPW>();
+            bnl_fixup(s, cstage);
             if (!(ABL & 8)) raw_barrier();       // everyone's DMA of stage s is in LDS, everyone is done with stage s-1
             kstep(std::true_type{}, cstage);
             if (++cstage == NST) cstage = 0;
@@ -320,6 +372,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
         for (; s < nsteps; ++s) {
             if (s + NST - 2 <= nsteps - 1) wait_vmcnt<(NST - 2) * LPW>();
             else wait_vmcnt<0>();
+            bnl_fixup(s, cstage);
             if (!(ABL & 8)) raw_barrier();
             kstep(std::false_type{}, cstage);
             if (++cstage == NST) cstage = 0;
@@ -403,7 +456,11 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 //   TPS taps per k-step (1 or 3): on the 16x16 maps a k-step of one tap is 257 MFMA cycles per SIMD between two barriers;
 //   a kernel row per k-step (weight stage = 3 slices) has 12 barriers per chunk-loop pass instead of 36.
 //   MINB = blocks per CU the register allocation has to allow (HIP's second launch bound counts waves per SIMD).
-template <typename T, int PH, int TC, int WP, int WC, int NWS, int TPS = 1, int MINB = 1>
+//   BNL (msc_conv_desc.in_bn, see conv_igemm_dma_kernel): the halo of a chunk is rewritten with relu(scale * y + shift) by the waves that
+//   fetched its pieces, at the k-step whose counted wait covers them (NWS - 1 k-steps after they were issued; the last ones at k-step 0 of the
+//   chunk that reads them, before its barrier).  Lanes whose pixel lies outside the image keep the zeros the DMA wrote (the padding is of the
+//   ACTIVATION); the blocks of channel tile 0 store the interior of what they transformed.
+template <typename T, int PH, int TC, int WP, int WC, int NWS, int TPS = 1, int MINB = 1, int BNL = 0>
 __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo_dma_kernel(ConvK p) {
     static_assert(sizeof(T) == 2, "16-bit types");
     static_assert(TPS == 1 || TPS == 3, "taps per k-step");
@@ -426,8 +483,9 @@ __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo
     static_assert(PH % WP == 0 && TC % (WC * 16) == 0, "wave tiling");
     static_assert(NWS - 1 <= SPC, "ring deeper than a chunk");
     static_assert(NIW % NW == 0 || (NIW < NW && TPS == 1), "weight tile / wave count");
-    static_assert(2 * HBUF + NWS * WSTAGE <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(16))) char smem[2 * HBUF + NWS * WSTAGE];
+    static_assert(2 * HBUF + NWS * WSTAGE + (BNL ? 8 * BNL_CMAX : 0) <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) char smem[2 * HBUF + NWS * WSTAGE + (BNL ? 8 * BNL_CMAX : 0)];
+    float* const bnl_tab = reinterpret_cast<float*>(smem + 2 * HBUF + NWS * WSTAGE);      // BNL: scale[BNL_CMAX], shift[BNL_CMAX], behind the rings
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -448,6 +506,10 @@ __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo
 
     const u32x4_t rx = make_srd(p.in, p.in_bytes);
     const u32x4_t rw = make_srd(p.wt, p.wt_bytes);
+    const u32x4_t ro = make_srd(p.bnl_out, p.bnl_out_bytes);      // BNL: where the blocks of channel tile 0 store the activation
+    // (ctile comes out of a float reciprocal, i.e. a vector register: made a scalar explicitly, or the branch on it counts as divergent and the
+    // SRD operand of the store inside it is no longer accepted as wave-uniform)
+    const bool bnl_wb = BNL != 0 && __builtin_amdgcn_readfirstlane((int)(ctile == 0 && p.bnl_out != nullptr)) != 0;
     const int lr = lane >> 3, slot = lane & 7;
     const unsigned pix_bytes = (unsigned)p.in_ld * ES;
     const unsigned tap_bytes = (unsigned)p.Cin * ES;
@@ -497,18 +559,18 @@ __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo
     char* const wbase = smem + 2 * HBUF;
     // ---- issue state: the next weight stage to fetch is (chunk iwc, first tap iwt) into ring slot iws
     int iwc = 0, iwt = 0, iws = 0;
-    auto w_piece = [&](int i) {                      // piece i of the stage: slice i / WI1 (a tap), rows of piece i % WI1
+    auto w_piece = [&](int i) __attribute__((always_inline)) {      // piece i of the stage: slice i / WI1 (a tap), rows of piece i % WI1
         const int ts = i / WI1, ii = i % WI1;
         const bool live = iwc < nchunks;
         const int soff = (iwt + ts) * (int)tap_bytes + iwc * KB;
         dma16(rw, wbase + iws * WSTAGE + ts * WSLICE + (NIW >= NW ? ii * NW + wid : wid % NIW) * 1024, live ? woff[ii] : OOB_OFF, live ? soff : 0);
     };
-    auto w_advance = [&]() {
+    auto w_advance = [&]() __attribute__((always_inline)) {
         iwt += TPS;
         if (iwt == 9) { iwt = 0; ++iwc; }
         if (++iws == NWS) iws = 0;
     };
-    auto h_piece = [&](int i, int chunk) {            // piece i of the halo of `chunk` into buffer chunk & 1
+    auto h_piece = [&](int i, int chunk) __attribute__((always_inline)) {      // piece i of the halo of `chunk` into buffer chunk & 1
         const bool live = chunk < nchunks;
         dma16(rx, hbase + (chunk & 1) * HBUF + (i * NW + wid) * 1024, live ? hoff[i] : OOB_OFF, live ? chunk * KB : 0);
     };
@@ -522,12 +584,59 @@ __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo
         for (int i = 0; i < WI; ++i) w_piece(i);
         w_advance();
     }
+    // BNL: pieces [i0, i1) of the halo of `chunk` (landed: the caller's counted wait covers them), rewritten in place by this wave
+    auto bnl_fixup = [&](int i0, int i1, int chunk) __attribute__((always_inline)) {
+        if constexpr (BNL != 0) {
+            if (chunk < nchunks) {
+#pragma unroll
+                for (int i = 0; i < XH; ++i) {
+                    if (i >= i0 && i < i1) {
+                        const bool ok = hoff[i] != OOB_OFF;        // outside the image (or past the halo): the zeros stay
+                        char* ptr = hbase + (chunk & 1) * HBUF + (i * NW + wid) * 1024 + lane * 16;
+                        const int hp = (i * NW + wid) * 8 + lr;
+                        const int ch = chunk * 64 + ((slot ^ ((hp >> 1) & 7)) << 3);
+                        const uint4 v = *reinterpret_cast<uint4*>(ptr);
+                        float f[8];
+                        Vec16<T>::unpack(v, f);
+                        const float4 s0 = *reinterpret_cast<const float4*>(&bnl_tab[ch]), s1 = *reinterpret_cast<const float4*>(&bnl_tab[ch + 4]);
+                        const float4 h0 = *reinterpret_cast<const float4*>(&bnl_tab[BNL_CMAX + ch]), h1 = *reinterpret_cast<const float4*>(&bnl_tab[BNL_CMAX + ch + 4]);
+                        f[0] = fmaxf(fmaf(f[0], s0.x, h0.x), 0.f); f[1] = fmaxf(fmaf(f[1], s0.y, h0.y), 0.f);
+                        f[2] = fmaxf(fmaf(f[2], s0.z, h0.z), 0.f); f[3] = fmaxf(fmaf(f[3], s0.w, h0.w), 0.f);
+                        f[4] = fmaxf(fmaf(f[4], s1.x, h1.x), 0.f); f[5] = fmaxf(fmaf(f[5], s1.y, h1.y), 0.f);
+                        f[6] = fmaxf(fmaf(f[6], s1.z, h1.z), 0.f); f[7] = fmaxf(fmaf(f[7], s1.w, h1.w), 0.f);
+                        const uint4 t = Vec16<T>::pack(f);
+                        const uint4 o = make_uint4(ok ? t.x : v.x, ok ? t.y : v.y, ok ? t.z : v.z, ok ? t.w : v.w);
+                        *reinterpret_cast<uint4*>(ptr) = o;
+                        // the activation, once per pixel: the interior of the patch, from the blocks of channel tile 0 (the per-lane part of
+                        // the condition goes into the offset: bstore16)
+                        if (bnl_wb) {
+                            const int hy = hp / HCOLS, hx = hp - hy * HCOLS;
+                            const bool st = ok && hy >= 1 && hy <= PH && hx >= 1 && hx <= 16;
+                            bstore16(ro, st ? ((unsigned)((n * p.Hi + y0 - 1 + hy) * p.Wi + x0 - 1 + hx) * (unsigned)p.bnl_out_ld + (unsigned)ch) * ES : OOB_OFF, o);
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+    };
+    if constexpr (BNL != 0) {
+        // the coefficient table, behind the prologue's fills (the compiler's vmcnt(0) for these loads waits for those as well)
+        for (int c = tid; c < p.Cin; c += NW * 64) {
+            float sc, sh;
+            bn_fwd_coeffs(p.bnl, p.Cin, c, blockIdx.x == 0, sc, sh);
+            bnl_tab[c] = sc; bnl_tab[BNL_CMAX + c] = sh;
+        }
+        __syncthreads();
+    }
 
     int cst = 0;                                      // ring slot of the weight stage being consumed
     constexpr int NM = 2 * FM * FN * TPS;             // MFMAs per k-step and wave
     for (int c = 0; c < nchunks; ++c) {
         const char* hb = hbase + (c & 1) * HBUF;
-        auto step = [&](auto jj) {
+        // (always_inline: with the BNL pass the body outgrew the inliner's budget, and a lambda left as a CALL gets its captures through memory --
+        // the LDS-DMA statements inside need their wave-uniform operands in scalar registers)
+        auto step = [&](auto jj) __attribute__((always_inline)) {
             constexpr int j = decltype(jj)::value;
             // halo pieces this k-step issues, and those the NWS-2 k-steps before it issued: the operations younger than the
             // last piece of this k-step's weight stage are the NWS-2 later stages and those halo pieces
@@ -542,6 +651,14 @@ __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo
                 return h;
             }();
             wait_vmcnt<(NWS - 2) * WI + NH>();
+            if constexpr (BNL != 0) {
+                // this wait covers the halo pieces issued NWS - 1 k-steps ago: at k-step 0 the last pieces of THIS chunk's halo (all of them for
+                // the first chunk, which the prologue fetched), from k-step NWS - 1 on pieces of the next chunk's
+                constexpr int jp = (j - (NWS - 1) + SPC) % SPC;
+                constexpr int F0 = jp * HPS < XH ? jp * HPS : XH, F1 = (jp + 1) * HPS < XH ? (jp + 1) * HPS : XH;
+                if (j == 0) bnl_fixup(c == 0 ? 0 : F0, c == 0 ? XH : F1, c);
+                else if (j >= NWS - 1) bnl_fixup(F0, F1, c + 1);
+            }
             raw_barrier();
             const char* wb = wbase + cst * WSTAGE;
 #pragma unroll
@@ -679,13 +796,17 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {128, 64, 4, 2, 64, 2},     // 58: halo-tile kernel for the stem (7x7 / stride 2 on the prepared 4-channel input)
 };
 
-template <typename T, int TP, int TC, int WP, int WC, int KB, int NST, int ABL = 0>
+template <typename T, int TP, int TC, int WP, int WC, int KB, int NST, int ABL = 0, int BNL = 0>
 int launch_dma(const ConvK& k0, int mode, hipStream_t st) {
     ConvK k = k0;
     k.ntc = ceil_div(k.Cout, TC);
     k.xcd_order = xcd_order_enabled() ? 1 : 0;
     dim3 grid(ceil_div(k.M, TP) * k.ntc * k.ksplit, 1, mode ? 4 : 1);
     constexpr int NT = WP * WC * 64;
+    if constexpr (BNL != 0) {      // in_bn: gather mode, 16-bit (conv_cfg_ok)
+        if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, NST, KB, ABL, 1>), grid, dim3(NT), 0, st, k);
+        return msc_check_launch("conv_igemm_dma (in_bn)");
+    }
     if (mode) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 1, NST, KB, ABL>), grid, dim3(NT), 0, st, k);
     else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, TP, TC, WP, WC, 0, NST, KB, ABL>), grid, dim3(NT), 0, st, k);
     if (k.ksplit > 1) {
@@ -697,20 +818,25 @@ int launch_dma(const ConvK& k0, int mode, hipStream_t st) {
     return msc_check_launch("conv_igemm_dma");
 }
 
-template <typename T, int PH, int TC, int WP, int WC, int NWS, int TPS = 1, int MINB = 1>
+template <typename T, int PH, int TC, int WP, int WC, int NWS, int TPS = 1, int MINB = 1, int BNL = 0>
 int launch_halo3(const ConvK& k0, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         ConvK k = k0;
         k.ntc = k.Cout / TC;
         k.xcd_order = xcd_order_enabled() ? 1 : 0;
         const int blocks = k.N * (k.Ho / PH) * (k.Wo / 16) * k.ntc;
-        hipLaunchKernelGGL((conv3x3_halo_dma_kernel<T, PH, TC, WP, WC, NWS, TPS, MINB>), dim3(blocks), dim3(WP * WC * 64), 0, st, k);
+        hipLaunchKernelGGL((conv3x3_halo_dma_kernel<T, PH, TC, WP, WC, NWS, TPS, MINB, BNL>), dim3(blocks), dim3(WP * WC * 64), 0, st, k);
     }
     return msc_check_launch("conv3x3_halo_dma");
 }
 
+// in_bn (BatchNorm + ReLU of the input on load): the implicit-GEMM kernel's 1x1 form on the two tiles it was measured on (1, 33) and three
+// tiles of the 3x3 halo kernel (42, 51, 53)
+static inline bool cfg_has_bnl(int cfg, int kh) { return kh == 1 ? (cfg == 1 || cfg == 33) : (cfg == 42 || cfg == 51 || cfg == 53); }
 bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
     if (cfg < 1 || cfg > N_CONV_CFG) return false;
+    if (k.bnl.slots && !(cfg_has_bnl(cfg, k.KH) && es == 2 && k.mode == 0 && k.KH == k.KW && (k.KH == 1 || k.KH == 3) && k.stride == 1 && k.pad == k.KH / 2 &&
+                         !k.flip && !k.span_bytes && k.ksplit == 1 && k.Cin <= BNL_CMAX && k.Cin % 64 == 0)) return false;
     if (k.fin_w && cfg != CFG_HALO) return false;           // the fused final 1x1 lives in the 32-channel halo kernel's epilogue only
     if (k.sz && cfg >= 29 && cfg <= 32) return false;       // the residual-join epilogue (stats_z) is not compiled for the 32-fragment wave tiles
     if (k.ksplit > 1 && (cfg == CFG_HALO || cfg == CFG_HALO_T || cfg == CFG_STREAM || cfg == CFG_STEM || cfg_is_halo3(cfg))) return false;      // split-K: the implicit-GEMM kernel only
@@ -752,12 +878,19 @@ int pick_cfg(const ConvK& k) {
 
 template <typename T>
 int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
-    if (cfg == 0) cfg = k.fin_w ? CFG_HALO : pick_cfg(k);
+    if (cfg == 0) cfg = k.fin_w ? CFG_HALO : k.bnl.slots ? (k.KH == 3 ? (k.Ho % 16 == 0 && k.Cout % 128 == 0 ? 42 : 51) : k.Cout % 256 == 0 ? 33 : 1) : pick_cfg(k);
     if (!conv_cfg_ok(k, (int)sizeof(T), cfg)) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: configuration %d is not valid for this layer", cfg);
     if (cfg == CFG_HALO) return halo32_conv_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     if (cfg == CFG_HALO_T) return halo32_deconv_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     if (cfg == CFG_STEM) return halo32_stem_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     if (cfg == CFG_STREAM) return conv1x1_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
+    if (k.bnl.slots) {
+        if (cfg == 1) return launch_dma<T, 256, 128, 4, 2, 128, 3, 0, 1>(k, mode, st);
+        if (cfg == 33) return launch_dma<T, 128, 256, 2, 4, 128, 3, 0, 1>(k, mode, st);
+        if (cfg == 42) return launch_halo3<T, 16, 128, 4, 2, 3, 1, 1, 1>(k, st);
+        if (cfg == 51) return launch_halo3<T, 8, 64, 4, 2, 3, 3, 1, 1>(k, st);
+        return launch_halo3<T, 16, 64, 4, 2, 2, 3, 1, 1>(k, st);
+    }
     switch (cfg) {
         case 1: return launch_dma<T, 256, 128, 4, 2, 128, 3>(k, mode, st);
         case 2: return launch_dma<T, 256, 128, 4, 2, 64, 4>(k, mode, st);
@@ -859,6 +992,18 @@ static int conv_fill(const msc_conv_desc* d, ConvK* k) {
         return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: split-K needs mode 0, no statistics, a 16-byte aligned fp32 workspace and at most 64 slices");
     if (d->final_w && (d->res || d->stats || (!d->final_logits && !d->final_probs)))
         return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: the fused final 1x1 takes no residual / statistics and needs a logits or probabilities output");
+    k->bnl = BnFwdFin{}; k->bnl_out = nullptr; k->bnl_out_ld = 0; k->bnl_out_bytes = 0;
+    if (d->in_bn) {
+        const msc_bn_input* b = d->in_bn;
+        if (!b->slots || !b->scale || !b->shift || b->count <= 0 || es != 2 || (b->out && ((b->out_ld * es) % 16 || ((uintptr_t)b->out & 15))))
+            return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: in_bn needs slots, scale / shift outputs, a pixel count, a 16-bit dtype and a 16-byte aligned activation");
+        k->bnl = BnFwdFin{b->slots, (double)b->count, b->gamma, b->beta, b->eps, b->momentum, b->running_mean, b->running_var, b->scale, b->shift,
+                          b->save_mean, b->save_invstd};
+        k->bnl_out = (char*)b->out; k->bnl_out_ld = b->out_ld;
+        const long out_b = (((long)d->N * d->Hi * d->Wi - 1) * b->out_ld + d->Cin) * es;
+        if (b->out && out_b >= 0x7fffffffL) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: in_bn activation beyond 2 GiB (%ld bytes)", out_b);
+        k->bnl_out_bytes = b->out ? (unsigned)out_b : 0;
+    }
     k->span_bytes = 0;
     if (d->mode == 1) {
         if (d->stride != 2 || (d->Ho & 1) || (d->Wo & 1)) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: transposed mode needs stride 2 and even output size");
@@ -947,6 +1092,7 @@ extern "C" int msc_conv_cfg_ok(const msc_conv_desc* d, int cfg) {
     ConvK k;
     if (!d) return 0;
     const msc_conv_desc first = conv_image_range(d, 0, conv_image_chunk(d));
+    if (d->in_bn && first.N < d->N) return 0;      // in_bn: one image range per launch (msc_conv_igemm)
     if (conv_fill(&first, &k) != MSC_OK) return 0;
     return conv_cfg_ok(k, msc_dtype_size(d->dtype), cfg) ? 1 : 0;
 }
@@ -955,6 +1101,8 @@ extern "C" int msc_conv_igemm(const msc_conv_desc* d, void* stream) {
     if (!d) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: null descriptor");
     hipStream_t st = (hipStream_t)stream;
     const int chunk = conv_image_chunk(d);
+    // in_bn: the first block of the launch publishes the coefficients and moves the running statistics -- once per layer, so one image range
+    if (d->in_bn && chunk < d->N) return msc_fail(MSC_ERR_UNSUPPORTED, "msc_conv_igemm: in_bn needs the whole batch in one image range (%d of %d images fit)", chunk, d->N);
     for (int n0 = 0; n0 < (d->N > 0 ? d->N : 1); n0 += chunk) {
         const msc_conv_desc part = conv_image_range(d, n0, d->N - n0 < chunk ? d->N - n0 : chunk);
         ConvK k;

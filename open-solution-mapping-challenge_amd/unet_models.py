@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._lib import BneckDesc, ConvDesc, WgradDesc, F32, BF16, F16
+from ._lib import BneckDesc, BnInput, ConvDesc, WgradDesc, F32, BF16, F16
 
 _DTYPES = {'bf16': (torch.bfloat16, BF16), 'fp16': (torch.float16, F16), 'fp32': (torch.float32, F32)}
 
@@ -644,6 +644,9 @@ class _Builder:
         self.gcount = {}              # activation slice -> number of launches that write its gradient
         self.gwriter = {}             # activation slice -> ConvDesc of the (mode 0, no residual) dgrad conv that wrote it first
         self.fuse_bn_bwd = _os_env.environ.get('MSC_FUSE_BN_BWD', '1') != '0'
+        # BatchNorm + ReLU of a Bottleneck's bn2 applied by conv3 on load (msc_conv_desc.in_bn, ABI v9): training, 16-bit on the device (the
+        # CPU interpreter follows the same launch list in fp32).  OPT-IN until it has run on the hardware: MSC_BN_ON_LOAD=1
+        self.bn_on_load = (training and _os_env.environ.get('MSC_BN_ON_LOAD', '0') == '1' and (self.dt != F32 or device.type != 'cuda'))
         # residual joins: the data-gradient conv that ACCUMULATES the last addend of the join's gradient also reduces the sums of the
         # join's BatchNorm backward (stats_kind 1 with stats_z, ABI v6) -- no msc_bn_bwd_reduce pass over three tensors
         self.fuse_join_bwd = _os_env.environ.get('MSC_FUSE_JOIN_BWD', '1') != '0'
@@ -731,9 +734,13 @@ class _Builder:
         lst.append((fn, args))
 
     def conv_desc(self, x, wt, out, KH, KW, stride, pad, mode=0, flip=0, relu=0, scale=None, shift=None, res=None,
-                  stats=None, in_hw=None, in_ld=None, cin=None, out_hw=None, want_stats=False, allow_split=False):
+                  stats=None, in_hw=None, in_ld=None, cin=None, out_hw=None, want_stats=False, allow_split=False, in_bn=None):
         d = ConvDesc()
         d.in_, d.wt, d.out = x.ptr, wt.data_ptr(), out.ptr
+        if in_bn is not None:          # BnInput: x is the raw output of a BatchNorm'd conv, normalised + rectified on load (ABI v9)
+            self.prog.keep.append(in_bn)
+            d.in_bn = C.addressof(in_bn)
+            d._in_bn = in_bn
         d.res = res.ptr if res is not None else None
         d.scale, d.shift, d.stats = _p(scale), _p(shift), _p(stats)
         d.in_ld = in_ld if in_ld is not None else x.ld
@@ -826,11 +833,15 @@ class _Builder:
         if not self.net.autotune or self.dev.type != 'cuda':
             return
         key = repr(('c', self.tune_dt, d.mode, d.flip, d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad,
-                    bool(d.res), want_stats, d.in_ld, d.out_ld, bool(d.relu)) + ((int(d.splitk),) if d.splitk > 1 else ()))
+                    bool(d.res), want_stats, d.in_ld, d.out_ld, bool(d.relu)) + ((int(d.splitk),) if d.splitk > 1 else ()) + (('in_bn',) if d.in_bn else ()))
         cache = _TUNE_CACHE
         lib = self.lib
         if key not in cache or (cache[key] and not lib.msc_conv_cfg_ok(C.byref(d), int(cache[key]))):
             best, best_t = 0, 1e30
+            bi = getattr(d, '_in_bn', None)
+            if bi is not None:         # the timed launches must not move the layer's running statistics (the first block of every launch would)
+                keep_rs = (bi.running_mean, bi.running_var)
+                bi.running_mean, bi.running_var = None, None
             for c in range(1, lib.msc_conv_num_cfgs() + 1):
                 if not lib.msc_conv_cfg_ok(C.byref(d), c):
                     continue
@@ -844,6 +855,8 @@ class _Builder:
                 if t is not None and t < best_t:
                     best, best_t = c, t
             d.stats = None
+            if bi is not None:
+                bi.running_mean, bi.running_var = keep_rs
             cache[key] = best
             self._tuned_new = True
         d.cfg = cache[key]
@@ -900,9 +913,13 @@ class _Builder:
         d.cfg = cache[key]
 
     # ---- layers -------------------------------------------------------------------------------
-    def conv_bn(self, name, x, conv, bn, stride, relu, out, res=None, stem=None):
+    def conv_bn(self, name, x, conv, bn, stride, relu, out, res=None, stem=None, defer=False, pend=None):
         """conv (no bias) + BatchNorm2d (+ residual) (+ ReLU) -> out.  `stem`: (Hp, Wp) of the prepared
-        NHWC4 image when this is encoder.conv1 expressed as a 7-tap x 32-wide implicit GEMM."""
+        NHWC4 image when this is encoder.conv1 expressed as a 7-tap x 32-wide implicit GEMM.
+        defer (training, round 4 / ABI v9): the msc_bn_apply launch is NOT emitted -- the returned BnInput describes the layer (raw output,
+        statistics slots, where the coefficients and the activation `out` go) and the consuming conv_bn(..., pend=that) applies
+        relu(scale*y + shift) to its operand on load and stores `out` on the way (the weight gradient of the consumer reads it).
+        Returns None when the apply was emitted here."""
         net, lib, P, fwd = self.net, self.lib, self.prog, self.prog.fwd
         w = net._pack['w'][name]
         cout = conv.out_channels
@@ -919,7 +936,13 @@ class _Builder:
             self.conv(fwd, x, w, out, relu=int(relu), scale=scale, shift=shift, res=res, **geo)
             return
         y = self.act(out.H, out.W, cout)
-        d = self.conv_desc(x, w, y, want_stats=True, **geo)
+        if pend is not None:           # the producer's BatchNorm + ReLU ride on this conv's operand fetch; `x` (its activation) is written on the way
+            d = self.conv_desc(Act(pend._y), w, y, want_stats=True, in_bn=pend, **geo)
+            if self.dev.type == 'cuda' and not any(lib.msc_conv_cfg_ok(C.byref(d), c) for c in range(1, lib.msc_conv_num_cfgs() + 1)):
+                raise _lib.MscError('%s: no kernel configuration applies BatchNorm on load for this layer (N=%d, %dx%d, %d -> %d channels); '
+                                    'run with MSC_BN_ON_LOAD=0' % (name, self.N, x.H, x.W, x.C, cout))
+        else:
+            d = self.conv_desc(x, w, y, want_stats=True, **geo)
         # batch statistics: the conv epilogue adds (sum, sum of squares) into one slot per XCD; bn_apply sums the slots in its
         # prologue (no finalize launch).  The slots of every layer live in one arena zeroed once per step.
         d.stats = self.slots(cout)
@@ -934,12 +957,24 @@ class _Builder:
             rmask = torch.empty((self.N, out.H, out.W, cout * self.es // 16), dtype=torch.uint8, device=self.dev)
             self.prog.bytes += rmask.numel()
             self.prog.keep.append(rmask)
-        self.emit(fwd, lib.msc_bn_apply, y.ptr, y.ld, res.ptr if res is not None else None, res.ld if res is not None else 0,
-                  out.ptr, out.ld, d.stats, count, bn.weight.data_ptr(), bn.bias.data_ptr(), BN_EPS, BN_MOMENTUM,
-                  bn.running_mean.data_ptr(), bn.running_var.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
-                  invstd.data_ptr(), rmask.data_ptr() if rmask is not None else None, rmask.shape[3] if rmask is not None else 0, int(relu), self.dt,
-                  count, cout)
+        bi = None
+        if defer and res is None and relu and stem is None:
+            bi = BnInput()
+            bi.slots, bi.count = d.stats, count
+            bi.gamma, bi.beta, bi.eps, bi.momentum = bn.weight.data_ptr(), bn.bias.data_ptr(), BN_EPS, BN_MOMENTUM
+            bi.running_mean, bi.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            bi.scale, bi.shift, bi.save_mean, bi.save_invstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+            bi.out, bi.out_ld = out.ptr, out.ld
+            bi._y = y.buf if y.c0 == 0 and y.C == y.buf.shape[3] else None
+            assert bi._y is not None
+        else:
+            self.emit(fwd, lib.msc_bn_apply, y.ptr, y.ld, res.ptr if res is not None else None, res.ld if res is not None else 0,
+                      out.ptr, out.ld, d.stats, count, bn.weight.data_ptr(), bn.bias.data_ptr(), BN_EPS, BN_MOMENTUM,
+                      bn.running_mean.data_ptr(), bn.running_var.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                      invstd.data_ptr(), rmask.data_ptr() if rmask is not None else None, rmask.shape[3] if rmask is not None else 0, int(relu), self.dt,
+                      count, cout)
         self.ops.append(lambda: self._conv_bn_bwd(name, x, conv, bn, geo, relu, out, res, y, mean, invstd, count, stem, scale, shift, rmask))
+        return bi
 
     def _conv_bn_bwd(self, name, x, conv, bn, geo, relu, out, res, y, mean, invstd, count, stem, scale, shift, rmask=None):
         net, lib, P, bwd = self.net, self.lib, self.prog, self.prog.bwd
@@ -1262,11 +1297,16 @@ class _Builder:
                 elif self.bottleneck_fused(base, cur, blk, out):
                     pass
                 else:
+                    # bn1 / bn2 + ReLU applied by the consuming conv on load instead of msc_bn_apply launches (ABI v9; MSC_BN_ON_LOAD=1): conv3 (1x1,
+                    # stride 1) always, conv2 where it is a stride-1 3x3 on a map the halo-tile kernel takes (8 x 16 pixel patches).  Measured for
+                    # conv3: +1.3-2.5 us against 3.8-9 us of the launch (profiles/r4_run28_bn_on_load_probe.txt)
+                    on_load = self.bn_on_load and planes <= 512
                     a = self.act(hh, ww, planes)
-                    self.conv_bn(base + '.conv1', cur, blk.conv1, blk.bn1, 1, True, a)
+                    pend1 = self.conv_bn(base + '.conv1', cur, blk.conv1, blk.bn1, 1, True, a,
+                                         defer=on_load and s == 1 and ww % 16 == 0 and hh % 8 == 0 and _os_env.environ.get('MSC_BN_ON_LOAD_3X3', '1') != '0')
                     b = self.act(ho, wo, planes)
-                    self.conv_bn(base + '.conv2', a, blk.conv2, blk.bn2, s, True, b)
-                    self.conv_bn(base + '.conv3', b, blk.conv3, blk.bn3, 1, True, out, res=idt)
+                    pend2 = self.conv_bn(base + '.conv2', a, blk.conv2, blk.bn2, s, True, b, defer=on_load, pend=pend1)
+                    self.conv_bn(base + '.conv3', b, blk.conv3, blk.bn3, 1, True, out, res=idt, pend=pend2)
                 cur = out
         c5 = cur
 

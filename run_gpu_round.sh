@@ -61,6 +61,10 @@ pmcsq) # SQ / LDS / L2 counters of the train step, one rocprofv3 pass per counte
        cd "$GRAFT_REPO_ROOT"; python tools/pmc_sq_summary.py gpurun_out/pmcsq_1 gpurun_out/pmcsq_2 gpurun_out/pmcsq_3 > gpurun_out/pmcsq_summary.txt 2>&1; head -30 gpurun_out/pmcsq_summary.txt | cut -c1-260;;
 b32)   timeout 900 python -m pytest tests/test_gpu_parity_timed.py tests/test_gpu_fullsize.py -m gpu -q -rf --tb=short -p no:cacheprovider -k "batch32" --durations=5 > gpurun_out/pytest_b32.log 2>&1; echo "pytest rc=$?"; tail -15 gpurun_out/pytest_b32.log; cat gpurun_out/parity_timed.json | head -60;;
 ktests) timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_unet.py -m gpu -q -rf --tb=short -p no:cacheprovider > gpurun_out/pytest_k.log 2>&1; echo "pytest rc=$?"; tail -15 gpurun_out/pytest_k.log;;
+bnl)   # BatchNorm + ReLU on load (msc_conv_desc.in_bn, ABI v9): the kernel test, the end-to-end comparison with the separate apply launches, then the step A/B
+       timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short -p no:cacheprovider -k "on_load" > gpurun_out/pytest_bnl.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/pytest_bnl.log
+       timeout 600 python -m pytest tests/test_gpu_unet.py -m gpu -q -rf --tb=short -p no:cacheprovider -k "bn_on_load" > gpurun_out/pytest_bnl2.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/pytest_bnl2.log
+       AB="MSC_BN_ON_LOAD=0 MSC_BN_ON_LOAD=1 MSC_BN_ON_LOAD=1,MSC_BN_ON_LOAD_3X3=0 MSC_BN_ON_LOAD=0" "$0" ab;;
 ab)    # A/B of environment switches on the train step: AB="NAME=VAL,NAME2=VAL2 NAME=VAL ..." (one run per word)
        python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
        for cfg in $AB; do

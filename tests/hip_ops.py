@@ -33,9 +33,11 @@ def _nhwc(t):
     return t.stride(2)
 
 
-def conv_igemm(x, w, out, stride=1, pad=0, mode=0, flip=0, relu=False, scale=None, shift=None, res=None, stats=None, cfg=0):
-    """w: [Cout, KH, KW, Cin] in x.dtype.  mode 0: gather conv; mode 1: transposed (stride 2)."""
+def conv_igemm(x, w, out, stride=1, pad=0, mode=0, flip=0, relu=False, scale=None, shift=None, res=None, stats=None, cfg=0, in_bn=None):
+    """w: [Cout, KH, KW, Cin] in x.dtype.  mode 0: gather conv; mode 1: transposed (stride 2).  in_bn: a _lib.BnInput (ABI v9)"""
     d = ConvDesc()
+    if in_bn is not None:
+        d.in_bn = C.addressof(in_bn)
     d.in_, d.wt, d.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.res = res.data_ptr() if res is not None else None
     d.scale = scale.data_ptr() if scale is not None else None

@@ -64,6 +64,36 @@ def test_deterministic_flag_comes_from_the_argument_the_environment_or_the_train
     assert 'MSC_WGRAD_ORDERED = 1' in hdr and '#define MSC_FINAL_BWD_WS_ROWS 1024' in hdr
 
 
+def test_bn_on_load_launch_list_matches_oracle_and_drops_the_apply_launches(interpreted, monkeypatch):
+    """MSC_BN_ON_LOAD=1 (ABI v9): bn2 + ReLU of every unfused Bottleneck ride on conv3's operand fetch (msc_conv_desc.in_bn), bn1 + ReLU on
+    conv2's where that is a stride-1 3x3 on a 16-pixel-wide map (layer1 at 64x64 input) -- 33 + 3 msc_bn_apply launches fewer for ResNet101, the
+    same loss, gradients and running statistics as the oracle (the activation the weight gradient reads is stored by the consuming conv)"""
+    x = unet_ref.synthetic_batch(2, 64, 64)
+    tgt = losses_ref.synthetic_target(2, 64, 64)
+    counts = {}
+    for on in ('0', '1'):
+        monkeypatch.setenv('MSC_BN_ON_LOAD', on)
+        ref, net = build(101)
+        ref.train(); net.train()
+        loss = losses_ref.mixed_dice_ce(ref(x), tgt)
+        loss.backward()
+        loss2 = losses_ref.mixed_dice_ce(net(x), tgt)
+        loss2.backward()
+        prog = next(iter(net._programs.values()))
+        names = [getattr(fn, '__name__', str(fn)) for fn, _ in prog.fwd]
+        counts[on] = (names.count('msc_bn_apply'), sum(1 for fn, a in prog.fwd if getattr(fn, '__name__', '') == 'msc_conv_igemm' and a[0]._obj.in_bn))
+        assert abs(loss.item() - loss2.item()) < 1e-5
+        pr = dict(ref.named_parameters())
+        for n, p in net._trainable():
+            scale = pr[n].grad.abs().max().item() + 1e-12
+            assert (p.grad - pr[n].grad).abs().max().item() / scale < 2e-3, n
+        for (n, b), (_, b2) in zip(sorted(ref.named_buffers()), sorted(net.named_buffers())):
+            if 'running' in n:
+                assert (b - b2).abs().max() < 1e-5, n
+    assert counts['0'][1] == 0 and counts['1'][1] == 36
+    assert counts['0'][0] - counts['1'][0] == 36
+
+
 def test_state_dict_roundtrip_and_flat_views(interpreted):
     ref, net = build(34)
     sd = net.state_dict()

@@ -369,6 +369,78 @@ def test_every_kernel_configuration_is_correct(dtype, cin, cout, k, stride, hw, 
         assert (dw.cpu() - gref).abs().max().item() / gref.abs().max().item() < (2e-5 if dtype == torch.float32 else 1e-2), c
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('cin,cout,hw,n,cfg,k', [(256, 1024, 16, 4, 0, 1), (256, 1024, 16, 4, 1, 1), (256, 1024, 16, 4, 33, 1), (64, 256, 24, 3, 1, 1),
+                                                 (128, 512, 20, 2, 33, 1), (512, 2048, 8, 5, 0, 1), (128, 128, 9, 3, 1, 1),
+                                                 (256, 256, 16, 3, 0, 3), (256, 256, 16, 3, 51, 3), (256, 256, 16, 3, 53, 3), (64, 128, 32, 2, 42, 3),
+                                                 (128, 128, 32, 2, 51, 3), (64, 128, 48, 1, 53, 3)])
+def test_conv_applies_batchnorm_and_relu_to_its_input_on_load(dtype, cin, cout, hw, n, cfg, k):
+    """msc_conv_desc.in_bn (ABI v9): the 1x1 conv reads the RAW output y of a training-mode BatchNorm'd conv, finalises that layer's
+    coefficients from its statistics slots and applies relu(scale*y + shift) to the operand in LDS -- against torch batch_norm + relu + conv2d,
+    with the coefficients / saved statistics / running statistics msc_bn_apply would publish and the activation stored for the weight gradient;
+    ragged pixel counts, pixel tiles that end inside a block, every tile that has the path; 3x3 (halo-tile kernel): the zero padding is of
+    the activation, the halo of a patch is transformed once for the nine taps"""
+    import ctypes as C
+    from mapping_challenge_amd import _lib
+    import hip_ops as ops
+    lib = _lib.load()
+    y = (rnd((n, cin, hw, hw), dtype, 1) * 1.5 + 0.25).to(dtype).float()
+    w = rnd((cout, cin, k, k), dtype, 2, (2.0 / (cin * k * k)) ** 0.5)
+    gamma, beta = rnd((cin,), torch.float32, 3) * 0.3 + 1.0, rnd((cin,), torch.float32, 4) * 0.2
+    rm0, rv0 = rnd((cin,), torch.float32, 5) * 0.1, rnd((cin,), torch.float32, 6).abs() + 0.5
+    rm, rv = rm0.clone(), rv0.clone()
+    a_ref = torch.relu(F.batch_norm(y, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5))      # updates rm / rv
+    a16 = a_ref.to(dtype).float()
+    ref = F.conv2d(a16, w, padding=k // 2)
+    yd = nhwc(y, dtype)
+    yf = yd.float().double()
+    count = n * hw * hw
+    slots = torch.zeros((8, cin, 2), dtype=torch.float64, device='cuda')
+    parts = yf.reshape(-1, cin).chunk(8, 0)                          # the sums spread over the per-XCD slots, as the producing conv leaves them
+    for i, pt in enumerate(parts):
+        slots[i, :, 0], slots[i, :, 1] = pt.sum(0), (pt * pt).sum(0)
+    bi = _lib.BnInput()
+    outs = {k: torch.full((cin,), float('nan'), device='cuda') for k in ('scale', 'shift', 'mean', 'invstd')}
+    gd, bd, rmd, rvd = gamma.cuda(), beta.cuda(), rm0.cuda(), rv0.cuda()
+    act = torch.full((n, hw, hw, cin), 7.0, dtype=dtype, device='cuda')
+    bi.slots, bi.count, bi.gamma, bi.beta, bi.eps, bi.momentum = slots.data_ptr(), count, gd.data_ptr(), bd.data_ptr(), 1e-5, 0.1
+    bi.running_mean, bi.running_var = rmd.data_ptr(), rvd.data_ptr()
+    bi.scale, bi.shift, bi.save_mean, bi.save_invstd = [outs[k].data_ptr() for k in ('scale', 'shift', 'mean', 'invstd')]
+    bi.out, bi.out_ld = act.data_ptr(), cin
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    out = torch.zeros((n, hw, hw, cout), dtype=dtype, device='cuda')
+    st = torch.zeros((8, cout, 2), dtype=torch.float64, device='cuda')      # the consumer's own BatchNorm statistics ride in its epilogue as usual
+    ops.conv_igemm(yd, wd, out, pad=k // 2, cfg=cfg, in_bn=bi, stats=st)
+    torch.cuda.synchronize()
+    # ... and see only the real pixels (tile rows past the last pixel must stay zero through the on-load pass)
+    assert torch.allclose(st.sum(0)[:, 0].cpu().float(), ref.sum((0, 2, 3)), rtol=2e-2, atol=2e-2 * ref.abs().sum((0, 2, 3)).max().item())
+    assert torch.allclose(st.sum(0)[:, 1].cpu().float(), (ref * ref).sum((0, 2, 3)), rtol=3e-2)
+    # the coefficients (the 16-bit y the kernel saw defines the statistics)
+    mean = yf.mean((0, 1, 2)); var = yf.var((0, 1, 2), unbiased=False)
+    inv = 1.0 / torch.sqrt(var + 1e-5)
+    assert torch.allclose(outs['mean'].cpu().double(), mean.cpu(), atol=1e-5)
+    assert torch.allclose(outs['invstd'].cpu().double(), inv.cpu(), rtol=1e-5)
+    assert torch.allclose(outs['scale'].cpu().double(), (gamma.double() * inv.cpu()), rtol=1e-5)
+    assert torch.allclose(rmd.cpu(), rm, atol=2e-3) and torch.allclose(rvd.cpu(), rv, rtol=5e-3)
+    # the stored activation = what msc_bn_apply would have written, and the conv of it
+    a_dev = torch.relu(yd.float() * outs['scale'] + outs['shift']).to(dtype)
+    assert (act.float() - a_dev.float()).abs().max().item() <= 2 * (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11) * a_dev.float().abs().max().item()
+    assert torch.allclose(to_nchw(act), a_ref, **tol(dtype))
+    assert torch.allclose(to_nchw(out), ref, **tol(dtype))
+    # not for the shapes / options it does not take
+    bad = _lib.ConvDesc()
+    bad.in_, bad.wt, bad.out, bad.in_ld, bad.out_ld, bad.dtype = yd.data_ptr(), wd.data_ptr(), out.data_ptr(), cin, cout, ops._dt(yd)
+    bad.N, bad.Hi, bad.Wi, bad.Cin, bad.Ho, bad.Wo, bad.Cout, bad.KH, bad.KW, bad.stride, bad.pad = n, hw, hw, cin, hw, hw, cout, k, k, 1, k // 2
+    bad.in_bn = C.addressof(bi)
+    valid = [c for c in range(1, lib.msc_conv_num_cfgs() + 1) if lib.msc_conv_cfg_ok(C.byref(bad), c)]
+    if k == 1:
+        assert valid == ([1] if cout % 256 else [1, 33])
+    else:
+        assert valid and set(valid) <= {42, 51, 53} and (cfg == 0 or cfg in valid)
+    bad.stride = 2
+    assert not any(lib.msc_conv_cfg_ok(C.byref(bad), c) for c in range(1, lib.msc_conv_num_cfgs() + 1))
+
+
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('steps,cap,ordered', [(64, 128, 0), (4, 64, 0), (1, 32, 0), (0, 128, 0), (4, 64, 1), (1, 128, 1), (64, 128, 1)])
 def test_grouped_weight_gradients_equal_separate_ones(dtype, steps, cap, ordered):

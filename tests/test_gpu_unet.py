@@ -231,6 +231,32 @@ def test_deterministic_mode_repeats_a_training_run_bit_for_bit(dtype, depth):
     assert runs[0][0][-1] < runs[0][0][0]
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_bn_on_load_training_matches_the_separate_apply_launches(dtype, monkeypatch):
+    """MSC_BN_ON_LOAD=1: bn2 + ReLU of every unfused Bottleneck applied by conv3 on load (msc_conv_desc.in_bn) -- the same four training steps
+    as with the msc_bn_apply launches: losses and parameters agree to the rounding of a different summation order in conv3, the running
+    statistics agree, and the forward holds 36 msc_bn_apply launches fewer (conv3 of the 33 blocks, conv2 of layer1's three at 64x64)"""
+    from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
+    x = unet_ref.synthetic_batch(4, 64, 64).cuda()
+    tgt = losses_ref.synthetic_target(4, 64, 64)[:, :1].contiguous().cuda()
+    runs = {}
+    for on in ('0', '1'):
+        monkeypatch.setenv('MSC_BN_ON_LOAD', on)
+        _, net = build(101, dtype)
+        net.deterministic = True
+        net.train()
+        step = TrainStep(net, LossSpec.plain_ce(), HipAdam(net, lr=1e-3), use_graph=True)
+        losses = [step(x, tgt).item() for _ in range(4)]
+        prog = next(p for k, p in net._programs.items() if p.training)
+        nb = sum(1 for fn, _ in prog.fwd if fn.__name__ == 'msc_bn_apply')
+        runs[on] = (losses, net.flat_params.clone(), net.encoder.layer3[5].bn2.running_var.clone(), nb)
+    assert runs['0'][3] - runs['1'][3] == 36
+    assert np.allclose(runs['0'][0], runs['1'][0], rtol=2e-2)
+    assert torch.allclose(runs['0'][2], runs['1'][2], rtol=2e-2)
+    assert (runs['0'][1] - runs['1'][1]).abs().mean().item() < 2e-4
+    assert runs['1'][0][-1] < runs['1'][0][0]
+
+
 def test_bf16_train_step_runs_and_reduces_loss():
     from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
     ref, net = build(34, 'bf16')
