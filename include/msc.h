@@ -313,6 +313,7 @@ typedef struct msc_loss_cfg {
     float w0, sigma, size_c;     /* get_weights(): 1 + w0*exp(-d^2/sigma^2), C = sqrt(h*w)/2 */
     float dice_weight, ce_weight, smooth, eps;
     int32_t weighted;            /* 0: plain CE (target channel 0 only), 1: distance/size weighted */
+    int32_t dice_sigmoid;        /* ABI v10: Dice activation, 0 = Softmax2d, 1 = Sigmoid of the class-1 logit (src/models.py:437-442) */
 } msc_loss_cfg;
 int msc_loss_sums(const float* logits, const float* target, int tc, const msc_loss_cfg* cfg, double* sums,
                   int N, int H, int W, void* stream);
@@ -363,13 +364,23 @@ int msc_adam_pack(float* p, const float* g, float* m, float* v, const msc_adam_i
 
 /* ---------------------------------------------------------------- mask post-processing --------
  * Batched over B images; each replaces a per-image Python/scipy/skimage loop of src/postprocessing.py. */
-/* resize_image (src/postprocessing.py:48-61): bilinear, scipy 'constant' edge rule; f32 [B,C,h,w] -> f32 [B,C,H,W] */
-int msc_resize_bilinear(const float* in, float* out, int B, int C, int h, int w, int H, int W, void* stream);
+/* resize_image (src/postprocessing.py:48-61 = skimage.transform.resize(order 1, mode 'constant') -> scipy map_coordinates): bilinear with
+ * half-pixel centres, scipy's 'constant' edge rule (no interpolation beyond the edges: cval 0), skimage's clip to the input range joined with 0.
+ * The interpolant is evaluated in double with numpy's roundings (no fused multiply-add); f32 [B,C,h,w] -> [B,C,H,W], stored as float64
+ * (`out_f64` = 1: what the reference function returns) or rounded to float32.  `minmax_ws`: float[2*B] scratch (ABI v10). */
+int msc_resize_bilinear(const float* in, void* out, int out_f64, float* minmax_ws, int B, int C, int h, int w, int H, int W, void* stream);
+/* ABI v10: resize_image + categorize_multilayer_image in one pass (src/postprocessing.py:48-61,77-84; Steps 'mask_resize' -> 'category_mapper',
+ * src/pipelines.py:249-268): the reference thresholds the FLOAT64 map the resize returns, so the layers are compared in double against the
+ * double interpolant; `out` gets the map rounded to float32 (what the scoring reads). */
+int msc_resize_threshold(const float* in, float* out, uint8_t* layers, float* minmax_ws, int B, int C, int h, int w, int H, int W,
+                         const int32_t* layer_class, const double* layer_thr, int L, void* stream);
 /* crop_image_center_per_class (src/postprocessing.py:239-258) */
 int msc_crop_center(const float* in, float* out, int B, int C, int h, int w, int hc, int wc, void* stream);
-/* categorize_multilayer_image (src/postprocessing.py:77-84): layers[b][l] = probs[b][cls(l)] > thr(l); u8 */
-int msc_threshold_layers(const float* probs, uint8_t* layers, int B, int C, int H, int W,
-                         const int32_t* layer_class, const float* layer_thr, int L, void* stream);
+/* categorize_multilayer_image (src/postprocessing.py:77-84): layers[b][l] = probs[b][cls(l)] > thr(l); u8.  ABI v10: thresholds are the
+ * reference's float64 values (np.arange(1/(L+1), 1, 1/(L+1))) and the comparison is in double (numpy: array > float64 scalar); `probs` is
+ * float32 or, with `probs_f64` = 1, the float64 map msc_resize_bilinear(out_f64 = 1) wrote */
+int msc_threshold_layers(const void* probs, int probs_f64, uint8_t* layers, int B, int C, int H, int W,
+                         const int32_t* layer_class, const double* layer_thr, int L, void* stream);
 /* categorize_image (src/postprocessing.py:64-74): argmax over channels (first maximum), int32 [B,H,W] */
 int msc_argmax_channels(const float* probs, int32_t* out, int B, int C, int H, int W, void* stream);
 /* erosion / dilation with a k x k rectangle, skimage origin convention (src/postprocessing.py:148-154,172-179):

@@ -75,7 +75,7 @@ FINAL_BWD_WS_ROWS = 1024     # msc_final_bwd ordered_ws rows
 class LossCfg(C.Structure):
     _fields_ = [('w0', C.c_float), ('sigma', C.c_float), ('size_c', C.c_float),
                 ('dice_weight', C.c_float), ('ce_weight', C.c_float), ('smooth', C.c_float), ('eps', C.c_float),
-                ('weighted', C.c_int32)]
+                ('weighted', C.c_int32), ('dice_sigmoid', C.c_int32)]
 
 
 _vp, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
@@ -132,9 +132,10 @@ SIGNATURES = {
     'msc_adam_tick': (_i, [_vp, _vp]),
     'msc_grad_check': (_i, [_vp, _i64, _vp, _vp]),
     'msc_adam_pack': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
-    'msc_resize_bilinear': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'msc_resize_bilinear': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'msc_resize_threshold': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     'msc_crop_center': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    'msc_threshold_layers': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    'msc_threshold_layers': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     'msc_argmax_channels': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'msc_erode_u8': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'msc_dilate_i32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -3,7 +3,7 @@
 // Reference semantics (file:line under /root/reference):
 //   plain CE                     src/steps/pytorch/validation.py:25-28
 //   distance x size weighted CE  src/models.py:310-381   (get_weights :339-370)
-//   soft Dice on softmax, class 1 only, sums over the whole batch   src/models.py:421-454, validation.py:8-16
+//   soft Dice on softmax (or, cfg.dice_sigmoid, on sigmoid: src/models.py:437-442), class 1 only, sums over the whole batch   src/models.py:421-454, validation.py:8-16
 //   mix                          src/models.py:384-418 (weights from neptune.yaml:42-43,55-57)
 // Two phases so that the four global sums can be all-reduced over ranks in between (the reference
 // computes the loss on the DataParallel-gathered full batch, src/steps/pytorch/models.py:92,104).
@@ -12,7 +12,7 @@
 
 namespace {
 
-struct PixelTerms { float ce, w, p0, p1, t1; int tcls; };
+struct PixelTerms { float ce, w, p0, p1, t1, q1; int tcls; };      // q1: the Dice activation of class 1 (softmax p1 or sigmoid(l1))
 
 __device__ __forceinline__ PixelTerms pixel_terms(const float* logits, const float* target, int tc, const msc_loss_cfg& cfg,
                                                   long n, long hw, long HW) {
@@ -25,6 +25,7 @@ __device__ __forceinline__ PixelTerms pixel_terms(const float* logits, const flo
     const float s = e0 + e1;
     const float lse = m + logf(s);
     r.p0 = e0 / s; r.p1 = e1 / s;
+    r.q1 = cfg.dice_sigmoid ? 1.f / (1.f + expf(-l1)) : r.p1;
     r.ce = lse - (r.tcls == 1 ? l1 : l0);
     r.t1 = r.tcls == 1 ? 1.f : 0.f;
     float w = 1.f;
@@ -49,8 +50,8 @@ __global__ void loss_sums_kernel(const float* __restrict__ logits, const float* 
         const long n = p / HW, hw = p - n * HW;
         const PixelTerms t = pixel_terms(logits, target, tc, cfg, n, hw, HW);
         a0 += (double)(t.w * t.ce);
-        a1 += (double)(t.p1 * t.t1);
-        a2 += (double)t.p1;
+        a1 += (double)(t.q1 * t.t1);
+        a2 += (double)t.q1;
         a3 += (double)t.t1;
     }
     a0 = wave_sum_d(a0); a1 = wave_sum_d(a1); a2 = wave_sum_d(a2); a3 = wave_sum_d(a3);
@@ -80,10 +81,11 @@ __global__ void loss_grad_kernel(const float* __restrict__ logits, const float* 
         const long n = p / HW, hw = p - n * HW;
         const PixelTerms t = pixel_terms(logits, target, tc, cfg, n, hw, HW);
         const float g1_ce = ce_k * t.w * (t.p1 - t.t1);          // d ce / d l1 ; d/d l0 is its negative (2 classes)
-        const float ddice = (dk_a - dk_b * t.t1) * t.p1 * t.p0;  // d dice / d l1
-        const float g1 = g1_ce + ddice;
-        dlogits[(n * 2) * HW + hw] = -g1;
-        dlogits[(n * 2 + 1) * HW + hw] = g1;
+        // d dice / d l1: softmax dq1/dl1 = p1 p0 = -dq1/dl0; sigmoid dq1/dl1 = q1 (1 - q1) and l0 does not enter
+        const float dq = cfg.dice_sigmoid ? t.q1 * (1.f - t.q1) : t.p1 * t.p0;
+        const float ddice = (dk_a - dk_b * t.t1) * dq;
+        dlogits[(n * 2) * HW + hw] = -g1_ce - (cfg.dice_sigmoid ? 0.f : ddice);
+        dlogits[(n * 2 + 1) * HW + hw] = g1_ce + ddice;
     }
 }
 

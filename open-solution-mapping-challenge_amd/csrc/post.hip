@@ -19,26 +19,70 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {  // scipy.ndimage 're
 }
 
 // ------------------------------------------------------------------ resize / crop / threshold / argmax
-__global__ void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int H, int W) {
+// The reference thresholds the FLOAT64 map skimage's resize returns (src/postprocessing.py:60,83).  The interpolant is therefore
+// computed here with exactly numpy's roundings: one rounding per operation in the order of the expression (no fused multiply-add:
+// hipcc contracts a*b+c by default), then skimage's clip to the input range joined with cval 0 (warp(..., clip=True)); thresholds
+// are compared in double against it, and only the stored float32 map (what the scoring reads) is rounded.
+__device__ __forceinline__ double bilinear_f64(const float* __restrict__ p, int h, int w, int oy, int ox, double fy, double fx, double lo, double hi) {
+#pragma clang fp contract(off)
+    const double ys = fy * (oy + 0.5) - 0.5, xs = fx * (ox + 0.5) - 0.5;
+    // scipy 'constant' mode: no interpolation beyond the edges -> cval
+    if (!(ys >= 0.0 && ys <= (double)(h - 1) && xs >= 0.0 && xs <= (double)(w - 1))) return fmin(fmax(0.0, lo), hi);
+    int y0 = (int)floor(ys), x0 = (int)floor(xs);
+    y0 = min(max(y0, 0), h - 1); x0 = min(max(x0, 0), w - 1);
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    // scipy's NI_GeometricTransform: weights 1-a and 1-(1-a) per axis, per tap (coefficient * row weight) * column weight, taps in raster order
+    const double wy0 = 1.0 - (ys - y0), wx0 = 1.0 - (xs - x0);
+    const double wy1 = 1.0 - wy0, wx1 = 1.0 - wx0;
+    double v = ((double)p[(long)y0 * w + x0] * wy0) * wx0;
+    v = v + ((double)p[(long)y0 * w + x1] * wy0) * wx1;
+    v = v + ((double)p[(long)y1 * w + x0] * wy1) * wx0;
+    v = v + ((double)p[(long)y1 * w + x1] * wy1) * wx1;
+    return fmin(fmax(v, lo), hi);
+}
+
+// per image: (min(image.min(), 0), max(image.max(), 0)) -- the range skimage clips the resized map to; one block per image
+__global__ void image_minmax_kernel(const float* __restrict__ in, float* __restrict__ minmax, long per_image) {
+    __shared__ float smn[16], smx[16];
+    const float* p = in + blockIdx.x * per_image;
+    float mn = 0.f, mx = 0.f;
+    for (long i = threadIdx.x; i < per_image; i += blockDim.x) { const float v = p[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    for (int o = 32; o; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) { mn = fminf(mn, smn[i]); mx = fmaxf(mx, smx[i]); }
+        minmax[2 * blockIdx.x] = mn; minmax[2 * blockIdx.x + 1] = mx;
+    }
+}
+
+template <typename OUT>
+__global__ void resize_bilinear_kernel(const float* __restrict__ in, OUT* __restrict__ out, const float* __restrict__ minmax, int C, int planes, int h, int w, int H, int W) {
     const long total = (long)planes * H * W;
     const double fy = (double)h / H, fx = (double)w / W;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int ox = (int)(i % W), oy = (int)((i / W) % H);
         const long pl = i / ((long)W * H);
-        const double ys = (oy + 0.5) * fy - 0.5, xs = (ox + 0.5) * fx - 0.5;
-        float r = 0.f;
-        // scipy 'constant' mode: no interpolation beyond the edges -> cval
-        if (ys >= 0.0 && ys <= (double)(h - 1) && xs >= 0.0 && xs <= (double)(w - 1)) {
-            int y0 = (int)floor(ys), x0 = (int)floor(xs);
-            y0 = min(max(y0, 0), h - 1); x0 = min(max(x0, 0), w - 1);
-            const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
-            const double ay = ys - y0, ax = xs - x0;
-            const float* p = in + pl * (long)h * w;
-            const double v = (1 - ay) * (1 - ax) * p[(long)y0 * w + x0] + (1 - ay) * ax * p[(long)y0 * w + x1] +
-                             ay * (1 - ax) * p[(long)y1 * w + x0] + ay * ax * p[(long)y1 * w + x1];
-            r = (float)v;
+        const long b = pl / C;
+        out[i] = (OUT)bilinear_f64(in + pl * (long)h * w, h, w, oy, ox, fy, fx, (double)minmax[2 * b], (double)minmax[2 * b + 1]);
+    }
+}
+
+// resize + categorize_multilayer_image in one pass: the float32 map for the scoring, the layers from the double interpolant
+__global__ void resize_threshold_kernel(const float* __restrict__ in, float* __restrict__ out, uint8_t* __restrict__ layers, const float* __restrict__ minmax,
+                                        int B, int C, int h, int w, int H, int W, const int32_t* __restrict__ layer_class, const double* __restrict__ layer_thr, int L) {
+    const long HW = (long)H * W, total = (long)B * HW;
+    const double fy = (double)h / H, fx = (double)w / W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long hw = i % HW, b = i / HW;
+        const int ox = (int)(hw % W), oy = (int)(hw / W);
+        const double lo = (double)minmax[2 * b], hi = (double)minmax[2 * b + 1];
+        for (int c = 0; c < C; ++c) {
+            const double v = bilinear_f64(in + (b * C + c) * (long)h * w, h, w, oy, ox, fy, fx, lo, hi);
+            out[(b * C + c) * HW + hw] = (float)v;
+            for (int l = 0; l < L; ++l)
+                if (layer_class[l] == c) layers[(b * L + l) * HW + hw] = v > layer_thr[l] ? 1 : 0;
         }
-        out[i] = r;
     }
 }
 
@@ -51,14 +95,15 @@ __global__ void crop_center_kernel(const float* __restrict__ in, float* __restri
     }
 }
 
-__global__ void threshold_layers_kernel(const float* __restrict__ probs, uint8_t* __restrict__ layers, int B, int C, long HW,
-                                        const int32_t* __restrict__ layer_class, const float* __restrict__ layer_thr, int L) {
+template <typename IN>
+__global__ void threshold_layers_kernel(const IN* __restrict__ probs, uint8_t* __restrict__ layers, int B, int C, long HW,
+                                        const int32_t* __restrict__ layer_class, const double* __restrict__ layer_thr, int L) {
     const long total = (long)B * L * HW;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long hw = i % HW;
         const int l = (int)((i / HW) % L);
         const long b = i / (HW * L);
-        layers[i] = probs[(b * C + layer_class[l]) * HW + hw] > layer_thr[l] ? 1 : 0;
+        layers[i] = (double)probs[(b * C + layer_class[l]) * HW + hw] > layer_thr[l] ? 1 : 0;      // numpy: array > float64 scalar compares in double
     }
 }
 
@@ -861,10 +906,23 @@ inline int flat_grid(long n) {
 #define POST_DIMS(name) \
     if (B <= 0 || H <= 0 || W <= 0 || (long)H * W > 0x3fffffffL) return msc_fail(MSC_ERR_ARG, name ": bad dims B=%d H=%d W=%d", B, H, W)
 
-extern "C" int msc_resize_bilinear(const float* in, float* out, int B, int C, int h, int w, int H, int W, void* stream) {
-    if (!in || !out || B <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return msc_fail(MSC_ERR_ARG, "msc_resize_bilinear: bad argument");
-    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(flat_grid((long)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, in, out, B * C, h, w, H, W);
+extern "C" int msc_resize_bilinear(const float* in, void* out, int out_f64, float* minmax_ws, int B, int C, int h, int w, int H, int W, void* stream) {
+    if (!in || !out || !minmax_ws || B <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return msc_fail(MSC_ERR_ARG, "msc_resize_bilinear: bad argument");
+    hipLaunchKernelGGL(image_minmax_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, in, minmax_ws, (long)C * h * w);
+    if (out_f64)
+        hipLaunchKernelGGL(resize_bilinear_kernel<double>, dim3(flat_grid((long)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, in, (double*)out, minmax_ws, C, B * C, h, w, H, W);
+    else
+        hipLaunchKernelGGL(resize_bilinear_kernel<float>, dim3(flat_grid((long)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, in, (float*)out, minmax_ws, C, B * C, h, w, H, W);
     return msc_check_launch("msc_resize_bilinear");
+}
+
+extern "C" int msc_resize_threshold(const float* in, float* out, uint8_t* layers, float* minmax_ws, int B, int C, int h, int w, int H, int W,
+                                    const int32_t* layer_class, const double* layer_thr, int L, void* stream) {
+    if (!in || !out || !layers || !minmax_ws || !layer_class || !layer_thr || B <= 0 || C <= 0 || L <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0)
+        return msc_fail(MSC_ERR_ARG, "msc_resize_threshold: bad argument");
+    hipLaunchKernelGGL(image_minmax_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, in, minmax_ws, (long)C * h * w);
+    hipLaunchKernelGGL(resize_threshold_kernel, dim3(flat_grid((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, in, out, layers, minmax_ws, B, C, h, w, H, W, layer_class, layer_thr, L);
+    return msc_check_launch("msc_resize_threshold");
 }
 
 extern "C" int msc_crop_center(const float* in, float* out, int B, int C, int h, int w, int hc, int wc, void* stream) {
@@ -877,11 +935,14 @@ extern "C" int msc_crop_center(const float* in, float* out, int B, int C, int h,
     return msc_check_launch("msc_crop_center");
 }
 
-extern "C" int msc_threshold_layers(const float* probs, uint8_t* layers, int B, int C, int H, int W,
-                                    const int32_t* layer_class, const float* layer_thr, int L, void* stream) {
+extern "C" int msc_threshold_layers(const void* probs, int probs_f64, uint8_t* layers, int B, int C, int H, int W,
+                                    const int32_t* layer_class, const double* layer_thr, int L, void* stream) {
     POST_DIMS("msc_threshold_layers");
     if (!probs || !layers || !layer_class || !layer_thr || L <= 0 || C <= 0) return msc_fail(MSC_ERR_ARG, "msc_threshold_layers: bad argument");
-    hipLaunchKernelGGL(threshold_layers_kernel, dim3(flat_grid((long)B * L * H * W)), dim3(256), 0, (hipStream_t)stream, probs, layers, B, C, (long)H * W, layer_class, layer_thr, L);
+    if (probs_f64)
+        hipLaunchKernelGGL(threshold_layers_kernel<double>, dim3(flat_grid((long)B * L * H * W)), dim3(256), 0, (hipStream_t)stream, (const double*)probs, layers, B, C, (long)H * W, layer_class, layer_thr, L);
+    else
+        hipLaunchKernelGGL(threshold_layers_kernel<float>, dim3(flat_grid((long)B * L * H * W)), dim3(256), 0, (hipStream_t)stream, (const float*)probs, layers, B, C, (long)H * W, layer_class, layer_thr, L);
     return msc_check_launch("msc_threshold_layers");
 }
 

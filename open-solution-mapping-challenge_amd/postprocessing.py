@@ -45,18 +45,37 @@ def layer_table(category_layers=CATEGORY_LAYERS):
         step = 1. / (n + 1)
         for t in np.arange(step, 1, step):
             cls.append(cat)
-            thr.append(np.float32(t))   # probabilities are float32 on the device
-    return np.asarray(cls, np.int32), np.asarray(thr, np.float32)
+            thr.append(t)               # the reference's float64 thresholds; the kernels compare in double (numpy: array > float64 scalar)
+    return np.asarray(cls, np.int32), np.asarray(thr, np.float64)
 
 
 # ------------------------------------------------------------------ device-level (batched) primitives
-def resize_batch(probs, target_size):
-    """probs: cuda f32 [B,C,h,w] -> cuda f32 [B,C,H,W]"""
+def resize_batch(probs, target_size, dtype=torch.float32):
+    """probs: cuda f32 [B,C,h,w] -> cuda [B,C,H,W]: the double interpolant the reference's skimage resize returns, stored as float64
+    (`dtype=torch.float64`) or rounded once to float32"""
     B, Cc, h, w = probs.shape
     H, W = target_size
-    out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=probs.device)
-    _lib.call('msc_resize_bilinear', probs.data_ptr(), out.data_ptr(), B, Cc, h, w, H, W, _stream())
+    out = torch.empty((B, Cc, H, W), dtype=dtype, device=probs.device)
+    ws = torch.empty(2 * B, dtype=torch.float32, device=probs.device)
+    _lib.call('msc_resize_bilinear', probs.data_ptr(), out.data_ptr(), int(dtype == torch.float64), ws.data_ptr(), B, Cc, h, w, H, W, _stream())
     return out
+
+
+def resize_threshold_batch(probs, target_size, category_layers=CATEGORY_LAYERS):
+    """resize_image + categorize_multilayer_image in one launch: cuda f32 [B,C,h,w] -> (cuda f32 [B,C,H,W] for the scoring, cuda u8
+    [B,L,H,W]); the layers are cut from the DOUBLE interpolant, as the reference cuts them from skimage's float64 map
+    (src/postprocessing.py:60,83), so they are bit-identical to the reference chain's and not a thresholding of the rounded map"""
+    B, Cc, h, w = probs.shape
+    H, W = target_size
+    cls, thr = layer_table(category_layers)
+    L = len(cls)
+    dcls, dthr = torch.from_numpy(cls).to(probs.device), torch.from_numpy(thr).to(probs.device)
+    out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=probs.device)
+    layers = torch.empty((B, L, H, W), dtype=torch.uint8, device=probs.device)
+    ws = torch.empty(2 * B, dtype=torch.float32, device=probs.device)
+    _lib.call('msc_resize_threshold', probs.data_ptr(), out.data_ptr(), layers.data_ptr(), ws.data_ptr(), B, Cc, h, w, H, W,
+              dcls.data_ptr(), dthr.data_ptr(), L, _stream())
+    return out, layers
 
 
 def crop_batch(images, h_crop, w_crop):
@@ -67,13 +86,15 @@ def crop_batch(images, h_crop, w_crop):
 
 
 def threshold_batch(probs, category_layers=CATEGORY_LAYERS):
-    """cuda f32 [B,C,H,W] -> cuda u8 [B,L,H,W]"""
+    """cuda f32 or f64 [B,C,H,W] -> cuda u8 [B,L,H,W]"""
+    if probs.dtype not in (torch.float32, torch.float64):
+        probs = probs.float()
     B, Cc, H, W = probs.shape
     cls, thr = layer_table(category_layers)
     L = len(cls)
     dcls, dthr = torch.from_numpy(cls).to(probs.device), torch.from_numpy(thr).to(probs.device)
     out = torch.empty((B, L, H, W), dtype=torch.uint8, device=probs.device)
-    _lib.call('msc_threshold_layers', probs.data_ptr(), out.data_ptr(), B, Cc, H, W, dcls.data_ptr(), dthr.data_ptr(), L, _stream())
+    _lib.call('msc_threshold_layers', probs.data_ptr(), int(probs.dtype == torch.float64), out.data_ptr(), B, Cc, H, W, dcls.data_ptr(), dthr.data_ptr(), L, _stream())
     return out
 
 
@@ -194,9 +215,11 @@ def _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, catego
     if not probs.is_cuda:
         probs = probs.to(_device())
     probs = probs.contiguous().float()
-    p = resize_batch(probs, target_size) if target_size is not None else probs
+    if target_size is not None:
+        p, layers = resize_threshold_batch(probs, target_size, category_layers)     # layers [B,L,H,W] u8 from the double interpolant
+    else:
+        p, layers = probs, threshold_batch(probs, category_layers)
     B, Cc, H, W = p.shape
-    layers = threshold_batch(p, category_layers)                 # [B,L,H,W] u8
     L = layers.shape[1]
     flat = layers.view(B * L, H, W)
     if erode_selem_size > 0:
@@ -256,9 +279,10 @@ def softmax(X, theta=1.0, axis=None):
 
 
 def resize_image(image, target_size):
-    """src/postprocessing.py:48-61.  image (C x H x W) -> (C x h x w), float32."""
+    """src/postprocessing.py:48-61.  image (C x H x W) -> (C x h x w), float64 like the reference's skimage resize (the network's
+    probabilities are float32; a float64 input is rounded to float32 first)."""
     d = _dev(image, np.float32)[None]
-    return resize_batch(d, tuple(target_size))[0].cpu().numpy()
+    return resize_batch(d, tuple(target_size), torch.float64)[0].cpu().numpy()
 
 
 def categorize_image(image):
@@ -271,8 +295,9 @@ def categorize_image(image):
 
 
 def categorize_multilayer_image(image):
-    """src/postprocessing.py:77-84 -> bool (L x H x W)."""
-    d = _dev(image, np.float32)[None]
+    """src/postprocessing.py:77-84 -> bool (L x H x W).  A float64 map (what resize_image returns) is thresholded as float64."""
+    image = np.asarray(image)
+    d = _dev(image, np.float64 if image.dtype == np.float64 else np.float32)[None]
     return threshold_batch(d)[0].cpu().numpy().astype(bool)
 
 

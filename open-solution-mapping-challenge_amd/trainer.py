@@ -23,8 +23,12 @@ class LossSpec:
     """Loss configuration in the reference's vocabulary."""
 
     def __init__(self, weighted=False, dice_weight=0.0, ce_weight=1.0, smooth=0.0, w0=50.0, sigma=10.0,
-                 imsize=(256, 256), eps=1e-7):
+                 imsize=(256, 256), eps=1e-7, dice_activation='softmax'):
+        if dice_activation not in ('softmax', 'sigmoid'):
+            raise NotImplementedError('only sigmoid and softmax are implemented')        # src/models.py:443
         self.cfg = LossCfg()
+        self.cfg.dice_sigmoid = int(dice_activation == 'sigmoid')
+        self.dice_activation = dice_activation
         self.cfg.weighted = int(bool(weighted))
         self.cfg.dice_weight, self.cfg.ce_weight = float(dice_weight), float(ce_weight)
         self.cfg.smooth, self.cfg.eps = float(smooth), float(eps)
@@ -44,7 +48,8 @@ class LossSpec:
         lw = architecture_config['loss_weights']
         dice = architecture_config['dice']
         return cls(weighted=True, dice_weight=lw['dice_mask'], ce_weight=lw['bce_mask'], smooth=dice.get('smooth', 0),
-                   w0=wce['w0'], sigma=wce['sigma'], imsize=tuple(wce['imsize']))
+                   w0=wce['w0'], sigma=wce['sigma'], imsize=tuple(wce['imsize']),
+                   dice_activation=dice.get('dice_activation', 'softmax'))           # src/models.py:158,437-442
 
 
 def _run(fn, args, device):
@@ -159,6 +164,7 @@ class HipAdam(torch.optim.Optimizer):
         self._pending = None          # a state_dict loaded before the flat buffers exist
         self._table = None            # (key, keep-alive tensors, msc_adam_pack table arguments)
         self.on_hyper_change = None   # TrainStep: drop captured graphs (betas / eps / weight_decay are launch arguments)
+        self._scale_restored = False  # a loaded state_dict brought its loss scale: TrainStep must not reset it to the default
 
     # the step count lives on the device once training runs: a skipped (overflowed) step does not advance it
     @property
@@ -290,6 +296,7 @@ class HipAdam(torch.optim.Optimizer):
 
     def state_dict(self):
         return {'m': self.m, 'v': self.v, 'steps': self.steps, 'lr': self.lr, 'loss_scale': self.current_loss_scale(),
+                'dynamic_scale': self.dynamic_scale, 'growth_interval': self.growth_interval,
                 'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
 
     def load_state_dict(self, state):
@@ -329,8 +336,17 @@ class HipAdam(torch.optim.Optimizer):
         self._apply_hyper(state)
         self.set_lr(self.lr)
         self.dev_state[_lib.OPT_STEP] = float(self._steps)
-        if state.get('loss_scale') and self.dynamic_scale:
-            self.dev_state[_lib.OPT_SCALE] = float(state['loss_scale'])
+        if state.get('loss_scale'):
+            # the (dynamic) loss scale a checkpoint carries is restored whatever order optimizer / TrainStep were built in; the
+            # clean-step counter and a pending overflow flag belong to the run that wrote the checkpoint
+            if 'dynamic_scale' in state:
+                self.dynamic_scale, self.growth_interval = bool(state['dynamic_scale']), int(state.get('growth_interval', self.growth_interval))
+            self.loss_scale = float(state['loss_scale'])
+            self.dev_state[_lib.OPT_SCALE] = self.loss_scale
+            self.dev_state[_lib.OPT_GROWTH] = float(self.growth_interval if self.dynamic_scale else 0)
+            self.dev_state[_lib.OPT_GOOD] = 0.0
+            self.dev_state[_lib.OPT_OVERFLOW] = 0.0
+            self._scale_restored = True
 
 
 DDP_FRACTIONS = (0.40, 0.65, 0.85)      # share of the gradient bytes that must be final before the first three exchanges
@@ -417,7 +433,10 @@ class TrainStep:
         # it; an explicit loss_scale argument pins a static one.
         fp16 = getattr(net, 'compute_dtype', '') == 'fp16'
         self.loss_scale = float(loss_scale) if loss_scale is not None else (4096.0 if fp16 else 1.0)
-        optimizer.set_loss_scale(self.loss_scale, dynamic=(fp16 and loss_scale is None))
+        if loss_scale is None and fp16 and optimizer._scale_restored and optimizer.dynamic_scale:
+            self.loss_scale = optimizer.loss_scale          # resumed fp16 run: keep the scale the checkpoint reached
+        else:
+            optimizer.set_loss_scale(self.loss_scale, dynamic=(fp16 and loss_scale is None))
         optimizer.on_hyper_change = self._drop_graphs
         self.dist = world is not None and (world.size > 1 or force_collectives)     # force: exercise RCCL with one rank
         self.use_graph = use_graph
@@ -508,6 +527,11 @@ class TrainStep:
                 st.graph = g
             return self.loss
         self.opt.sync_lr()                # a scheduler callback may have changed it: the captured Adam reads it from the device
+        if self.net._packed_version != self.net._version:
+            # the master weights changed between two replays (load_state_dict, load_encoder_state_dict, weights_changed()): the replay
+            # reads the 16-bit compute copies, which only the Adam launch at the END of a step rewrites -- repack first
+            from .unet_models import _stream_of
+            self.net._refresh_weights(_stream_of(st.x.device))
         if st.pieces is not None:
             self._replay_pieces()
         else:

@@ -4,7 +4,7 @@ Restates src/steps/pytorch/validation.py:8-28 (DiceLoss, multiclass_segmentation
 src/models.py:310-454 (distance x size weighted cross entropy, soft Dice on softmax, the mix), plus
 the Adam+L2 update the reference configures at src/models.py:57,287-292 (torch.optim.Adam with
 weight_decay).  Pinned against the literal reference functions in
-tests/test_oracle_vs_reference.py and tests/golden/loss_*.npz.
+tests/test_oracle.py and tests/golden/loss_*.npz.
 """
 import math
 
@@ -36,9 +36,11 @@ def weighted_ce(output, target, w0, sigma, imsize):
     return torch.mean(per_pixel * w)
 
 
-def dice(output, target_cls, smooth=0.0, eps=1e-7, excluded=(0,)):
-    # src/models.py:421-454 with validation.py:8-16; softmax over channels, sums over the WHOLE batch
-    p = torch.softmax(output, dim=1)
+def dice(output, target_cls, smooth=0.0, eps=1e-7, excluded=(0,), activation='softmax'):
+    # src/models.py:421-454 with validation.py:8-16; softmax over channels (or elementwise sigmoid, :437-442), sums over the WHOLE batch
+    if activation not in ('softmax', 'sigmoid'):
+        raise NotImplementedError('only sigmoid and softmax are implemented')
+    p = torch.softmax(output, dim=1) if activation == 'softmax' else torch.sigmoid(output)
     loss = 0
     for c in range(output.shape[1]):
         if c in excluded:
@@ -50,9 +52,9 @@ def dice(output, target_cls, smooth=0.0, eps=1e-7, excluded=(0,)):
 
 
 def mixed_dice_ce(output, target, dice_weight=0.2, ce_weight=1.0, smooth=1.0, w0=50.0, sigma=10.0,
-                  imsize=(256, 256)):
+                  imsize=(256, 256), dice_activation='softmax'):
     # src/models.py:384-418 as configured by PyTorchUNetWeighted (:149-161) and neptune.yaml:42-57
-    return dice_weight * dice(output, target[:, 0].long(), smooth) + \
+    return dice_weight * dice(output, target[:, 0].long(), smooth, activation=dice_activation) + \
         ce_weight * weighted_ce(output, target, w0, sigma, imsize)
 
 

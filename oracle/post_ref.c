@@ -57,19 +57,25 @@ void msc_ref_dilate_i32(const int32_t* in, int32_t* out, int h, int w, int k) {
         }
 }
 
-void msc_ref_resize(const float* in, double* out, int h, int w, int H, int W) {
+/* scipy's arithmetic rounding for rounding (see oracle/post_ref.py resize_image): weights 1-a and 1-(1-a), per tap (coefficient * row weight) *
+ * column weight, taps in raster order; then skimage's clip to [lo, hi] = the input range joined with cval 0.  Build with -ffp-contract=off. */
+void msc_ref_resize(const float* in, double* out, int h, int w, int H, int W, double lo, double hi) {
     const double fy = (double)h / H, fx = (double)w / W;
     for (int oy = 0; oy < H; ++oy)
         for (int ox = 0; ox < W; ++ox) {
-            const double ys = (oy + 0.5) * fy - 0.5, xs = (ox + 0.5) * fx - 0.5;
+            const double ys = fy * (oy + 0.5) - 0.5, xs = fx * (ox + 0.5) - 0.5;
             double r = 0.0;
             if (ys >= 0.0 && ys <= h - 1 && xs >= 0.0 && xs <= w - 1) {
                 int y0 = (int)floor(ys), x0 = (int)floor(xs);
                 const int y1 = y0 + 1 < h ? y0 + 1 : h - 1, x1 = x0 + 1 < w ? x0 + 1 : w - 1;
-                const double ay = ys - y0, ax = xs - x0;
-                r = (1 - ay) * (1 - ax) * in[y0 * w + x0] + (1 - ay) * ax * in[y0 * w + x1] + ay * (1 - ax) * in[y1 * w + x0] + ay * ax * in[y1 * w + x1];
+                const double wy0 = 1.0 - (ys - y0), wx0 = 1.0 - (xs - x0);
+                const double wy1 = 1.0 - wy0, wx1 = 1.0 - wx0;
+                r = ((double)in[y0 * w + x0] * wy0) * wx0;
+                r = r + ((double)in[y0 * w + x1] * wy0) * wx1;
+                r = r + ((double)in[y1 * w + x0] * wy1) * wx0;
+                r = r + ((double)in[y1 * w + x1] * wy1) * wx1;
             }
-            out[oy * W + ox] = r;
+            out[oy * W + ox] = r < lo ? lo : (r > hi ? hi : r);
         }
 }
 
@@ -84,8 +90,10 @@ int msc_ref_postprocess(const float* probs, int h, int w, int H, int W, int dila
     double* sum = (double*)malloc(sizeof(double) * (size_t)(max_labels + 1));
     int64_t* area = (int64_t*)malloc(sizeof(int64_t) * (size_t)(max_labels + 1));
     int rc = 0;
+    double lo = 0.0, hi = 0.0;
+    for (size_t i = 0; i < (size_t)2 * h * w; ++i) { if (probs[i] < lo) lo = probs[i]; if (probs[i] > hi) hi = probs[i]; }
     for (int c = 0; c < 2 && rc == 0; ++c) {
-        msc_ref_resize(probs + (size_t)c * h * w, r, h, w, H, W);
+        msc_ref_resize(probs + (size_t)c * h * w, r, h, w, H, W, lo, hi);
         for (size_t i = 0; i < HW; ++i) m[i] = r[i] > 0.5;
         int32_t* lab = labels + c * HW;
         const int n = msc_ref_label4(m, dilate > 0 ? tmp : lab, H, W);

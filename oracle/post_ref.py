@@ -3,7 +3,7 @@
 Each function restates one reference function (file:line given) in window / loop form so that it
 does not depend on scikit-image (unpinned in the reference, not installed here).  scipy.ndimage
 (installed, and the library the reference itself calls for labelling) is used only for `label`.
-Pinned in tests/test_oracle_vs_reference.py against the reference's own functions executed through
+Pinned in tests/test_oracle.py against the reference's own functions executed through
 the skimage-on-scipy shim, and by the docstring known-answer example of label_multiclass_image
 (src/postprocessing.py:96-111).  Unpinned by the reference: skimage's even-kernel origin, resize
 edge handling / output dtype.
@@ -24,29 +24,39 @@ def softmax(x, axis):
 def resize_image(image, target_size):
     # src/postprocessing.py:48-61 -> skimage resize(order=1, mode='constant') -> for a (C,H,W)->(C,h,w)
     # request skimage's n-d branch: scipy.ndimage.map_coordinates(order=1, mode='constant', cval=0)
-    # sampled at src = (dst+0.5)*in/out-0.5.  scipy's 'constant' mode does NOT interpolate beyond
+    # sampled at src = in/out*(dst+0.5)-0.5.  scipy's 'constant' mode does NOT interpolate beyond
     # the edges: a sample whose coordinate falls outside [0, n-1] on any axis is cval (0) outright,
     # so when upscaling the first and last output row/column are 0.  float64 result.
+    # The ARITHMETIC is scipy's, rounding for rounding (NI_GeometricTransform: per tap the coefficient is
+    # multiplied by the weight of each axis in turn, taps summed in raster order; weights 1-a and 1-(1-a)):
+    # tests/test_oracle.py pins this function to the installed scipy's map_coordinates with array_equal,
+    # because the reference thresholds this float64 map and a tie at 0.5 is decided by the last bit.
     c, h, w = image.shape
     th, tw = target_size
     img = image.astype(np.float64)
-    ys = (np.arange(th) + 0.5) * (h / th) - 0.5
-    xs = (np.arange(tw) + 0.5) * (w / tw) - 0.5
+    ys = (h / th) * (np.arange(th) + 0.5) - 0.5
+    xs = (w / tw) * (np.arange(tw) + 0.5) - 0.5
     oky = (ys >= 0) & (ys <= h - 1)
     okx = (xs >= 0) & (xs <= w - 1)
     y0 = np.clip(np.floor(ys).astype(np.int64), 0, h - 1)
     x0 = np.clip(np.floor(xs).astype(np.int64), 0, w - 1)
     y1 = np.minimum(y0 + 1, h - 1)
     x1 = np.minimum(x0 + 1, w - 1)
-    fy = (ys - y0)[None, :, None]
-    fx = (xs - x0)[None, None, :]
+    wy0 = 1.0 - (ys - y0)
+    wy1 = 1.0 - wy0
+    wx0 = 1.0 - (xs - x0)
+    wx1 = 1.0 - wx0
+    wy0, wy1 = wy0[None, :, None], wy1[None, :, None]
+    wx0, wx1 = wx0[None, None, :], wx1[None, None, :]
 
     def tap(yy, xx):
         return img[:, yy[:, None], xx[None, :]]
-    out = ((1 - fy) * (1 - fx) * tap(y0, x0) + (1 - fy) * fx * tap(y0, x1) +
-           fy * (1 - fx) * tap(y1, x0) + fy * fx * tap(y1, x1))
+    out = (tap(y0, x0) * wy0) * wx0
+    out = out + (tap(y0, x1) * wy0) * wx1
+    out = out + (tap(y1, x0) * wy1) * wx0
+    out = out + (tap(y1, x1) * wy1) * wx1
     out = out * (oky[None, :, None] & okx[None, None, :])
-    return np.clip(out, min(img.min(), 0.0), max(img.max(), 0.0))
+    return np.clip(out, min(img.min(), 0.0), max(img.max(), 0.0))       # skimage: warp(..., clip=True)
 
 
 def categorize_image(image):

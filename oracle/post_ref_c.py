@@ -17,7 +17,7 @@ def load(build_if_missing=True):
     if _lib is None:
         if not os.path.exists(_SO) and build_if_missing:
             os.makedirs(os.path.dirname(_SO), exist_ok=True)
-            subprocess.run(['gcc', '-O2', '-shared', '-fPIC', '-o', _SO, os.path.join(_HERE, 'post_ref.c'), '-lm'], check=True)
+            subprocess.run(['gcc', '-O2', '-ffp-contract=off', '-shared', '-fPIC', '-o', _SO, os.path.join(_HERE, 'post_ref.c'), '-lm'], check=True)
         _lib = C.CDLL(_SO)
         _lib.msc_ref_postprocess.restype = C.c_int
         _lib.msc_ref_postprocess.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE -- run the reference's own Python, unmodified, on top of import shims.
 
 Only usable where /root/reference exists (the build container).  Used by
-tests/test_oracle_vs_reference.py and tests/golden/make_golden.py to pin the restatements in
+tests/test_oracle.py and tests/golden/make_golden.py to pin the restatements in
 oracle/ against the literal reference code.  Never imported by the product.
 
 What is patched (never by editing the reference):

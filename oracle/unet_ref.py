@@ -7,7 +7,7 @@ The module tree and therefore the state_dict keys are the reference's, including
 of the encoder stages (`conv1.0.* == encoder.conv1.*`, `conv2.* == encoder.layer1.*`, ...), so a
 state_dict moves freely between the reference class, this oracle and the HIP engine.
 
-Pinned against the literal reference class in tests/test_oracle_vs_reference.py (bitwise equal
+Pinned against the literal reference class in tests/test_oracle.py (bitwise equal
 outputs for identical weights, run where /root/reference exists) and by tests/golden/unet_*.npz.
 """
 import numpy as np

@@ -178,12 +178,13 @@ def _loss_terms(logits, target, tc, cfg, N, H, W):
         dw = np.where(d == 0, 1.0, 1.0 + cfg.w0 * np.exp(-(d * d) / (cfg.sigma * cfg.sigma)))
         s1 = np.where(sz == 0, 1.0, sz)
         w = dw * np.where(s1 == 1, 1.0, cfg.size_c / s1)
-    return ce, w, p0, p1, t1
+    q1 = 1.0 / (1.0 + np.exp(-lg[:, 1])) if getattr(cfg, 'dice_sigmoid', 0) else p1       # the Dice activation of class 1
+    return ce, w, p0, p1, t1, q1
 
 
 def loss_sums(logits, target, tc, cfg, sums, N, H, W):
-    ce, w, p0, p1, t1 = _loss_terms(logits, target, tc, cfg, N, H, W)
-    _arr(sums, 4, np.float64)[...] = [(w * ce).sum(), (p1 * t1).sum(), p1.sum(), t1.sum()]
+    ce, w, p0, p1, t1, q1 = _loss_terms(logits, target, tc, cfg, N, H, W)
+    _arr(sums, 4, np.float64)[...] = [(w * ce).sum(), (q1 * t1).sum(), q1.sum(), t1.sum()]
 
 
 OPT_STEP, OPT_LR, OPT_OVERFLOW, OPT_SKIP, OPT_SCALE, OPT_GOOD, OPT_GROWTH, OPT_SKIPPED, OPT_UNSCALE = range(9)      # include/msc.h MSC_OPT_*
@@ -193,14 +194,16 @@ OPT_STATE = 12
 def loss_grad(logits, target, tc, cfg, sums, total_pixels, grad_scale, scale_state, loss, dlogits, N, H, W):
     if scale_state and _arr(scale_state, OPT_STATE)[OPT_SCALE] > 0:
         grad_scale = grad_scale * float(_arr(scale_state, OPT_STATE)[OPT_SCALE])
-    ce, w, p0, p1, t1 = _loss_terms(logits, target, tc, cfg, N, H, W)
+    ce, w, p0, p1, t1, q1 = _loss_terms(logits, target, tc, cfg, N, H, W)
     s = _arr(sums, 4, np.float64)
     A, B = 2.0 * s[1] + cfg.smooth, s[2] + s[3] + cfg.smooth + cfg.eps
     if loss:
         _arr(loss, 1)[0] = cfg.ce_weight * s[0] / total_pixels + cfg.dice_weight * (1.0 - A / B)
-    g1 = (cfg.ce_weight / total_pixels) * w * (p1 - t1) + (cfg.dice_weight * A / (B * B) - cfg.dice_weight * 2.0 / B * t1) * p1 * p0
+    sig = getattr(cfg, 'dice_sigmoid', 0)
+    g_ce = (cfg.ce_weight / total_pixels) * w * (p1 - t1)
+    g_dice = (cfg.dice_weight * A / (B * B) - cfg.dice_weight * 2.0 / B * t1) * (q1 * (1 - q1) if sig else p1 * p0)
     dl = _arr(dlogits, N * 2 * H * W).reshape(N, 2, H * W)
-    dl[:, 0], dl[:, 1] = -g1 * grad_scale, g1 * grad_scale
+    dl[:, 0], dl[:, 1] = (-g_ce - (0 if sig else g_dice)) * grad_scale, (g_ce + g_dice) * grad_scale
 
 
 def adam_tick(state):

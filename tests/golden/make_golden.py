@@ -16,14 +16,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import ref_import, unet_ref, post_ref, losses_ref  # noqa: E402
 
 
-def ref_loss(rm, weighted):
+def ref_loss(rm, weighted, dice_activation='softmax'):
     if not weighted:
         return ref_import.ref('steps.pytorch.validation').multiclass_segmentation_loss
     wf = partial(rm.get_weights, w0=50, sigma=10, imsize=(256, 256))
     return partial(rm.mixed_dice_cross_entropy_loss, dice_weight=0.2, cross_entropy_weight=1.0,
                    dice_loss=partial(rm.multiclass_dice_loss, excluded_classes=[0]),
                    cross_entropy_loss=partial(rm.multiclass_weighted_cross_entropy, weights_function=wf),
-                   smooth=1, dice_activation='softmax')
+                   smooth=1, dice_activation=dice_activation)
 
 
 def main():
@@ -74,10 +74,10 @@ def main():
     logits = torch.from_numpy(rng.standard_normal((2, 2, 64, 64)).astype(np.float32) * 3).requires_grad_(True)
     tgt = losses_ref.synthetic_target(2, 64, 64, seed=7)
     rec = {}
-    for name, weighted in (('ce', False), ('mixed', True)):
+    for name, weighted, act in (('ce', False, 'softmax'), ('mixed', True, 'softmax'), ('mixed_sigmoid', True, 'sigmoid')):
         logits.grad = None
         t = tgt if weighted else tgt[:, :1]
-        loss = ref_loss(rm, weighted)(logits, t)
+        loss = ref_loss(rm, weighted, act)(logits, t)
         loss.backward()
         rec['loss_' + name] = np.float32(loss.item())
         rec['dlogits_' + name] = logits.grad.numpy().copy()

@@ -229,6 +229,74 @@ def test_hipadam_state_dict_roundtrip_resume_order_and_fresh_compute_copies(inte
     assert opt3.steps == 3 and torch.equal(after, net3.flat_params)
 
 
+def test_dice_activation_reaches_the_loss_kernels(interpreted):
+    """round-4 verdict: `dice_activation: sigmoid` (src/models.py:437-442) used to train with softmax-Dice without a word; LossSpec.mixed reads
+    it, the launch carries msc_loss_cfg.dice_sigmoid, and loss + dlogits of the launch pair equal the oracle's for both activations"""
+    from mapping_challenge_amd.trainer import LossSpec, loss_forward_backward
+    arch = {'weighted_cross_entropy': {'w0': 50, 'sigma': 10, 'imsize': (256, 256)}, 'loss_weights': {'dice_mask': 0.2, 'bce_mask': 1.0}}
+    torch.manual_seed(3)
+    logits = (torch.randn(2, 2, 32, 32) * 2)
+    tgt = losses_ref.synthetic_target(2, 32, 32, seed=5)
+    for act in ('softmax', 'sigmoid'):
+        spec = LossSpec.mixed(dict(arch, dice={'smooth': 1, 'dice_activation': act}))
+        assert spec.cfg.dice_sigmoid == int(act == 'sigmoid')
+        lg = logits.clone().requires_grad_(True)
+        ref = losses_ref.mixed_dice_ce(lg, tgt, dice_activation=act)
+        ref.backward()
+        d, loss, sums = torch.empty_like(logits), torch.zeros(1), torch.zeros(4, dtype=torch.float64)
+        loss_forward_backward(logits, tgt, spec, d, loss, sums)
+        assert abs(loss.item() - ref.item()) < 1e-5 and torch.allclose(d, lg.grad, atol=1e-8, rtol=1e-4)
+    with pytest.raises(NotImplementedError):
+        LossSpec.mixed(dict(arch, dice={'dice_activation': 'tanh'}))
+
+
+class _ReplayOf:
+    """stands in for a captured hipGraph on the CPU interpreter: replay() executes the launches the capture recorded"""
+
+    def __init__(self, body):
+        self.body = body
+
+    def replay(self):
+        self.body()
+
+
+def test_graph_replay_repacks_weights_a_loaded_state_dict_changed(interpreted):
+    """round-4 advisory: the captured step reads the COMPUTE COPIES of the weights, which only the Adam launch at the end of a step
+    rewrites; a load_state_dict between two replays must be followed by a repack before the next replay (and a checkpointed dynamic
+    loss scale comes back whatever order optimizer and TrainStep are built in)"""
+    from mapping_challenge_amd import _lib
+    from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
+    x = unet_ref.synthetic_batch(1, 64, 64)
+    t = losses_ref.synthetic_target(1, 64, 64)[:, :1].contiguous()
+    ref, net = build(34)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    net.train()
+    opt = HipAdam(net, lr=1e-3)
+    ts = TrainStep(net, LossSpec.plain_ce(), opt)
+    l_first = ts(x, t).item()                       # eager first step of the shape, as under use_graph
+    ts.use_graph, ts.cur.graph = True, _ReplayOf(ts._body_captured)
+    ts(x, t)
+    net.load_state_dict(sd0)                        # back to the initial weights between two replays
+    opt.load_state_dict(dict(opt.state_dict(), m=None, v=None, steps=0))
+    assert net._packed_version != net._version
+    l_again = ts(x, t).item()
+    assert abs(l_again - l_first) < 1e-6            # stale compute copies would give the loss of the twice-updated weights
+    assert net._packed_version == net._version
+    # loss scale of a checkpoint: restored into a flattened optimizer BEFORE the TrainStep is built (fp16 resume order)
+    opt.set_loss_scale(512.0, dynamic=True, growth_interval=7)
+    state = opt.state_dict()
+    assert state['dynamic_scale'] is True and state['growth_interval'] == 7
+    opt2 = HipAdam(net, lr=1e-3)
+    opt2.load_state_dict(state)
+    net.compute_dtype = 'fp16'                      # only the flag TrainStep looks at
+    try:
+        ts2 = TrainStep(net, LossSpec.plain_ce(), opt2)
+    finally:
+        net.compute_dtype = 'fp32'
+    assert ts2.loss_scale == 512.0 and opt2.current_loss_scale() == 512.0 and opt2.dynamic_scale and opt2.growth_interval == 7
+    assert float(opt2.dev_state[_lib.OPT_GROWTH]) == 7.0 and float(opt2.dev_state[_lib.OPT_GOOD]) == 0.0
+
+
 def test_dynamic_loss_scale_skips_an_overflowed_step(interpreted):
     """fp16 `fit()` safety (the device-side protocol, run here on the interpreter in fp32 arithmetic): with a dynamic scale an
     overflowing gradient leaves parameters, moments and the step count untouched and halves the scale; the next clean step trains"""

@@ -317,7 +317,12 @@ def test_loss_kernels_match_oracle_and_golden(golden_dir):
     tgt = losses_ref.synthetic_target(2, 64, 64, seed=7)
     arch = {'weighted_cross_entropy': {'w0': 50, 'sigma': 10, 'imsize': (256, 256)},
             'loss_weights': {'dice_mask': 0.2, 'bce_mask': 1.0}, 'dice': {'smooth': 1, 'dice_activation': 'softmax'}}
-    for name, spec, t in (('ce', LossSpec.plain_ce(), tgt[:, :1].contiguous()), ('mixed', LossSpec.mixed(arch), tgt)):
+    arch_s = dict(arch, dice={'smooth': 1, 'dice_activation': 'sigmoid'})      # src/models.py:440-441 (round 5: was silently softmax)
+    assert LossSpec.mixed(arch_s).cfg.dice_sigmoid == 1 and LossSpec.mixed(arch).cfg.dice_sigmoid == 0
+    with pytest.raises(NotImplementedError):
+        LossSpec.mixed(dict(arch, dice={'smooth': 1, 'dice_activation': 'tanh'}))
+    for name, spec, t in (('ce', LossSpec.plain_ce(), tgt[:, :1].contiguous()), ('mixed', LossSpec.mixed(arch), tgt),
+                          ('mixed_sigmoid', LossSpec.mixed(arch_s), tgt)):
         d = torch.empty((2, 2, 64, 64), device='cuda')
         loss = torch.zeros(1, device='cuda')
         sums = torch.zeros(4, dtype=torch.float64, device='cuda')

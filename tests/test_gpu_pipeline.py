@@ -52,7 +52,7 @@ def test_unet_weighted_pipeline_fit_transform(tmp_path, fused):
     # post-processing parity: recompute the chain with the oracle from the model's own probabilities
     probs = inf.get_step('unet').transformer.transform(([[X]], 1))['multichannel_map_prediction']
     for p, (lab, sc) in zip(probs, out2['y_pred']):
-        r = post_ref.resize_image(p, (75, 75)).astype(np.float32)
+        r = post_ref.resize_image(p, (75, 75))       # float64, as the reference thresholds it
         exp = post_ref.dilate_image(post_ref.label_multilayer_image(post_ref.categorize_multilayer_image(r)), 2)
         assert (lab == exp).all()
 
@@ -92,7 +92,7 @@ def test_unet_tta_and_unet_padded_inference_pipelines(tmp_path):
     net = pipe.get_step('unet').transformer.unet.model
     exp = tta.predict_tta(net, X.cuda(), tta.tta_specs(flip_ud=True, flip_lr=True, rotation=True), 'gmean').cpu().numpy()
     for p, (lab, sc) in zip(exp, out['y_pred']):
-        r = post_ref.resize_image(p, (75, 75)).astype(np.float32)
+        r = post_ref.resize_image(p, (75, 75))       # float64, as the reference thresholds it
         assert (lab == post_ref.dilate_image(post_ref.label_multilayer_image(post_ref.categorize_multilayer_image(r)), 2)).all()
     cfg['execution']['stream_mode'] = True
     with pytest.raises(Exception, match='stream mode'):
@@ -104,7 +104,7 @@ def test_unet_tta_and_unet_padded_inference_pipelines(tmp_path):
     probs = net.predict_proba(X.cuda()).cpu().numpy()
     for p, (lab, sc) in zip(probs, out['y_pred']):
         c = post_ref.crop_image_center_per_class(p, 48, 48)
-        r = post_ref.resize_image(c, (48, 48)).astype(np.float32)
+        r = post_ref.resize_image(c, (48, 48))       # float64, as the reference thresholds it
         assert (lab == post_ref.dilate_image(post_ref.label_multilayer_image(post_ref.categorize_multilayer_image(r)), 2)).all()
 
 
@@ -117,7 +117,7 @@ def test_fused_postprocessing_honours_per_image_target_sizes():
     assert len(out) == 5
     for p, size, (lab, sc) in zip(probs, sizes, out):
         assert lab.shape == (2,) + size
-        r = post_ref.resize_image(p, size).astype(np.float32)
+        r = post_ref.resize_image(p, size)       # float64, as the reference thresholds it
         assert (lab == post_ref.dilate_image(post_ref.label_multilayer_image(post_ref.categorize_multilayer_image(r)), 2)).all()
 
 

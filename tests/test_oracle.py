@@ -31,6 +31,27 @@ def test_unionfind_matches_scipy_on_adversarial_masks():
         assert (post_ref.label_unionfind(m) == post_ref.label(m)).all()
 
 
+def test_resize_oracle_is_scipy_map_coordinates_bit_for_bit():
+    """the reference's resize is skimage's n-d branch = scipy.ndimage.map_coordinates(order 1, 'constant') + clip, and its float64 output
+    is what gets thresholded: the restatement the GPU tests compare with (and the kernel follows) must equal the INSTALLED scipy --
+    the reference's real dependency -- in every bit, also on maps made of values a float32 ulp around the 0.5 threshold"""
+    from scipy import ndimage as ndi
+    rng = np.random.default_rng(3)
+    cases = [((2, 64, 64), (75, 75)), ((2, 256, 256), (300, 300)), ((3, 96, 80), (112, 100)), ((2, 64, 64), (48, 48)), ((2, 5, 7), (300, 251))]
+    cases += [((2, int(rng.integers(5, 120)), int(rng.integers(5, 120))), (int(rng.integers(5, 200)), int(rng.integers(5, 200)))) for _ in range(12)]
+    vals = np.array([0.5 - 2.0 ** -25, 0.5, 0.5 + 2.0 ** -24, 1.0, 0.0], np.float32)
+    for shape, (th, tw) in cases:
+        for img in (rng.random(shape).astype(np.float32), vals[rng.integers(0, 5, shape)]):
+            factors = [1.0, shape[1] / th, shape[2] / tw]
+            coords = [factors[i] * (np.arange(d) + 0.5) - 0.5 for i, d in enumerate((shape[0], th, tw))]
+            cm = np.array(np.meshgrid(*coords, sparse=False, indexing='ij'))
+            img64 = img.astype(np.float64)
+            exp = ndi.map_coordinates(img64, cm, order=1, mode='constant', cval=0)
+            exp = np.clip(exp, min(img64.min(), 0), max(img64.max(), 0))
+            got = post_ref.resize_image(img, (th, tw))
+            assert got.dtype == np.float64 and np.array_equal(got, exp), (shape, th, tw)
+
+
 def test_post_chain_matches_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, 'post.npz'))
     assert (post_ref.label_multiclass_image(KAT_IN) == g['kat_multiclass']).all()
@@ -130,6 +151,14 @@ def test_loss_oracle_matches_golden(golden_dir):
     loss = losses_ref.mixed_dice_ce(logits, tgt)
     loss.backward()
     assert abs(loss.item() - float(g['loss_mixed'])) < 1e-5 and np.allclose(logits.grad.numpy(), g['dlogits_mixed'], atol=1e-7)
+    # dice_activation = 'sigmoid' (src/models.py:440-441), generated by the reference's multiclass_dice_loss like the rest
+    logits.grad = None
+    loss = losses_ref.mixed_dice_ce(logits, tgt, dice_activation='sigmoid')
+    loss.backward()
+    assert abs(loss.item() - float(g['loss_mixed_sigmoid'])) < 1e-5 and np.allclose(logits.grad.numpy(), g['dlogits_mixed_sigmoid'], atol=1e-8, rtol=1e-5)
+    assert np.abs(g['dlogits_mixed_sigmoid'] - g['dlogits_mixed']).max() > 1e-6       # the two activations are told apart at this tolerance
+    with pytest.raises(NotImplementedError):
+        losses_ref.mixed_dice_ce(logits, tgt, dice_activation='tanh')
 
 
 def test_adam_oracle_matches_torch_optim():
@@ -190,7 +219,7 @@ def test_oracle_post_equals_reference_functions():
     probs = post_ref.synthetic_probs(2, 96, 96, seed=5, smooth=3.0)
     for p in probs:
         a, b = pp.resize_image(p, (112, 112)), post_ref.resize_image(p, (112, 112))
-        assert np.allclose(a, b, atol=1e-12)
+        assert a.dtype == np.float64 and np.array_equal(a, b)       # bit for bit: the reference thresholds this map (ties at 0.5)
         la, lb = pp.categorize_multilayer_image(a), post_ref.categorize_multilayer_image(b)
         assert (la == lb).all()
         lab = pp.label_multilayer_image(la)
@@ -220,6 +249,11 @@ def test_oracle_losses_equal_reference_functions():
                                            cross_entropy_loss=partial(rm.multiclass_weighted_cross_entropy, weights_function=wf),
                                            smooth=1, dice_activation='softmax')
     assert torch.allclose(mix, losses_ref.mixed_dice_ce(out, t), rtol=1e-6)
+    mix_s = rm.mixed_dice_cross_entropy_loss(out, t, dice_weight=0.2, cross_entropy_weight=1.0,
+                                             dice_loss=partial(rm.multiclass_dice_loss, excluded_classes=[0]),
+                                             cross_entropy_loss=partial(rm.multiclass_weighted_cross_entropy, weights_function=wf),
+                                             smooth=1, dice_activation='sigmoid')
+    assert torch.allclose(mix_s, losses_ref.mixed_dice_ce(out, t, dice_activation='sigmoid'), rtol=1e-6) and not torch.equal(mix, mix_s)
     assert torch.allclose(val.multiclass_segmentation_loss(out, t[:, :1]), losses_ref.segmentation_ce(out, t[:, :1]))
 
 
