@@ -6,8 +6,8 @@ oracle/ against the literal reference code.  Never imported by the product.
 
 What is patched (never by editing the reference):
   * sys.path gets oracle/shims first: torchvision (ResNet restated), skimage (on scipy.ndimage),
-    pydensecrf (on oracle/crf_ref.py), pycocotools.mask (on oracle/annot_ref.py), attrdict
-  * permissive stubs for neptune, imgaug, cv2, pycocotools.coco/cocoeval, lightgbm, xgboost, imageio, pydot_ng,
+    pydensecrf (on oracle/crf_ref.py), pycocotools.mask (on oracle/annot_ref.py), attrdict, imgaug (identity augmenters)
+  * permissive stubs for neptune, cv2, pycocotools.coco/cocoeval, lightgbm, xgboost, imageio, pydot_ng,
     IPython
   * sklearn.externals.joblib -> joblib ; collections.Iterable -> collections.abc.Iterable
   * yaml.load default Loader (PyYAML 6) ; env NEPTUNE_API_TOKEN / CONFIG_PATH
@@ -43,7 +43,7 @@ def install():
         sys.path.insert(0, shims)
     import pycocotools.mask            # the shim package; its coco / cocoeval submodules become stubs below
     import _anystub
-    _anystub.install('neptune', 'imgaug', 'imgaug.augmenters', 'cv2',
+    _anystub.install('neptune', 'cv2',
                      'pycocotools.coco', 'pycocotools.cocoeval', 'lightgbm', 'xgboost', 'imageio',
                      'pydot_ng', 'IPython', 'IPython.display')
     import joblib

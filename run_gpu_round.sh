@@ -36,22 +36,22 @@ bench) # every line DESIGN.md quotes; the default command (BASELINE.json's metri
        bench_line e2e 900 --workload e2e
        bench_line train 1200;;
 benchq) bench_line train 1200 --no-cpu-baseline;;
-prof)  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1   # fills the tune cache so the profile holds no tuning launches
+prof)  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown --no-north-star > gpurun_out/tune_warm.log 2>&1   # fills the tune cache so the profile holds no tuning launches
        prof_stats train --steps 20 --warmup 2
-       python bench.py --workload infer --encoder 101 --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
+       python bench.py --workload infer --encoder 101 --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown --no-north-star > gpurun_out/tune_warm.log 2>&1
        prof_stats infer_r101 --workload infer --encoder 101 --steps 20 --warmup 2
        prof_stats post --workload post --steps 20 --warmup 2
        prof_stats e2e --workload e2e --steps 5 --warmup 2;;
-proft) python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
+proft) python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown --no-north-star > gpurun_out/tune_warm.log 2>&1
        prof_stats train --steps 20 --warmup 2;;
-pmc)   python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
+pmc)   python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown --no-north-star > gpurun_out/tune_warm.log 2>&1
        cd /tmp; export TMPDIR=/tmp
        for c in FETCH_SIZE WRITE_SIZE; do
          timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c" -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-breakdown > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log" 2>&1; echo "pmc $c rc=$?"
        done
        cd "$GRAFT_REPO_ROOT"; python tools/pmc_summary.py gpurun_out gpurun_out/pmc_traffic.json > gpurun_out/pmc_summary.txt 2>&1; head -12 gpurun_out/pmc_summary.txt;;
 pmcsq) # SQ / LDS / L2 counters of the train step, one rocprofv3 pass per counter group (counter runs carry kernel-trace only)
-       python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
+       python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown --no-north-star > gpurun_out/tune_warm.log 2>&1
        cd /tmp; export TMPDIR=/tmp
        i=0
        for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum"; do
@@ -66,10 +66,10 @@ bnl)   # BatchNorm + ReLU on load (msc_conv_desc.in_bn, ABI v9): the kernel test
        timeout 600 python -m pytest tests/test_gpu_unet.py -m gpu -q -rf --tb=short -p no:cacheprovider -k "bn_on_load" > gpurun_out/pytest_bnl2.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/pytest_bnl2.log
        AB="MSC_BN_ON_LOAD=0 MSC_BN_ON_LOAD=1 MSC_BN_ON_LOAD=1,MSC_BN_ON_LOAD_3X3=0 MSC_BN_ON_LOAD=0" "$0" ab;;
 ab)    # A/B of environment switches on the train step: AB="NAME=VAL,NAME2=VAL2 NAME=VAL ..." (one run per word)
-       python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > gpurun_out/tune_warm.log 2>&1
+       python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown --no-north-star > gpurun_out/tune_warm.log 2>&1
        for cfg in $AB; do
          tag=$(echo "$cfg" | tr ',=' '__')
-         ( IFS=,; for kv in $cfg; do export "$kv"; done; unset IFS; timeout 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline $ABFLAGS > "gpurun_out/ab_$tag.log" 2>&1 )
+         ( IFS=,; for kv in $cfg; do export "$kv"; done; unset IFS; timeout 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-north-star $ABFLAGS > "gpurun_out/ab_$tag.log" 2>&1 )
          echo "$cfg: $(grep -o '"ms_per_step": [0-9.]*' "gpurun_out/ab_$tag.log" | head -1) $(grep -o '"wgrad": {[^}]*}' "gpurun_out/ab_$tag.log" | head -1) $(grep -o '"msc_adam_pack": [0-9.]*' "gpurun_out/ab_$tag.log" | head -1)"
        done;;
 esac

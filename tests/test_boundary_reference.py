@@ -112,6 +112,102 @@ def test_hip_transformer_inside_reference_step_with_reference_callbacks(interpre
     assert out3['multichannel_map_prediction'].shape == (4, 2, 64, 64) and t3.epoch_losses == []
 
 
+def _synthetic_tiles(root, n_train=4, n_valid=2):
+    """300x300 RGB PNG tiles + class-index mask PNGs on disk and the metadata frame the reference's XYSplit / loaders read
+    (X_COLUMNS / Y_COLUMNS of src/pipeline_config.py:11-13; masks as overlay_masks writes them, src/preparation.py:84-95)"""
+    import pandas as pd
+    from PIL import Image
+    from scipy import ndimage as ndi
+    os.makedirs(os.path.join(root, 'data'), exist_ok=True)
+    rng = np.random.default_rng(1234)
+    rows = []
+    for i in range(n_train + n_valid):
+        img = (ndi.gaussian_filter(rng.random((300, 300, 3)), (4, 4, 0)) * 4 % 1 * 255).astype(np.uint8)
+        z = ndi.gaussian_filter(rng.standard_normal((300, 300)), 12)
+        mask = (z > np.quantile(z, 0.7)).astype(np.uint8)
+        fi, fm = os.path.join(root, 'data', 'img_%d.png' % i), os.path.join(root, 'data', 'mask_%d.png' % i)
+        Image.fromarray(img).save(fi)
+        Image.fromarray(mask).save(fm)
+        rows.append({'ImageId': i, 'file_path_image': fi, 'file_path_mask_eroded_0_dilated_0': fm,
+                     'is_train': int(i < n_train), 'is_valid': int(i >= n_train)})
+    return pd.DataFrame(rows)
+
+
+def _plain(x):
+    return {k: _plain(v) for k, v in x.items()} if isinstance(x, dict) else x
+
+
+@needs_ref
+def test_configs0_the_references_own_unet_pipeline_graph_with_the_hip_transformer_swapped_in(interpreted, tmp_path):
+    """BASELINE.json configs[0] (ResNet34-U-Net, 4 synthetic 300x300 tiles, 1 epoch; plumbing): the graph is the REFERENCE's --
+    src.pipelines.PIPELINES['unet']['train'] built from src.pipeline_config.SOLUTION_CONFIG (src/pipelines.py:12-52,395-411), its
+    XYSplit, its MetadataImageSegmentationLoaderResize reading PNG tiles from disk (src/loaders.py:287-304), its Step caching, its
+    callbacks (neptune stubbed), its six mask_postprocessing Steps -- driven the way src/pipeline_manager.py:126-137 drives it;
+    the ONLY change is the one INTEGRATION.md section 3 names: get_step('unet').transformer = the HIP transformer built from the
+    same config.unet.  (The reference's own transformer cannot finish an epoch on this torch: `loss.data.cpu().numpy()[0]`,
+    src/steps/pytorch/callbacks.py:135, indexes a 0-d array.)  Compute back end: tests/emu.py.  Then the inference graph
+    (train_mode False) loads the transformer the train graph persisted and its y_pred equals the oracle chain on the transformer's
+    own probabilities."""
+    from oracle import post_ref
+    pc, pl = ref_import.ref('pipeline_config'), ref_import.ref('pipelines')
+    from attrdict import AttrDict                      # the shim ref_import puts on the path
+    root = str(tmp_path)
+    meta = _synthetic_tiles(root)
+    cfg = _plain(pc.SOLUTION_CONFIG)
+    cfg['env']['cache_dirpath'] = os.path.join(root, 'exp')
+    cfg['execution'].update(num_workers=0, batch_size_train=2, batch_size_inference=2, loader_mode='resize', stream_mode=False)
+    for k in ('training', 'inference'):
+        cfg['loader']['loader_params'][k].update(batch_size=2, num_workers=0, pin_memory=False)
+    cfg['loader']['dataset_params'].update(h=64, w=64)             # network input edge (256 in neptune.yaml): the interpreter is slow
+    u = cfg['unet']
+    u['architecture_config']['model_params']['encoder'] = 'ResNet34'
+    u['training_config']['epochs'] = 1
+    u['callbacks_config']['model_checkpoint'].update(filepath=os.path.join(root, 'exp', 'checkpoints', 'unet', 'best.torch'), minimize=True)
+    u['callbacks_config']['validation_monitor'].update(validate_with_map=0, data_dir=root)
+    u['callbacks_config']['early_stopping']['minimize'] = True
+    cfg = AttrDict(cfg)
+
+    def hip_transformer():
+        ucfg = _plain(cfg.unet)
+        ucfg['architecture_config']['model_params']['compute_dtype'] = 'fp32'
+        return hip_models.PyTorchUNet(**ucfg)
+    pipe = pl.PIPELINES['unet']['train'](cfg)
+    assert type(pipe.get_step('unet').transformer).__module__ == 'src.models'            # the reference's class, about to be swapped
+    t = hip_transformer()
+    t.model.load_state_dict(unet_ref.seeded_state_dict(unet_ref.UNetResNetRef(34)))
+    pipe.get_step('unet').transformer = t                                                  # INTEGRATION.md section 3
+    train_meta, valid_meta = meta[meta.is_train == 1], meta[meta.is_valid == 1]
+    data = {'input': {'meta': train_meta, 'target_sizes': [(300, 300)] * len(train_meta), 'annotations': None},
+            'specs': {'train_mode': True, 'num_threads': 1}, 'callback_input': {'meta_valid': valid_meta}}
+    pipe.clean_cache()
+    out = pipe.fit_transform(data)
+    assert list(out) == ['y_pred'] and len(out['y_pred']) == 4
+    for labels, scores in out['y_pred']:
+        assert labels.shape == (2, 300, 300) and labels.dtype == np.int32
+        assert [len(s) for s in scores] == [int(l.max()) for l in labels]
+    # one epoch over 2 batches of 2 tiles ran through the reference's callback list; validation on the 2 valid tiles; checkpoint
+    assert len(t.epoch_losses) == 1 and t.optimizer.steps == 2 and sorted(t.validation_loss) == [0]
+    assert os.path.exists(cfg.unet.callbacks_config.model_checkpoint.filepath)
+    assert os.path.exists(os.path.join(root, 'exp', 'transformers', 'unet'))              # Step persisted the fitted transformer
+    # inference graph: loader without shuffling, the Step LOADS the persisted HIP transformer (Model.load, module.-prefixed keys)
+    inf = pl.PIPELINES['unet']['inference'](cfg)
+    t2 = hip_transformer()
+    inf.get_step('unet').transformer = t2
+    data_inf = {'input': {'meta': train_meta, 'target_sizes': [(300, 300)] * len(train_meta)},
+                'specs': {'train_mode': False, 'num_threads': 1}, 'callback_input': {'meta_valid': None}}
+    out2 = inf.transform(data_inf)
+    assert t2.epoch_losses == [] and all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(t.model.state_dict().values(), t2.model.state_dict().values()))
+    loader_out = inf.get_step('loader').transform(data_inf)
+    probs = t2.transform(loader_out['datagen'])['multichannel_map_prediction']
+    assert probs.shape == (4, 2, 64, 64)
+    for p, (labels, scores) in zip(probs, out2['y_pred']):
+        r = post_ref.resize_image(p, (300, 300))
+        exp = post_ref.dilate_image(post_ref.label_multilayer_image(post_ref.categorize_multilayer_image(r)), cfg.postprocessor.mask_dilation.dilate_selem_size)
+        assert (labels == exp).all()
+        _, exp_sc = post_ref.build_score(exp, r)
+        assert all(np.allclose(a, b, rtol=1e-9) for a, b in zip(scores, exp_sc))
+
+
 def test_fit_with_own_callbacks_validates_stops_early_and_checkpoints_best(interpreted, tmp_path):
     """the standalone mirror of the protocol (mapping_challenge_amd.callbacks): same observable behaviour"""
     from mapping_challenge_amd import callbacks as cb

@@ -246,14 +246,23 @@ def test_bn_on_load_training_matches_the_separate_apply_launches(dtype, monkeypa
         net.deterministic = True
         net.train()
         step = TrainStep(net, LossSpec.plain_ce(), HipAdam(net, lr=1e-3), use_graph=True)
-        losses = [step(x, tgt).item() for _ in range(4)]
+        losses = [step(x, tgt).item()]
+        bn2 = net.encoder.layer3[5].bn2
+        first = (bn2.running_mean.clone(), bn2.running_var.clone(), net.encoder.layer1[0].bn1.running_var.clone())     # after ONE step
+        losses += [step(x, tgt).item() for _ in range(3)]
         prog = next(p for k, p in net._programs.items() if p.training)
         nb = sum(1 for fn, _ in prog.fwd if fn.__name__ == 'msc_bn_apply')
-        runs[on] = (losses, net.flat_params.clone(), net.encoder.layer3[5].bn2.running_var.clone(), nb)
+        runs[on] = (losses, net.flat_params.clone(), first, nb)
     assert runs['0'][3] - runs['1'][3] == 36
-    assert np.allclose(runs['0'][0], runs['1'][0], rtol=2e-2)
-    assert torch.allclose(runs['0'][2], runs['1'][2], rtol=2e-2)
-    assert (runs['0'][1] - runs['1'][1]).abs().mean().item() < 2e-4
+    # the first step's forward differs only by the summation order inside conv3 / conv2 (same bits in, measured by the kernel tests): loss and
+    # the running statistics the consumer's prologue now writes agree tightly.  (Four Adam steps at lr 1e-3 on 64-pixel BatchNorm populations
+    # amplify a last-bit difference -- sign flips of near-zero gradients move a weight by 2 lr -- so later steps are held to a band, as the
+    # first GPU run of this test showed: running_var of layer3 after four steps differs by up to 5 % between the two modes.)
+    assert abs(runs['0'][0][0] - runs['1'][0][0]) < 2e-3 * abs(runs['0'][0][0])
+    for a, b in zip(runs['0'][2], runs['1'][2]):
+        assert torch.allclose(a, b, rtol=2e-3, atol=1e-6)
+    assert np.allclose(runs['0'][0], runs['1'][0], rtol=3e-2)
+    assert (runs['0'][1] - runs['1'][1]).abs().mean().item() < 4e-4
     assert runs['1'][0][-1] < runs['1'][0][0]
 
 
