@@ -19,8 +19,12 @@ def test_gpus_n_reexec_argv_is_the_drivers_launch_line():
     assert 1024 < port < 65536
 
 
-def test_reexec_line_really_starts_n_ranks_with_the_torchrun_environment(tmp_path):
-    """the same launch line with a stand-in script: torch.distributed.run starts 2 processes that see RANK / LOCAL_RANK /
+import pytest
+
+
+@pytest.mark.parametrize('W', [2, 8])
+def test_reexec_line_really_starts_n_ranks_with_the_torchrun_environment(tmp_path, W):
+    """the same launch line with a stand-in script: torch.distributed.run starts W (2, 8) processes that see RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_ADDR = 127.0.0.1, and World.from_env turns them into a 2-rank gloo group"""
     import bench
     script = tmp_path / 'probe.py'
@@ -37,12 +41,13 @@ def test_reexec_line_really_starts_n_ranks_with_the_torchrun_environment(tmp_pat
         'w.barrier()\n'
         'line = "RANK %%d %%d %%s %%s %%s %%.1f" %% (w.rank, w.size, os.environ["LOCAL_RANK"], os.environ["MASTER_ADDR"], w.grad_wire, t.item())\n'
         'open(os.path.join(%r, "rank%%d.txt" %% w.rank), "w").write(line)\n' % (ROOT, str(tmp_path)))
-    argv = bench.reexec_argv(2, [])
+    argv = bench.reexec_argv(W, [])
     argv[argv.index(os.path.join(ROOT, 'bench.py'))] = str(script)
     env = dict(os.environ, OMP_NUM_THREADS='1')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     out = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [open(str(tmp_path / ('rank%d.txt' % r))).read() for r in range(2)]      # one file per rank: stdout of the ranks interleaves
-    assert lines == ['RANK 0 2 0 127.0.0.1 bf16 3.0', 'RANK 1 2 1 127.0.0.1 bf16 3.0'], (lines, out.stdout)
+    lines = [open(str(tmp_path / ('rank%d.txt' % r))).read() for r in range(W)]      # one file per rank: stdout of the ranks interleaves
+    # W = 8: the first 8-rank run of the launch line must not be the driver's (round-4 verdict)
+    assert lines == ['RANK %d %d %d 127.0.0.1 bf16 %.1f' % (r, W, r, W * (W + 1) / 2.0) for r in range(W)], (lines, out.stdout)

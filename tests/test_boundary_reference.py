@@ -138,7 +138,7 @@ def _plain(x):
 
 
 @needs_ref
-def test_configs0_the_references_own_unet_pipeline_graph_with_the_hip_transformer_swapped_in(interpreted, tmp_path):
+def test_configs0_the_references_own_unet_pipeline_graph_with_the_hip_transformer_swapped_in(interpreted, tmp_path, monkeypatch):
     """BASELINE.json configs[0] (ResNet34-U-Net, 4 synthetic 300x300 tiles, 1 epoch; plumbing): the graph is the REFERENCE's --
     src.pipelines.PIPELINES['unet']['train'] built from src.pipeline_config.SOLUTION_CONFIG (src/pipelines.py:12-52,395-411), its
     XYSplit, its MetadataImageSegmentationLoaderResize reading PNG tiles from disk (src/loaders.py:287-304), its Step caching, its
@@ -190,6 +190,10 @@ def test_configs0_the_references_own_unet_pipeline_graph_with_the_hip_transforme
     assert os.path.exists(cfg.unet.callbacks_config.model_checkpoint.filepath)
     assert os.path.exists(os.path.join(root, 'exp', 'transformers', 'unet'))              # Step persisted the fitted transformer
     # inference graph: loader without shuffling, the Step LOADS the persisted HIP transformer (Model.load, module.-prefixed keys)
+    # (inference feeds y = None through `squeeze_inputs` = np.squeeze(None, axis=1), src/utils.py:227-228: the numpy of the reference's era
+    # ignored the axis for objects without a squeeze method and returned array(None); numpy 2 raises -- restore that one behaviour)
+    ref_squeeze = pl.squeeze_inputs
+    monkeypatch.setattr(pl, 'squeeze_inputs', lambda inputs: None if inputs[0] is None else ref_squeeze(inputs))
     inf = pl.PIPELINES['unet']['inference'](cfg)
     t2 = hip_transformer()
     inf.get_step('unet').transformer = t2

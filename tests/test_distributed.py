@@ -136,7 +136,7 @@ def _engine_worker(rank, world_size, port, q, wire='fp32'):
 import pytest
 
 
-@pytest.mark.parametrize('wire,W', [('fp32', 2), ('bf16', 3), ('fp32', 4)])
+@pytest.mark.parametrize('wire,W', [('fp32', 2), ('bf16', 3), ('fp32', 4), ('fp32', 8)])       # 8: one image per rank, the node size bench.py --gpus 8 runs at
 def test_product_backward_in_pieces_with_async_allreduce_matches_full_batch(wire, W):
     """wire 'bf16': the 16-bit gradient exchange (cast -> all-to-all -> fp32 accumulate, one rounding -> all-gather -> widen);
     W = 3: a world size that divides none of the gradient ranges -- every exchanged range is padded to W shards of a multiple of 8
