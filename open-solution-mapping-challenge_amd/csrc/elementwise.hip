@@ -236,11 +236,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 #pragma unroll
             for (int e = 0; e < CE; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        Vec16<T>::store(out + pix * out_ld + c, v);
+        const uint4 pk = Vec16<T>::pack(v);
+        store16(out + pix * out_ld + c, pk);
         if (mask) {                  // ReLU mask of this lane's CE channels as one byte (bit e = channel c + e): what the backward reads instead of `out`
+            // taken from the STORED (rounded) value, so that it is what [out > 0] gives (MSC_RELU_BITS=0 and the reference mask on the stored
+            // activation): an fp16 value below 2^-25 rounds to 0 and must not count as active (round-4 advisory)
+            float w[CE];
+            Vec16<T>::unpack(pk, w);
             unsigned m = 0;
 #pragma unroll
-            for (int e = 0; e < CE; ++e) m |= (v[e] > 0.f ? 1u : 0u) << e;
+            for (int e = 0; e < CE; ++e) m |= (w[e] > 0.f ? 1u : 0u) << e;
             mask[pix * mask_ld + c / CE] = (uint8_t)m;
         }
     }

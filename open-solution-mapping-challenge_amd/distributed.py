@@ -8,8 +8,9 @@ replicate / scatter / gather / reduce-add becomes:
     value the reference computes on its gathered batch (src/steps/pytorch/models.py:92,104);
   * gradients all-reduced (sum) in a few large buckets of the flat fp32 gradient buffer -- xGMI is
     point-to-point (7 links x ~153 GB/s per GPU), ring collectives are per-link bound, so few large
-    messages beat many small ones.  Wire format (`grad_wire`): 'fp32' = one ring all-reduce per bucket;
-    16-bit ('bf16' / 'fp16', the default when the network computes in that dtype) = reduce-scatter by
+    messages beat many small ones.  Wire format (`grad_wire`): 'fp32' (the DEFAULT since round 4: the precision of
+    the reference's reduce-add) = one ring all-reduce per bucket; 16-bit ('bf16', opt-in: training_config['grad_wire']
+    / MSC_GRAD_WIRE=bf16) = reduce-scatter by
     all-to-all of 16-bit shards + fp32 accumulation on receive + all-gather of the once-rounded sum,
     i.e. half the bytes per step (R101: 311 -> 155 MB) over the same links, and every rank ends up
     with bit-identical gradients (the rounding happens once, at the owner of the shard);

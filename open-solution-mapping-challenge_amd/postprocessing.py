@@ -53,6 +53,7 @@ def layer_table(category_layers=CATEGORY_LAYERS):
 def resize_batch(probs, target_size, dtype=torch.float32):
     """probs: cuda f32 [B,C,h,w] -> cuda [B,C,H,W]: the double interpolant the reference's skimage resize returns, stored as float64
     (`dtype=torch.float64`) or rounded once to float32"""
+    probs = probs.contiguous().float()
     B, Cc, h, w = probs.shape
     H, W = target_size
     out = torch.empty((B, Cc, H, W), dtype=dtype, device=probs.device)
@@ -65,6 +66,7 @@ def resize_threshold_batch(probs, target_size, category_layers=CATEGORY_LAYERS):
     """resize_image + categorize_multilayer_image in one launch: cuda f32 [B,C,h,w] -> (cuda f32 [B,C,H,W] for the scoring, cuda u8
     [B,L,H,W]); the layers are cut from the DOUBLE interpolant, as the reference cuts them from skimage's float64 map
     (src/postprocessing.py:60,83), so they are bit-identical to the reference chain's and not a thresholding of the rounded map"""
+    probs = probs.contiguous().float()
     B, Cc, h, w = probs.shape
     H, W = target_size
     cls, thr = layer_table(category_layers)
@@ -89,6 +91,7 @@ def threshold_batch(probs, category_layers=CATEGORY_LAYERS):
     """cuda f32 or f64 [B,C,H,W] -> cuda u8 [B,L,H,W]"""
     if probs.dtype not in (torch.float32, torch.float64):
         probs = probs.float()
+    probs = probs.contiguous()          # a numpy map built by fancy indexing arrives with permuted strides
     B, Cc, H, W = probs.shape
     cls, thr = layer_table(category_layers)
     L = len(cls)

@@ -229,7 +229,10 @@ class UNetResNet(nn.Module):
     the static loss scale TrainStep applies, inference does not) or 'fp32' (exact-f32 parity mode).
     deterministic (or MSC_DETERMINISTIC=1; read when a training program is built): the weight gradients' partial sums are added in a
     fixed order instead of by fp32 atomics (msc_wgrad_group_create MSC_WGRAD_ORDERED, msc_final_bwd ordered_ws) -- two runs of the same
-    steps from the same state give the same bits, at the price of one more pass over the split planes per step.
+    steps from the same state give the same bits, at the price of one more pass over the split planes per step.  What stays atomic in
+    this mode: the BatchNorm / bias sums (per-XCD slots of float64 added in arrival order -- fp32 partials summed in double, so the
+    result can differ between runs only when a rounding of the DOUBLE sum falls differently, which the repeat test has not seen but the
+    arithmetic does not exclude); it needs MSC_WGRAD_GROUP > 1 and raises otherwise.
     """
 
     def __init__(self, encoder_depth, num_classes, num_filters=32, dropout_2d=0.2, pretrained=False,
@@ -640,6 +643,10 @@ class _Builder:
         self.group_steps = int(env.get('MSC_WGRAD_GROUP_STEPS', '128'))      # k-steps per block: fewer, longer blocks = fewer fp32-atomic passes over dW
         self.group_tile = int(env.get('MSC_WGRAD_GROUP_TILE', '128'))
         self.ordered = bool(getattr(net, 'deterministic', False)) and self.group_max > 1      # fixed-order sums (MSC_WGRAD_ORDERED); the per-layer launches stay atomic
+        if training and getattr(net, 'deterministic', False) and not self.ordered and device.type == 'cuda':
+            # round-4 advisory: the flag used to be dropped without a word when the grouped launches are off
+            raise _lib.MscError('deterministic=True needs the grouped weight-gradient launches (MSC_WGRAD_GROUP > 1, got %d): the per-layer '
+                                'launches add their split-K partials with fp32 atomics in arrival order' % self.group_max)
         self.pending = []             # deferred (WgradDesc, gradient address or None)
         self.gcount = {}              # activation slice -> number of launches that write its gradient
         self.gwriter = {}             # activation slice -> ConvDesc of the (mode 0, no residual) dgrad conv that wrote it first
