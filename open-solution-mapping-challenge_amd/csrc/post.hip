@@ -727,7 +727,16 @@ struct CrfHaloR {
 // NORM: the normalisers (sum of the kernel weights over the window clipped to the image) instead of one iteration
 template <int R> struct CrfCols { float gx[2 * R + 1], bx[2 * R + 1]; };      // column factors, computed on the host: kernel arguments = SGPR operands
 
-template <int R, bool NORM>
+// ---- round 5: the same kernel on PACKED fp32 math.  The vector peak the roofline quotes (157 TFLOP/s) is the rate of v_pk_fma_f32 -- two
+// lanes' worth of fp32 FMA per issue slot; scalar-fp32 code tops out at half of it, and the round-4 form (13 VALU + 1 v_exp_f32 per tap and
+// pixel, all unpacked) sat at 0.20 of that peak = 0.40 of what unpacked code can reach.  Here a lane's four vertical pixels are two PAIRS
+// (k, k+1): colour differences, squared distance, exponent argument, the Gaussian factor and the four accumulations are v_pk_* over the
+// pair (13 packed ops + 2 v_exp_f32 per tap and pair: ~10.5 issue slots per tap and pixel instead of 17); a pair's window is 12 halo rows
+// (the row that only one of the two pixels reaches runs with a zero / -1e30 factor for the other).  Same arithmetic per element as the
+// unpacked form (IEEE fma either way), so the results agree with it to the last bit wherever the compiler contracts the same products.
+typedef float crf_f2 __attribute__((ext_vector_type(2)));
+
+template <int R, bool NORM, bool PK = false>
 __global__ __launch_bounds__(256, 4) void crf_r_kernel(const float* __restrict__ probs, const uint8_t* __restrict__ rgb, float* __restrict__ ng,
                                                     float* __restrict__ nb, const float* __restrict__ qin, float* __restrict__ qout, CrfP c,
                                                     CrfCols<R> cols) {
@@ -760,17 +769,75 @@ __global__ __launch_bounds__(256, 4) void crf_r_kernel(const float* __restrict__
     // column factors of the two kernels come as kernel arguments (scalar registers: the dx loop below is unrolled, so cols.gx[i] is a
     // fixed SGPR); a kernel whose own radius is smaller has zeros / -1e30 there
     const float kg2 = c.inv2g * 1.44269504f, kb2 = c.inv2b * 1.44269504f, krgb = c.inv2rgb * 1.44269504f;
+    float g0[CRF_PV], g1[CRF_PV], b0[CRF_PV], b1[CRF_PV];
+    if constexpr (PK) {
+        static_assert(CRF_PV % 2 == 0, "pairs of vertical pixels");
+        constexpr int NP = CRF_PV / 2;
+        crf_f2 mr[NP], mg[NP], mb[NP], G0[NP], G1[NP], B0[NP], B1[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const uint32_t m0 = s.c[(ty + 2 * j + R) * hw + tx + R], m1 = s.c[(ty + 2 * j + 1 + R) * hw + tx + R];
+            mr[j] = crf_f2{(float)(m0 & 255u), (float)(m1 & 255u)};
+            mg[j] = crf_f2{(float)((m0 >> 8) & 255u), (float)((m1 >> 8) & 255u)};
+            mb[j] = crf_f2{(float)((m0 >> 16) & 255u), (float)((m1 >> 16) & 255u)};
+            G0[j] = G1[j] = B0[j] = B1[j] = crf_f2{0.f, 0.f};
+        }
+        for (int hy = 0; hy < CRF_PV + 2 * R; ++hy) {
+            crf_f2 gy[NP], by[NP];
+            bool on[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const int dy0 = hy - 2 * j - R, dy1 = dy0 - 1, a0 = dy0 < 0 ? -dy0 : dy0, a1 = dy1 < 0 ? -dy1 : dy1;
+                on[j] = a0 <= R || a1 <= R;                                   // wave-uniform: the pair's 12-row window
+                gy[j] = crf_f2{a0 <= c.rg ? __builtin_amdgcn_exp2f(-(float)(dy0 * dy0) * kg2) : 0.f,
+                               a1 <= c.rg ? __builtin_amdgcn_exp2f(-(float)(dy1 * dy1) * kg2) : 0.f};
+                by[j] = crf_f2{a0 <= c.rb ? -(float)(dy0 * dy0) * kb2 : -1e30f, a1 <= c.rb ? -(float)(dy1 * dy1) * kb2 : -1e30f};
+            }
+            const int h0 = (ty + hy) * hw + tx;
+            uint32_t oc[2 * R + 1];
+            float4 qv[2 * R + 1];
+#pragma unroll
+            for (int i = 0; i <= 2 * R; ++i) {
+                oc[i] = s.c[h0 + i];
+                if (!NORM) qv[i] = s.a[h0 + i];
+            }
+#pragma unroll
+            for (int i = 0; i <= 2 * R; ++i) {
+                const float orr = (float)(oc[i] & 255u), og = (float)((oc[i] >> 8) & 255u), ob = (float)((oc[i] >> 16) & 255u);
+                const float ins = (float)(oc[i] >> 24);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    if (!on[j]) continue;
+                    const crf_f2 d0 = orr - mr[j], d1 = og - mg[j], d2 = ob - mb[j];
+                    const crf_f2 dist = d0 * d0 + d1 * d1 + d2 * d2;
+                    const crf_f2 arg = (cols.bx[i] + by[j]) - dist * krgb;       // <= 0
+                    const crf_f2 kb = crf_f2{__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+                    const crf_f2 kg = cols.gx[i] * gy[j];
+                    if (NORM) {
+                        G0[j] += kg * ins;
+                        B0[j] += kb * ins;
+                    } else {
+                        G0[j] += kg * qv[i].x; G1[j] += kg * qv[i].y;
+                        B0[j] += kb * qv[i].z; B1[j] += kb * qv[i].w;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            g0[2 * j] = G0[j].x; g0[2 * j + 1] = G0[j].y; g1[2 * j] = G1[j].x; g1[2 * j + 1] = G1[j].y;
+            b0[2 * j] = B0[j].x; b0[2 * j + 1] = B0[j].y; b1[2 * j] = B1[j].x; b1[2 * j + 1] = B1[j].y;
+        }
+    } else {
     float mr[CRF_PV], mg[CRF_PV], mb[CRF_PV];
 #pragma unroll
     for (int k = 0; k < CRF_PV; ++k) {
         const uint32_t m = s.c[(ty + k + R) * hw + tx + R];
         mr[k] = (float)(m & 255u); mg[k] = (float)((m >> 8) & 255u); mb[k] = (float)((m >> 16) & 255u);
     }
-    float g0[CRF_PV], g1[CRF_PV], b0[CRF_PV], b1[CRF_PV];
 #pragma unroll
     for (int k = 0; k < CRF_PV; ++k) { g0[k] = 0.f; g1[k] = 0.f; b0[k] = 0.f; b1[k] = 0.f; }
     for (int hy = 0; hy < CRF_PV + 2 * R; ++hy) {
-        // row factors for the (up to four) pixels this halo row is in the window of; dy is the same for every lane
         // row factors for the (up to four) pixels this halo row is in the window of; dy is the same for every lane.  Rows outside a pixel's
         // window are skipped with a wave-uniform branch -- measured against the branch-free form (factors 0 / -1e30 for those rows, the
         // four pixels' chains interleaved by the scheduler): that one needs 182-254 registers (two or three waves per SIMD) or spills at
@@ -811,6 +878,7 @@ __global__ __launch_bounds__(256, 4) void crf_r_kernel(const float* __restrict__
                 }
             }
         }
+    }
     }
 #pragma unroll
     for (int k = 0; k < CRF_PV; ++k) {
@@ -1096,14 +1164,17 @@ extern "C" int msc_dense_crf(const float* probs, const uint8_t* rgb, float* out,
         cols.gx[i] = ad <= c.rg ? exp2f(-(float)(dx * dx) * c.inv2g * 1.44269504f) : 0.f;
         cols.bx[i] = ad <= c.rb ? -(float)(dx * dx) * c.inv2b * 1.44269504f : -1e30f;
     }
-    if (fast) hipLaunchKernelGGL((crf_r_kernel<5, true>), gt, dim3(256), 0, st, (const float*)nullptr, rgb, ng, nb, (const float*)nullptr, (float*)nullptr, c, cols);
+    static const bool pk_off = [] { const char* e = getenv("MSC_CRF_PK"); return e && e[0] == '0'; }();                // A/B: the unpacked round-4 inner loop
+    if (fast && !pk_off) hipLaunchKernelGGL((crf_r_kernel<5, true, true>), gt, dim3(256), 0, st, (const float*)nullptr, rgb, ng, nb, (const float*)nullptr, (float*)nullptr, c, cols);
+    else if (fast) hipLaunchKernelGGL((crf_r_kernel<5, true>), gt, dim3(256), 0, st, (const float*)nullptr, rgb, ng, nb, (const float*)nullptr, (float*)nullptr, c, cols);
     else if (tiled) hipLaunchKernelGGL(crf_norm_tiled_kernel, gt, dim3(256), 0, st, rgb, ng, nb, c, r);
     else hipLaunchKernelGGL(crf_norm_kernel, g, dim3(256), 0, st, rgb, ng, nb, c);
     hipLaunchKernelGGL(crf_init_kernel, g, dim3(256), 0, st, probs, iterations == 0 ? out : qa, HW);
     float* cur = qa;
     for (int it = 0; it < iterations; ++it) {
         float* dst = (it == iterations - 1) ? out : (cur == qa ? qb : qa);
-        if (fast) hipLaunchKernelGGL((crf_r_kernel<5, false>), gt, dim3(256), 0, st, probs, rgb, ng, nb, (const float*)cur, dst, c, cols);
+        if (fast && !pk_off) hipLaunchKernelGGL((crf_r_kernel<5, false, true>), gt, dim3(256), 0, st, probs, rgb, ng, nb, (const float*)cur, dst, c, cols);
+        else if (fast) hipLaunchKernelGGL((crf_r_kernel<5, false>), gt, dim3(256), 0, st, probs, rgb, ng, nb, (const float*)cur, dst, c, cols);
         else if (tiled) hipLaunchKernelGGL(crf_iter_tiled_kernel, gt, dim3(256), 0, st, probs, rgb, ng, nb, cur, dst, c, r);
         else hipLaunchKernelGGL(crf_iter_kernel, g, dim3(256), 0, st, probs, rgb, ng, nb, cur, dst, c);
         cur = dst;

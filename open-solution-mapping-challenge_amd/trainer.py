@@ -349,6 +349,12 @@ class HipAdam(torch.optim.Optimizer):
             self._scale_restored = True
 
 
+def DDP_PIECES():
+    """pieces the backward is cut into around the gradient exchanges (MSC_DDP_PIECES, default 4; measurement switch)"""
+    import os
+    return max(1, int(os.environ.get('MSC_DDP_PIECES', '4')))
+
+
 DDP_FRACTIONS = (0.40, 0.65, 0.85)      # share of the gradient bytes that must be final before the first three exchanges
 
 
@@ -486,7 +492,7 @@ class TrainStep:
         net = self.net
         flat_g = net.flat_grads
         if getattr(prog, '_ddp_plan', None) is None:
-            prog._ddp_plan = ddp_plan(prog, flat_g)
+            prog._ddp_plan = ddp_plan(prog, flat_g, nchunks=DDP_PIECES())
         flat_g.zero_()
         prog.stem_dw.zero_()
         works, beg = [], 0
@@ -550,7 +556,7 @@ class TrainStep:
         total = float(N * H * W) * (self.world.size if self.world.size > 1 else 1)
         flat_g = net.flat_grads
         if getattr(prog, '_ddp_plan', None) is None:
-            prog._ddp_plan = ddp_plan(prog, flat_g)
+            prog._ddp_plan = ddp_plan(prog, flat_g, nchunks=DDP_PIECES())
 
         from .unet_models import _stream_of
 
