@@ -14,7 +14,7 @@ bench_line() {   # bench_line <tag> <timeout> <bench.py args...>: one JSON line 
 prof_stats() {   # prof_stats <tag> <bench.py args...>: rocprofv3 kernel-trace statistics of the same command -> gpurun_out/prof_<tag>/
   local tag=$1; shift
   ( cd /tmp; export TMPDIR=/tmp; rm -rf "$R/gpurun_out/prof_$tag"
-    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_$tag" -- python "$R/bench.py" "$@" --no-cpu-baseline > "$R/gpurun_out/prof_$tag.log" 2>&1; echo "prof $tag rc=$?" )
+    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_$tag" -- python "$R/bench.py" "$@" --no-cpu-baseline --no-north-star > "$R/gpurun_out/prof_$tag.log" 2>&1; echo "prof $tag rc=$?" )
   python tools/kernel_stats_summary.py gpurun_out/prof_$tag > gpurun_out/kernel_stats_$tag.txt 2>&1; head -12 gpurun_out/kernel_stats_$tag.txt | cut -c1-200
 }
 for s in $STAGES; do
@@ -47,7 +47,7 @@ proft) python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown --n
 pmc)   python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown --no-north-star > gpurun_out/tune_warm.log 2>&1
        cd /tmp; export TMPDIR=/tmp
        for c in FETCH_SIZE WRITE_SIZE; do
-         timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c" -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-breakdown > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log" 2>&1; echo "pmc $c rc=$?"
+         timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c" -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-breakdown --no-north-star > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log" 2>&1; echo "pmc $c rc=$?"
        done
        cd "$GRAFT_REPO_ROOT"; python tools/pmc_summary.py gpurun_out gpurun_out/pmc_traffic.json > gpurun_out/pmc_summary.txt 2>&1; head -12 gpurun_out/pmc_summary.txt;;
 pmcsq) # SQ / LDS / L2 counters of the train step, one rocprofv3 pass per counter group (counter runs carry kernel-trace only)
@@ -56,7 +56,7 @@ pmcsq) # SQ / LDS / L2 counters of the train step, one rocprofv3 pass per counte
        i=0
        for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum"; do
          i=$((i+1)); rm -rf "$GRAFT_REPO_ROOT/gpurun_out/pmcsq_$i"
-         timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmcsq_$i" -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-breakdown > "$GRAFT_REPO_ROOT/gpurun_out/pmcsq_$i.log" 2>&1; echo "pmcsq $i rc=$?"
+         timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmcsq_$i" -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-breakdown --no-north-star > "$GRAFT_REPO_ROOT/gpurun_out/pmcsq_$i.log" 2>&1; echo "pmcsq $i rc=$?"
        done
        cd "$GRAFT_REPO_ROOT"; python tools/pmc_sq_summary.py gpurun_out/pmcsq_1 gpurun_out/pmcsq_2 gpurun_out/pmcsq_3 > gpurun_out/pmcsq_summary.txt 2>&1; head -30 gpurun_out/pmcsq_summary.txt | cut -c1-260;;
 b32)   timeout 900 python -m pytest tests/test_gpu_parity_timed.py tests/test_gpu_fullsize.py -m gpu -q -rf --tb=short -p no:cacheprovider -k "batch32" --durations=5 > gpurun_out/pytest_b32.log 2>&1; echo "pytest rc=$?"; tail -15 gpurun_out/pytest_b32.log; cat gpurun_out/parity_timed.json | head -60;;
