@@ -652,9 +652,12 @@ class _Builder:
         self.gwriter = {}             # activation slice -> ConvDesc of the (mode 0, no residual) dgrad conv that wrote it first
         self.fuse_bn_bwd = _os_env.environ.get('MSC_FUSE_BN_BWD', '1') != '0'
         # BatchNorm + ReLU of a Bottleneck's bn2 applied by conv3 on load (msc_conv_desc.in_bn, ABI v9): training, 16-bit on the device (the
-        # CPU interpreter follows the same launch list in fp32).  Default since round 5 (kernel tests, end-to-end comparison and the batch-32
-        # parity test ran on the MI355X; A/B 10.87 -> 10.85 ms per step, profiles/r5_run1_bn_on_load_ab.txt); MSC_BN_ON_LOAD=0: separate launches
-        self.bn_on_load = (training and _os_env.environ.get('MSC_BN_ON_LOAD', '1') == '1' and (self.dt != F32 or device.type != 'cuda'))
+        # CPU interpreter follows the same launch list in fp32).  Round 5 ran it on the MI355X: kernel tests, end-to-end comparison and the batch-32 parity
+        # test pass, and three same-box A/Bs put the step at -0.02 / +0.04 / +0.03...0.05 ms (profiles/r5_run1_bn_on_load_ab.txt): the 59 msc_bn_apply
+        # launches it removes (-0.27 ms) come back as longer convolutions (+0.2...0.4 ms: the in_bn configurations are the eight-wave tiles, layer3's natural
+        # tile is 128x64) -- NEUTRAL, so it stays opt-in: MSC_BN_ON_LOAD=1 (MSC_BN_ON_LOAD_MIN_PIXELS=n restricts it to the layers of >= n pixels)
+        self.bn_on_load = (training and _os_env.environ.get('MSC_BN_ON_LOAD', '0') == '1' and (self.dt != F32 or device.type != 'cuda'))
+        self.bn_on_load_min_pixels = int(_os_env.environ.get('MSC_BN_ON_LOAD_MIN_PIXELS', '0'))
         # residual joins: the data-gradient conv that ACCUMULATES the last addend of the join's gradient also reduces the sums of the
         # join's BatchNorm backward (stats_kind 1 with stats_z, ABI v6) -- no msc_bn_bwd_reduce pass over three tensors
         self.fuse_join_bwd = _os_env.environ.get('MSC_FUSE_JOIN_BWD', '1') != '0'
@@ -1315,7 +1318,9 @@ class _Builder:
                     # bn1 / bn2 + ReLU applied by the consuming conv on load instead of msc_bn_apply launches (ABI v9; MSC_BN_ON_LOAD=1): conv3 (1x1,
                     # stride 1) always, conv2 where it is a stride-1 3x3 on a map the halo-tile kernel takes (8 x 16 pixel patches).  Measured for
                     # conv3: +1.3-2.5 us against 3.8-9 us of the launch (profiles/r4_run28_bn_on_load_probe.txt)
-                    on_load = self.bn_on_load and planes <= 512
+                    # layer3's 8 k-pixel maps are where it costs most (conv3 14.6 -> 21.8 us against the 3.8 us launch it saves,
+                    # profiles/r5_run6_rocprofv3_kernel_stats_train_bn_on_load_all.txt); restricted to layer1 / layer2 (MSC_BN_ON_LOAD_MIN_PIXELS=30000) it is as neutral
+                    on_load = self.bn_on_load and planes <= 512 and self.N * hh * ww >= self.bn_on_load_min_pixels
                     a = self.act(hh, ww, planes)
                     pend1 = self.conv_bn(base + '.conv1', cur, blk.conv1, blk.bn1, 1, True, a,
                                          defer=on_load and s == 1 and ww % 16 == 0 and hh % 8 == 0 and _os_env.environ.get('MSC_BN_ON_LOAD_3X3', '1') != '0')

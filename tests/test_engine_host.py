@@ -73,6 +73,7 @@ def test_bn_on_load_launch_list_matches_oracle_and_drops_the_apply_launches(inte
     counts = {}
     for on in ('0', '1'):
         monkeypatch.setenv('MSC_BN_ON_LOAD', on)
+        monkeypatch.setenv('MSC_BN_ON_LOAD_MIN_PIXELS', '0')        # every layer
         ref, net = build(101)
         ref.train(); net.train()
         loss = losses_ref.mixed_dice_ce(ref(x), tgt)

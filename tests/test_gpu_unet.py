@@ -242,6 +242,7 @@ def test_bn_on_load_training_matches_the_separate_apply_launches(dtype, monkeypa
     runs = {}
     for on in ('0', '1'):
         monkeypatch.setenv('MSC_BN_ON_LOAD', on)
+        monkeypatch.setenv('MSC_BN_ON_LOAD_MIN_PIXELS', '0')        # every layer
         _, net = build(101, dtype)
         net.deterministic = True
         net.train()
