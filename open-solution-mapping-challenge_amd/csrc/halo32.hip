@@ -258,7 +258,11 @@ __global__ __launch_bounds__(512) void deconv4_c128_c32_halo_kernel(ConvK p) {  
     const T* wt = reinterpret_cast<const T*>(p.wt);          // [Cout][4][4][Cin]
     T* out = reinterpret_cast<T*>(p.out);
     const T* res = reinterpret_cast<const T*>(p.res);
-    const int c0 = 8 * g;
+    // Round 5: Cout = 32 G (dec2's 128 -> 128 up-sampling: G = 4).  A block keeps ONE group of 32 output channels -- block b works on group
+    // b % G, so the weights of its phases still enter the registers once -- and walks the patches b / G, b / G + gridDim.x / G, ...; the four
+    // groups of a patch read the same halo (from the L2: four blocks, not four passes of one block over 128 KB of weight fragments).
+    const int G = p.Cout / 32, cg = (int)blockIdx.x % G, bidx = (int)blockIdx.x / G, nblk = (int)gridDim.x / G;
+    const int c0 = 32 * cg + 8 * g;
     const bool has_sc = p.scale != nullptr, has_sh = p.shift != nullptr;
     float sc[8], sh[8];
 #pragma unroll
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(512) void deconv4_c128_c32_halo_kernel(ConvK p) {  
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                const int co = 8 * (pl >> 2) + 4 * a + (pl & 3);
+                const int co = 32 * cg + 8 * (pl >> 2) + 4 * a + (pl & 3);
                 aw[t][kk][a] = *reinterpret_cast<const uint4*>(wt + ((long)(co * 4 + kh) * 4 + kw) * 128 + (kk * 4 + g) * 8);
             }
     }
@@ -315,14 +319,14 @@ __global__ __launch_bounds__(512) void deconv4_c128_c32_halo_kernel(ConvK p) {  
             dma16(rx, reinterpret_cast<char*>(halo2 + buf * HBUF + 512 * i + 64 * wid), ok ? (unsigned)(org + hrel[i]) : OOB_OFF, 0);
         }
     };
-    if ((int)blockIdx.x < npatch) request(blockIdx.x, 0);
+    if (bidx < npatch) request(bidx, 0);
     int buf = 0;
-    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x, buf ^= 1) {
+    for (int patch = bidx; patch < npatch; patch += nblk, buf ^= 1) {
         const int bx = patch % tiles_x, by = (patch / tiles_x) % tiles_y, n = patch / (tiles_x * tiles_y);
         const int qy0 = by * 8, qx0 = bx * 16;
         wait_vmcnt<0>();                                              // this patch's halo has landed ...
         raw_barrier();                                                // ... for every wave, and everyone is done with the other buffer
-        if (patch + (int)gridDim.x < npatch) request(patch + gridDim.x, buf ^ 1);
+        if (patch + nblk < npatch) request(patch + nblk, buf ^ 1);
         const uint4* halo = halo2 + buf * HBUF;
 #pragma unroll 1
         for (int b = b0; b < b0 + 4; ++b) {
@@ -450,9 +454,12 @@ int conv_launch(const ConvK& k, hipStream_t st) {
 
 template <typename T>
 int deconv_launch(const ConvK& k, hipStream_t st) {
+    const int G = k.Cout / 32;                                  // groups of 32 output channels: block b -> group b % G
     const int patches = k.N * (k.Hi / 8) * (k.Wi / 16);
     static const int persist = [] { const char* e = getenv("MSC_DECONV_BLOCKS"); return e ? atoi(e) : 256; }();      // one resident block per CU (98 KB of LDS)
-    hipLaunchKernelGGL(deconv4_c128_c32_halo_kernel<T>, dim3(persist > 0 && patches > persist ? persist : patches), dim3(512), 0, st, k);
+    int blocks = persist > 0 && patches * G > persist ? persist / G * G : patches * G;
+    if (blocks < G) blocks = G;
+    hipLaunchKernelGGL(deconv4_c128_c32_halo_kernel<T>, dim3(blocks), dim3(512), 0, st, k);
     return msc_check_launch("deconv4_c128_c32_halo");
 }
 

@@ -764,27 +764,35 @@ def test_halo_tile_kernel_for_32_channel_3x3(hw, n, flip, with_res, relu, dtype)
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('hw,n,relu,with_res', [(16, 2, True, False), (32, 1, False, True), (8, 3, True, False)])
-def test_halo_tile_kernel_for_the_128_to_32_transposed_conv(hw, n, relu, with_res, dtype):
-    """ConvTranspose2d(128, 32, k4, s2, p1) + bias (+ReLU) through the halo-tile configuration, against torch"""
+@pytest.mark.parametrize('hw,n,relu,with_res,cout', [(16, 2, True, False, 32), (32, 1, False, True, 32), (8, 3, True, False, 32),
+                                                     (16, 2, True, False, 128), (8, 3, False, True, 128), (32, 2, True, False, 64)])
+def test_halo_tile_kernel_for_the_128_to_32_transposed_conv(hw, n, relu, with_res, cout, dtype):
+    """ConvTranspose2d(128, 32 G, k4, s2, p1) + bias (+ReLU) through the halo-tile configuration, against torch: dec1's 128 -> 32 and, since
+    round 5, groups of 32 output channels per block (dec2's 128 -> 128: G = 4), written into a channel slice of a wider buffer"""
     from mapping_challenge_amd import _lib
     import hip_ops as ops
     cfg = _lib.CFG_HALO_T
     x = rnd((n, 128, hw, 2 * hw), dtype, 1)                     # non-square: 8 | H, 16 | W
-    wt = rnd((128, 32, 4, 4), dtype, 2, 0.05)
-    bias = rnd((32,), torch.float32, 3)
-    prev = rnd((n, 32, 2 * hw, 4 * hw), dtype, 4)
+    wt = rnd((128, cout, 4, 4), dtype, 2, 0.05)
+    bias = rnd((cout,), torch.float32, 3)
+    prev = rnd((n, cout, 2 * hw, 4 * hw), dtype, 4)
     ref = F.conv_transpose2d(x, wt, stride=2, padding=1) + bias.view(1, -1, 1, 1)
     if with_res:
         ref = ref + prev
     if relu:
         ref = torch.relu(ref)
     xd = nhwc(x, dtype)
-    wk = ops.pack_transpose(wt.permute(0, 2, 3, 1).contiguous().view(128, 16, 32).cuda(), dtype).view(32, 4, 4, 128)
-    out = nhwc(prev, dtype) if with_res else torch.empty((n, 2 * hw, 4 * hw, 32), dtype=dtype, device='cuda')
+    wk = ops.pack_transpose(wt.permute(0, 2, 3, 1).contiguous().view(128, 16, cout).cuda(), dtype).view(cout, 4, 4, 128)
+    out = nhwc(prev, dtype) if with_res else torch.empty((n, 2 * hw, 4 * hw, cout), dtype=dtype, device='cuda')
     assert cfg in ops.conv_valid_cfgs(xd, wk, out, 2, 1, mode=1)
     ops.conv_igemm(xd, wk, out, stride=2, pad=1, mode=1, relu=relu, shift=bias.cuda(), res=out if with_res else None, cfg=cfg)
     assert torch.allclose(to_nchw(out), ref, **tol(dtype))
+    # the same layer through the implicit-GEMM configurations gives the same result (the tuner may pick either)
+    other = [c for c in ops.conv_valid_cfgs(xd, wk, out, 2, 1, mode=1) if c != cfg][:2]
+    for c in other:
+        out2 = nhwc(prev, dtype) if with_res else torch.empty_like(out)
+        ops.conv_igemm(xd, wk, out2, stride=2, pad=1, mode=1, relu=relu, shift=bias.cuda(), res=out2 if with_res else None, cfg=c)
+        assert torch.allclose(to_nchw(out2), ref, **tol(dtype)), c
 
 
 @pytest.mark.parametrize('dtype', DT)
