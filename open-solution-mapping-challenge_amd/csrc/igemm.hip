@@ -848,9 +848,12 @@ bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
     if (cfg == CFG_HALO)
         return es == 2 && k.mode == 0 && k.KH == 3 && k.KW == 3 && k.stride == 1 && k.pad == 1 && k.Cin == 32 && k.Cout == 32 &&
                k.Ho % 16 == 0 && k.Wo % 16 == 0 && k.Hi == k.Ho && k.Wi == k.Wo && (!k.stats || k.stats_kind == 2) && k.res_ld % 8 == 0 && k.out_ld % 8 == 0;
-    if (cfg == CFG_HALO_T)
+    if (cfg == CFG_HALO_T) {
+        static const bool wide_off = [] { const char* e = getenv("MSC_DECONV_WIDE"); return e && e[0] == '0'; }();      // A/B: 32 output channels only (round 4)
+        if (wide_off && k.Cout != 32) return false;
         return es == 2 && k.mode == 1 && k.KH == 4 && k.KW == 4 && k.stride == 2 && k.pad == 1 && k.Cin == 128 && k.Cout % 32 == 0 && k.Cout <= 256 &&
                k.Hi % 8 == 0 && k.Wi % 16 == 0 && k.Ho == 2 * k.Hi && k.Wo == 2 * k.Wi && !k.stats && k.res_ld % 8 == 0 && k.out_ld % 8 == 0;
+    }
     const ConvCfg& c = CONV_CFGS[cfg];
     if (cfg_is_halo3(cfg))
         return es == 2 && k.mode == 0 && k.KH == 3 && k.KW == 3 && k.stride == 1 && k.pad == 1 && k.Hi == k.Ho && k.Wi == k.Wo &&

@@ -514,6 +514,9 @@ class TrainStep:
         if st.graph is None and st.pieces is None:
             # the first step of a shape runs eagerly (builds the program, allocates, packs) and IS this call's step;
             # capturing afterwards does not execute anything, replays start with the next call of this shape
+            if st.x.is_cuda:
+                from .unet_models import _quiesce
+                _quiesce(st.x.device)          # nothing of an earlier user of the device in flight while the step that gets captured is built
             self._body()
             if st.x.is_cuda:
                 torch.cuda.synchronize()

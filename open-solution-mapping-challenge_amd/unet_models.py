@@ -148,6 +148,19 @@ _OVERLAP_WGRAD = _os_env.environ.get('MSC_OVERLAP_WGRAD', '0') == '1'
 _SIDE_STREAMS = {}
 
 
+def _quiesce(device):
+    """Before the flat buffers / a program's buffers are allocated and its kernels timed: collect what earlier users of the device left behind and
+    wait for EVERYTHING they still have in flight (a device-wide synchronise, not a stream one).  Round 5 found that a captured training step built
+    while another component's work was still pending on the device could replay with garbage gradients later on (tests/test_gpu_configs.py in
+    file order: the [1, 19] post-processing test, then the training-trajectory test; eager launches were never affected; `gc.collect()` alone or a
+    stream synchronise did not help, a device synchronise before the build did -- tools/dirty_probe5.py).  The root cause is
+    not understood; this is the measured mitigation, paid once per program."""
+    if device is not None and torch.device(device).type == 'cuda' and torch.cuda.is_available():
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+
+
 def _side_stream(device):
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     if key not in _SIDE_STREAMS:
@@ -326,6 +339,7 @@ class UNetResNet(nn.Module):
         ([Cin][KH][KW][Cout] for ConvTranspose2d) -- the k-contiguous layout the kernels read --
         while keeping their torch-logical shapes, so state_dicts stay interchangeable."""
         device = torch.device(device if device is not None else 'cuda')
+        _quiesce(device)
         params = self._trainable()
         offs, total = [], 0
         for _, p in params:
@@ -455,6 +469,7 @@ class UNetResNet(nn.Module):
         key = (N, H, W, training, self.compute_dtype)
         prog = self._programs.get(key)
         if prog is None:
+            _quiesce(device)
             if H % 64 or W % 64:
                 raise ValueError('UNetResNet needs H and W divisible by 64 (got %dx%d): the reference fails at the '
                                  'first skip-concat otherwise (src/unet_models.py:360-363,392-397)' % (H, W))
@@ -616,6 +631,10 @@ class _GroupHandle(C.c_void_p):
     """msc_wgrad_group* plus the descriptors it was made from (for FLOP accounting in bench.py)"""
 
 
+_ZERO_ALLOC = int(_os_env.environ.get('MSC_ZERO_ALLOC', '0'))      # bits: 1 activations, 2 vectors, 4 gradient buffers, 8 ReLU byte masks
+_TUNE_ONLY = _os_env.environ.get('MSC_TUNE_ONLY', '').split(',') if _os_env.environ.get('MSC_TUNE_ONLY') else []      # debugging aid: c0 / c1 / j      # debugging aid: program buffers start as zeros instead of recycled allocator memory
+
+
 class _Builder:
     def __init__(self, net, N, H, W, training, device):
         self.net, self.N, self.H, self.W, self.training, self.dev = net, N, H, W, training, device
@@ -673,13 +692,13 @@ class _Builder:
 
     # ---- memory
     def buf(self, H, W, C, dtype=None):
-        t = torch.empty((self.N, H, W, C), dtype=dtype or self.tdtype, device=self.dev)
+        t = (torch.zeros if _ZERO_ALLOC & 1 else torch.empty)((self.N, H, W, C), dtype=dtype or self.tdtype, device=self.dev)
         self.prog.bytes += t.numel() * t.element_size()
         self.prog.keep.append(t)
         return t
 
     def vec(self, n, dtype=torch.float32, zero=False):
-        t = (torch.zeros if zero else torch.empty)(n, dtype=dtype, device=self.dev)
+        t = (torch.zeros if (zero or _ZERO_ALLOC & 2) else torch.empty)(n, dtype=dtype, device=self.dev)
         self.prog.bytes += t.numel() * t.element_size()
         self.prog.keep.append(t)
         return t
@@ -718,7 +737,7 @@ class _Builder:
     def grad_of(self, a):
         g = self.gbuf.get(id(a.buf))
         if g is None:
-            g = torch.empty_like(a.buf)
+            g = torch.zeros_like(a.buf) if _ZERO_ALLOC & 4 else torch.empty_like(a.buf)
             self.prog.bytes += g.numel() * g.element_size()
             self.gbuf[id(a.buf)] = g
             self.slices[id(g)] = self.slices.get(id(a.buf), set())
@@ -843,6 +862,8 @@ class _Builder:
     def tune_conv(self, d, want_stats):
         if not self.net.autotune or self.dev.type != 'cuda':
             return
+        if _TUNE_ONLY and ('c%d' % int(bool(d.flip))) not in _TUNE_ONLY and ('m%d' % d.mode) not in _TUNE_ONLY:      # debugging aid
+            return
         key = repr(('c', self.tune_dt, d.mode, d.flip, d.N, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad,
                     bool(d.res), want_stats, d.in_ld, d.out_ld, bool(d.relu)) + ((int(d.splitk),) if d.splitk > 1 else ()) + (('in_bn',) if d.in_bn else ()))
         cache = _TUNE_CACHE
@@ -871,11 +892,18 @@ class _Builder:
             cache[key] = best
             self._tuned_new = True
         d.cfg = cache[key]
+        if d.mode == 1 and _os_env.environ.get('MSC_TUNE_DEBUG'):       # debugging aid: which configuration a transposed-mode launch got
+            force = _os_env.environ.get('MSC_FORCE_DECONV28')
+            if force == '1' and lib.msc_conv_cfg_ok(C.byref(d), 28):
+                d.cfg = 28
+            print('tune mode1 %s -> cfg %d' % (key, d.cfg), flush=True)
 
     def tune_join(self, d):
         """the configuration of a data-gradient conv that carries a residual join's reductions (stats_kind 1 with stats_z): its epilogue
         reads three more tensors than the launch tune_conv timed, which shifts the best tile towards more, smaller blocks"""
         if not self.net.autotune or self.dev.type != 'cuda' or _os_env.environ.get('MSC_TUNE_JOIN', '1') == '0':
+            return
+        if _TUNE_ONLY and 'j' not in _TUNE_ONLY:
             return
         key = repr(('j', self.tune_dt, d.N, d.Hi, d.Wi, d.Cin, d.Cout, d.KH, d.KW, bool(d.res), d.in_ld, d.out_ld) +
                    ((d.flip, d.pad) if (d.flip, d.pad) != (1, 0) else ()) + (('t', d.stride) if d.mode else ()))      # (the shipped db holds the 1x1 data-gradient keys without the pair)
@@ -968,7 +996,7 @@ class _Builder:
         # activation's bytes on both reads (round 4; MSC_RELU_BITS=0: the backward reads the activation)
         rmask = None
         if res is not None and relu and _os_env.environ.get('MSC_RELU_BITS', '1') != '0':
-            rmask = torch.empty((self.N, out.H, out.W, cout * self.es // 16), dtype=torch.uint8, device=self.dev)
+            rmask = (torch.zeros if _ZERO_ALLOC & 8 else torch.empty)((self.N, out.H, out.W, cout * self.es // 16), dtype=torch.uint8, device=self.dev)
             self.prog.bytes += rmask.numel()
             self.prog.keep.append(rmask)
         bi = None

@@ -1,4 +1,5 @@
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
-export MSC_TUNE_CACHE="$PWD/gpurun_out/tune_cache.json"
-timeout 300 python tools/deconv_probe.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/deconv_probe.txt
-timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short -p no:cacheprovider -k "transposed_conv" 2>&1 | tail -6
+# the product's own mitigation without the conftest fixture: the failing order through tools/dirty_probe5.py (plain = no manual synchronise)
+MODE=plain timeout 900 python tools/dirty_probe5.py 2>&1 | grep "^MODE"
+MODE=plain timeout 900 python tools/dirty_probe5.py 2>&1 | grep "^MODE"
+timeout 900 python -m pytest tests/test_gpu_configs.py -m gpu -q --tb=line -p no:cacheprovider 2>&1 | tail -3
