@@ -197,6 +197,8 @@ int msc_maxpool2_bwd(const void* dout, int64_t dout_ld, const void* in, int64_t 
 #define MSC_BN_SLOTS 8
 /* stream-ordered fill / device-to-device copy: with these the whole training step is a list of C-ABI launches (capturable
  * as hipGraph nodes, interpretable on the host by the tests) */
+/* (round 5: both are KERNEL launches -- captured into a hipGraph, hipMemsetAsync / hipMemcpyAsync become memset / memcpy nodes, and replayed training
+ * steps holding such nodes were seen to run with garbage gradients; MSC_MEMOPS_KERNEL=0 restores the runtime calls for A/B) */
 int msc_memset_zero(void* ptr, int64_t bytes, void* stream);
 int msc_copy(void* dst, const void* src, int64_t bytes, void* stream);
 int msc_bn_apply(const void* y, int64_t y_ld, const void* res, int64_t res_ld, void* out, int64_t out_ld,

@@ -1218,8 +1218,52 @@ extern "C" int msc_bn_pool_bwd_apply(const void* dpool, int64_t dpool_ld, void* 
     return msc_check_launch("msc_bn_pool_bwd_apply");
 }
 
+// Round 5: stream-ordered fills and copies are KERNELS, not hipMemsetAsync / hipMemcpyAsync.  Captured into a hipGraph those calls become memset /
+// memcpy NODES, and a replayed training step that held them could run with garbage gradients when the program had been built while other work was
+// still pending on the device (same launch lists eagerly -- fine; the same graph with these two entry points as kernels -- fine,
+// with or without the device synchronise that otherwise hides it; tools/dirty_probe5.py).  A captured step now holds kernel nodes only.
+// MSC_MEMOPS_KERNEL=0 brings the runtime calls back (A/B).
+__global__ __launch_bounds__(256) void fill_zero_kernel(char* __restrict__ p, long bytes) {
+    const long head = min((long)((16 - ((uintptr_t)p & 15)) & 15), bytes);          // bytes in front of the first 16-byte boundary
+    const long n16 = (bytes - head) / 16, tail0 = head + n16 * 16;
+    uint4* q = reinterpret_cast<uint4*>(p + head);
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) q[i] = z;
+    if (blockIdx.x == 0) {
+        if ((long)threadIdx.x < head) p[threadIdx.x] = 0;
+        if (tail0 + (long)threadIdx.x < bytes && threadIdx.x < 16) p[tail0 + threadIdx.x] = 0;
+    }
+}
+__global__ __launch_bounds__(256) void copy_kernel(char* __restrict__ d, const char* __restrict__ s, long bytes) {
+    if ((((uintptr_t)d ^ (uintptr_t)s) & 15) == 0) {                                   // same phase within 16 bytes: vector body
+        const long head = min((long)((16 - ((uintptr_t)d & 15)) & 15), bytes);
+        const long n16 = (bytes - head) / 16, tail0 = head + n16 * 16;
+        uint4* q = reinterpret_cast<uint4*>(d + head);
+        const uint4* r = reinterpret_cast<const uint4*>(s + head);
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) q[i] = r[i];
+        if (blockIdx.x == 0) {
+            if ((long)threadIdx.x < head) d[threadIdx.x] = s[threadIdx.x];
+            if (tail0 + (long)threadIdx.x < bytes && threadIdx.x < 16) d[tail0 + threadIdx.x] = s[tail0 + threadIdx.x];
+        }
+    } else {
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < bytes; i += (long)gridDim.x * blockDim.x) d[i] = s[i];
+    }
+}
+static bool memops_as_kernels() {
+    static const bool off = [] { const char* e = getenv("MSC_MEMOPS_KERNEL"); return e && e[0] == '0'; }();
+    return !off;
+}
+static int memop_blocks(long bytes) {
+    long blocks = (bytes / 16 + 255) / 256;
+    return (int)(blocks > 4096 ? 4096 : blocks < 1 ? 1 : blocks);
+}
+
 extern "C" int msc_copy(void* dst, const void* src, int64_t bytes, void* stream) {
     if (!dst || !src || bytes < 0) return msc_fail(MSC_ERR_ARG, "msc_copy: bad argument");
+    if (bytes && memops_as_kernels()) {
+        hipLaunchKernelGGL(copy_kernel, dim3(memop_blocks(bytes)), dim3(256), 0, (hipStream_t)stream, (char*)dst, (const char*)src, (long)bytes);
+        return msc_check_launch("msc_copy");
+    }
     if (bytes && hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
         return msc_fail(MSC_ERR_HIP, "msc_copy: copy failed");
     return MSC_OK;
@@ -1227,6 +1271,10 @@ extern "C" int msc_copy(void* dst, const void* src, int64_t bytes, void* stream)
 
 extern "C" int msc_memset_zero(void* ptr, int64_t bytes, void* stream) {
     if (!ptr || bytes < 0) return msc_fail(MSC_ERR_ARG, "msc_memset_zero: bad argument");
+    if (bytes && memops_as_kernels()) {
+        hipLaunchKernelGGL(fill_zero_kernel, dim3(memop_blocks(bytes)), dim3(256), 0, (hipStream_t)stream, (char*)ptr, (long)bytes);
+        return msc_check_launch("msc_memset_zero");
+    }
     if (bytes && hipMemsetAsync(ptr, 0, (size_t)bytes, (hipStream_t)stream) != hipSuccess) return msc_fail(MSC_ERR_HIP, "msc_memset_zero: memset failed");
     return MSC_OK;
 }

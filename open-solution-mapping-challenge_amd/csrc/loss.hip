@@ -104,7 +104,7 @@ extern "C" int msc_loss_sums(const float* logits, const float* target, int tc, c
     if (rc) return rc;
     if (!sums) return msc_fail(MSC_ERR_ARG, "msc_loss_sums: null sums");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, 4 * sizeof(double), st) != hipSuccess) return msc_fail(MSC_ERR_HIP, "msc_loss_sums: memset failed");
+    if (msc_memset_zero(sums, 4 * sizeof(double), stream) != MSC_OK) return MSC_ERR_HIP;       // (a kernel under MSC_MEMOPS_KERNEL=1)
     const long total = (long)N * H * W;
     long blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;

@@ -150,11 +150,12 @@ _SIDE_STREAMS = {}
 
 def _quiesce(device):
     """Before the flat buffers / a program's buffers are allocated and its kernels timed: collect what earlier users of the device left behind and
-    wait for EVERYTHING they still have in flight (a device-wide synchronise, not a stream one).  Round 5 found that a captured training step built
-    while another component's work was still pending on the device could replay with garbage gradients later on (tests/test_gpu_configs.py in
-    file order: the [1, 19] post-processing test, then the training-trajectory test; eager launches were never affected; `gc.collect()` alone or a
-    stream synchronise did not help, a device synchronise before the build did -- tools/dirty_probe5.py).  The root cause is
-    not understood; this is the measured mitigation, paid once per program."""
+    wait for EVERYTHING they still have in flight (a device-wide synchronise, not a stream one).  Round 5: a captured training step built while another
+    component's work was still pending could replay with garbage gradients (tests/test_gpu_configs.py in file order).  The cause turned out to be the
+    memset / memcpy NODES hipMemsetAsync / hipMemcpyAsync become under capture -- msc_memset_zero / msc_copy are kernels since then (csrc/elementwise.hip,
+    DESIGN.md section 3) -- and this synchronise was the first mitigation that worked; it stays, once per program, because it costs nothing."""
+    if _os_env.environ.get('MSC_NO_QUIESCE') == '1':          # measurement switch (tools/dirty_probe5.py)
+        return
     if device is not None and torch.device(device).type == 'cuda' and torch.cuda.is_available():
         import gc
         gc.collect()

@@ -32,7 +32,7 @@ def golden_dir():
 @pytest.fixture(autouse=True)
 def _device_quiet_between_gpu_tests(request):
     """every GPU test starts on an idle device: collect the previous test's garbage and wait for all of its work (round 5: a training graph built
-    while the previous test's work was still pending replayed with garbage gradients -- mapping_challenge_amd.unet_models._quiesce)"""
+    while the previous test's work was still pending replayed with garbage gradients; traced to memset / memcpy graph nodes, DESIGN.md section 3 -- mapping_challenge_amd.unet_models._quiesce)"""
     yield
     if 'gpu' in request.keywords:
         import gc
