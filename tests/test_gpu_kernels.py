@@ -1360,3 +1360,29 @@ def test_conv_epilogue_batchnorm_backward_sums_of_a_residual_join(dtype, cin, co
     d.stats_z = None
     d.res, d.res_ld = out.data_ptr(), cout
     assert lib.msc_conv_igemm(C.byref(d), stream) != 0
+
+
+def test_stream_ordered_fill_and_copy_are_exact_at_any_alignment_and_size():
+    """msc_memset_zero / msc_copy are kernels since round 5 (a captured step must hold kernel nodes only): every byte of the range and
+    no byte outside it, for unaligned starts, sizes around the 16-byte vector width and a size that wraps the grid; the copy also with source and destination
+    in different phases of 16 bytes"""
+    from mapping_challenge_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator().manual_seed(5)
+    for n in (1, 15, 16, 17, 31, 255, 1000, 4097, (1 << 22) + 3, 4096 * 256 * 16 * 2 + 48):
+        for off in (0, 1, 4, 8, 15):
+            buf = torch.randint(1, 256, (n + 64,), dtype=torch.uint8, generator=gen).cuda()
+            keep = buf.clone()
+            _lib.check(lib.msc_memset_zero(buf.data_ptr() + off, n, st), 'msc_memset_zero')
+            torch.cuda.synchronize()
+            assert int(buf[off:off + n].max()) == 0, (n, off)
+            assert torch.equal(buf[:off], keep[:off]) and torch.equal(buf[off + n:], keep[off + n:]), (n, off)
+            for soff in (off, (off + 3) % 16):
+                src = torch.randint(0, 256, (n + 64,), dtype=torch.uint8, generator=gen).cuda()
+                dst = keep.clone()
+                _lib.check(lib.msc_copy(dst.data_ptr() + off, src.data_ptr() + soff, n, st), 'msc_copy')
+                torch.cuda.synchronize()
+                assert torch.equal(dst[off:off + n], src[soff:soff + n]), (n, off, soff)
+                assert torch.equal(dst[:off], keep[:off]) and torch.equal(dst[off + n:], keep[off + n:]), (n, off, soff)
+    assert lib.msc_memset_zero(None, 16, st) != 0 and lib.msc_copy(None, None, 16, st) != 0       # null pointers are refused
