@@ -12,6 +12,23 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _start_ranks(procs, world_size):
+    """start the rank processes with the host's cores divided between them: W processes of torch / BLAS with all cores each spend their time in
+    each other's spin-waits (the two-rank protocol test took 72 s that way, 10 s with 4 threads per rank)"""
+    threads = str(max(1, (os.cpu_count() or 2) // world_size))
+    saved = {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS')}
+    os.environ.update({k: threads for k in saved})
+    try:
+        for p in procs:
+            p.start()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def _worker(rank, world_size, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
@@ -61,8 +78,7 @@ def test_two_rank_protocol_matches_full_batch():
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
+    _start_ranks(procs, 2)
     res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(60)
@@ -146,18 +162,7 @@ def test_product_backward_in_pieces_with_async_allreduce_matches_full_batch(wire
     q = ctx.Queue()
     port = 31500 + os.getpid() % 2000 + (7 if wire == 'bf16' else 0) + 13 * (W - 2)
     procs = [ctx.Process(target=_engine_worker, args=(r, W, port, q, wire)) for r in range(W)]
-    threads = str(max(1, (os.cpu_count() or 2) // W))          # the ranks share the host's cores: no BLAS oversubscription
-    saved = {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS')}
-    os.environ.update({k: threads for k in saved})
-    try:
-        for p in procs:
-            p.start()
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    _start_ranks(procs, W)                                     # the ranks share the host's cores: no BLAS oversubscription
     res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(60)
