@@ -83,3 +83,21 @@ def test_postprocessing_argument_errors():
     assert lib.msc_dilate_i32(1, 2, 1, 8, 8, 0, None) < 0          # k <= 0: the reference returns the input unchanged
     assert lib.msc_label_workspace_bytes(2, 16, 16) == 2 * 16 * 16 * 4
     assert lib.msc_crop_center(1, 2, 1, 2, 320, 320, 301, 301, None) < 0   # asymmetric margins: undefined in the reference
+
+
+def test_capturable_entry_points_issue_kernels_only():
+    """round 5: hipMemsetAsync / hipMemcpyAsync inside an entry point of the training step become memset / memcpy NODES of the captured hipGraph, and a
+    replayed step holding them ran with garbage gradients.  The translation units whose entry points a captured step may call must
+    not contain the runtime calls -- except the two A/B fall-backs of msc_memset_zero / msc_copy behind MSC_MEMOPS_KERNEL=0"""
+    import re
+    csrc = os.path.join(os.path.dirname(__file__), '..', 'open-solution-mapping-challenge_amd', 'csrc')
+    capturable = ['api.hip', 'igemm.hip', 'wgrad.hip', 'conv1x1.hip', 'halo32.hip', 'bottleneck.hip', 'elementwise.hip', 'reduce.hip', 'loss.hip',
+                  'common.h', 'conv_common.h', 'dma.h']
+    hits = []
+    for f in capturable:
+        for i, line in enumerate(open(os.path.join(csrc, f)), 1):
+            code = line.split('//')[0]
+            if re.search(r'hipMem(set|cpy)\w*Async\(', code):      # the synchronous ones build tables (msc_wgrad_group_create), never inside a capture
+                hits.append((f, i, code.strip()[:80]))
+    assert [h[0] for h in hits] == ['elementwise.hip', 'elementwise.hip'], hits
+    assert 'hipMemcpyAsync' in hits[0][2] and 'hipMemsetAsync' in hits[1][2]
