@@ -79,6 +79,9 @@ class UNetResNetRef(nn.Module):
         return self.final(d0)       # dropout2d p=0.0 in every shipped config (src/models.py:34,39,44)
 
 
+_SEEDED = {}
+
+
 def seeded_state_dict(module, seed=1234):
     """Deterministic, torch-RNG-independent weights for any module with the reference's key set.
 
@@ -94,8 +97,12 @@ def seeded_state_dict(module, seed=1234):
     last_bn = '.bn3.' if bottleneck else '.bn2.'
     out = {}
     for key, t in sd.items():
-        rng = np.random.default_rng([seed, zlib.crc32(key.encode())])
         shape = tuple(t.shape)
+        memo = (seed, key, shape, t.dtype, bottleneck)      # the draw is a function of exactly these: drawn once per process, handed out as copies
+        if memo in _SEEDED:
+            out[key] = _SEEDED[memo].clone()
+            continue
+        rng = np.random.default_rng([seed, zlib.crc32(key.encode())])
         if key.endswith('num_batches_tracked'):
             out[key] = torch.zeros(shape, dtype=t.dtype)
             continue
@@ -115,7 +122,8 @@ def seeded_state_dict(module, seed=1234):
             v = rng.uniform(0.1, 0.3, shape) if last_bn in key else rng.uniform(0.8, 1.2, shape)
         else:                                          # BN beta / conv bias / fc bias
             v = rng.standard_normal(shape) * 0.05
-        out[key] = torch.from_numpy(np.asarray(v, dtype=np.float32))
+        _SEEDED[memo] = torch.from_numpy(np.asarray(v, dtype=np.float32))
+        out[key] = _SEEDED[memo].clone()
     return out
 
 

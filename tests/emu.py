@@ -261,24 +261,28 @@ def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, step, gscale, state):
     pp, gg, mm, vv = _arr(p, n), _arr(g, n), _arr(m, n), _arr(v, n)
     # same operations and rounding points as the kernel, with two scratch arrays instead of a dozen temporaries (the flat buffers are
     # 20-80 M elements: the allocations, not the arithmetic, were what this function spent its time on)
-    f = np.float32
-    gr = gg * f(gscale)
-    tmp = pp * f(wd)
+    # torch's in-place float32 multiply / add / divide round like numpy's and run on every core; its sqrt does NOT (vectorised, not correctly
+    # rounded), so that one pass stays in numpy
+    import torch
+    f = lambda c: float(np.float32(c))
+    P, G, M, V = (torch.from_numpy(a) for a in (pp, gg, mm, vv))
+    gr = G * f(gscale)
+    tmp = P * f(wd)
     gr += tmp
-    mm *= f(b1)
-    np.multiply(gr, f(1 - b1), out=tmp)
-    mm += tmp
-    vv *= f(b2)
-    np.multiply(gr, f(1 - b2), out=tmp)
+    M *= f(b1)
+    torch.mul(gr, f(1 - b1), out=tmp)
+    M += tmp
+    V *= f(b2)
+    torch.mul(gr, f(1 - b2), out=tmp)
     tmp *= gr
-    vv += tmp
+    V += tmp
     bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
-    np.sqrt(vv, out=tmp)
+    np.sqrt(vv, out=tmp.numpy())
     tmp /= f(np.sqrt(bc2))
     tmp += f(eps)
-    np.divide(mm, tmp, out=gr)
+    torch.div(M, tmp, out=gr)
     gr *= f(lr / bc1)
-    pp -= gr
+    P -= gr
 
 
 def pack_transpose(src, dst, dtype, A, T, B):
