@@ -100,7 +100,7 @@ typedef struct msc_conv_desc {
  * that conv fetches y, finalises the layer's coefficients from its statistics slots (what msc_bn_apply's prologue does, same arithmetic)
  * and rewrites every landed operand stage in LDS.  The fields are msc_bn_apply's; `out` (may be NULL) receives the activation relu(scale*y +
  * shift), stored once per pixel by the blocks of the first channel tile -- the weight gradient of the consuming conv reads it.
- * Supported: mode 0, stride 1, 1x1 (cfg 0 / 1 / 33) or 3x3 with pad 1 (the halo-tile kernel: cfg 0 / 42 / 51 / 53; the zero padding is of the
+ * Supported: mode 0, stride 1, 1x1 (cfg 33 / 1, or 0 = the first of the two that takes the layer) or 3x3 with pad 1 (the halo-tile kernel: cfg 42 / 51 / 53, or 0 = the first of them that takes the layer; the zero padding is of the
  * activation, not of y), 16-bit dtype, Cin % 64 == 0, Cin <= 512, one image range per launch; msc_conv_cfg_ok tells. */
 typedef struct msc_bn_input {
     const double* slots;      /* [MSC_BN_SLOTS][Cin][2] partial (sum, sum of squares) of y, as msc_conv_igemm's `stats` leaves them */

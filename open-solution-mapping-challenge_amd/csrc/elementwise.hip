@@ -1221,7 +1221,7 @@ extern "C" int msc_bn_pool_bwd_apply(const void* dpool, int64_t dpool_ld, void* 
 // Round 5: stream-ordered fills and copies are KERNELS, not hipMemsetAsync / hipMemcpyAsync.  Captured into a hipGraph those calls become memset /
 // memcpy NODES, and a replayed training step that held them could run with garbage gradients when the program had been built while other work was
 // still pending on the device (same launch lists eagerly -- fine; the same graph with these two entry points as kernels -- fine,
-// with or without the device synchronise that otherwise hides it; tools/dirty_probe5.py).  A captured step now holds kernel nodes only.
+// with or without the device synchronise that otherwise hides it; probes/replay_order_probe.py, tests/test_gpu_replay_hazard.py).  A captured step now holds kernel nodes only.
 // MSC_MEMOPS_KERNEL=0 brings the runtime calls back (A/B).
 __global__ __launch_bounds__(256) void fill_zero_kernel(char* __restrict__ p, long bytes) {
     const long head = min((long)((16 - ((uintptr_t)p & 15)) & 15), bytes);          // bytes in front of the first 16-byte boundary

@@ -881,7 +881,17 @@ int pick_cfg(const ConvK& k) {
 
 template <typename T>
 int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
-    if (cfg == 0) cfg = k.fin_w ? CFG_HALO : k.bnl.slots ? (k.KH == 3 ? (k.Ho % 16 == 0 && k.Cout % 128 == 0 ? 42 : 51) : k.Cout % 256 == 0 ? 33 : 1) : pick_cfg(k);
+    if (cfg == 0) {
+        if (k.fin_w) cfg = CFG_HALO;
+        else if (k.bnl.slots) {          // in_bn: the first of the configurations that apply BatchNorm on load and take this layer
+            static const int cand3[] = {42, 51, 53}, cand1[] = {33, 1};
+            const int* cand = k.KH == 3 ? cand3 : cand1;
+            const int nc = k.KH == 3 ? 3 : 2;
+            cfg = cand[0];
+            for (int i = 0; i < nc; ++i)
+                if (conv_cfg_ok(k, (int)sizeof(T), cand[i])) { cfg = cand[i]; break; }
+        } else cfg = pick_cfg(k);
+    }
     if (!conv_cfg_ok(k, (int)sizeof(T), cfg)) return msc_fail(MSC_ERR_ARG, "msc_conv_igemm: configuration %d is not valid for this layer", cfg);
     if (cfg == CFG_HALO) return halo32_conv_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     if (cfg == CFG_HALO_T) return halo32_deconv_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);

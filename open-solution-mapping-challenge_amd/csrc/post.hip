@@ -1108,7 +1108,7 @@ extern "C" int msc_add_dropped(const uint8_t* processed, const int32_t* labels_o
     if (!processed || !labels_orig || !out || !workspace) return msc_fail(MSC_ERR_ARG, "msc_add_dropped: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const long HW = (long)H * W;
-    if (hipMemsetAsync(workspace, 0, (size_t)B * HW * 4, st) != hipSuccess) return msc_fail(MSC_ERR_HIP, "msc_add_dropped: memset failed");
+    if (msc_memset_zero(workspace, (int64_t)B * HW * 4, st) != MSC_OK) return MSC_ERR_HIP;      // a kernel, not a memset node (elementwise.hip, round 5)
     const dim3 g = plane_grid(HW, B);
     hipLaunchKernelGGL(dropped_mark_kernel, g, dim3(256), 0, st, processed, labels_orig, (int32_t*)workspace, HW);
     hipLaunchKernelGGL(dropped_apply_kernel, g, dim3(256), 0, st, processed, labels_orig, (const int32_t*)workspace, out, HW, bool_sum);
@@ -1122,7 +1122,7 @@ extern "C" int msc_build_score(const int32_t* labels, const float* probs, double
     hipStream_t st = (hipStream_t)stream;
     const long HW = (long)H * W;
     const long n = (long)B * max_labels;
-    if (hipMemsetAsync(sums, 0, n * sizeof(double), st) != hipSuccess || hipMemsetAsync(areas, 0, n * sizeof(int32_t), st) != hipSuccess)
+    if (msc_memset_zero(sums, (int64_t)(n * sizeof(double)), st) != MSC_OK || msc_memset_zero(areas, (int64_t)(n * sizeof(int32_t)), st) != MSC_OK)
         return msc_fail(MSC_ERR_HIP, "msc_build_score: memset failed");
     hipLaunchKernelGGL(score_accum_kernel, plane_grid(HW, B), dim3(256), 0, st, labels, probs, sums, areas, HW, max_labels);
     hipLaunchKernelGGL(score_final_kernel, dim3(flat_grid(n)), dim3(256), 0, st, sums, areas, score, n);

@@ -204,7 +204,7 @@ extern "C" int msc_prep_targets(const uint8_t* masks, const uint8_t* border_mask
     int* xhi = (int*)w;
     const int hw = H * W;
     if (n > 0) {
-        if (hipMemsetAsync(area, 0, 2 * up256(nn * 4), st) != hipSuccess) return msc_fail(MSC_ERR_HIP, "msc_prep_targets: memset");
+        if (msc_memset_zero(area, (int64_t)(2 * up256(nn * 4)), st) != MSC_OK) return MSC_ERR_HIP;
         int bx = ceil_div(hw, 256 * 8);
         if (border_masks && border_masks != masks) {     // is_on_border() looks at the annotation, the rest at its eroded / dilated form
             hipLaunchKernelGGL(inst_stats_kernel, dim3(bx < 1 ? 1 : bx, n), dim3(256), 0, st, border_masks, H, W, 2, (int*)nullptr, interior);
@@ -217,7 +217,7 @@ extern "C" int msc_prep_targets(const uint8_t* masks, const uint8_t* border_mask
     }
     hipLaunchKernelGGL(two_nearest_kernel, dim3(ceil_div(hw, 256)), dim3(256), 0, st, g, keep, xlo, xhi, category_nr, mask_overlayed,
                        distances_f16, second_nearest, n, H, W);
-    if (kept && n > 0 && hipMemcpyAsync(kept, keep, (size_t)n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    if (kept && n > 0 && msc_copy(kept, keep, (int64_t)n * 4, st) != MSC_OK)
         return msc_fail(MSC_ERR_HIP, "msc_prep_targets: copy");
     return msc_check_launch("msc_prep_targets");
 }
@@ -237,7 +237,7 @@ extern "C" int msc_prep_morph(const uint8_t* masks, int n, int H, int W, int ero
     uint8_t* eroded = (uint8_t*)w;       w += up256((size_t)total);
     uint8_t* dilated = (uint8_t*)w;      w += up256((size_t)total);
     int* area = (int*)w;
-    if (hipMemsetAsync(area, 0, (size_t)n * 4, st) != hipSuccess) return msc_fail(MSC_ERR_HIP, "msc_prep_morph: memset");
+    if (msc_memset_zero(area, (int64_t)n * 4, st) != MSC_OK) return MSC_ERR_HIP;
     int bx = ceil_div(hw, 256 * 8);
     hipLaunchKernelGGL(inst_stats_kernel, dim3(bx < 1 ? 1 : bx, n), dim3(256), 0, st, masks, H, W, 2, area, (int*)nullptr);
     // skimage binary_erosion / binary_dilation with rectangle(k, k) = scipy's: windows -(k/2).. resp. -((k-1)/2)..
@@ -266,7 +266,7 @@ extern "C" int msc_prep_border(uint8_t* mask_overlayed, const double* second_nea
     hipStream_t st = (hipStream_t)stream;
     const int hw = H * W;
     int mx = 0;
-    if (hipMemsetAsync(scratch, 0, 4, st) != hipSuccess) return msc_fail(MSC_ERR_HIP, "msc_prep_border: memset");
+    if (msc_memset_zero(scratch, 4, st) != MSC_OK) return MSC_ERR_HIP;
     hipLaunchKernelGGL(max_u8_kernel, dim3(ceil_div(hw, 256 * 16) < 1 ? 1 : ceil_div(hw, 256 * 16)), dim3(256), 0, st, mask_overlayed, hw, scratch);
     if (hipMemcpyAsync(&mx, scratch, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
         return msc_fail(MSC_ERR_HIP, "msc_prep_border: copy");
@@ -278,7 +278,7 @@ extern "C" int msc_size_matrix(const int32_t* labels, int32_t* sizes, int32_t* a
     if (!labels || !sizes || !areas || B <= 0 || H <= 0 || W <= 0 || max_labels < 0) return msc_fail(MSC_ERR_ARG, "msc_size_matrix: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const long total = (long)B * H * W;
-    if (hipMemsetAsync(areas, 0, (size_t)B * (max_labels + 1) * 4, st) != hipSuccess) return msc_fail(MSC_ERR_HIP, "msc_size_matrix: memset");
+    if (msc_memset_zero(areas, (int64_t)B * (max_labels + 1) * 4, st) != MSC_OK) return MSC_ERR_HIP;
     long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(area_count_kernel, dim3((int)blocks), dim3(256), 0, st, labels, areas, total, H * W, max_labels);

@@ -38,8 +38,14 @@ def _dev(a, dtype):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(_device(), non_blocking=False)
 
 
-def layer_table(category_layers=CATEGORY_LAYERS):
-    """(class index, threshold) per layer: thresholds arange(1/(L+1), 1, 1/(L+1)) for each class (:80-83)."""
+def layer_table(category_layers=CATEGORY_LAYERS, channels=None):
+    """(class index, threshold) per layer: thresholds arange(1/(L+1), 1, 1/(L+1)) for each class (:80-83).  `channels`: the map's channel
+    count -- the reference walks the CHANNELS and looks the layer count up (:79-80), so classes beyond the last channel are not cut and a
+    table shorter than the map raises its IndexError (the kernels index the map by class: a class >= C would read out of bounds)"""
+    if channels is not None:
+        if len(category_layers) < channels:
+            raise IndexError('list index out of range')        # CATEGORY_LAYERS[category_id], src/postprocessing.py:80
+        category_layers = category_layers[:channels]
     cls, thr = [], []
     for cat, n in enumerate(category_layers):
         step = 1. / (n + 1)
@@ -69,7 +75,7 @@ def resize_threshold_batch(probs, target_size, category_layers=CATEGORY_LAYERS):
     probs = probs.contiguous().float()
     B, Cc, h, w = probs.shape
     H, W = target_size
-    cls, thr = layer_table(category_layers)
+    cls, thr = layer_table(category_layers, Cc)
     L = len(cls)
     dcls, dthr = torch.from_numpy(cls).to(probs.device), torch.from_numpy(thr).to(probs.device)
     out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=probs.device)
@@ -93,7 +99,7 @@ def threshold_batch(probs, category_layers=CATEGORY_LAYERS):
         probs = probs.float()
     probs = probs.contiguous()          # a numpy map built by fancy indexing arrives with permuted strides
     B, Cc, H, W = probs.shape
-    cls, thr = layer_table(category_layers)
+    cls, thr = layer_table(category_layers, Cc)
     L = len(cls)
     dcls, dthr = torch.from_numpy(cls).to(probs.device), torch.from_numpy(thr).to(probs.device)
     out = torch.empty((B, L, H, W), dtype=torch.uint8, device=probs.device)
@@ -228,7 +234,7 @@ def _postprocess(probs, target_size, erode_selem_size, dilate_selem_size, catego
     if erode_selem_size > 0:
         flat = add_dropped_batch(flat, erode_batch(flat, erode_selem_size))
     if watershed_selem_size > 0:      # extension (WATERSHED.md): instances split along the probability ridges instead of plain labelling
-        cls = torch.as_tensor(_layer_classes(category_layers), device=p.device)
+        cls = torch.as_tensor(_layer_classes(category_layers[:Cc]), device=p.device)
         labels, counts = watershed_batch(flat, p.index_select(1, cls).reshape(B * L, H, W), watershed_selem_size)
     else:
         labels, counts = label_batch(flat)

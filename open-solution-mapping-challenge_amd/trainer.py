@@ -59,7 +59,7 @@ def _run(fn, args, device):
 
 
 def _zero(t, stream):
-    """stream-ordered zero fill of a tensor as a C-ABI launch (a memset node under capture)"""
+    """stream-ordered zero fill of a tensor as a C-ABI launch (msc_memset_zero: a kernel, so a kernel node under capture)"""
     from .unet_models import _Program
     _Program.run([(_lib.load().msc_memset_zero, (t.data_ptr(), t.numel() * t.element_size()))], stream)
 
@@ -165,6 +165,7 @@ class HipAdam(torch.optim.Optimizer):
         self._table = None            # (key, keep-alive tensors, msc_adam_pack table arguments)
         self.on_hyper_change = None   # TrainStep: drop captured graphs (betas / eps / weight_decay are launch arguments)
         self._scale_restored = False  # a loaded state_dict brought its loss scale: TrainStep must not reset it to the default
+        self._scale_pinned = False    # TrainStep(loss_scale=...) pinned a static scale: it wins over a checkpoint's, in any construction order
 
     # the step count lives on the device once training runs: a skipped (overflowed) step does not advance it
     @property
@@ -336,11 +337,15 @@ class HipAdam(torch.optim.Optimizer):
         self._apply_hyper(state)
         self.set_lr(self.lr)
         self.dev_state[_lib.OPT_STEP] = float(self._steps)
-        if state.get('loss_scale'):
-            # the (dynamic) loss scale a checkpoint carries is restored whatever order optimizer / TrainStep were built in; the
-            # clean-step counter and a pending overflow flag belong to the run that wrote the checkpoint
+        if state.get('loss_scale') and not self._scale_pinned:
+            # the (dynamic) loss scale a checkpoint carries is restored whatever order optimizer / TrainStep were built in -- unless the TrainStep
+            # pinned an explicit static scale, which always wins; the clean-step counter and a pending overflow flag belong to the run that wrote
+            # the checkpoint
             if 'dynamic_scale' in state:
+                was = (self.dynamic_scale, self.growth_interval)
                 self.dynamic_scale, self.growth_interval = bool(state['dynamic_scale']), int(state.get('growth_interval', self.growth_interval))
+                if (self.dynamic_scale, self.growth_interval) != was and self.on_hyper_change is not None:
+                    self.on_hyper_change()       # launches() holds msc_grad_check only in the dynamic mode: a captured step is stale
             self.loss_scale = float(state['loss_scale'])
             self.dev_state[_lib.OPT_SCALE] = self.loss_scale
             self.dev_state[_lib.OPT_GROWTH] = float(self.growth_interval if self.dynamic_scale else 0)
@@ -443,9 +448,11 @@ class TrainStep:
             self.loss_scale = optimizer.loss_scale          # resumed fp16 run: keep the scale the checkpoint reached
         else:
             optimizer.set_loss_scale(self.loss_scale, dynamic=(fp16 and loss_scale is None))
+        optimizer._scale_pinned = loss_scale is not None
         optimizer.on_hyper_change = self._drop_graphs
         self.dist = world is not None and (world.size > 1 or force_collectives)     # force: exercise RCCL with one rank
         self.use_graph = use_graph
+        self.keep_graph = False       # tests: keep the captured hipGraph_t (torch.cuda.CUDAGraph(keep_graph=True)) so that its nodes can be inspected
         self.shapes = {}
         self.cur = None
         self.loss = self.sums = None
@@ -530,9 +537,11 @@ class TrainStep:
                         torch.cuda.synchronize()
                     st.pieces, self.use_graph = None, False
             else:
-                g = torch.cuda.CUDAGraph()
+                g = torch.cuda.CUDAGraph(keep_graph=True) if self.keep_graph else torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._body_captured()
+                if self.keep_graph:
+                    g.instantiate()
                 st.graph = g
             return self.loss
         self.opt.sync_lr()                # a scheduler callback may have changed it: the captured Adam reads it from the device
@@ -565,7 +574,7 @@ class TrainStep:
 
         def capture(fn):
             # thread_local: the RCCL watchdog thread of torch.distributed may poll events while we capture.  Everything a
-            # piece does is a C-ABI launch (kernels, memset and copy nodes): nothing runs at capture time
+            # piece does is a C-ABI launch (kernel nodes only, the fills and copies included): nothing runs at capture time
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 fn(_stream_of(dev))

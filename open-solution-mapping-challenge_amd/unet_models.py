@@ -145,6 +145,7 @@ import os as _os_env
 # measured on MI355X (R101 train step, hipGraph): 18.8 ms with the wgrad kernels on a second stream vs 17.6 ms
 # serial -- the concurrent kernels fight over L2/LDS-DMA bandwidth -- so the fork/join path is opt-in
 _OVERLAP_WGRAD = _os_env.environ.get('MSC_OVERLAP_WGRAD', '0') == '1'
+_WGRAD_FLUSH_DEFAULT = ''
 _SIDE_STREAMS = {}
 
 
@@ -154,7 +155,7 @@ def _quiesce(device):
     component's work was still pending could replay with garbage gradients (tests/test_gpu_configs.py in file order).  The cause turned out to be the
     memset / memcpy NODES hipMemsetAsync / hipMemcpyAsync become under capture -- msc_memset_zero / msc_copy are kernels since then (csrc/elementwise.hip,
     DESIGN.md section 3) -- and this synchronise was the first mitigation that worked; it stays, once per program, because it costs nothing."""
-    if _os_env.environ.get('MSC_NO_QUIESCE') == '1':          # measurement switch (tools/dirty_probe5.py)
+    if _os_env.environ.get('MSC_NO_QUIESCE') == '1':          # measurement switch (tests/test_gpu_replay_hazard.py, probes/replay_order_probe.py)
         return
     if device is not None and torch.device(device).type == 'cuda' and torch.cuda.is_available():
         import gc
@@ -632,8 +633,9 @@ class _GroupHandle(C.c_void_p):
     """msc_wgrad_group* plus the descriptors it was made from (for FLOP accounting in bench.py)"""
 
 
-_ZERO_ALLOC = int(_os_env.environ.get('MSC_ZERO_ALLOC', '0'))      # bits: 1 activations, 2 vectors, 4 gradient buffers, 8 ReLU byte masks
-_TUNE_ONLY = _os_env.environ.get('MSC_TUNE_ONLY', '').split(',') if _os_env.environ.get('MSC_TUNE_ONLY') else []      # debugging aid: c0 / c1 / j      # debugging aid: program buffers start as zeros instead of recycled allocator memory
+# debugging aid: program buffers start as zeros instead of recycled allocator memory (bits: 1 activations, 2 vectors, 4 gradient buffers, 8 ReLU byte masks)
+_ZERO_ALLOC = int(_os_env.environ.get('MSC_ZERO_ALLOC', '0'))
+_TUNE_ONLY = _os_env.environ.get('MSC_TUNE_ONLY', '').split(',') if _os_env.environ.get('MSC_TUNE_ONLY') else []      # debugging aid: c0 / c1 / j
 
 
 class _Builder:
@@ -668,6 +670,10 @@ class _Builder:
             raise _lib.MscError('deterministic=True needs the grouped weight-gradient launches (MSC_WGRAD_GROUP > 1, got %d): the per-layer '
                                 'launches add their split-K partials with fp32 atomics in arrival order' % self.group_max)
         self.pending = []             # deferred (WgradDesc, gradient address or None)
+        # round 6: the grouped launches as a PARALLEL BRANCH of the step's graph.  MSC_WGRAD_FLUSH names the points of the backward at which what
+        # is pending goes out ('dec' = the decoder's backward is complete, 'l4'..'l1' = that encoder stage's): with MSC_OVERLAP_WGRAD=1 those
+        # launches run on the side stream beside the latency-bound data-gradient chain of the stages that follow (_Program.run_backward)
+        self.flush_at = set(f for f in env.get('MSC_WGRAD_FLUSH', _WGRAD_FLUSH_DEFAULT).split(',') if f) if self.group_max > 1 else set()
         self.gcount = {}              # activation slice -> number of launches that write its gradient
         self.gwriter = {}             # activation slice -> ConvDesc of the (mode 0, no residual) dgrad conv that wrote it first
         self.fuse_bn_bwd = _os_env.environ.get('MSC_FUSE_BN_BWD', '1') != '0'
@@ -893,11 +899,6 @@ class _Builder:
             cache[key] = best
             self._tuned_new = True
         d.cfg = cache[key]
-        if d.mode == 1 and _os_env.environ.get('MSC_TUNE_DEBUG'):       # debugging aid: which configuration a transposed-mode launch got
-            force = _os_env.environ.get('MSC_FORCE_DECONV28')
-            if force == '1' and lib.msc_conv_cfg_ok(C.byref(d), 28):
-                d.cfg = 28
-            print('tune mode1 %s -> cfg %d' % (key, d.cfg), flush=True)
 
     def tune_join(self, d):
         """the configuration of a data-gradient conv that carries a residual join's reductions (stats_kind 1 with stats_z): its epilogue
@@ -980,7 +981,7 @@ class _Builder:
             d = self.conv_desc(Act(pend._y), w, y, want_stats=True, in_bn=pend, **geo)
             if self.dev.type == 'cuda' and not any(lib.msc_conv_cfg_ok(C.byref(d), c) for c in range(1, lib.msc_conv_num_cfgs() + 1)):
                 # no kernel configuration applies BatchNorm on load for this layer shape: the producer's msc_bn_apply runs as its own
-                # launch after all (on load is the default since round 5, so an unusual shape must not fail)
+                # launch after all (on load is opt-in, MSC_BN_ON_LOAD=1; an unusual shape must not fail with it)
                 self.emit(fwd, *pend._apply)
                 self.prog.on_load_fallbacks = getattr(self.prog, 'on_load_fallbacks', 0) + 1
                 d = self.conv_desc(x, w, y, want_stats=True, **geo)
@@ -1325,6 +1326,8 @@ class _Builder:
         # encoder.layer1-4 (torchvision BasicBlock / Bottleneck)
         for li in range(1, 5):
             blocks = getattr(enc, 'layer%d' % li)
+            if self.training and ('l%d' % li) in self.flush_at:
+                self.ops.append(self.flush_wgrads)      # backward runs the ops in reverse: after this stage's backward
             for bi, blk in enumerate(blocks):
                 base = 'encoder.layer%d.%d' % (li, bi)
                 s = blk.stride
@@ -1361,6 +1364,8 @@ class _Builder:
 
         # decoder (:392-401)
         self.ops.append(self.flush_bias_slots)      # backward runs the ops in reverse: this one right after the decoder's
+        if self.training and 'dec' in self.flush_at:
+            self.ops.append(self.flush_wgrads)
         pooled = self.act(H // 64, W // 64, c5.C)
         self.maxpool(c5, pooled)
         specs = [('center', pooled, self.slice(cat5, 0, nf * 8)), ('dec5', Act(cat5), self.slice(cat4, 0, nf * 8)),
