@@ -163,7 +163,7 @@ def cpu_baseline_train(encoder, hw, budget_s=25.0):
         k += 1
     dt = time.time() - t0
     return {'value': n * k / dt, 'unit': 'img/s', 'cores': cpu_threads(), 'kind': 'port',
-            'sample': 'oracle UNetResNetRef(%d) fp32 torch-CPU train step (fwd+mixed loss+bwd+Adam), batch %d at %dx%d, %d steps'
+            'sample': 'oracle port UNetResNetRef(%d) (torch.equal to src.unet_models.UNetResNet, tests/test_oracle.py) fp32 torch-CPU train step (fwd+mixed loss+bwd+Adam), batch %d at %dx%d, %d steps'
                       % (encoder, n, hw, hw, k)}
 
 
@@ -222,7 +222,8 @@ def bench_e2e(args, world, dev, stream, timed):
     from mapping_challenge_amd import postprocessing as post, utils
     from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
     from mapping_challenge_amd.unet_models import UNetResNet
-    from oracle import losses_ref, unet_ref
+    import synthetic_inputs as losses_ref
+    unet_ref = losses_ref
     enc = args.encoder or 101
     batch = args.batch or 32
     hw = args.size
@@ -349,7 +350,7 @@ def north_star_block(net, x, batch, hw, enc, dtype, dev, stream):
     configs[3] chain -- plain (resize, threshold, label, dilate, score) and full (+ dense CRF + watershed extension), with and without
     the annotation encoding.  Inputs resident in HBM; ~3 s of GPU time."""
     from mapping_challenge_amd import postprocessing as post, utils
-    from oracle import post_ref                                   # synthetic blob-like probability maps only (inputs)
+    import synthetic_inputs as post_ref                           # synthetic blob-like probability maps (inputs; nothing of oracle/ on a measured leg)
 
     def per_call(fn, iters, warm=2):
         for _ in range(warm):
@@ -479,7 +480,8 @@ def main():
     if args.workload in ('train', 'infer', 'tta'):
         from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
         from mapping_challenge_amd.unet_models import UNetResNet
-        from oracle import losses_ref, unet_ref     # synthetic data / seeded weights only (inputs, not the product path)
+        import synthetic_inputs as losses_ref       # synthetic data / seeded weights (inputs; oracle/ is imported by the cpu_baseline leg only)
+        unet_ref = losses_ref
         enc = args.encoder or {'train': 101, 'infer': 34, 'tta': 152}[args.workload]
         batch = args.batch or (64 if args.workload == 'tta' else 32)
         net = UNetResNet(enc, 2, num_filters=32, dropout_2d=0.0, is_deconv=True, compute_dtype=args.dtype)
@@ -611,7 +613,7 @@ def main():
     elif args.workload == 'annot':
         # labelled 300x300 layers (2 per image, on the device) -> COCO RLE strings + boxes on the host
         from mapping_challenge_amd import postprocessing as post, utils
-        from oracle import post_ref
+        import synthetic_inputs as post_ref
         batch = args.batch or 64
         probs_h = post_ref.synthetic_probs(batch, 256, 256, seed=1234 + world.rank)
         res = post.postprocess_batch(torch.from_numpy(probs_h).to(dev), (300, 300), 0, 2)
@@ -633,7 +635,7 @@ def main():
             result['cpu_baseline'] = cpu_baseline_annot(layers_h)
     else:
         from mapping_challenge_amd import postprocessing as post
-        from oracle import post_ref
+        import synthetic_inputs as post_ref
         batch = args.batch or 64
         probs_h = post_ref.synthetic_probs(batch, 256, 256, seed=1234 + world.rank)
         probs = torch.from_numpy(probs_h).to(dev)

@@ -284,7 +284,9 @@ __global__ __launch_bounds__(512, MINB * 2) void bottleneck_fused_kernel(BnkK p)
             for (int a = 0; a < FM; ++a)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[a * 4 + q] = ok ? fmaxf(fmaf(acc[a][b][q], sc[a * 4 + q], sh[a * 4 + q]), 0.f) : 0.f;
-            *reinterpret_cast<uint4*>(mid1 + (cb >> 6) * PLANE1 + r * 128 + ((((cb & 63) >> 3) ^ ((r >> 1) & 7)) * 16)) = pack8<T>(v);
+            // (round 6) the swizzle key of the conv1 halo is its COLUMN, hx & 7: phase 2 reads 16-pixel windows that start at any column, and the
+            // pixel-pair key put two lanes of a ds_read_b128 group on one slot for two of the three column shifts (conv3x3_halo_dma_kernel, igemm.hip)
+            *reinterpret_cast<uint4*>(mid1 + (cb >> 6) * PLANE1 + r * 128 + ((((cb & 63) >> 3) ^ (hx & 7)) * 16)) = pack8<T>(v);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(512, MINB * 2) void bottleneck_fused_kernel(BnkK p)
 #pragma unroll
             for (int b = 0; b < FN; ++b) {
                 const int hp = hp0[b] + delta;
-                boff[b] = hp * 128 + ((g ^ ((hp >> 1) & 7)) * 16);
+                boff[b] = hp * 128 + ((g ^ ((pl + dx) & 7)) * 16);      // column of the halo pixel: pl + 1 + (dx - 1)
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {

@@ -522,7 +522,7 @@ __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo
         const int hy = hp / HCOLS, hx = hp - hy * HCOLS;
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
         const bool ok = hp < HPIX && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        hoff[i] = ok ? (unsigned)((n * p.Hi + iy) * p.Wi + ix) * pix_bytes + (unsigned)(slot ^ ((hp >> 1) & 7)) * 16u : OOB_OFF;
+        hoff[i] = ok ? (unsigned)((n * p.Hi + iy) * p.Wi + ix) * pix_bytes + (unsigned)(slot ^ (hx & 7)) * 16u : OOB_OFF;      // halo_key: the COLUMN, see boff
     }
     unsigned woff[WI1];
 #pragma unroll
@@ -544,8 +544,14 @@ __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo
         const int dy = p.flip ? 1 - kh : kh - 1, dx = p.flip ? 1 - kw : kw - 1;
 #pragma unroll
         for (int b = 0; b < FN; ++b) {
-            const int hp = (wp * FN + b + 1 + dy) * HCOLS + pl + 1 + dx;
-            boff[t][b] = hp * KB + ((g ^ ((hp >> 1) & 7)) * 16);
+            // round 6: the swizzle key is the halo COLUMN (hx & 7), not (pixel >> 1) & 7.  A tap's fragment is 16 consecutive halo pixels starting at an
+            // arbitrary column: with the pixel-pair key two of the three column shifts put two lanes of a ds_read_b128 lane group on one 16-byte slot
+            // (checked exhaustively; SQ_LDS_BANK_CONFLICT = 21 % of SQ_LDS_IDX_ACTIVE on the decoder layers, profiles/r5_final_sq_summary.txt, against 0
+            // for the implicit-GEMM kernel, whose fragments start on 16-pixel boundaries).  Rows are 18 x 128 B = 9 x 256 B apart, so the row does not
+            // enter the bank: hx & 7 is conflict-free for every shift.
+            const int hx = pl + 1 + dx;
+            const int hp = (wp * FN + b + 1 + dy) * HCOLS + hx;
+            boff[t][b] = hp * KB + ((g ^ (hx & 7)) * 16);
         }
     }
 
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(WP * WC * 64, MINB * WP * WC / 4) void conv3x3_halo
                         const bool ok = hoff[i] != OOB_OFF;        // outside the image (or past the halo): the zeros stay
                         char* ptr = hbase + (chunk & 1) * HBUF + (i * NW + wid) * 1024 + lane * 16;
                         const int hp = (i * NW + wid) * 8 + lr;
-                        const int ch = chunk * 64 + ((slot ^ ((hp >> 1) & 7)) << 3);
+                        const int ch = chunk * 64 + ((slot ^ ((hp % HCOLS) & 7)) << 3);
                         const uint4 v = *reinterpret_cast<uint4*>(ptr);
                         float f[8];
                         Vec16<T>::unpack(v, f);

@@ -141,6 +141,58 @@ __global__ void rect_filter_kernel(const T* __restrict__ in, T* __restrict__ out
     }
 }
 
+// round 6: the same filter, separable and tiled.  min / max over a k x k window is the min / max over the rows of the row-wise min / max, with scipy's
+// 'reflect' indices on either axis (a reflected index only repeats values the window holds anyway) -- identical results.  A block owns a 32 x 64 tile:
+// its halo goes to LDS once (coalesced rows), the row pass and the column pass read LDS.  The 2-D loop above re-reads k*k global values per pixel through
+// byte-wide gathers: 434 us for the 5 x 5 erosion of 256 planes of 300 x 300 (the watershed markers), 106 us for the 2 x 2 label dilation.
+constexpr int RF_TH = 32, RF_TW = 64, RF_MAXK = 17;      // window extents hi - lo + 1 up to 17
+template <typename T, bool IS_MAX>
+__global__ __launch_bounds__(256) void rect_filter_tiled_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W, int lo, int hi) {
+    __shared__ T a[(RF_TH + RF_MAXK - 1) * (RF_TW + RF_MAXK - 1)];
+    __shared__ T r[(RF_TH + RF_MAXK - 1) * RF_TW];
+    const int ext = hi - lo, hh = RF_TH + ext, ww = RF_TW + ext;
+    const int x0 = blockIdx.x * RF_TW, y0 = blockIdx.y * RF_TH;
+    const T* p = in + (long)blockIdx.z * H * W;
+    for (int i = threadIdx.x; i < hh * ww; i += 256) {
+        const int yy = i / ww, xx = i - yy * ww;
+        // rows / columns past H - 1 + hi feed no pixel of the image (partial tiles): any in-range value will do
+        const int y = reflect_idx(min(y0 + lo + yy, H - 1 + hi), H), x = reflect_idx(min(x0 + lo + xx, W - 1 + hi), W);
+        a[i] = p[(long)y * W + x];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < hh * RF_TW; i += 256) {
+        const int yy = i / RF_TW, x = i - yy * RF_TW;
+        T v = a[yy * ww + x];
+        for (int d = 1; d <= ext; ++d) {
+            const T u = a[yy * ww + x + d];
+            v = IS_MAX ? (u > v ? u : v) : (u < v ? u : v);
+        }
+        r[i] = v;
+    }
+    __syncthreads();
+    T* o = out + (long)blockIdx.z * H * W;
+    for (int i = threadIdx.x; i < RF_TH * RF_TW; i += 256) {
+        const int y = i / RF_TW, x = i - y * RF_TW;
+        if (y0 + y >= H || x0 + x >= W) continue;
+        T v = r[i];
+        for (int d = 1; d <= ext; ++d) {
+            const T u = r[(y + d) * RF_TW + x];
+            v = IS_MAX ? (u > v ? u : v) : (u < v ? u : v);
+        }
+        o[(long)(y0 + y) * W + x0 + x] = v;
+    }
+}
+template <typename T, bool IS_MAX>
+static void launch_rect_filter(const T* in, T* out, int B, int H, int W, int lo, int hi, hipStream_t st) {
+    static const bool tiled_off = [] { const char* e = getenv("MSC_RECT_TILED"); return e && e[0] == '0'; }();      // A/B: the 2-D loop of rounds 1-5
+    if (hi - lo + 1 <= RF_MAXK && !tiled_off)
+        hipLaunchKernelGGL((rect_filter_tiled_kernel<T, IS_MAX>), dim3((W + RF_TW - 1) / RF_TW, (H + RF_TH - 1) / RF_TH, B), dim3(256), 0, st, in, out, H, W, lo, hi);
+    else {
+        long blocks = ((long)B * H * W + 255) / 256;
+        hipLaunchKernelGGL((rect_filter_kernel<T, IS_MAX>), dim3((unsigned)(blocks > 4096 ? 4096 : blocks < 1 ? 1 : blocks)), dim3(256), 0, st, in, out, B, H, W, lo, hi);
+    }
+}
+
 // ------------------------------------------------------------------ connected components, 4-connectivity
 // Union-find over pixel indices with atomicMin links: the root of a component is its smallest pixel
 // index = its first pixel in raster order, so numbering roots by an exclusive prefix count in raster
@@ -217,6 +269,92 @@ __global__ void ccl_compress_kernel(int32_t* __restrict__ L, long HW) {
             const int r = uf_find(l, v);
             __hip_atomic_store(l + p, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+}
+// round 6: the unions of a strip of rows in LDS.  ccl_merge_kernel chases parent pointers through global memory (a dependent L2 round trip per hop, atomicMin
+// links contended by every run that touches a component): 137 us per 64 tiles, and ccl_compress_kernel's chains were as deep as the image (93 us).  Here a
+// block owns CCL_STRIP_PIX / W rows: run labelling (as ccl_init_kernel), the vertical unions and the path compression all happen on an int array in LDS,
+// the strip leaves as finished roots; the rows where two strips meet are united in global memory (ccl_seam_kernel: one row per seam) and the final
+// compression finds every root within a hop or two.  Label values are pixel indices of the PLANE throughout (LDS index + base), so the root of a
+// component stays its first pixel in raster order.
+constexpr int CCL_STRIP_PIX = 16384;       // 64 KB of LDS: two 1024-thread blocks per CU
+__device__ __forceinline__ int ufl_load(const int* lab, int base, int a) {
+    return __hip_atomic_load(lab + (a - base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int ufl_find(const int* lab, int base, int a) {
+    int p = ufl_load(lab, base, a);
+    while (p != a) { a = p; p = ufl_load(lab, base, a); }
+    return a;
+}
+__device__ __forceinline__ void ufl_union(int* lab, int base, int a, int b) {
+    bool done = false;
+    while (!done) {
+        a = ufl_find(lab, base, a);
+        b = ufl_find(lab, base, b);
+        if (a < b) {
+            const int old = atomicMin(lab + (b - base), a);
+            done = (old == b);
+            b = old;
+        } else if (b < a) {
+            const int old = atomicMin(lab + (a - base), b);
+            done = (old == a);
+            a = old;
+        } else {
+            done = true;
+        }
+    }
+}
+__global__ __launch_bounds__(1024) void ccl_strip_kernel(const uint8_t* __restrict__ mask, int32_t* __restrict__ L, int H, int W, int SR) {
+    __shared__ int lab[CCL_STRIP_PIX];
+    const long HW = (long)H * W;
+    const long b = blockIdx.y;
+    const int y0 = blockIdx.x * SR;
+    const int rows = min(SR, H - y0);
+    const int base = y0 * W, total = rows * W;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // runs of every row: a foreground pixel starts as a child of the first pixel of its horizontal run (ccl_init_kernel)
+    for (int r = wid; r < rows; r += 16) {
+        const uint8_t* m = mask + b * HW + base + (long)r * W;
+        int* l = lab + r * W;
+        int carry = -1;
+        for (int x0 = 0; x0 < W; x0 += 64) {
+            const int x = x0 + lane;
+            const bool fg = x < W && m[x] != 0;
+            const unsigned long long f = __ballot(fg);
+            const unsigned long long starts = f & ~((f << 1) | (carry >= 0 ? 1ull : 0ull));
+            const unsigned long long below = starts & (~0ull >> (63 - lane));
+            const int sx = below ? x0 + 63 - __clzll((long long)below) : carry;
+            if (x < W) l[x] = fg ? base + r * W + sx : -1;
+            const int last = __shfl(fg ? sx : -1, 63, 64);
+            carry = (f >> 63) ? last : -1;
+        }
+    }
+    __syncthreads();
+    // vertical unions inside the strip, once per pair of touching runs (ccl_merge_kernel's rule; foreground = label >= 0)
+    for (int i = W + threadIdx.x; i < total; i += 1024) {
+        if (lab[i] < 0 || lab[i - W] < 0) continue;
+        const int x = i % W;
+        if (x > 0 && lab[i - 1] >= 0 && lab[i - W - 1] >= 0) continue;
+        ufl_union(lab, base, base + i, base + i - W);
+    }
+    __syncthreads();
+    int* out = L + b * HW + base;
+    for (int i = threadIdx.x; i < total; i += 1024) {
+        const int v = lab[i];
+        out[i] = v >= 0 ? ufl_find(lab, base, v) : -1;
+    }
+}
+// the first row of every strip but the first against the row above it, in global memory (labels are strip roots by now)
+__global__ void ccl_seam_kernel(int32_t* __restrict__ L, int H, int W, int SR) {
+    const long HW = (long)H * W;
+    int* l = L + blockIdx.y * HW;
+    const int y = (blockIdx.x + 1) * SR;
+    if (y >= H) return;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        const int p = y * W + x;
+        if (uf_load(l, p) < 0 || uf_load(l, p - W) < 0) continue;
+        if (x > 0 && uf_load(l, p - 1) >= 0 && uf_load(l, p - W - 1) >= 0) continue;
+        uf_union(l, p, p - W);
     }
 }
 // one block per image: rank[p] = number of roots before p (raster order), for roots only.  The image is walked in chunks of
@@ -472,6 +610,54 @@ __global__ void score_accum_kernel(const int32_t* __restrict__ labels, const flo
             }
             active = active && !mine;
             todo &= ~mm;
+        }
+    }
+}
+// round 6: the same sums with the label accumulators of a 4096-pixel chunk in LDS (ds_add_f64 / ds_add_u32) and ONE pass of global atomics per chunk and
+// touched label.  The first form issued its atomics per wave (64 pixels): ~1400 waves per plane adding into a few dozen addresses serialise in the
+// L2 -- 138 us per 64 tiles for 92 MB of reads.  Labels above SCORE_LDS_MAX go the old way (msc_build_score falls back to score_accum_kernel).
+constexpr int SCORE_LDS_MAX = 2048, SCORE_CHUNK = 4096;
+__global__ __launch_bounds__(256) void score_accum_lds_kernel(const int32_t* __restrict__ labels, const float* __restrict__ probs, double* __restrict__ sums,
+                                                              int32_t* __restrict__ areas, long HW, int max_labels) {
+    __shared__ double s_sum[SCORE_LDS_MAX];
+    __shared__ int s_area[SCORE_LDS_MAX];
+    const long b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < max_labels; i += 256) { s_sum[i] = 0.0; s_area[i] = 0; }
+    __syncthreads();
+    const long p0 = (long)blockIdx.x * SCORE_CHUNK;
+    int lab[SCORE_CHUNK / 256];
+    float pr[SCORE_CHUNK / 256];
+#pragma unroll
+    for (int k = 0; k < SCORE_CHUNK / 256; ++k) {          // all loads of the chunk in flight together
+        const long p = p0 + k * 256 + threadIdx.x;
+        lab[k] = p < HW ? labels[b * HW + p] : 0;
+        pr[k] = p < HW ? probs[b * HW + p] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < SCORE_CHUNK / 256; ++k) {
+        bool active = lab[k] > 0 && lab[k] <= max_labels;
+        unsigned long long todo = __ballot(active);
+        while (todo) {                                      // one LDS add per distinct label of the wave's 64 pixels (a row segment has 1-3)
+            const int leader = __ffsll((long long)todo) - 1;
+            const int l0 = __shfl(lab[k], leader, 64);
+            const bool mine = active && lab[k] == l0;
+            const double s = wave_sum_d(mine ? (double)pr[k] : 0.0);
+            const unsigned long long mm = __ballot(mine);
+            if (lane == leader) {
+                atomicAdd(&s_sum[l0 - 1], s);
+                atomicAdd(&s_area[l0 - 1], (int)__popcll(mm));
+            }
+            active = active && !mine;
+            todo &= ~mm;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < max_labels; i += 256) {
+        const int a = s_area[i];
+        if (a) {
+            atomicAdd(sums + b * max_labels + i, s_sum[i]);
+            atomicAdd(areas + b * max_labels + i, a);
         }
     }
 }
@@ -899,6 +1085,181 @@ __global__ __launch_bounds__(256, 4) void crf_r_kernel(const float* __restrict__
     }
 }
 
+// ---- round 6: the bilateral kernel on EXACT integer colour distances from a dot product, the Gaussian kernel as a separable blur in its own launch.
+// (a) The colours are 8-bit: |o - m|^2 = |o|^2 + |m|^2 - 2 o.m, and every term is an integer below 2^24, i.e. exact in fp32 whatever the order -- the
+//     three subtractions and three multiply-adds per tap and pair become one add and three multiply-adds against the centre pixel's -2 m (per halo pixel
+//     |o|^2 is computed once when the tile is loaded; 1e30 outside the image, which zeroes the weight), and the exponent argument is the same
+//     fma(dist, -k, bx + by) as before: the weights are those of crf_r_kernel bit for bit.
+// (b) exp(-(dx^2+dy^2)/2s^2) does not depend on the image: the Gaussian message is a separable 11 + 11 tap blur of Q * n_g (crf_gauss_kernel, ~1/10 of the
+//     multiply-adds of the 121-tap form), its normaliser the product of two 1-D window sums.  The hot loop keeps 8 packed operations + 2 v_exp_f32 per tap
+//     and pixel pair (13 + 2 before), 16 bytes of LDS per halo pixel (20 before).
+template <int R>
+struct CrfHaloX {
+    static constexpr int HW_ = CRF_T + 2 * R;
+    float4 v[HW_ * HW_];        // (bits: r | g << 8 | b << 16, |rgb|^2 (1e30 outside the image), q0 * nb, q1 * nb)
+};
+
+// Gaussian message of one iteration: gmsg[b][p] = (sum_w kg * q0 * ng, sum_w kg * q1 * ng), window clipped to the image (zeros outside)
+template <int R>
+__global__ __launch_bounds__(256) void crf_gauss_kernel(const float* __restrict__ qin, const float* __restrict__ ng, float2* __restrict__ gmsg, CrfP c, CrfCols<R> cols) {
+    constexpr int hw = CRF_T + 2 * R;
+    __shared__ float2 qn[hw * hw];
+    __shared__ float2 hb[hw * CRF_T];
+    const long HW = (long)c.H * c.W, b = blockIdx.z;
+    const int x0 = blockIdx.x * CRF_T, y0 = blockIdx.y * CRF_T;
+    const float* q0 = qin + (b * 2) * HW;
+    const float* q1 = q0 + HW;
+    for (int i = threadIdx.x; i < hw * hw; i += 256) {
+        const int yy = y0 - R + i / hw, xx = x0 - R + i % hw;
+        float2 v = make_float2(0.f, 0.f);
+        if ((unsigned)yy < (unsigned)c.H && (unsigned)xx < (unsigned)c.W) {
+            const long j = (long)yy * c.W + xx;
+            const float n = ng[b * HW + j];
+            v = make_float2(q0[j] * n, q1[j] * n);
+        }
+        qn[i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < hw * CRF_T; i += 256) {
+        const int row = i / CRF_T, x = i % CRF_T;
+        float h0 = 0.f, h1 = 0.f;
+#pragma unroll
+        for (int t = 0; t <= 2 * R; ++t) {
+            const float2 v = qn[row * hw + x + t];
+            h0 = fmaf(cols.gx[t], v.x, h0); h1 = fmaf(cols.gx[t], v.y, h1);
+        }
+        hb[i] = make_float2(h0, h1);
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = (threadIdx.x >> 5) * CRF_PV;
+    const int x = x0 + tx;
+    if (x >= c.W) return;
+#pragma unroll
+    for (int k = 0; k < CRF_PV; ++k) {
+        const int y = y0 + ty + k;
+        if (y >= c.H) break;
+        float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+        for (int t = 0; t <= 2 * R; ++t) {
+            const float2 v = hb[(ty + k + t) * CRF_T + tx];
+            g0 = fmaf(cols.gx[t], v.x, g0); g1 = fmaf(cols.gx[t], v.y, g1);      // the spatial kernel is symmetric: one table for both axes
+        }
+        gmsg[b * HW + (long)y * c.W + x] = make_float2(g0, g1);
+    }
+}
+
+template <int R, bool NORM>
+__global__ __launch_bounds__(256, 4) void crf_x_kernel(const float* __restrict__ probs, const uint8_t* __restrict__ rgb, float* __restrict__ ng,
+                                                       float* __restrict__ nb, const float* __restrict__ qin, const float2* __restrict__ gmsg,
+                                                       float* __restrict__ qout, CrfP c, CrfCols<R> cols) {
+    __shared__ CrfHaloX<R> s;
+    constexpr int hw = CRF_T + 2 * R;
+    const long HW = (long)c.H * c.W, b = blockIdx.z;
+    const int x0 = blockIdx.x * CRF_T, y0 = blockIdx.y * CRF_T;
+    const float* q0 = NORM ? nullptr : qin + (b * 2) * HW;
+    const float* q1 = NORM ? nullptr : q0 + HW;
+    for (int i = threadIdx.x; i < hw * hw; i += blockDim.x) {
+        const int yy = y0 - R + i / hw, xx = x0 - R + i % hw;
+        float4 v = make_float4(0.f, 1e30f, 0.f, 0.f);
+        if ((unsigned)yy < (unsigned)c.H && (unsigned)xx < (unsigned)c.W) {
+            const long j = (long)yy * c.W + xx;
+            const uint8_t* px = rgb + (b * HW + j) * 3;
+            const uint32_t r = px[0], g = px[1], bl = px[2];
+            v.x = __uint_as_float(r | (g << 8) | (bl << 16));
+            v.y = (float)(r * r + g * g + bl * bl);
+            if (!NORM) {
+                const float n_b = nb[b * HW + j];
+                v.z = q0[j] * n_b; v.w = q1[j] * n_b;
+            }
+        }
+        s.v[i] = v;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = (threadIdx.x >> 5) * CRF_PV;
+    const int x = x0 + tx;
+    if (x >= c.W || y0 + ty >= c.H) return;
+    const float kb2 = c.inv2b * 1.44269504f, krgb = c.inv2rgb * 1.44269504f;
+    static_assert(CRF_PV % 2 == 0, "pairs of vertical pixels");
+    constexpr int NP = CRF_PV / 2;
+    crf_f2 m2r[NP], m2g[NP], m2b[NP], km[NP], B0[NP], B1[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const float4 a0 = s.v[(ty + 2 * j + R) * hw + tx + R], a1 = s.v[(ty + 2 * j + 1 + R) * hw + tx + R];
+        const uint32_t c0 = __float_as_uint(a0.x), c1 = __float_as_uint(a1.x);
+        m2r[j] = crf_f2{-2.f * (float)(c0 & 255u), -2.f * (float)(c1 & 255u)};
+        m2g[j] = crf_f2{-2.f * (float)((c0 >> 8) & 255u), -2.f * (float)((c1 >> 8) & 255u)};
+        m2b[j] = crf_f2{-2.f * (float)((c0 >> 16) & 255u), -2.f * (float)((c1 >> 16) & 255u)};
+        km[j] = crf_f2{a0.y, a1.y};              // the centre pixels are inside the image or not stored
+        B0[j] = B1[j] = crf_f2{0.f, 0.f};
+    }
+    // one halo row against the pairs J0 .. J1-1 (compile-time: no branch inside, so the chains of the taps and of the two pairs interleave; a pair's
+    // window is the 12 halo rows 2j .. 2j + 2R + 1 -- the first two rows belong to pair 0 alone, the last two to the last pair)
+    auto row = [&](int hy, auto j0_tag, auto j1_tag) __attribute__((always_inline)) {
+        constexpr int J0 = decltype(j0_tag)::value, J1 = decltype(j1_tag)::value;
+        crf_f2 by[NP];
+#pragma unroll
+        for (int j = J0; j < J1; ++j) {
+            const int dy0 = hy - 2 * j - R, dy1 = dy0 - 1, a0 = dy0 < 0 ? -dy0 : dy0, a1 = dy1 < 0 ? -dy1 : dy1;
+            by[j] = crf_f2{a0 <= c.rb ? -(float)(dy0 * dy0) * kb2 : -1e30f, a1 <= c.rb ? -(float)(dy1 * dy1) * kb2 : -1e30f};
+        }
+        const int h0 = (ty + hy) * hw + tx;
+        float4 hv[2 * R + 1];
+#pragma unroll
+        for (int i = 0; i <= 2 * R; ++i) hv[i] = s.v[h0 + i];
+#pragma unroll
+        for (int i = 0; i <= 2 * R; ++i) {
+            const uint32_t oc = __float_as_uint(hv[i].x);
+            const float orr = (float)(oc & 255u), og = (float)((oc >> 8) & 255u), ob = (float)((oc >> 16) & 255u);
+#pragma unroll
+            for (int j = J0; j < J1; ++j) {
+                crf_f2 dist = km[j] + hv[i].y;                               // integers below 2^24 all the way: exact
+                dist = orr * m2r[j] + dist;
+                dist = og * m2g[j] + dist;
+                dist = ob * m2b[j] + dist;
+                const crf_f2 arg = (cols.bx[i] + by[j]) - dist * krgb;       // <= 0; -1e30 outside the window, -3e26 outside the image
+                const crf_f2 kb = crf_f2{__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+                if (NORM) {
+                    B0[j] += kb;
+                } else {
+                    B0[j] += kb * hv[i].z; B1[j] += kb * hv[i].w;
+                }
+            }
+        }
+    };
+    static_assert(NP == 2, "two pairs of vertical pixels per lane");
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    row(0, I0{}, I1{}); row(1, I0{}, I1{});
+    for (int hy = 2; hy < 2 * R + 2; ++hy) row(hy, I0{}, I2{});
+    row(2 * R + 2, I1{}, I2{}); row(2 * R + 3, I1{}, I2{});
+    float sx = 0.f;
+    if (NORM) {
+#pragma unroll
+        for (int i = 0; i <= 2 * R; ++i) sx += (unsigned)(x + i - R) < (unsigned)c.W ? cols.gx[i] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < CRF_PV; ++k) {
+        const int y = y0 + ty + k;
+        if (y >= c.H) break;
+        const long p = (long)y * c.W + x;
+        const float b0 = (k & 1) ? B0[k / 2].y : B0[k / 2].x, b1 = (k & 1) ? B1[k / 2].y : B1[k / 2].x;
+        if (NORM) {
+            float sy = 0.f;
+#pragma unroll
+            for (int i = 0; i <= 2 * R; ++i) sy += (unsigned)(y + i - R) < (unsigned)c.H ? cols.gx[i] : 0.f;
+            ng[b * HW + p] = 1.f / sqrtf(sx * sy + 1e-20f);
+            nb[b * HW + p] = 1.f / sqrtf(b0 + 1e-20f);
+        } else {
+            const float u0 = -logf(fminf(fmaxf(probs[(b * 2) * HW + p], 1e-5f), 1.f));
+            const float u1 = -logf(fminf(fmaxf(probs[(b * 2 + 1) * HW + p], 1e-5f), 1.f));
+            const float n_g = ng[b * HW + p], n_b = nb[b * HW + p];
+            const float2 gm = gmsg[b * HW + p];
+            const float t0 = -u0 + c.compat_g * gm.x * n_g + c.compat_b * b0 * n_b;
+            const float t1 = -u1 + c.compat_g * gm.y * n_g + c.compat_b * b1 * n_b;
+            softmax2(t0, t1, &qout[(b * 2) * HW + p], &qout[(b * 2 + 1) * HW + p]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ test-time augmentation (src/loaders.py:401-517)
 // spec bits: 0 = ud flip, 1 = lr flip (the reference's elif chain: ud wins), 2-3 = rotation / 90 (counter-clockwise,
 // as skimage.rotate / np.rot90).  transformed = rot90^k(flip(image)).
@@ -1034,7 +1395,7 @@ extern "C" int msc_erode_u8(const uint8_t* in, uint8_t* out, int B, int H, int W
     if (!in || !out || in == out) return msc_fail(MSC_ERR_ARG, "msc_erode_u8: bad pointers");
     int lo, hi, rc = window(k, H, W, "msc_erode_u8", &lo, &hi);
     if (rc) return rc;
-    hipLaunchKernelGGL((rect_filter_kernel<uint8_t, false>), dim3(flat_grid((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, lo, hi);
+    launch_rect_filter<uint8_t, false>(in, out, B, H, W, lo, hi, (hipStream_t)stream);
     return msc_check_launch("msc_erode_u8");
 }
 
@@ -1043,7 +1404,7 @@ extern "C" int msc_dilate_i32(const int32_t* in, int32_t* out, int B, int H, int
     if (!in || !out || in == out) return msc_fail(MSC_ERR_ARG, "msc_dilate_i32: bad pointers");
     int lo, hi, rc = window(k, H, W, "msc_dilate_i32", &lo, &hi);
     if (rc) return rc;
-    hipLaunchKernelGGL((rect_filter_kernel<int32_t, true>), dim3(flat_grid((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, lo, hi);
+    launch_rect_filter<int32_t, true>(in, out, B, H, W, lo, hi, (hipStream_t)stream);
     return msc_check_launch("msc_dilate_i32");
 }
 
@@ -1051,9 +1412,8 @@ extern "C" int msc_rect_filter_u8(const uint8_t* in, uint8_t* out, int B, int H,
     POST_DIMS("msc_rect_filter_u8");
     if (!in || !out || in == out || lo > 0 || hi < 0 || hi >= H || hi >= W || -lo >= H || -lo >= W)
         return msc_fail(MSC_ERR_ARG, "msc_rect_filter_u8: bad argument");
-    const dim3 g(flat_grid((long)B * H * W));
-    if (is_max) hipLaunchKernelGGL((rect_filter_kernel<uint8_t, true>), g, dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, lo, hi);
-    else hipLaunchKernelGGL((rect_filter_kernel<uint8_t, false>), g, dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, lo, hi);
+    if (is_max) launch_rect_filter<uint8_t, true>(in, out, B, H, W, lo, hi, (hipStream_t)stream);
+    else launch_rect_filter<uint8_t, false>(in, out, B, H, W, lo, hi, (hipStream_t)stream);
     return msc_check_launch("msc_rect_filter_u8");
 }
 
@@ -1069,8 +1429,16 @@ extern "C" int msc_label4(const uint8_t* mask, int32_t* labels, int32_t* counts,
     const long HW = (long)H * W;
     const dim3 g = plane_grid(HW, B);
     int32_t* rank = (int32_t*)workspace;
-    hipLaunchKernelGGL(ccl_init_kernel, dim3(ceil_div((long)B * H, 4)), dim3(256), 0, st, mask, labels, H, W, (long)B * H);
-    hipLaunchKernelGGL(ccl_merge_kernel, g, dim3(256), 0, st, mask, labels, H, W);
+    static const bool strip_off = [] { const char* e = getenv("MSC_CCL_STRIP"); return e && e[0] == '0'; }();      // A/B: the global-memory unions of rounds 1-5
+    const int SR = W <= CCL_STRIP_PIX ? CCL_STRIP_PIX / W : 0;      // rows per strip
+    if (SR >= 2 && HW < (1L << 31) && !strip_off) {
+        const int strips = ceil_div(H, SR);
+        hipLaunchKernelGGL(ccl_strip_kernel, dim3(strips, B), dim3(1024), 0, st, mask, labels, H, W, SR);
+        if (strips > 1) hipLaunchKernelGGL(ccl_seam_kernel, dim3(strips - 1, B), dim3(256), 0, st, labels, H, W, SR);
+    } else {
+        hipLaunchKernelGGL(ccl_init_kernel, dim3(ceil_div((long)B * H, 4)), dim3(256), 0, st, mask, labels, H, W, (long)B * H);
+        hipLaunchKernelGGL(ccl_merge_kernel, g, dim3(256), 0, st, mask, labels, H, W);
+    }
     hipLaunchKernelGGL(ccl_compress_kernel, g, dim3(256), 0, st, labels, HW);
     hipLaunchKernelGGL(ccl_rank_kernel, dim3(B), dim3(1024), 0, st, labels, rank, counts, HW);
     hipLaunchKernelGGL(ccl_relabel_kernel, g, dim3(256), 0, st, labels, rank, HW);
@@ -1124,7 +1492,11 @@ extern "C" int msc_build_score(const int32_t* labels, const float* probs, double
     const long n = (long)B * max_labels;
     if (msc_memset_zero(sums, (int64_t)(n * sizeof(double)), st) != MSC_OK || msc_memset_zero(areas, (int64_t)(n * sizeof(int32_t)), st) != MSC_OK)
         return msc_fail(MSC_ERR_HIP, "msc_build_score: memset failed");
-    hipLaunchKernelGGL(score_accum_kernel, plane_grid(HW, B), dim3(256), 0, st, labels, probs, sums, areas, HW, max_labels);
+    static const bool lds_off = [] { const char* e = getenv("MSC_SCORE_LDS"); return e && e[0] == '0'; }();      // A/B: the per-wave global atomics of rounds 1-5
+    if (max_labels <= SCORE_LDS_MAX && !lds_off)
+        hipLaunchKernelGGL(score_accum_lds_kernel, dim3((unsigned)ceil_div(HW, SCORE_CHUNK), B), dim3(256), 0, st, labels, probs, sums, areas, HW, max_labels);
+    else
+        hipLaunchKernelGGL(score_accum_kernel, plane_grid(HW, B), dim3(256), 0, st, labels, probs, sums, areas, HW, max_labels);
     hipLaunchKernelGGL(score_final_kernel, dim3(flat_grid(n)), dim3(256), 0, st, sums, areas, score, n);
     return msc_check_launch("msc_build_score");
 }
@@ -1132,7 +1504,7 @@ extern "C" int msc_build_score(const int32_t* labels, const float* probs, double
 extern "C" int64_t msc_crf_workspace_bytes(int B, int H, int W, int radius) {
     (void)radius;
     if (B <= 0 || H <= 0 || W <= 0) return 0;
-    return (int64_t)B * H * W * 4 * (2 + 2 + 2);  // two norms + two ping-pong Q buffers of 2 channels
+    return (int64_t)B * H * W * 4 * (2 + 2 + 2 + 2);  // two norms + two ping-pong Q buffers of 2 channels + the Gaussian message of an iteration (round 6)
 }
 
 extern "C" int msc_dense_crf(const float* probs, const uint8_t* rgb, float* out, void* workspace, int B, int H, int W,
@@ -1151,6 +1523,7 @@ extern "C" int msc_dense_crf(const float* probs, const uint8_t* rgb, float* out,
     float* nb = ng + (long)B * HW;
     float* qa = nb + (long)B * HW;
     float* qb = qa + 2L * B * HW;
+    float2* gmsg = (float2*)(qb + 2L * B * HW);
     const dim3 g = plane_grid(HW, B);
     const int r = c.rg > c.rb ? c.rg : c.rb;
     static const bool naive = [] { const char* e = getenv("MSC_CRF_NAIVE"); return e && e[0] == '1'; }();      // A/B: the global-memory kernels
@@ -1165,7 +1538,10 @@ extern "C" int msc_dense_crf(const float* probs, const uint8_t* rgb, float* out,
         cols.bx[i] = ad <= c.rb ? -(float)(dx * dx) * c.inv2b * 1.44269504f : -1e30f;
     }
     static const bool pk_off = [] { const char* e = getenv("MSC_CRF_PK"); return e && e[0] == '0'; }();                // A/B: the unpacked round-4 inner loop
-    if (fast && !pk_off) hipLaunchKernelGGL((crf_r_kernel<5, true, true>), gt, dim3(256), 0, st, (const float*)nullptr, rgb, ng, nb, (const float*)nullptr, (float*)nullptr, c, cols);
+    static const bool x_off = [] { const char* e = getenv("MSC_CRF_X"); return e && e[0] == '0'; }();                  // A/B: round 5's kernel (Gaussian + bilateral in one 121-tap loop)
+    const bool xform = fast && !pk_off && !x_off;
+    if (xform) hipLaunchKernelGGL((crf_x_kernel<5, true>), gt, dim3(256), 0, st, (const float*)nullptr, rgb, ng, nb, (const float*)nullptr, (const float2*)nullptr, (float*)nullptr, c, cols);
+    else if (fast && !pk_off) hipLaunchKernelGGL((crf_r_kernel<5, true, true>), gt, dim3(256), 0, st, (const float*)nullptr, rgb, ng, nb, (const float*)nullptr, (float*)nullptr, c, cols);
     else if (fast) hipLaunchKernelGGL((crf_r_kernel<5, true>), gt, dim3(256), 0, st, (const float*)nullptr, rgb, ng, nb, (const float*)nullptr, (float*)nullptr, c, cols);
     else if (tiled) hipLaunchKernelGGL(crf_norm_tiled_kernel, gt, dim3(256), 0, st, rgb, ng, nb, c, r);
     else hipLaunchKernelGGL(crf_norm_kernel, g, dim3(256), 0, st, rgb, ng, nb, c);
@@ -1173,7 +1549,10 @@ extern "C" int msc_dense_crf(const float* probs, const uint8_t* rgb, float* out,
     float* cur = qa;
     for (int it = 0; it < iterations; ++it) {
         float* dst = (it == iterations - 1) ? out : (cur == qa ? qb : qa);
-        if (fast && !pk_off) hipLaunchKernelGGL((crf_r_kernel<5, false, true>), gt, dim3(256), 0, st, probs, rgb, ng, nb, (const float*)cur, dst, c, cols);
+        if (xform) {
+            hipLaunchKernelGGL((crf_gauss_kernel<5>), gt, dim3(256), 0, st, (const float*)cur, (const float*)ng, gmsg, c, cols);
+            hipLaunchKernelGGL((crf_x_kernel<5, false>), gt, dim3(256), 0, st, probs, rgb, ng, nb, (const float*)cur, (const float2*)gmsg, dst, c, cols);
+        } else if (fast && !pk_off) hipLaunchKernelGGL((crf_r_kernel<5, false, true>), gt, dim3(256), 0, st, probs, rgb, ng, nb, (const float*)cur, dst, c, cols);
         else if (fast) hipLaunchKernelGGL((crf_r_kernel<5, false>), gt, dim3(256), 0, st, probs, rgb, ng, nb, (const float*)cur, dst, c, cols);
         else if (tiled) hipLaunchKernelGGL(crf_iter_tiled_kernel, gt, dim3(256), 0, st, probs, rgb, ng, nb, cur, dst, c, r);
         else hipLaunchKernelGGL(crf_iter_kernel, g, dim3(256), 0, st, probs, rgb, ng, nb, cur, dst, c);

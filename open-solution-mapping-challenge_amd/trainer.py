@@ -360,6 +360,12 @@ def DDP_PIECES():
     return max(1, int(os.environ.get('MSC_DDP_PIECES', '4')))
 
 
+def DDP_ONE_GRAPH():
+    """the distributed step captured as ONE graph with the RCCL calls inside (MSC_DDP_ONE_GRAPH=1; default: piecewise graphs around eager calls)"""
+    import os
+    return os.environ.get('MSC_DDP_ONE_GRAPH', '0') == '1'
+
+
 DDP_FRACTIONS = (0.40, 0.65, 0.85)      # share of the gradient bytes that must be final before the first three exchanges
 
 
@@ -419,12 +425,12 @@ def ddp_plan(prog, flat_grads, nchunks=4, fractions=None):
 
 class _ShapeState:
     """everything of a TrainStep that is bound to one batch shape: staging buffers, the program, captured graphs"""
-    __slots__ = ('x', 't', 'prog', 'graph', 'pieces')
+    __slots__ = ('x', 't', 'prog', 'graph', 'pieces', 'one')
 
     def __init__(self, x, target):
         self.x = torch.empty_like(x, dtype=torch.float32)
         self.t = torch.empty_like(target, dtype=torch.float32)
-        self.prog = self.graph = self.pieces = None
+        self.prog = self.graph = self.pieces = self.one = None
 
 
 class TrainStep:
@@ -467,7 +473,7 @@ class TrainStep:
     def _drop_graphs(self):
         """captured launches carry betas / eps / weight_decay as arguments: re-capture after they changed"""
         for st in self.shapes.values():
-            st.graph = st.pieces = None
+            st.graph = st.pieces = st.one = None
 
     def _setup(self, x, target):
         key = (tuple(x.shape), tuple(target.shape), x.device)
@@ -518,7 +524,7 @@ class TrainStep:
         if not self.use_graph:
             self._body()
             return self.loss
-        if st.graph is None and st.pieces is None:
+        if st.graph is None and st.pieces is None and st.one is None:
             # the first step of a shape runs eagerly (builds the program, allocates, packs) and IS this call's step;
             # capturing afterwards does not execute anything, replays start with the next call of this shape
             if st.x.is_cuda:
@@ -527,7 +533,18 @@ class TrainStep:
             self._body()
             if st.x.is_cuda:
                 torch.cuda.synchronize()
-            if self.dist:
+            if self.dist and DDP_ONE_GRAPH():
+                # round 6: the whole distributed step as ONE graph, the RCCL calls captured as forked branches; a capture that fails falls back
+                # to the piecewise graphs below (and those to eager launches)
+                try:
+                    self._capture_one()
+                except RuntimeError as e:
+                    import warnings
+                    warnings.warn('one-graph capture of the distributed step failed (%s); falling back to piecewise graphs' % e)
+                    if st.x.is_cuda:
+                        torch.cuda.synchronize()
+                    st.one = None
+            if self.dist and st.one is None:
                 try:
                     self._capture_pieces()
                 except RuntimeError as e:          # capture next to a live communicator is the fragile part: keep training
@@ -550,7 +567,9 @@ class TrainStep:
             # reads the 16-bit compute copies, which only the Adam launch at the END of a step rewrites -- repack first
             from .unet_models import _stream_of
             self.net._refresh_weights(_stream_of(st.x.device))
-        if st.pieces is not None:
+        if st.one is not None:
+            st.one.replay()
+        elif st.pieces is not None:
             self._replay_pieces()
         else:
             st.graph.replay()
@@ -602,6 +621,41 @@ class TrainStep:
             pieces.append((capture(piece(beg, end, beg == 0)), lo, hi))
             beg = end
         st.pieces = (capture(forward), pieces, capture(adam))
+
+    def _capture_one(self):
+        """The distributed step as ONE hipGraph (MSC_DDP_ONE_GRAPH=1): forward, loss sums, their all-reduce, loss gradient, the backward pieces with
+        the gradient exchange of each piece forked off as it completes (torch.distributed issues a collective on its own stream behind an event of
+        the caller's stream; under capture that is a parallel branch of the graph), the joins, Adam.  No host round trip and no idle gap at the
+        hand-overs between graphs (profiles/r5_run3_collectives_gaps.txt: +2.6-3.2 % for the six-graph form on one GPU).  Validated with a process
+        group of ONE rank only (gpurun exposes one GPU): opt-in until it has run on a multi-GPU node."""
+        from .unet_models import _Program, _stream_of
+        net, st = self.net, self.cur
+        prog, dev = st.prog, st.x.device
+        N, _, H, W = prog.logits.shape
+        total = float(N * H * W) * (self.world.size if self.world.size > 1 else 1)
+        flat_g = net.flat_grads
+        if getattr(prog, '_ddp_plan', None) is None:
+            prog._ddp_plan = ddp_plan(prog, flat_g, nchunks=DDP_PIECES())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
+            stream = _stream_of(dev)
+            _copy(prog.x_in, st.x, stream)
+            _Program.run(prog.fwd, stream)
+            loss_sums(prog.logits, st.t, self.spec, self.sums)
+            self.world.all_reduce(self.sums)
+            loss_grad(prog.logits, st.t, self.spec, prog.dlogits, self.loss, self.sums, total, 1.0, self.opt.dev_state)
+            _zero(flat_g, stream)
+            _zero(prog.stem_dw, stream)
+            works, beg = [], 0
+            for end, lo, hi in prog._ddp_plan:
+                _Program.run_backward(prog.bwd[beg:end], dev)
+                beg = end
+                if lo is not None:
+                    works.append(self.world.all_reduce_grad_range(flat_g, lo, hi))
+            for w in works:
+                w.wait()
+            _Program.run(self.opt.launches(), stream)
+        st.one = g
 
     def _replay_pieces(self):
         fwd, pieces, adam = self.cur.pieces

@@ -70,28 +70,4 @@ def adam_l2_step(p, g, m, v, step, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, we
     return p
 
 
-def synthetic_target(n, h, w, seed=1234):
-    """Seeded f32[n,3,h,w] training target in the reference's format: ch0 mask
-    {0,1}, ch1 distance map (sum of the two nearest building distances, cast to uint8 as `to_pil`
-    does, src/utils.py:284-285), ch2 sqrt(component size) (uint8 as well)."""
-    import numpy as np
-    from scipy import ndimage as ndi
-    rng = np.random.default_rng(seed)
-    out = np.zeros((n, 3, h, w), np.float32)
-    for i in range(n):
-        z = ndi.gaussian_filter(rng.standard_normal((h, w)), 5.0, mode='wrap')
-        mask = z > np.quantile(z, 0.75)
-        lab, k = ndi.label(mask)
-        if k >= 2:
-            dists = np.stack([ndi.distance_transform_edt(lab != j) for j in range(1, k + 1)], -1)
-            dists.sort(-1)
-            dist = dists[..., 0] + dists[..., 1]
-        else:
-            dist = np.zeros((h, w))
-        sizes = np.zeros((h, w))
-        for j in range(1, k + 1):
-            sizes[lab == j] = np.sqrt((lab == j).sum())
-        out[i, 0] = mask
-        out[i, 1] = (dist * ~mask).astype(np.uint16).astype(np.uint8)
-        out[i, 2] = sizes.astype(np.uint8)
-    return torch.from_numpy(out)
+from synthetic_inputs import synthetic_target      # noqa: E402,F401  (input generator, shared with bench.py)

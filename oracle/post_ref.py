@@ -219,10 +219,4 @@ def postprocess(probs, target_size=None, erode=0, dilate=0):
     return build_score(dilated, p)
 
 
-def synthetic_probs(n, h, w, seed=1234, smooth=4.0):
-    """Seeded f32[n,2,h,w] softmax maps with blob structure (~20-60 components per image):
-    softmax of low-pass filtered Gaussian noise."""
-    rng = np.random.default_rng(seed)
-    z = rng.standard_normal((n, 2, h, w)).astype(np.float32)
-    z = ndi.gaussian_filter(z, sigma=(0, 0, smooth, smooth), mode='wrap') * np.float32(8.0 * smooth)
-    return softmax(z, axis=1).astype(np.float32)
+from synthetic_inputs import synthetic_probs      # noqa: E402,F401  (input generator, shared with bench.py)

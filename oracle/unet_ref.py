@@ -79,59 +79,4 @@ class UNetResNetRef(nn.Module):
         return self.final(d0)       # dropout2d p=0.0 in every shipped config (src/models.py:34,39,44)
 
 
-_SEEDED = {}
-
-
-def seeded_state_dict(module, seed=1234):
-    """Deterministic, torch-RNG-independent weights for any module with the reference's key set.
-
-    Values depend only on (key, shape, seed): every tensor is drawn from its own
-    numpy Generator seeded with (seed, crc32(key)), so aliasing / key order cannot change them.
-    Conv / deconv weights ~ N(0, 2/fan_in); biases and BN beta ~ N(0, .05); BN gamma ~ U(.8,1.2)
-    (U(.1,.3) on the last BN of every residual branch so activations stay O(1) in eval mode with
-    un-calibrated running stats); running_mean ~ N(0,.1), running_var ~ U(.8,1.2).
-    """
-    import zlib
-    sd = module.state_dict()
-    bottleneck = any('.bn3.' in k for k in sd)
-    last_bn = '.bn3.' if bottleneck else '.bn2.'
-    out = {}
-    for key, t in sd.items():
-        shape = tuple(t.shape)
-        memo = (seed, key, shape, t.dtype, bottleneck)      # the draw is a function of exactly these: drawn once per process, handed out as copies
-        if memo in _SEEDED:
-            out[key] = _SEEDED[memo].clone()
-            continue
-        rng = np.random.default_rng([seed, zlib.crc32(key.encode())])
-        if key.endswith('num_batches_tracked'):
-            out[key] = torch.zeros(shape, dtype=t.dtype)
-            continue
-        leaf = key.rsplit('.', 1)[-1]
-        if t.dim() == 4:
-            fan_in = shape[1] * shape[2] * shape[3]
-            if 'block.1' in key:                       # ConvTranspose2d weight is [Cin, Cout, kh, kw]
-                fan_in = shape[0] * shape[2] * shape[3] / 4.0
-            v = rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)
-        elif t.dim() == 2:
-            v = rng.standard_normal(shape) * 0.01
-        elif leaf == 'running_var':
-            v = rng.uniform(0.8, 1.2, shape)
-        elif leaf == 'running_mean':
-            v = rng.standard_normal(shape) * 0.1
-        elif leaf == 'weight':                         # BN gamma; small on the residual branch's last BN
-            v = rng.uniform(0.1, 0.3, shape) if last_bn in key else rng.uniform(0.8, 1.2, shape)
-        else:                                          # BN beta / conv bias / fc bias
-            v = rng.standard_normal(shape) * 0.05
-        _SEEDED[memo] = torch.from_numpy(np.asarray(v, dtype=np.float32))
-        out[key] = _SEEDED[memo].clone()
-    return out
-
-
-def synthetic_batch(n, h, w, seed=1234):
-    """Normalised network input f32[n,3,h,w] from uint8 noise tiles: uniform 0..255,
-    /255, minus MEAN over STD (src/pipeline_config.py:19-20)."""
-    rng = np.random.default_rng(seed)
-    img = rng.integers(0, 256, size=(n, 3, h, w), dtype=np.uint8).astype(np.float32) / 255.0
-    mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(1, 3, 1, 1)
-    std = np.array([0.229, 0.224, 0.225], np.float32).reshape(1, 3, 1, 1)
-    return torch.from_numpy((img - mean) / std)
+from synthetic_inputs import seeded_state_dict, synthetic_batch      # noqa: E402,F401  (input generators: shared with bench.py, which may not import oracle/ on its product legs)

@@ -380,6 +380,43 @@ def test_rccl_world1_piecewise_graph_step_equals_eager():
         dist.destroy_process_group()
 
 
+def test_rccl_world1_one_graph_step_equals_the_piecewise_graphs(monkeypatch):
+    """round 6: the distributed step as ONE hipGraph with the RCCL calls captured inside (MSC_DDP_ONE_GRAPH=1) on a process group of size 1:
+    the capture succeeds (no silent fall-back), and six replayed steps give the loss trajectory and parameters of the piecewise-graph step
+    -- bit for bit in the deterministic mode, the launches being the same ones in the same order"""
+    import os
+    import torch.distributed as dist
+    from mapping_challenge_amd.distributed import World
+    from mapping_challenge_amd.trainer import HipAdam, LossSpec, TrainStep
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(29600 + os.getpid() % 1000))
+        dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        arch = {'weighted_cross_entropy': {'w0': 50, 'sigma': 10, 'imsize': (256, 256)},
+                'loss_weights': {'dice_mask': 0.2, 'bce_mask': 1.0}, 'dice': {'smooth': 1, 'dice_activation': 'softmax'}}
+        x = unet_ref.synthetic_batch(2, 64, 64).cuda()
+        tgt = losses_ref.synthetic_target(2, 64, 64).cuda()
+        out = {}
+        for mode in ('pieces', 'one'):
+            monkeypatch.setenv('MSC_DDP_ONE_GRAPH', '1' if mode == 'one' else '0')
+            ref, net = build(34, 'bf16')
+            net.deterministic = True
+            net.train()
+            step = TrainStep(net, LossSpec.mixed(arch), HipAdam(net, lr=5e-4, weight_decay=1e-4), world=World(), use_graph=True, force_collectives=True)
+            losses = [step(x, tgt).item() for _ in range(6)]
+            if mode == 'one':
+                assert step.cur.one is not None and step.pieces is None
+            else:
+                assert step.pieces is not None and step.cur.one is None
+            out[mode] = (losses, net.flat_params.clone(), net.flat_grads.clone())
+        assert out['one'][0] == out['pieces'][0]
+        assert torch.equal(out['one'][1], out['pieces'][1]) and torch.equal(out['one'][2], out['pieces'][2])
+        assert out['one'][0][-1] < out['one'][0][0]
+    finally:
+        dist.destroy_process_group()
+
+
 def test_ddp_plan_of_the_multi_gpu_program_shape_resnet101(monkeypatch):
     """the backward as torch.distributed runs it (weight gradients grouped 24 layers at a time, MSC_WGRAD_GROUP=24) for the
     timed network: the gradient exchange is cut by bytes -- several pieces leave while backward still runs, the decoder's
