@@ -198,6 +198,16 @@ template <> struct Vec16<f16_t> {
     static __device__ __forceinline__ void store(f16_t* p, const float* v) { store16(p, pack(v)); }
 };
 
+// Sum over the 16 lanes of a DPP row (the lanes that share lane >> 4: the 16 pixels of an MFMA fragment column), result in every lane: four VALU adds with
+// DPP operands (two quad permutes, two row rotations).  __shfl_xor compiles to ds_bpermute_b32 -- a round trip through the LDS crossbar per value and step;
+// the statistics epilogue of the convolutions did 128 of them per wave (round 6: +2-3 us on a 12 us layer3 launch, tools/conv_cfg_table.py --stats).
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));       // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));       // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));      // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));      // row_ror:8
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -277,11 +277,8 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvK& p, float (&s1)[
     {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                s1[j] += __shfl_xor(s1[j], o, 64);
-                s2[j] += __shfl_xor(s2[j], o, 64);
-            }
+            s1[j] = row16_sum(s1[j]);
+            s2[j] = row16_sum(s2[j]);
         }
         // One slot per XCD, layout [MSC_BN_SLOTS][Cout][2] (common.h); the consumer (msc_bn_apply / msc_bn_bwd_apply) sums the
         // slots in its prologue.  The block's waves fold their sums through LDS and ONE coalesced atomic instruction per

@@ -21,6 +21,8 @@ namespace {
 // block, the filter orientation is a template parameter (the 36 shifted-window reads are immediates) and the epilogue has one
 // straight-line body per use (statistics / fused final 1x1 / plain) behind uniform branches.  Before that the kernel issued 1142 VALU
 // instructions per wave and patch for 72 MFMAs -- 4x the matrix time in address arithmetic and predicated options.
+__device__ __forceinline__ int c32_key(int hx) { return ((0xFC30 >> hx) & 1) << 1; }      // halo column 0..17 -> chunk permutation of the 64-byte pixel
+
 template <typename T, bool FLIP>
 __global__ __launch_bounds__(256, 2) void conv3x3_c32_halo_kernel(ConvK p, int npatch) {      // 2 blocks per CU: 256 VGPRs
     constexpr int HCH = (18 * 18 * 4 + 255) / 256;   // halo chunks per thread (the last one of most threads is past the end)
@@ -46,7 +48,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_halo_kernel(ConvK p, int n
     for (int i = 0; i < HCH; ++i) {
         const int c = tid + 256 * i, pix = c >> 2;
         const int hy = pix / 18 - 1, hx = pix - (pix / 18) * 18 - 1;
-        hrel[i] = ((hy * p.Wi + hx) * (int)p.in_ld + (c & 3) * 8) * 2;
+        // (round 6) the pixel's four 16-byte chunks are XOR-permuted by c32_key(halo column): a pixel is 64 bytes, so four pixels share a 256-byte bank
+        // window and the 16 lanes of a ds_read_b128 group (8 of channel group g, 8 of g ^ 1, 16 consecutive pixels) met two by two on every read of the
+        // linear layout -- SQ_LDS_BANK_CONFLICT 45-48 % of the LDS cycles.  The key (0 or 2 per column, found by exhaustive search over the three column
+        // shifts of the taps) makes every read conflict-free.
+        hrel[i] = ((hy * p.Wi + hx) * (int)p.in_ld + ((c & 3) ^ c32_key(hx + 1)) * 8) * 2;
         hyx[i] = c >= 18 * 18 * 4 ? -(1 << 28) : hy * 65536 + hx + 1;       // past the end: never inside the image
     }
     T* out = reinterpret_cast<T*>(p.out);
@@ -74,7 +80,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_halo_kernel(ConvK p, int n
     // pl+16, pl+32, pl+48) are folded by two cross-lane adds
     float fb0 = 0.f, fb1 = 0.f;
     if (fin && p.fin_b) { fb0 = p.fin_b[0]; fb1 = p.fin_b[1]; }
-    const int lbase = ((wid * 4 + 1) * 18 + pl + 1) * 4 + g;      // halo chunk of (patch row 4*wid, pixel pl), this lane's input channels
+    int lbase[3];                                                 // halo chunk of (patch row 4*wid, pixel pl + dx), this lane's input channels, dx = -1, 0, 1
+#pragma unroll
+    for (int d = 0; d < 3; ++d) lbase[d] = ((wid * 4 + 1) * 18 + pl + d) * 4 + (g ^ c32_key(pl + d));
     const long hw = (long)p.Ho * p.Wo;
 
     // The halo goes HBM -> LDS by DMA (out-of-image chunks as out-of-range offsets: zeros), the NEXT patch's into the other buffer as
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_halo_kernel(ConvK p, int n
             constexpr int kh = t / 3, kw = t - kh * 3;
             constexpr int dy = FLIP ? 1 - kh : kh - 1, dx = FLIP ? 1 - kw : kw - 1;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) bf[t & 1][b] = halo[lbase + ((b + dy) * 18 + dx) * 4];
+            for (int b = 0; b < 4; ++b) bf[t & 1][b] = halo[lbase[dx + 1] + (b + dy) * 18 * 4];
         };
         auto tap = [&](auto tt) {
             constexpr int t = decltype(tt)::value;
@@ -221,10 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_halo_kernel(ConvK p, int n
         // fold the 16 pixel lanes of a channel group, then the four waves through LDS (the halo is no longer read), and add the
         // block's 32 sums (of all its patches) to this XCD's slot ([MSC_BN_SLOTS][32][2] doubles, first of each pair) with one coalesced atomic
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) bs[j] += __shfl_xor(bs[j], o, 64);
-        }
+        for (int j = 0; j < 8; ++j) bs[j] = row16_sum(bs[j]);
         float* red = reinterpret_cast<float*>(halo2);
         __syncthreads();
         if (pl == 0) {
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_halo_kernel(ConvK p, int n
 // ConvTranspose2d(k4, s2, p1) 128 -> 32 channels (dec1's up-sampling to full resolution): per output-parity phase the DMA
 // kernel re-reads four taps of 256-byte input rows for a 32-channel output tile.  Here a block owns 8x16 input pixels
 // (16x32 outputs): their 10x18 halo goes to LDS once (46 KB), each phase's four taps of weights (32 KB) follow, both with
-// the 16-byte chunks of a row XOR-swizzled by the row index so that 16 lanes reading 16 different rows hit 16 bank groups.
+// the 16-byte chunks of a row XOR-swizzled by the pixel index so that 16 lanes reading 16 different pixels hit 16 bank groups.
 template <typename T>
 __global__ __launch_bounds__(512) void deconv4_c128_c32_halo_kernel(ConvK p) {      // one block of 8 waves per CU (two halo buffers): up to 256 VGPRs
     constexpr int HR = 10, HC = 18;                   // halo rows / columns
@@ -299,13 +304,16 @@ __global__ __launch_bounds__(512) void deconv4_c128_c32_halo_kernel(ConvK p) {  
                 aw[t][kk][a] = *reinterpret_cast<const uint4*>(wt + ((long)(co * 4 + kh) * 4 + kw) * 128 + (kk * 4 + g) * 8);
             }
     }
-    // the thread's halo chunks: LDS slot c = 256 i + tid is chunk (c & 15) ^ (pix & 15) of halo pixel pix = c >> 4
+    // the thread's halo chunks: LDS slot c = 256 i + tid is chunk (c & 15) ^ ((pix & 7) << 1) of halo pixel pix = c >> 4.  (Round 6: the key was
+    // pix & 15.  A ds_read_b128 lane group holds 8 lanes of channel group g and 8 of g ^ 1, reading 16 consecutive pixels; with the full pixel index as
+    // key a lane of one half and a lane of the other whose pixels differ in bit 0 only fall on one slot -- SQ_LDS_BANK_CONFLICT 33 % of the LDS cycles.
+    // Keyed on bits 1-3 alone, the slot's bit 0 is the channel group's: the two halves cannot meet, and 8 consecutive pixels differ in the key.)
     int hyx[HCH], hrel[HCH];                         // (hy << 16 | hx + 1), byte offset from the patch's first pixel (the tensor is below 2 GiB)
 #pragma unroll
     for (int i = 0; i < HCH; ++i) {
         const int c = tid + 512 * i, pix = c >> 4;
         const int hy = pix / HC - 1, hx = pix - (pix / HC) * HC - 1;
-        hrel[i] = ((hy * p.Wi + hx) * (int)p.in_ld + ((c & 15) ^ (pix & 15)) * 8) * 2;
+        hrel[i] = ((hy * p.Wi + hx) * (int)p.in_ld + ((c & 15) ^ ((pix & 7) << 1)) * 8) * 2;
         hyx[i] = c >= NCH ? -(1 << 28) : hy * 65536 + hx + 1;          // past the end: never inside the image
     }
     auto request = [&](int patch, int buf) {
@@ -338,7 +346,7 @@ __global__ __launch_bounds__(512) void deconv4_c128_c32_halo_kernel(ConvK p) {  
                 const int pix = (b + 1 + dy) * HC + (pl + 1 + dx);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const uint4 bf = halo[pix * 16 + ((kk * 4 + g) ^ (pix & 15))];
+                    const uint4 bf = halo[pix * 16 + ((kk * 4 + g) ^ ((pix & 7) << 1))];
                     Mma<T>::run(aw[t][kk][0], bf, acc[0]);
                     Mma<T>::run(aw[t][kk][1], bf, acc[1]);
                 }

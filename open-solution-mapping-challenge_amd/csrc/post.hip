@@ -1148,7 +1148,9 @@ __global__ __launch_bounds__(256) void crf_gauss_kernel(const float* __restrict_
     }
 }
 
-template <int R, bool NORM>
+// FUSEG: the separable Gaussian message of the tile is computed by the same block first, in the LDS the bilateral halo then overwrites (Q * n_g of the
+// halo: 14 KB, row-blurred: 10.5 KB, against 28 KB) -- no crf_gauss_kernel launch, no message buffer written and read back (64 of 400 us per iteration)
+template <int R, bool NORM, bool FUSEG = false>
 __global__ __launch_bounds__(256, 4) void crf_x_kernel(const float* __restrict__ probs, const uint8_t* __restrict__ rgb, float* __restrict__ ng,
                                                        float* __restrict__ nb, const float* __restrict__ qin, const float2* __restrict__ gmsg,
                                                        float* __restrict__ qout, CrfP c, CrfCols<R> cols) {
@@ -1158,6 +1160,48 @@ __global__ __launch_bounds__(256, 4) void crf_x_kernel(const float* __restrict__
     const int x0 = blockIdx.x * CRF_T, y0 = blockIdx.y * CRF_T;
     const float* q0 = NORM ? nullptr : qin + (b * 2) * HW;
     const float* q1 = NORM ? nullptr : q0 + HW;
+    float2 gfused[CRF_PV];
+    if constexpr (FUSEG && !NORM) {
+        static_assert(sizeof(float2) * (hw * hw + hw * CRF_T) <= sizeof(CrfHaloX<R>), "the Gaussian scratch fits under the bilateral halo");
+        float2* qn = reinterpret_cast<float2*>(&s);
+        float2* hb = qn + hw * hw;
+        for (int i = threadIdx.x; i < hw * hw; i += 256) {
+            const int yy = y0 - R + i / hw, xx = x0 - R + i % hw;
+            float2 v = make_float2(0.f, 0.f);
+            if ((unsigned)yy < (unsigned)c.H && (unsigned)xx < (unsigned)c.W) {
+                const long j = (long)yy * c.W + xx;
+                const float n = ng[b * HW + j];
+                v = make_float2(q0[j] * n, q1[j] * n);
+            }
+            qn[i] = v;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < hw * CRF_T; i += 256) {
+            const int row = i / CRF_T, x = i % CRF_T;
+            float h0 = 0.f, h1 = 0.f;
+#pragma unroll
+            for (int t = 0; t <= 2 * R; ++t) {
+                const float2 v = qn[row * hw + x + t];
+                h0 = fmaf(cols.gx[t], v.x, h0); h1 = fmaf(cols.gx[t], v.y, h1);
+            }
+            hb[i] = make_float2(h0, h1);
+        }
+        __syncthreads();
+        {
+            const int tx = threadIdx.x & 31, ty = (threadIdx.x >> 5) * CRF_PV;
+#pragma unroll
+            for (int k = 0; k < CRF_PV; ++k) {
+                float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+                for (int t = 0; t <= 2 * R; ++t) {
+                    const float2 v = hb[(ty + k + t) * CRF_T + tx];
+                    g0 = fmaf(cols.gx[t], v.x, g0); g1 = fmaf(cols.gx[t], v.y, g1);
+                }
+                gfused[k] = make_float2(g0, g1);
+            }
+        }
+        __syncthreads();               // the bilateral halo goes over the scratch
+    }
     for (int i = threadIdx.x; i < hw * hw; i += blockDim.x) {
         const int yy = y0 - R + i / hw, xx = x0 - R + i % hw;
         float4 v = make_float4(0.f, 1e30f, 0.f, 0.f);
@@ -1252,7 +1296,7 @@ __global__ __launch_bounds__(256, 4) void crf_x_kernel(const float* __restrict__
             const float u0 = -logf(fminf(fmaxf(probs[(b * 2) * HW + p], 1e-5f), 1.f));
             const float u1 = -logf(fminf(fmaxf(probs[(b * 2 + 1) * HW + p], 1e-5f), 1.f));
             const float n_g = ng[b * HW + p], n_b = nb[b * HW + p];
-            const float2 gm = gmsg[b * HW + p];
+            const float2 gm = (FUSEG && !NORM) ? gfused[k] : gmsg[b * HW + p];
             const float t0 = -u0 + c.compat_g * gm.x * n_g + c.compat_b * b0 * n_b;
             const float t1 = -u1 + c.compat_g * gm.y * n_g + c.compat_b * b1 * n_b;
             softmax2(t0, t1, &qout[(b * 2) * HW + p], &qout[(b * 2 + 1) * HW + p]);
@@ -1549,7 +1593,10 @@ extern "C" int msc_dense_crf(const float* probs, const uint8_t* rgb, float* out,
     float* cur = qa;
     for (int it = 0; it < iterations; ++it) {
         float* dst = (it == iterations - 1) ? out : (cur == qa ? qb : qa);
-        if (xform) {
+        static const bool fuseg_off = [] { const char* e = getenv("MSC_CRF_FUSEG"); return e && e[0] == '0'; }();            // A/B: the Gaussian message as its own launch
+        if (xform && !fuseg_off) {
+            hipLaunchKernelGGL((crf_x_kernel<5, false, true>), gt, dim3(256), 0, st, probs, rgb, ng, nb, (const float*)cur, (const float2*)nullptr, dst, c, cols);
+        } else if (xform) {
             hipLaunchKernelGGL((crf_gauss_kernel<5>), gt, dim3(256), 0, st, (const float*)cur, (const float*)ng, gmsg, c, cols);
             hipLaunchKernelGGL((crf_x_kernel<5, false>), gt, dim3(256), 0, st, probs, rgb, ng, nb, (const float*)cur, (const float2*)gmsg, dst, c, cols);
         } else if (fast && !pk_off) hipLaunchKernelGGL((crf_r_kernel<5, false, true>), gt, dim3(256), 0, st, probs, rgb, ng, nb, (const float*)cur, dst, c, cols);

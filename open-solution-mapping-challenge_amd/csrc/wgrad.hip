@@ -81,7 +81,14 @@ __device__ __forceinline__ void wgrad_block(const WgK& p, int orig, int nwg, int
 template <typename T, int QS = 1> __device__ __forceinline__ int wg_swz(int unit, int row, int upr) {
     if (sizeof(T) == 2) {
         if (QS == 2) row >>= 1;
-        const int key = ((row & 3) | (((row >> 3) & 1) << 2)) & (upr / 2 - 1);
+        int key = ((row & 3) | (((row >> 3) & 1) << 2)) & (upr / 2 - 1);
+        // round 6: rows of 128 / 64 bytes (the 64- and 32-channel tiles).  A 32-lane group of ds_read_b64_tr_b16 reads rows {r .. r+3, r+8 .. r+11}, 32 bytes of
+        // each; the LDS bank window is 256 bytes, so with 128-byte rows the row's parity already selects the half and the key has to tell r, r+2, r+8, r+10
+        // apart (bits 1 and 3 of the row), with 64-byte rows r&3 selects the quarter and only r and r+8 collide (bit 3).  The masked 256-byte key above used
+        // bits 0-1 there: rows r and r+8 got the same unit pair -- SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE on the 64x64 / 64x32 / 32x32 grouped
+        // kernels (profiles/r5_final_sq_summary.txt), 4 % on the 128x128 ones.
+        if (QS == 1 && upr / 2 == 4) key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+        if (QS == 1 && upr / 2 == 2) key = (row >> 3) & 1;
         return (((unit >> 1) ^ key) << 1) | (unit & 1);
     }
     return unit ^ ((((row >> 2) & 1) << 2) & (upr - 1));

@@ -25,17 +25,18 @@ SHAPES = {
 }
 
 
-def time_cfg(x, w, out, k, flip, cfg, reps=20):
+def time_cfg(x, w, out, k, flip, cfg, reps=20, stats=None):
     pad = k // 2
+    kw = dict(relu=False, stats=stats) if stats is not None else dict(relu=True)
     try:
-        ops.conv_igemm(x, w, out, stride=1, pad=pad, flip=flip, relu=True, cfg=cfg)
+        ops.conv_igemm(x, w, out, stride=1, pad=pad, flip=flip, cfg=cfg, **kw)
     except Exception:
         return None
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
-        ops.conv_igemm(x, w, out, stride=1, pad=pad, flip=flip, relu=True, cfg=cfg)
+        ops.conv_igemm(x, w, out, stride=1, pad=pad, flip=flip, cfg=cfg, **kw)
     b.record()
     b.synchronize()
     return a.elapsed_time(b) / reps * 1e3
@@ -45,6 +46,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--shapes', default='dec')
     ap.add_argument('--cfgs', default='')
+    ap.add_argument('--stats', action='store_true', help='with the BatchNorm statistics epilogue (training forward)')
     args = ap.parse_args()
     only = [int(c) for c in args.cfgs.split(',') if c]
     for group in args.shapes.split(','):
@@ -54,14 +56,15 @@ def main():
             out = torch.empty(N, H, W, Cout, device='cuda', dtype=torch.bfloat16)
             gf = 2.0 * N * H * W * Cin * Cout * K * K / 1e9
             rows = []
+            stats = torch.zeros(8 * Cout * 2, dtype=torch.float64, device='cuda') if args.stats else None
             for cfg in ops.conv_valid_cfgs(x, w, out, stride=1, pad=K // 2):
                 if only and cfg not in only:
                     continue
-                t = time_cfg(x, w, out, K, flip, cfg)
+                t = time_cfg(x, w, out, K, flip, cfg, stats=stats)
                 if t is not None:
                     rows.append((t, cfg))
             rows.sort()
-            print('%s  (%.1f GFLOP)' % (name, gf))
+            print('%s  (%.1f GFLOP)%s' % (name, gf, '  + statistics epilogue' if args.stats else ''))
             for t, cfg in rows[:12]:
                 print('   cfg %2d  %8.1f us  %7.0f TFLOP/s' % (cfg, t, gf / t * 1e3))
             sys.stdout.flush()
