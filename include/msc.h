@@ -152,6 +152,10 @@ typedef struct msc_wgrad_group msc_wgrad_group;
 int msc_wgrad_group_create(const msc_wgrad_desc* descs, int n, int steps_per_block, int tile_cap, int flags, msc_wgrad_group** out);
 int msc_wgrad_group_run(const msc_wgrad_group* g, void* stream);
 int msc_wgrad_group_launches(const msc_wgrad_group* g);
+/* ABI v11: launch `part` of the group alone (0 .. msc_wgrad_group_launches() - 1; the launches of a group -- one per tile shape -- write
+ * disjoint gradient buffers, so a caller may put them on different streams / graph branches; with MSC_WGRAD_ORDERED the LAST part is the
+ * pass that adds the planes and must follow all others). */
+int msc_wgrad_group_run_part(const msc_wgrad_group* g, int part, void* stream);
 void msc_wgrad_group_destroy(msc_wgrad_group* g);
 
 /* fp32 master weight -> compute copy.  msc_pack_cast: same layout.  msc_pack_transpose: [A][T][B] -> [B][T][A]

@@ -93,6 +93,7 @@ SIGNATURES = {
     'msc_wgrad_group_create': (_i, [C.POINTER(WgradDesc), _i, _i, _i, _i, C.POINTER(_vp)]),
     'msc_wgrad_group_run': (_i, [_vp, _vp]),
     'msc_wgrad_group_launches': (_i, [_vp]),
+    'msc_wgrad_group_run_part': (_i, [_vp, _i, _vp]),
     'msc_wgrad_group_destroy': (None, [_vp]),
     'msc_pack_cast': (_i, [_vp, _vp, _i, _i64, _vp]),
     'msc_pack_transpose': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

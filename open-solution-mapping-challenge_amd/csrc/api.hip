@@ -21,4 +21,4 @@ int msc_check_launch(const char* what) {
 }
 
 extern "C" const char* msc_last_error(void) { return msc_err_buf; }
-extern "C" int msc_abi_version(void) { return 10; }
+extern "C" int msc_abi_version(void) { return 11; }

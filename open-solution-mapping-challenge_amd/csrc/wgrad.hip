@@ -1007,6 +1007,20 @@ extern "C" int msc_wgrad_group_run(const msc_wgrad_group* g, void* stream) {
     return msc_check_launch("wgrad_group");
 }
 
+extern "C" int msc_wgrad_group_run_part(const msc_wgrad_group* g, int part, void* stream) {
+    if (!g) return msc_fail(MSC_ERR_ARG, "msc_wgrad_group_run_part: null group");
+    const int nb = (int)g->buckets.size();
+    if (part < 0 || part >= nb + (g->fin_blocks > 0 ? 1 : 0)) return msc_fail(MSC_ERR_ARG, "msc_wgrad_group_run_part: part %d of %d", part, nb);
+    hipStream_t st = (hipStream_t)stream;
+    if (part < nb) {
+        const auto& bk = g->buckets[part];
+        if (bk.blocks > 0) wgrad_tile_dispatch(bk.dtype, bk.ta, bk.tb, WgLaunchGroup{bk.tab, bk.blk, bk.blocks, st, bk.kw3});
+    } else {
+        hipLaunchKernelGGL(wgrad_finish_kernel, dim3(g->fin_blocks), dim3(256), 0, st, reinterpret_cast<const WgFin*>(g->fin_items), g->fin_blk);
+    }
+    return msc_check_launch("wgrad_group_part");
+}
+
 extern "C" int msc_wgrad_group_launches(const msc_wgrad_group* g) {
     return g ? (int)g->buckets.size() + (g->fin_blocks > 0 ? 1 : 0) : -1;
 }

@@ -146,6 +146,9 @@ import os as _os_env
 # serial -- the concurrent kernels fight over L2/LDS-DMA bandwidth -- so the fork/join path is opt-in
 _OVERLAP_WGRAD = _os_env.environ.get('MSC_OVERLAP_WGRAD', '0') == '1'
 _WGRAD_FLUSH_DEFAULT = ''
+# round 6: the launches of a weight-gradient group (one per tile shape) as parallel branches of the step's graph, on this many side streams (1 = in a row)
+_WGRAD_PARTS = int(_os_env.environ.get('MSC_WGRAD_PARTS', '1'))
+_PART_STREAMS = {}
 _SIDE_STREAMS = {}
 
 
@@ -201,12 +204,54 @@ class _Program:
     SIDE = ('msc_conv_wgrad', 'msc_wgrad_group_run', 'msc_stem_unpack_grad')
 
     @staticmethod
+    def run_group_parts(handle, device, nstreams):
+        """The launches of one weight-gradient group (one per tile shape; disjoint gradient buffers) as parallel branches: part i on side stream
+        i % nstreams, forked from the current stream and joined back into it (graph edges under capture).  (round 6, MSC_WGRAD_PARTS=n; msc_wgrad_group_run_part, ABI v11)"""
+        lib = _lib.load()
+        main = torch.cuda.current_stream(device)
+        if getattr(handle, 'ordered', False):           # the deterministic form keeps its launches in a row (the finishing pass follows all of them)
+            rc = lib.msc_wgrad_group_run(handle, main.cuda_stream)
+            if rc != 0:
+                _lib.check(rc, 'msc_wgrad_group_run')
+            return
+        nb = lib.msc_wgrad_group_launches(handle)
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        pool = _PART_STREAMS.setdefault(key, [])
+        while len(pool) < nstreams:
+            pool.append(torch.cuda.Stream(device=device))
+        ev = torch.cuda.Event()
+        ev.record(main)
+        used = []
+        for i in range(nb):
+            st = pool[i % nstreams]
+            if st not in used:
+                st.wait_event(ev)
+                used.append(st)
+            rc = lib.msc_wgrad_group_run_part(handle, i, st.cuda_stream)
+            if rc != 0:
+                _lib.check(rc, 'msc_wgrad_group_run_part')
+        for st in used:
+            done = torch.cuda.Event()
+            done.record(st)
+            main.wait_event(done)
+
+    @staticmethod
     def run_backward(launches, device):
         """Backward launch list with the weight-gradient kernels on a second HIP stream.  A wgrad only reads buffers
         that are final once it is reached in list order (dy, the layer input) and atomically adds into its own slice
         of the flat gradient buffer, so it can run beside the rest of the backward chain (BN backward -> dgrad -> ...),
         which on the small layers of the encoder leaves most CUs idle.  The side stream waits for everything launched
         so far before each wgrad and is joined at the end; under hipGraph capture this becomes graph edges."""
+        if device.type == 'cuda' and _WGRAD_PARTS > 1 and not _OVERLAP_WGRAD:
+            mh = _stream_of(device)
+            for fn, args in launches:
+                if fn.__name__ == 'msc_wgrad_group_run':
+                    _Program.run_group_parts(args[0], device, _WGRAD_PARTS)
+                else:
+                    rc = fn(*args, mh)
+                    if rc != 0:
+                        _lib.check(rc, fn.__name__)
+            return
         if device.type != 'cuda' or not _OVERLAP_WGRAD:
             return _Program.run(launches, _stream_of(device))
         main = torch.cuda.current_stream(device)
@@ -844,6 +889,7 @@ class _Builder:
         _lib.check(self.lib.msc_wgrad_group_create(arr, n, self.group_steps, self.group_tile, _lib.WGRAD_ORDERED if self.ordered else 0, C.byref(h)),
                    'msc_wgrad_group_create')
         h.descs = [d for d, _ in self.pending]
+        h.ordered = bool(self.ordered)
         self.prog.groups.append(h)
         idx = len(self.prog.bwd)
         self.emit(self.prog.bwd, self.lib.msc_wgrad_group_run, h)
@@ -1357,7 +1403,10 @@ class _Builder:
                     pend1 = self.conv_bn(base + '.conv1', cur, blk.conv1, blk.bn1, 1, True, a,
                                          defer=on_load and s == 1 and ww % 16 == 0 and hh % 8 == 0 and _os_env.environ.get('MSC_BN_ON_LOAD_3X3', '1') != '0')
                     b = self.act(ho, wo, planes)
-                    pend2 = self.conv_bn(base + '.conv2', a, blk.conv2, blk.bn2, s, True, b, defer=on_load, pend=pend1)
+                    # MSC_BN_ON_LOAD_1X1=0: conv2 (the 3x3 halo kernel: the pass is amortised over nine taps, on its natural tile) applies bn1 on load,
+                    # conv3 reads a materialised activation (its pass costs more than the launch it saves, profiles/r5_run1_bn_on_load_ab.txt)
+                    pend2 = self.conv_bn(base + '.conv2', a, blk.conv2, blk.bn2, s, True, b,
+                                         defer=on_load and _os_env.environ.get('MSC_BN_ON_LOAD_1X1', '1') != '0', pend=pend1)
                     self.conv_bn(base + '.conv3', b, blk.conv3, blk.bn3, 1, True, out, res=idt, pend=pend2)
                 cur = out
         c5 = cur

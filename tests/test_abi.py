@@ -22,7 +22,7 @@ def test_library_exports_every_header_symbol():
     assert names == set(_lib.SIGNATURES), (names ^ set(_lib.SIGNATURES))
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.msc_abi_version() == 10
+    assert lib.msc_abi_version() == 11
 
 
 def test_missing_library_fails_loudly(monkeypatch):
