@@ -68,7 +68,7 @@ bnl)   # BatchNorm + ReLU on load (msc_conv_desc.in_bn, ABI v9): the kernel test
 ab)    # A/B of environment switches on the train step: AB="NAME=VAL,NAME2=VAL2 NAME=VAL ..." (one run per word)
        python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown --no-north-star > gpurun_out/tune_warm.log 2>&1
        for cfg in $AB; do
-         tag=$(echo "$cfg" | tr ',=' '__')
+         tag=$(echo "$cfg" | tr ',=/' '___')
          ( IFS=,; for kv in $cfg; do export "$kv"; done; unset IFS; timeout 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-north-star $ABFLAGS > "gpurun_out/ab_$tag.log" 2>&1 )
          echo "$cfg: $(grep -o '"ms_per_step": [0-9.]*' "gpurun_out/ab_$tag.log" | head -1) $(grep -o '"wgrad": {[^}]*}' "gpurun_out/ab_$tag.log" | head -1) $(grep -o '"msc_adam_pack": [0-9.]*' "gpurun_out/ab_$tag.log" | head -1)"
        done;;
