@@ -453,6 +453,8 @@ def main():
     if args.gpus != world.size:
         raise SystemExit('--gpus %d but WORLD_SIZE is %d' % (args.gpus, world.size))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('MSC_DIST_ONE_DEVICE') == '1':      # validation only (with MSC_DIST_BACKEND=gloo): every rank on cuda:0 of a one-GPU box
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     stream = torch.cuda.current_stream(dev).cuda_stream

@@ -60,7 +60,8 @@ class World:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
             if backend is None:
-                backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+                # MSC_DIST_BACKEND=gloo: the ranks of a validation run that share ONE GPU (RCCL refuses two ranks on a device); never the default
+                backend = os.environ.get('MSC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
             if backend == 'nccl':
                 torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
             dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=world_size)

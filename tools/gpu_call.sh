@@ -1,5 +1,5 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
-MSC_WGRAD_PERSIST=40 timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_unet.py -m gpu -q -rf --tb=short -p no:cacheprovider -k "wgrad or group or train or grad" 2>&1 | tail -5
-O="MSC_OVERLAP_WGRAD=1,MSC_WGRAD_FLUSH=dec,l3"
-AB="MSC_X=0 MSC_CORUN=1 MSC_CORUN=1,$O,MSC_WGRAD_PERSIST=256 MSC_CORUN=1,$O,MSC_WGRAD_PERSIST=512 $O,MSC_WGRAD_PERSIST=256 MSC_CORUN=1,$O,MSC_WGRAD_PERSIST=256,MSC_WGRAD_GROUP_TILE=64 MSC_WGRAD_PERSIST=512 MSC_WGRAD_PERSIST=768 MSC_X=0" ./run_gpu_round.sh ab
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+MSC_DIST_BACKEND=gloo MSC_DIST_ONE_DEVICE=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 > gpurun_out/bench_two_ranks_one_gpu.log 2>&1; echo "rc=$?"
+grep '^{' gpurun_out/bench_two_ranks_one_gpu.log | cut -c1-900; tail -5 gpurun_out/bench_two_ranks_one_gpu.log | cut -c1-300
