@@ -533,7 +533,16 @@ class TrainStep:
             self._body()
             if st.x.is_cuda:
                 torch.cuda.synchronize()
-            if self.dist and DDP_ONE_GRAPH():
+            one_graph = self.dist and DDP_ONE_GRAPH()
+            if one_graph:
+                # only RCCL's collectives are stream work that a capture can record: gloo's device path synchronises on the host and a
+                # capture around it never returns (seen with two gloo ranks on one GPU, tests/test_gpu_two_ranks.py) -- refuse, do not try
+                import torch.distributed as dist
+                if not (dist.is_initialized() and dist.get_backend(self.world.group) == 'nccl'):
+                    import warnings
+                    warnings.warn('MSC_DDP_ONE_GRAPH=1 needs the nccl (RCCL) backend; using the piecewise graphs')
+                    one_graph = False
+            if one_graph:
                 # round 6: the whole distributed step as ONE graph, the RCCL calls captured as forked branches; a capture that fails falls back
                 # to the piecewise graphs below (and those to eager launches)
                 try:

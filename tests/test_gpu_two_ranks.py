@@ -51,7 +51,8 @@ def _run(world, rank, spec_name, same_shard, steps, use_graph):
     return losses, net.flat_params.detach().cpu().numpy().copy(), net.flat_grads.detach().cpu().numpy().copy(), captured
 
 
-def _worker(rank, port, spec_name, same_shard, steps, use_graph, q):
+def _worker(rank, port, spec_name, same_shard, steps, use_graph, q, env=None):
+    os.environ.update(env or {})
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK='0',
@@ -70,11 +71,11 @@ def _worker(rank, port, spec_name, same_shard, steps, use_graph, q):
         q.put((rank, 'error', '%s\n%s' % (e, traceback.format_exc())))
 
 
-def _two_ranks(spec_name, same_shard, steps=3, use_graph=True):
+def _two_ranks(spec_name, same_shard, steps=3, use_graph=True, env=None):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = 29700 + os.getpid() % 200
-    procs = [ctx.Process(target=_worker, args=(r, port, spec_name, same_shard, steps, use_graph, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, port, spec_name, same_shard, steps, use_graph, q, env)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}
@@ -128,5 +129,15 @@ def test_two_ranks_eager_step_equals_the_piecewise_graphs():
     a = _two_ranks('mixed', same_shard=False, steps=3, use_graph=False)
     b = _two_ranks('mixed', same_shard=False, steps=3, use_graph=True)
     assert not a[0][3] and b[0][3]
+    assert a[0][0] == b[0][0]
+    assert np.array_equal(a[0][1], b[0][1]) and np.array_equal(a[1][1], b[1][1])
+
+
+def test_one_graph_mode_is_refused_for_a_backend_that_cannot_be_captured():
+    """MSC_DDP_ONE_GRAPH=1 with gloo (whose device collectives synchronise on the host: a capture around them never returns): TrainStep warns
+    and runs the piecewise graphs, same results"""
+    a = _two_ranks('mixed', same_shard=False, steps=3, use_graph=True)
+    b = _two_ranks('mixed', same_shard=False, steps=3, use_graph=True, env={'MSC_DDP_ONE_GRAPH': '1'})
+    assert b[0][3] and b[1][3]
     assert a[0][0] == b[0][0]
     assert np.array_equal(a[0][1], b[0][1]) and np.array_equal(a[1][1], b[1][1])

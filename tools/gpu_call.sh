@@ -1,5 +1,3 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
-export HSA_ENABLE_IPC_MODE_LEGACY=0
-MSC_DIST_BACKEND=gloo MSC_DIST_ONE_DEVICE=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 > gpurun_out/bench_two_ranks_one_gpu.log 2>&1; echo "rc=$?"
-grep '^{' gpurun_out/bench_two_ranks_one_gpu.log | cut -c1-900; tail -5 gpurun_out/bench_two_ranks_one_gpu.log | cut -c1-300
+timeout 240 python -m pytest tests/test_gpu_two_ranks.py -m gpu -q -rf --tb=short -p no:cacheprovider -k "refused" 2>&1 | tail -30
