@@ -330,5 +330,6 @@ int conv1x1_launch(const ConvK& k, int dtype, hipStream_t st);
 int halo32_conv_launch(const ConvK& k, int dtype, hipStream_t st);
 int halo32_deconv_launch(const ConvK& k, int dtype, hipStream_t st);
 int halo32_stem_launch(const ConvK& k, int dtype, hipStream_t st);       // configuration 58: the 7x7 / stride 2 stem on the prepared input
+int halo32_down_launch(const ConvK& k, int dtype, hipStream_t st);       // configuration 59: Conv2d(k4, s2, p1) 32 -> 128, the data gradient of dec1's ConvTranspose2d
 
 }  // namespace msc_conv

@@ -450,6 +450,156 @@ __global__ __launch_bounds__(512) void stem7_halo_kernel(ConvK p, int npatch) {
     }
 }
 
+// Conv2d(k4, s2, p1) 32 -> 128 channels on a full-resolution 32-channel map: the DATA GRADIENT of dec1's ConvTranspose2d 128 -> 32
+// (src/unet_models.py:136-141; dX[ci](y, x) = sum_{co, kh, kw} dY[co](2y - 1 + kh, 2x - 1 + kw) W[ci][co][kh][kw]).  As an implicit GEMM it is
+// sixteen 64-byte k-steps per tile -- the slow LDS-DMA case -- and ran 155 us for 268 MB of traffic (ResNet101, batch 32, 256x256: the launch
+// furthest above its HBM floor in the train step, round 6).  Here a block owns 8 x 16 output pixels: the 18 x 34 input pixels under them go to
+// LDS once per patch by DMA, two patches ahead of the one a persistent block multiplies, as TWO column-parity planes -- a tap (kh, kw) reads
+// columns 2 x + kw, all of one parity, so in a plane the 16 pixels of a fragment are neighbours (64 bytes apart) and the 16-byte chunk of a
+// pixel is XOR-swizzled by (column >> 1) & 2, which makes the sixteen lanes of every ds_read_b128 service group hit sixteen different bank
+// quads for both column offsets (kw >> 1 = 0, 1; found by exhaustive search over the instruction's lane groups; SQ_LDS_BANK_CONFLICT = 0).
+// Eight waves: two halves of the patch rows x four groups of 32 output channels, each wave with its 16 taps x 2 weight fragments in registers.
+// EVERY vector-memory instruction of the loop is inline asm with counted waits (as in bottleneck.hip): with the shared epilogue of
+// conv_common.h in the loop the compiler's own s_waitcnt vmcnt(0) -- for the mask loads, and conservatively at the head of the MFMA section --
+// drained the halo requests it cannot see right after they were issued: 74 % of the wave cycles parked, 152 us (SQ_WAIT_ANY, first version).
+// Epilogues: none, or stats_kind 2 (ReLU backward by [sy > 0] + bias-gradient sums); msc_conv_cfg_ok admits nothing else for configuration 59.
+__device__ __forceinline__ void bload16(u32x4_t& r, u32x4_t srd, unsigned voff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(srd) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_loaded4(u32x4_t (&r)[4]) {
+    asm volatile("s_waitcnt vmcnt(%[cnt])" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : [cnt] "n"(N) : "memory");
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void down4_c32_halo_kernel(ConvK p, int npatch) {
+    constexpr int HR = 18, PCOLS = 18, RU = 2 * PCOLS * 4;     // halo rows; columns per parity plane (17 used); 16-byte units per halo row
+    constexpr int NU = HR * RU;                               // 2592 units per patch
+    constexpr int XH = 6, HBUF = XH * 8 * 64;                 // DMA instructions per wave and patch; units per buffer (>= NU)
+    static_assert(HBUF >= NU, "halo buffer");
+    __shared__ uint4 halo2[3 * HBUF];      // three buffers: the patch being multiplied and the next two in flight
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, pl = lane & 15;
+    const int wp = wid >> 2, wc = wid & 3;
+    const int tiles_x = p.Wo / 16, tiles_y = p.Ho / 8;
+    const bool k2 = p.stats != nullptr;
+    const u32x4_t rx = make_srd(p.in, p.in_bytes);
+    const u32x4_t ro = make_srd(p.out, (unsigned)((((long)p.M - 1) * p.out_ld + p.Cout) * 2));
+    const u32x4_t rs = make_srd(k2 ? p.sy : p.out, k2 ? (unsigned)((((long)p.M - 1) * p.sy_ld + p.Cout) * 2) : 16u);
+    const T* wt = reinterpret_cast<const T*>(p.wt);          // [128][4][4][32]
+    // row pl of weight fragment a is output channel 32 wc + 8*(pl>>2) + 4a + (pl&3): a lane ends with channels 32 wc + 8g .. + 7
+    uint4 wf[16][2];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+            wf[t][a] = *reinterpret_cast<const uint4*>(wt + ((long)(32 * wc + 8 * (pl >> 2) + 4 * a + (pl & 3)) * 16 + t) * 32 + g * 8);
+    // The fragments are USED here, ahead of the loop: left to their first use inside it, the compiler's wait for them (s_waitcnt vmcnt(31) ... vmcnt(0),
+    // one per fragment) is part of the loop body and drains the halo requests and the stores of every patch, not just the first
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        u32x4_t w0 = __builtin_bit_cast(u32x4_t, wf[t][0]), w1 = __builtin_bit_cast(u32x4_t, wf[t][1]);
+        asm volatile("" : "+v"(w0), "+v"(w1));
+        wf[t][0] = __builtin_bit_cast(uint4, w0); wf[t][1] = __builtin_bit_cast(uint4, w1);
+    }
+    // the thread's halo units: LDS unit u = (i*8 + wid)*64 + lane is [halo row][column parity][plane column][chunk slot]; the slot holds channel
+    // chunk slot ^ key(plane column).  The decode is redone per request (a dozen integer operations per unit) instead of living in 18 registers across
+    // the loop.  A patch past the end is requested all the same, with every lane out of range: each iteration issues the same number of memory
+    // instructions, so the counted waits are constants
+    const int pix_bytes = (int)p.in_ld * 2;
+    auto request = [&](int patch, int buf) {
+        const bool live = patch < npatch;
+        const int bx = patch % tiles_x, by = (patch / tiles_x) % tiles_y, n = patch / (tiles_x * tiles_y);
+        const int iy0 = 16 * by - 1, ix0 = 32 * bx - 1;
+        const int org = ((n * p.Hi + iy0) * p.Wi + ix0) * pix_bytes;      // of the halo's first pixel (outside the image on the top / left edge)
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));                                    // keeps the decode below inside the loop
+#pragma unroll
+        for (int i = 0; i < XH; ++i) {
+            const int u = (i * 8 + wid) * 64 + lane_;
+            const int r = u / RU, rem = u - r * RU;
+            const int par = rem / (PCOLS * 4), rem2 = rem - par * (PCOLS * 4);
+            const int col = rem2 >> 2, ch = (rem2 & 3) ^ ((col >> 1) & 2);
+            const int cx = 2 * col + par;
+            const bool ok = live && u < NU && col < 17 && (unsigned)(iy0 + r) < (unsigned)p.Hi && (unsigned)(ix0 + cx) < (unsigned)p.Wi;
+            dma16(rx, reinterpret_cast<char*>(halo2 + buf * HBUF + (i * 8 + wid) * 64), ok ? (unsigned)(org + (r * p.Wi + cx) * pix_bytes + ch * 16) : OOB_OFF, 0);
+        }
+    };
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    // unit of (halo row 0, parity 0, the lane's pixel at column offset s = kw >> 1, its k-chunk g)
+    const int l0 = pl * 4 + (g ^ ((pl >> 1) & 2)), l1 = (pl + 1) * 4 + (g ^ (((pl + 1) >> 1) & 2));
+    const int cb = 32 * wc + 8 * g;
+    // Memory instructions of a wave in program order: prologue = halo requests of its first two patches (XH each); patch i = 4 mask loads (the
+    // wave's four pixel rows; out of range when there is no mask), XH halo requests of patch i+2, then 4 stores.  Loads complete in order among
+    // loads, so "at most XH outstanding" proves everything older than the youngest XH loads has landed -- stores in flight only make the wait stricter:
+    //   top of patch i:       its halo is older than the requests of patch i+1           -> vmcnt(XH)
+    //   first epilogue of i:  the mask loads are older than the requests of patch i+2    -> vmcnt(XH)
+    const int step = (int)gridDim.x;
+    request(blockIdx.x, 0);
+    request(blockIdx.x + step, 1);
+    int buf = 0;
+    for (int patch = blockIdx.x; patch < npatch; patch += step, buf = buf == 2 ? 0 : buf + 1) {
+        const int bx = patch % tiles_x, by = (patch / tiles_x) % tiles_y, n = patch / (tiles_x * tiles_y);
+        wait_vmcnt<XH>();
+        raw_barrier();
+        const int m0 = (n * p.Ho + 8 * by) * p.Wo + 16 * bx;
+        u32x4_t sv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            bload16(sv[q], rs, k2 ? (unsigned)((m0 + (wp * 4 + q) * p.Wo + pl) * (int)p.sy_ld + cb) * 2u : OOB_OFF);
+        request(patch + 2 * step, buf == 0 ? 2 : buf - 1);
+        const uint4* halo = halo2 + buf * HBUF;
+        // the wave's four patch rows in two passes of two: 16 accumulator registers beside the 128 of the weights
+#pragma unroll
+        for (int bh = 0; bh < 2; ++bh) {
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw) {
+                    const int lb = (kw >> 1) ? l1 : l0;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const uint4 bf = halo[lb + (2 * (wp * 4 + bh * 2 + b) + kh) * RU + (kw & 1) * (PCOLS * 4)];
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) Mma<T>::run(wf[kh * 4 + kw][a], bf, acc[a][b]);
+                    }
+                }
+            if (bh == 0) wait_loaded4<XH>(sv);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float v[8];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][b][r];
+                if (k2) {                            // dh = acc * [sy > 0]; the bias gradient is the sum of what is stored
+                    float yv[8];
+                    const u32x4_t t = sv[bh * 2 + b];
+                    Vec16<T>::unpack(make_uint4(t.x, t.y, t.z, t.w), yv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        v[j] = yv[j] > 0.f ? v[j] : 0.f;
+                        s1[j] += v[j];
+                    }
+                }
+                bstore16(ro, (unsigned)((m0 + (wp * 4 + bh * 2 + b) * p.Wo + pl) * (int)p.out_ld + cb) * 2u, Vec16<T>::pack(v));
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.stats) {
+        __syncthreads();
+        conv_epilogue_stats<T, 2, 2, 4>(p, s1, s2, wp, wc, pl, 0, reinterpret_cast<float*>(halo2));
+    }
+}
+
 template <typename T>
 int conv_launch(const ConvK& k, hipStream_t st) {
     const int patches = k.N * (k.Ho / 16) * (k.Wo / 16);
@@ -479,10 +629,19 @@ int stem_launch(const ConvK& k, hipStream_t st) {
     return msc_check_launch("stem7_halo");
 }
 
+template <typename T>
+int down_launch(const ConvK& k, hipStream_t st) {
+    const int patches = k.N * (k.Ho / 8) * (k.Wo / 16);
+    static const int persist = [] { const char* e = getenv("MSC_DOWN4_BLOCKS"); return e ? atoi(e) : 256; }();      // one resident block per CU (144 KB of LDS)
+    hipLaunchKernelGGL(down4_c32_halo_kernel<T>, dim3(persist > 0 && patches > persist ? persist : patches), dim3(512), 0, st, k, patches);
+    return msc_check_launch("down4_c32_halo");
+}
+
 }  // namespace
 
 int halo32_stem_launch(const ConvK& k, int dtype, hipStream_t st) { return dtype == MSC_F16 ? stem_launch<f16_t>(k, st) : stem_launch<bf16_t>(k, st); }
 int halo32_conv_launch(const ConvK& k, int dtype, hipStream_t st) { return dtype == MSC_F16 ? conv_launch<f16_t>(k, st) : conv_launch<bf16_t>(k, st); }
 int halo32_deconv_launch(const ConvK& k, int dtype, hipStream_t st) { return dtype == MSC_F16 ? deconv_launch<f16_t>(k, st) : deconv_launch<bf16_t>(k, st); }
+int halo32_down_launch(const ConvK& k, int dtype, hipStream_t st) { return dtype == MSC_F16 ? down_launch<f16_t>(k, st) : down_launch<bf16_t>(k, st); }
 
 }  // namespace msc_conv

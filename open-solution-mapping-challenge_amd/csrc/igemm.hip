@@ -719,11 +719,12 @@ namespace {
 // heuristic (cfg 0) the caller may pick one explicitly -- UNetResNet times the valid ones per layer when it builds
 // a program (msc_conv_cfg_ok enumerates them).
 struct ConvCfg { int tp, tc, wp, wc, kb, nst; };
-constexpr int N_CONV_CFG = 58;
+constexpr int N_CONV_CFG = 59;
 static inline bool cfg_is_halo3(int cfg) { return (cfg >= 42 && cfg <= 46) || (cfg >= 51 && cfg <= 56); }      // conv3x3_halo_dma_kernel
 constexpr int CFG_HALO = 27;          // conv3x3_c32_halo_kernel (not a tile of the DMA kernel)
 constexpr int CFG_HALO_T = 28;        // deconv4_c128_c32_halo_kernel
 constexpr int CFG_STEM = 58;          // stem7_halo_kernel (halo32.hip)
+constexpr int CFG_DOWN4 = 59;         // down4_c32_halo_kernel (halo32.hip)
 static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {0, 0, 0, 0, 0, 0},
     {256, 128, 4, 2, 128, 3},   //  1: 144 KB, 8 waves, 1 block/CU
@@ -800,6 +801,7 @@ static const ConvCfg CONV_CFGS[N_CONV_CFG + 1] = {
     {256, 128, 4, 2, 128, 2},   // 56: 16x16 patch x 128 ch, 8 waves, 128 KB
     {64, 256, 1, 8, 128, 2},    // 57: persistent streaming kernel for 1x1 / stride 1 layers of 64..512 input channels (tile shape per layer: STREAM_VARS)
     {128, 64, 4, 2, 64, 2},     // 58: halo-tile kernel for the stem (7x7 / stride 2 on the prepared 4-channel input)
+    {128, 128, 2, 4, 64, 2},    // 59: halo-tile kernel for Conv2d(k4, s2, p1) 32 -> 128 (the data gradient of dec1's ConvTranspose2d), 96 KB
 };
 
 template <typename T, int TP, int TC, int WP, int WC, int KB, int NST, int ABL = 0, int BNL = 0>
@@ -845,12 +847,21 @@ bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
                          !k.flip && !k.span_bytes && k.ksplit == 1 && k.Cin <= BNL_CMAX && k.Cin % 64 == 0)) return false;
     if (k.fin_w && cfg != CFG_HALO) return false;           // the fused final 1x1 lives in the 32-channel halo kernel's epilogue only
     if (k.sz && cfg >= 29 && cfg <= 32) return false;       // the residual-join epilogue (stats_z) is not compiled for the 32-fragment wave tiles
-    if (k.ksplit > 1 && (cfg == CFG_HALO || cfg == CFG_HALO_T || cfg == CFG_STREAM || cfg == CFG_STEM || cfg_is_halo3(cfg))) return false;      // split-K: the implicit-GEMM kernel only
+    if (k.ksplit > 1 && (cfg == CFG_HALO || cfg == CFG_HALO_T || cfg == CFG_STREAM || cfg == CFG_STEM || cfg == CFG_DOWN4 || cfg_is_halo3(cfg))) return false;      // split-K: the implicit-GEMM kernel only
     if (cfg == CFG_STREAM) return conv1x1_cfg_ok(k, es);
     if (cfg == CFG_STEM)
         return es == 2 && k.mode == 0 && k.KH == 7 && k.KW == 1 && k.stride == 2 && k.pad == 0 && k.Cin == 32 && k.in_ld == 4 && k.Cout == 64 && !k.flip &&
                !k.span_bytes && k.ksplit == 1 && k.Ho % 8 == 0 && k.Wo % 16 == 0 && k.Hi >= 2 * k.Ho + 5 && k.Wi >= 2 * k.Wo + 6 &&
                (!k.stats || k.stats_kind == 0) && k.out_ld % 8 == 0 && k.res_ld % 8 == 0;
+    if (cfg == CFG_DOWN4) {
+        static const bool off = [] { const char* e = getenv("MSC_DOWN4"); return e && e[0] == '0'; }();      // A/B: the implicit-GEMM tiles for this layer
+        if (off) return false;
+    }
+    if (cfg == CFG_DOWN4)
+        return es == 2 && k.mode == 0 && k.KH == 4 && k.KW == 4 && k.stride == 2 && k.pad == 1 && k.Cin == 32 && k.Cout == 128 && !k.flip && !k.span_bytes &&
+               k.Ho % 8 == 0 && k.Wo % 16 == 0 && k.Hi == 2 * k.Ho && k.Wi == 2 * k.Wo && (!k.stats || (k.stats_kind == 2 && k.sy && k.sy_ld % 8 == 0)) &&
+               k.in_ld % 8 == 0 && k.out_ld % 8 == 0 && !k.res && !k.scale && !k.shift && !k.relu &&       // its own epilogue: plain, or ReLU backward + bias sums
+               (long)k.M * k.out_ld * 2 < 0x7fffffffL && (long)k.M * k.sy_ld * 2 < 0x7fffffffL;
     if (cfg == CFG_HALO)
         return es == 2 && k.mode == 0 && k.KH == 3 && k.KW == 3 && k.stride == 1 && k.pad == 1 && k.Cin == 32 && k.Cout == 32 &&
                k.Ho % 16 == 0 && k.Wo % 16 == 0 && k.Hi == k.Ho && k.Wi == k.Wo && (!k.stats || k.stats_kind == 2) && k.res_ld % 8 == 0 && k.out_ld % 8 == 0;
@@ -902,6 +913,7 @@ int conv_dispatch(const ConvK& k, int mode, int cfg, hipStream_t st) {
     if (cfg == CFG_HALO) return halo32_conv_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     if (cfg == CFG_HALO_T) return halo32_deconv_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     if (cfg == CFG_STEM) return halo32_stem_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
+    if (cfg == CFG_DOWN4) return halo32_down_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     if (cfg == CFG_STREAM) return conv1x1_launch(k, std::is_same<T, f16_t>::value ? MSC_F16 : MSC_BF16, st);
     if (k.bnl.slots) {
         if (cfg == 1) return launch_dma<T, 256, 128, 4, 2, 128, 3, 0, 1>(k, mode, st);

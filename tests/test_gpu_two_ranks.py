@@ -125,19 +125,23 @@ def test_two_ranks_different_shards_mixed_loss_stay_in_step():
     assert not np.array_equal(single[1], got[0][1])
 
 
-def test_two_ranks_eager_step_equals_the_piecewise_graphs():
-    a = _two_ranks('mixed', same_shard=False, steps=3, use_graph=False)
-    b = _two_ranks('mixed', same_shard=False, steps=3, use_graph=True)
+@pytest.fixture(scope='module')
+def piecewise_run():
+    """three steps of the mixed loss on different shards through the piecewise hipGraphs: the twin of the two tests below"""
+    return _two_ranks('mixed', same_shard=False, steps=3, use_graph=True)
+
+
+def test_two_ranks_eager_step_equals_the_piecewise_graphs(piecewise_run):
+    a, b = _two_ranks('mixed', same_shard=False, steps=3, use_graph=False), piecewise_run
     assert not a[0][3] and b[0][3]
     assert a[0][0] == b[0][0]
     assert np.array_equal(a[0][1], b[0][1]) and np.array_equal(a[1][1], b[1][1])
 
 
-def test_one_graph_mode_is_refused_for_a_backend_that_cannot_be_captured():
+def test_one_graph_mode_is_refused_for_a_backend_that_cannot_be_captured(piecewise_run):
     """MSC_DDP_ONE_GRAPH=1 with gloo (whose device collectives synchronise on the host: a capture around them never returns): TrainStep warns
     and runs the piecewise graphs, same results"""
-    a = _two_ranks('mixed', same_shard=False, steps=3, use_graph=True)
-    b = _two_ranks('mixed', same_shard=False, steps=3, use_graph=True, env={'MSC_DDP_ONE_GRAPH': '1'})
+    a, b = piecewise_run, _two_ranks('mixed', same_shard=False, steps=3, use_graph=True, env={'MSC_DDP_ONE_GRAPH': '1'})
     assert b[0][3] and b[1][3]
     assert a[0][0] == b[0][0]
     assert np.array_equal(a[0][1], b[0][1]) and np.array_equal(a[1][1], b[1][1])
