@@ -394,7 +394,7 @@ __global__ __launch_bounds__(512) void stem7_halo_kernel(ConvK p, int npatch) {
     constexpr int HR = 21, HCK = 19;                  // halo rows; 16-byte chunks (pixel pairs) per row
     constexpr int NCH = HR * HCK;                     // 399 chunks
     constexpr int HBUF = 512;                         // chunks per buffer: one DMA instruction per wave
-    __shared__ uint4 halo2[2 * HBUF];
+    __shared__ uint4 halo2[3 * HBUF];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, pl = lane & 15;
     const int wp = wid >> 1, wc = wid & 1;
@@ -408,25 +408,50 @@ __global__ __launch_bounds__(512) void stem7_halo_kernel(ConvK p, int npatch) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
             wf[kh][a] = *reinterpret_cast<const uint4*>(wt + ((long)(32 * wc + 8 * (pl >> 2) + 4 * a + (pl & 3)) * 7 + kh) * 32 + g * 8);
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh) {      // used ahead of the loop: the compiler's wait for them stays out of it
+        u32x4_t w0 = __builtin_bit_cast(u32x4_t, wf[kh][0]), w1 = __builtin_bit_cast(u32x4_t, wf[kh][1]);
+        asm volatile("" : "+v"(w0), "+v"(w1));
+        wf[kh][0] = __builtin_bit_cast(uint4, w0); wf[kh][1] = __builtin_bit_cast(uint4, w1);
+    }
     // the thread's halo chunk: LDS slot c = tid is pixel pair c % 19 of halo row c / 19
     const int hr = tid / HCK, hj = tid - hr * HCK;
     const int hrel = (hr * p.Wi * 4 + hj * 8) * 2;            // bytes from the patch's first input pixel (in_ld = 4)
     auto request = [&](int patch, int buf) {
         const int bx = patch % tiles_x, by = (patch / tiles_x) % tiles_y, n = patch / (tiles_x * tiles_y);
         const int org = (((n * p.Hi + 16 * by) * p.Wi + 32 * bx) * 4) * 2;
-        dma16(rx, reinterpret_cast<char*>(halo2 + buf * HBUF + 64 * wid), tid < NCH ? (unsigned)(org + hrel) : OOB_OFF, 0);
+        dma16(rx, reinterpret_cast<char*>(halo2 + buf * HBUF + 64 * wid), tid < NCH && patch < npatch ? (unsigned)(org + hrel) : OOB_OFF, 0);
     };
     float s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    // Round 6 (as down4_c32_halo_kernel below): three halo buffers, two patches in flight, every vector-memory instruction of the loop inline asm with a
+    // counted wait, the epilogue written out here (BatchNorm statistics of the raw accumulators and / or scale, shift, ReLU; what msc_conv_cfg_ok admits
+    // for configuration 58).  With the shared epilogue in the loop and one patch ahead, the wait at the top was vmcnt(0): for the halo AND for the stores
+    // of the patch before.  Program order of a wave: prologue = two requests; patch i = the request of patch i+2 (past the end: out of range, same
+    // count), then 2 stores -- "at most 1 outstanding" at the top of patch i proves its halo, older than the request of patch i+1, has landed.
+    const int cb = 32 * wc + 8 * g;
+    const bool has_sc = p.scale != nullptr, has_sh = p.shift != nullptr, k3 = p.stats != nullptr;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = has_sc ? p.scale[cb + j] : 1.f; sh[j] = has_sh ? p.shift[cb + j] : 0.f; }
+    {
+        float t = 0.f;                      // the coefficients are used ahead of the loop (their wait stays out of it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += sc[j] + sh[j];
+        asm volatile("" ::"v"(t));
+    }
+    const u32x4_t ro = make_srd(p.out, (unsigned)((((long)p.M - 1) * p.out_ld + p.Cout) * 2));
     const int lbase = (4 * wp * HCK + pl + g);                // chunk of (kernel row 0, first of the wave's two output rows, pixel pl)
-    if ((int)blockIdx.x < npatch) request(blockIdx.x, 0);
+    const int step = (int)gridDim.x;
+    request((int)blockIdx.x, 0);
+    request((int)blockIdx.x + step, 1);
     int buf = 0;
-    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x, buf ^= 1) {
+    for (int patch = blockIdx.x; patch < npatch; patch += step, buf = buf == 2 ? 0 : buf + 1) {
         const int bx = patch % tiles_x, by = (patch / tiles_x) % tiles_y, n = patch / (tiles_x * tiles_y);
-        wait_vmcnt<0>();
+        wait_vmcnt<1>();
         raw_barrier();
-        if (patch + (int)gridDim.x < npatch) request(patch + gridDim.x, buf ^ 1);
+        request(patch + 2 * step, buf == 0 ? 2 : buf - 1);
         const uint4* halo = halo2 + buf * HBUF;
         f32x4 acc[2][2];
 #pragma unroll
@@ -442,8 +467,35 @@ __global__ __launch_bounds__(512) void stem7_halo_kernel(ConvK p, int npatch) {
                 for (int a = 0; a < 2; ++a) Mma<T>::run(wf[kh][a], bf, acc[a][b]);
             }
         const int m0 = (n * p.Ho + 8 * by) * p.Wo + 16 * bx;
-        conv_epilogue_tile<T, 2, 2, 32, 4, 0, true>(p, acc, m0, wp, 32 * wc + 8 * g, pl, 0, 0, s1, s2);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float v[8];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[a * 4 + r] = acc[a][b][r];
+            if (k3) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+            }
+            if (has_sc) {
+                asm volatile("" ::: "memory");                        // the options stay branches (conv_common.h)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
+            } else if (has_sh) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += sh[j];
+            }
+            if (p.relu) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            bstore16(ro, (unsigned)((m0 + (wp * 2 + b) * p.Wo + pl) * (int)p.out_ld + cb) * 2u, Vec16<T>::pack(v));
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (p.stats) {
         __syncthreads();
         conv_epilogue_stats<T, 2, 4, 2>(p, s1, s2, wp, wc, pl, 0, reinterpret_cast<float*>(halo2));
@@ -624,7 +676,7 @@ int deconv_launch(const ConvK& k, hipStream_t st) {
 template <typename T>
 int stem_launch(const ConvK& k, hipStream_t st) {
     const int patches = k.N * (k.Ho / 8) * (k.Wo / 16);
-    static const int persist = [] { const char* e = getenv("MSC_STEM_BLOCKS"); return e ? atoi(e) : 256; }();      // measured: 0 (one block per patch) 52 us, 256: 36, 512: 39, 1024: 43
+    static const int persist = [] { const char* e = getenv("MSC_STEM_BLOCKS"); return e ? atoi(e) : 512; }();      // measured (round 6, three buffers + counted waits): 256: 27.8 us, 512: 25.7, 1024: 30.5; before: 0 (one block per patch) 52, 256: 36, 512: 39
     hipLaunchKernelGGL(stem7_halo_kernel<T>, dim3(persist > 0 && patches > persist ? persist : patches), dim3(512), 0, st, k, patches);
     return msc_check_launch("stem7_halo");
 }

@@ -852,7 +852,7 @@ bool conv_cfg_ok(const ConvK& k, int es, int cfg) {
     if (cfg == CFG_STEM)
         return es == 2 && k.mode == 0 && k.KH == 7 && k.KW == 1 && k.stride == 2 && k.pad == 0 && k.Cin == 32 && k.in_ld == 4 && k.Cout == 64 && !k.flip &&
                !k.span_bytes && k.ksplit == 1 && k.Ho % 8 == 0 && k.Wo % 16 == 0 && k.Hi >= 2 * k.Ho + 5 && k.Wi >= 2 * k.Wo + 6 &&
-               (!k.stats || k.stats_kind == 0) && k.out_ld % 8 == 0 && k.res_ld % 8 == 0;
+               (!k.stats || k.stats_kind == 0) && k.out_ld % 8 == 0 && !k.res && (long)k.M * k.out_ld * 2 < 0x7fffffffL;      // (round 6: its own epilogue, buffer stores)
     if (cfg == CFG_DOWN4) {
         static const bool off = [] { const char* e = getenv("MSC_DOWN4"); return e && e[0] == '0'; }();      // A/B: the implicit-GEMM tiles for this layer
         if (off) return false;
