@@ -62,12 +62,7 @@ __device__ __forceinline__ unsigned udiv24(unsigned a, unsigned d) { return udiv
 // One body per KIND behind a uniform switch, the optional steps behind uniform branches: written as one body with the options as
 // selects (the first form) the compiler flattened everything into predicated code -- 21 VALU instructions per output element whatever
 // the launch needed, which bounded the HBM-bound 1x1 layers (84 MB in 25-35 us) and sat at the end of every block of every conv.
-struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
-// "this register is used HERE": an empty asm statement that reads and rewrites it.  The compiler has to wait for a load into it before the
-// statement and knows of nothing pending afterwards (see conv_epilogue_body)
-__device__ __forceinline__ void used_here(float& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void used_here(unsigned& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void used_here(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }      // four coefficients: a bias is a view into the flat parameter buffer, 4-byte aligned only
+struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };      // four coefficients: a bias is a view into the flat parameter buffer, 4-byte aligned only
 
 template <typename T, int FM, int FN, int WTP, int WP, int MODE, bool PATCH, int KIND>
 __device__ __forceinline__ void conv_epilogue_body(const ConvK& p, f32x4 (&acc)[FM][FN], int m0, int wp, int cb, int pl, int py, int px,
@@ -116,7 +111,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvK& p, f32x4 (&acc)[
         }
         opixs[b] = opix;
     }
-    uint4 pre[PRE ? FN : 1][PRE ? NV / CE : 1] = {};
+    uint4 pre[PRE ? FN : 1][PRE ? NV / CE : 1];
     if (PRE && side) {
 #pragma unroll
         for (int b = 0; b < FN; ++b)
@@ -127,8 +122,8 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvK& p, f32x4 (&acc)[
     // fragment by fragment inside the loop they were FN dependent round trips to HBM at the end of every block (+8-16 us per launch)
     constexpr bool JOIN = KIND == 1 && FM * FN <= 16;      // the residual-join form (sz / res) is compiled for wave tiles of up to 16 fragments (msc_conv_cfg_ok)
     constexpr bool PRE2 = JOIN && PRE;
-    uint4 prez[PRE2 ? FN : 1][PRE2 ? NV / CE : 1] = {}, prer[PRE2 ? FN : 1][PRE2 ? NV / CE : 1] = {};
-    unsigned zbits[JOIN ? FN : 1][JOIN ? NV / CE : 1] = {};      // sz_bits: the mask bytes of this lane's channel vectors (one byte where the activation is 16)
+    uint4 prez[PRE2 ? FN : 1][PRE2 ? NV / CE : 1], prer[PRE2 ? FN : 1][PRE2 ? NV / CE : 1];
+    unsigned zbits[JOIN ? FN : 1][JOIN ? NV / CE : 1];      // sz_bits: the mask bytes of this lane's channel vectors (one byte where the activation is 16)
     if (JOIN && p.sz && p.sz_bits) {
         const uint8_t* zb = reinterpret_cast<const uint8_t*>(p.sz);
 #pragma unroll
@@ -148,31 +143,6 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvK& p, f32x4 (&acc)[
         for (int b = 0; b < FN; ++b)
 #pragma unroll
             for (int j = 0; j < NV; j += CE) prer[PRE2 ? b : 0][PRE2 ? j / CE : 0] = *reinterpret_cast<const uint4*>(res + opixs[b] * p.res_ld + cb + j);
-    }
-    // (round 6) Everything requested above is USED here, before the first fragment is stored.  The options below are real branches, and at their
-    // joins the compiler no longer knows which loads are pending: it put `s_waitcnt vmcnt(0)` in front of the first use of a coefficient or a
-    // prefetched vector in EVERY fragment -- behind the store of the fragment before, i.e. a wave waited for each of its stores to be acknowledged
-    // before it computed the next fragment (FN write round trips at the end of every block of every launch that has a scale, a shift or a side
-    // tensor: the data gradients of the encoder, every convolution of the eval forward).  One wait here, while nothing but loads is in flight.
-#pragma unroll
-    for (int j = 0; j < NV; ++j) { used_here(sc[j]); used_here(sh[j]); }
-    if (PRE) {
-#pragma unroll
-        for (int b = 0; b < FN; ++b)
-#pragma unroll
-            for (int j = 0; j < NV / CE; ++j) used_here(pre[PRE ? b : 0][PRE ? j : 0]);
-    }
-    if (PRE2) {
-#pragma unroll
-        for (int b = 0; b < FN; ++b)
-#pragma unroll
-            for (int j = 0; j < NV / CE; ++j) { used_here(prez[PRE2 ? b : 0][PRE2 ? j : 0]); used_here(prer[PRE2 ? b : 0][PRE2 ? j : 0]); }
-    }
-    if (JOIN) {
-#pragma unroll
-        for (int b = 0; b < FN; ++b)
-#pragma unroll
-            for (int j = 0; j < NV / CE; ++j) used_here(zbits[JOIN ? b : 0][JOIN ? j : 0]);
     }
 #pragma unroll
     for (int b = 0; b < FN; ++b) {

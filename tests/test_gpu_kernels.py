@@ -536,7 +536,8 @@ def test_conv_epilogue_batchnorm_backward_sums(dtype, cin, cout, k, hw, n, maske
 
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('cin,cout,k,stride,hw,n,flip', [(128, 64, 3, 1, 16, 2, 1), (32, 128, 4, 2, 32, 2, 0), (32, 32, 3, 1, 32, 3, 1),
-                                                         (128, 320, 3, 1, 12, 2, 1), (32, 64, 4, 2, 26, 3, 0)])
+                                                         (128, 320, 3, 1, 12, 2, 1), (32, 64, 4, 2, 26, 3, 0),
+                                                         (32, 128, 4, 2, 256, 8, 0)])      # 1024 patches: four per persistent block of configuration 59
 def test_conv_epilogue_relu_backward_and_bias_sums(dtype, cin, cout, k, stride, hw, n, flip):
     """stats_kind 2: a data-gradient conv stores its result masked by [act > 0] (ReLU backward of the layer whose activation it
     is given) and reduces the per-channel sums of what it stored (that layer's bias gradient, folded by
@@ -575,7 +576,10 @@ def test_conv_epilogue_relu_backward_and_bias_sums(dtype, cin, cout, k, stride, 
         db = torch.zeros(cout + 3, device='cuda')
         _lib.check(lib.msc_bias_slots_finalize(stats.data_ptr(), cout, db.data_ptr(), cout, torch.cuda.current_stream().cuda_stream), 'fin')
         assert (stats[:, :, 1] == 0).all(), c
-        assert torch.allclose(db[:cout].cpu().double(), stored, rtol=2e-3, atol=(5e-2 if dtype == torch.float32 else 0.5)), c
+        # (the rounding noise of the stored tensor grows with the square root of the pixels summed: 512 in the first shapes, 131 072 in the last one)
+        noise = max(1.0, (n * ho * ho / 512.0) ** 0.5)
+        assert torch.allclose(db[:cout].cpu().double(), stored, rtol=2e-3, atol=(5e-2 if dtype == torch.float32 else 0.5) * noise), c
+        assert torch.allclose(db[:cout].cpu().double(), ref.double().sum((0, 2, 3)), rtol=2e-3, atol=(5e-2 if dtype == torch.float32 else 0.5)), c      # against the unrounded result
         assert (db[cout:] == 0).all()
         # several layers in one launch (what the program emits after the decoder's backward)
         items = (_lib.BiasSlotsItem * 2)()
@@ -589,7 +593,7 @@ def test_conv_epilogue_relu_backward_and_bias_sums(dtype, cin, cout, k, stride, 
         if cout >= 64:
             db2 = torch.ones(32, device='cuda')
             _lib.check(lib.msc_bias_slots_finalize(stats.data_ptr() + 16 * 32, cout, db2.data_ptr(), 32, torch.cuda.current_stream().cuda_stream), 'fin')
-            assert torch.allclose(db2.cpu().double() - 1, stored[32:64], rtol=2e-3, atol=(5e-2 if dtype == torch.float32 else 0.5)), c
+            assert torch.allclose(db2.cpu().double() - 1, stored[32:64], rtol=2e-3, atol=(5e-2 if dtype == torch.float32 else 0.5) * noise), c
     assert tried >= 2
     if cin == 32 and cout == 32 and dtype != torch.float32:
         d.cfg = _lib.CFG_HALO
@@ -1255,7 +1259,7 @@ def test_streaming_1x1_kernel(dtype, cin, cout):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('n,hw', [(3, 64), (2, 256)])
+@pytest.mark.parametrize('n,hw', [(3, 64), (2, 256), (12, 256)])      # (12, 256): 1536 patches = three per persistent block (all three halo buffers)
 def test_stem_halo_kernel(dtype, n, hw):
     """stem7_halo_kernel (configuration 58): the 7x7 / stride 2 / pad 3 stem on the prepared 4-channel input equals torch's conv and the
     implicit-GEMM configurations of the same descriptor: raw output + BatchNorm statistics (training), folded coefficients + ReLU (eval)"""
