@@ -1,3 +1,3 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short -p no:cacheprovider -k "relu_backward_and_bias or stem" 2>&1 | tail -5
+timeout 60 ./probes/kernarg_latency_probe 2>&1 | tee gpurun_out/kernarg_latency.txt
