@@ -103,6 +103,12 @@ __global__ __launch_bounds__(WP * WC * 64) void conv_igemm_dma_kernel(ConvK p) {
     static_assert(!BNL || (NST * STAGE + 8 * BNL_CMAX <= 160 * 1024 && NIX >= NW && MODE == 0 && ES == 2),
                   "BNL: LDS with the table; every pixel-tile piece has ONE fetching wave; gather mode; 16-bit");
 
+    // (round 6) The kernel arguments the prologue needs are fetched in ONE round trip, here: left to the compiler, the 328-byte descriptor arrived in five
+    // dependent s_load rounds spread over the prologue, the last of them (the tensor pointers) right in front of the first fill
+    // (probes/conv_timeline.hip: 2960 clk from block entry to the first fill)
+    asm volatile("" ::"s"(p.in), "s"(p.wt), "s"(p.out), "s"(p.in_ld), "s"(p.N), "s"(p.Hi), "s"(p.Wi), "s"(p.Cin), "s"(p.Ho), "s"(p.Wo), "s"(p.Cout), "s"(p.KH), "s"(p.KW),
+                 "s"(p.stride), "s"(p.pad), "s"(p.flip), "s"(p.M), "s"(p.Hq), "s"(p.Wq), "s"(p.span_bytes), "s"(p.in_bytes), "s"(p.wt_bytes), "s"(p.ntc), "s"(p.ksplit),
+                 "s"(p.xcd_order), "s"(p.rcp_hw), "s"(p.rcp_w));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
