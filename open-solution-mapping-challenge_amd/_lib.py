@@ -14,6 +14,7 @@ F32, BF16, F16 = 0, 1, 2
 BN_SLOTS = 8                      # MSC_BN_SLOTS: per-XCD accumulation slots of the BatchNorm sums
 CFG_HALO, CFG_HALO_T = 27, 28     # msc_conv_igemm configurations that are halo-tile kernels, not tiles of the DMA kernel
 CFG_STREAM = 57                   # ... the persistent streaming kernel for 1x1 / stride 1 layers
+CFG_STEM, CFG_DOWN4 = 58, 59      # ... the stem's 7x7 / stride 2 halo kernel; Conv2d(k4, s2, p1) 32 -> 128 (the data gradient of dec1's ConvTranspose2d, round 6)
 
 
 class MscError(RuntimeError):
