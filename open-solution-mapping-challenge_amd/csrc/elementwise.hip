@@ -1313,6 +1313,10 @@ static int final_bwd_launch(const float* dlogits, const void* in, long in_ld, co
     const int vc = C / CE;
     long blocks = ceil_div((long)N * hw, (256 / vc) * 4);
     if (blocks > MSC_FINAL_BWD_WS_ROWS) blocks = MSC_FINAL_BWD_WS_ROWS;
+    // the unordered form ends every block in 3 C + 2 float atomics on the same few lines (serialised by the L2): fewer, longer blocks.  Measured on the train step
+    // (round 6, tools/gpu_tail_atomics_ab.sh): 1024 blocks 99.7 us, 512: 86.6-86.9, 256: 112-117, 128: 207.  MSC_FINAL_BWD_BLOCKS sets the cap
+    static const long cap = [] { const char* e = getenv("MSC_FINAL_BWD_BLOCKS"); return e ? atol(e) : 512L; }();
+    if (!ws && blocks > cap) blocks = cap;
 #define MSC_FB(VC) \
     if (ws) hipLaunchKernelGGL((final_bwd_kernel<T, VC, true>), dim3((int)blocks), dim3(256), 0, st, dlogits, (const T*)in, in_ld, w, (T*)din, din_ld, dw, db, dbin, ws, N, hw); \
     else hipLaunchKernelGGL((final_bwd_kernel<T, VC, false>), dim3((int)blocks), dim3(256), 0, st, dlogits, (const T*)in, in_ld, w, (T*)din, din_ld, dw, db, dbin, ws, N, hw)

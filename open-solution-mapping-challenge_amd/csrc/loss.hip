@@ -7,6 +7,8 @@
 //   mix                          src/models.py:384-418 (weights from neptune.yaml:42-43,55-57)
 // Two phases so that the four global sums can be all-reduced over ranks in between (the reference
 // computes the loss on the DataParallel-gathered full batch, src/steps/pytorch/models.py:92,104).
+#include <stdlib.h>
+
 #include "common.h"
 #include "msc_internal.h"
 
@@ -107,7 +109,10 @@ extern "C" int msc_loss_sums(const float* logits, const float* target, int tc, c
     if (msc_memset_zero(sums, 4 * sizeof(double), stream) != MSC_OK) return MSC_ERR_HIP;       // (a kernel under MSC_MEMOPS_KERNEL=1)
     const long total = (long)N * H * W;
     long blocks = (total + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    // every block ends in four fp64 atomics on the SAME four addresses, which the L2 serialises (~12 ns each).  Measured on the train step (round 6,
+    // tools/gpu_tail_atomics_ab.sh): 2048 blocks 34.2 us, 1024: 25.9, 512: 28.6, 256: 42.9, 128: 78.5 (too few waves for the loads).  MSC_LOSS_BLOCKS sets the cap
+    static const long cap = [] { const char* e = getenv("MSC_LOSS_BLOCKS"); return e ? atol(e) : 1024L; }();
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(loss_sums_kernel, dim3((int)blocks), dim3(256), 0, st, logits, target, tc, *cfg, sums, N, (long)H * W);
     return msc_check_launch("msc_loss_sums");
 }
